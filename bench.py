@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Benchmark of the IQ hot path on MI355X — BASELINE.json's metric:
+
+    MSamples/s (complex IQ) through shift -> FIR -> decimate -> FFT; % HBM roofline
+
+Workload (BASELINE configs[1], SURVEY §8(d) "cfg2"): one channel at 200 MS/s,
+FreqShifter 25 MHz (1 Hz precision) -> 64-tap low-pass Filter (|f| <= 20 MHz,
+Kaiser null-at-bin 2) -> Downsampler(4096, 50 MS/s, 40 MHz) (L = 120, 4x) ->
+Fourier 4096-pt, Kaiser null-at-bin 2.  A step = one pass of the chain over one
+batch of 2^26 synthetic complex samples already resident in HBM (the stream
+continues from step to step, so every step is steady state).
+
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: launched by torch.distributed.run, one rank per GPU, one independent IQ
+channel per rank (seed = rank + 1).  The path shards by channel: there is NO
+data-path collective; torch.distributed (RCCL) is used only for the barriers and
+the max-over-ranks of the elapsed time.  scaling = weak.
+
+The JSON line also carries
+  roofline     — dominant kernel: algorithmic bytes (10 B per input sample:
+                 8 B read + 8 B / 4 written) / its average
+                 duration from hipEvents recorded by the library around each
+                 launch on the stream it runs on, against the 8 TB/s HBM peak.
+  cpu_baseline — the CPU oracle (C restatement of the reference blocks,
+                 kind = "port", 1 thread) timed on this host on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ALG_BYTES_PER_SAMPLE = 10.0  # 8 B read + 8 B / D written at D = 4
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def lowpass20(_bin, f):
+    return 1.0 if abs(f) <= 20e6 else 0.0
+
+
+def cpu_baseline(budget_s: float = 12.0):
+    """Oracle chain (oracle/rr_oracle.c, -O3, scalar, 1 thread) on a bounded
+    sample of the same workload; sized from a short probe to ~budget_s."""
+    import numpy as np
+
+    from oracle import rr_oracle as o
+
+    kw = dict(shift=25e6, filter_len=64, freq_resp=lowpass20, output_rate=50e6, bandwidth=40e6, fft_len=4096,
+              fft_window=o.Kaiser.with_null_at_bin(2.0), flt=np.float32, max_frames=1)
+    probe = 1 << 20
+    x = o.synth_iq(1, 0, probe)
+    t = time.perf_counter()
+    o.run_chain_c(x, 200e6, **kw)
+    rate = probe / (time.perf_counter() - t)
+    n = int(min(max(rate * budget_s, probe), 1 << 28))
+    n = max(probe, n // probe * probe)
+    x = o.synth_iq(1, 0, n)
+    t = time.perf_counter()
+    _, frames = o.run_chain_c(x, 200e6, **kw)
+    dt = time.perf_counter() - t
+    return {
+        "value": round(n / dt / 1e6, 3),
+        "unit": "MSamples/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{n} complex samples of the same cfg2 stream ({frames} spectra), {dt:.1f} s, "
+                  f"C restatement of the reference blocks chunk by chunk (gcc -O3, scalar)",
+        "host_cores_available": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--samples", type=int, default=1 << 26, help="complex samples per step per GPU")
+    ap.add_argument("--no-fused", action="store_true", help="force the block-by-block kernels")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-json", default=None, help="file holding measured HBM bytes per launch (PMC pass)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the backend has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0:
+        print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world} rank(s)", file=sys.stderr)
+
+    import radiorust_amd as rr
+
+    rr._lib.lib()
+    fs, n = 200e6, int(args.samples)
+    stream = torch.cuda.current_stream().cuda_stream
+    chain = rr.Chain(shift=25e6, filter_len=64, freq_resp=lowpass20, output_rate=50e6, bandwidth=40e6, fft_len=4096,
+                     fft_window=rr.Kaiser.with_null_at_bin(2.0), device=local_rank, allow_fused=not args.no_fused)
+    chain.set_stream(stream)
+    d_in = torch.empty(n, dtype=torch.complex64, device="cuda")
+    rr.synth_iq_dev(local_rank, stream, rank + 1, 0, n, d_in.data_ptr())  # one channel per rank
+    cap = (n // 4 // 4096 + 2) * 4096
+    d_out = torch.empty(cap, dtype=torch.complex64, device="cuda")
+
+    def step():
+        return chain.process_dev(fs, d_in.data_ptr(), n, d_out.data_ptr(), cap)
+
+    # parity spot check on the very first output frame (not timed)
+    first_frames = step() // 4096
+    torch.cuda.synchronize()
+    parity = None
+    if rank == 0:
+        from oracle import rr_oracle as o
+
+        head = 4096 * 4 + 64 + 4  # inputs the first spectrum depends on
+        ref, _ = o.run_chain_c(o.synth_iq(1, 0, head + 64), fs, shift=25e6, filter_len=64, freq_resp=lowpass20,
+                               output_rate=50e6, bandwidth=40e6, fft_len=4096,
+                               fft_window=o.Kaiser.with_null_at_bin(2.0), flt=np.float64)
+        got = d_out[:4096].cpu().numpy().astype(np.complex128)
+        parity = float(np.sqrt(np.sum(np.abs(got - ref[0]) ** 2) / np.sum(np.abs(ref[0]) ** 2)))
+    for _ in range(max(args.warmup - 1, 0)):
+        step()
+
+    lib = rr._lib.lib()
+    import ctypes as C
+
+    lib.rr_chain_timing_enable(chain._h, 1)
+    lib.rr_chain_timing_reset(chain._h)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frames = 0
+    for _ in range(args.steps):
+        frames += step() // 4096
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    fused = chain.last_path_fused()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel device time from the library's hipEvents
+    stages = {}
+    i = 0
+    while True:
+        name = lib.rr_chain_timing_stage_name(i)
+        if not name:
+            break
+        ms, cnt = C.c_double(), C.c_uint64()
+        rr._lib.check(lib.rr_chain_timing_read(chain._h, i, C.byref(ms), C.byref(cnt)))
+        if cnt.value:
+            stages[name.decode()] = {"launches": cnt.value, "avg_ms": ms.value / cnt.value}
+        i += 1
+
+    if rank == 0:
+        total_samples = float(world) * n * args.steps
+        value = total_samples / elapsed / 1e6
+        dom = max(stages, key=lambda k: stages[k]["avg_ms"])
+        avg_s = stages[dom]["avg_ms"] * 1e-3
+        achieved = ALG_BYTES_PER_SAMPLE * n / avg_s / 1e9
+        traffic = None
+        if args.traffic_json and os.path.exists(args.traffic_json):
+            traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "MSamples/s (complex IQ) through shift->FIR->decimate->FFT chain; % HBM roofline",
+            "value": round(value, 1),
+            "unit": "MSamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "cfg2: 1 channel/GPU @200 MS/s, FreqShifter 25 MHz -> Filter 64-tap LP 20 MHz -> "
+                            "Downsampler 4x (L=120) -> Fourier 4096 Kaiser(null@2)",
+                "samples_per_step_per_gpu": n,
+                "spectra_per_step_per_gpu": frames // max(args.steps, 1),
+                "path": "fused" if fused else "block-by-block",
+                "sharding": "one independent channel per GPU, no collective",
+            },
+            "pct_hbm_roofline_whole_chain": round(100.0 * ALG_BYTES_PER_SAMPLE * value * 1e6 / world / (HBM_PEAK_GBS * 1e9), 3),
+            "roofline": {
+                "bound": "hbm",
+                "kernel": dom,
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": traffic,
+                "alg_bytes_per_launch": ALG_BYTES_PER_SAMPLE * n,
+                "avg_launch_ms": round(stages[dom]["avg_ms"], 5),
+            },
+            "kernels": {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 5)} for k, v in stages.items()},
+            "parity_first_spectrum_rms": parity,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        assert first_frames >= 0
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,296 @@
+/*
+ * radiorust_amd.h — C ABI of the MI355X (gfx950) IQ-stream DSP backend.
+ *
+ * The reference (JanBeh/radiorust v0.5.0, 100 % Rust) has no FFI seam of its
+ * own; the seam this library replaces is the body of a block's task between
+ * `receiver.recv()` and `sender.send()` (template: NopSignal,
+ * src/blocks/mod.rs:206-238, the line marked "no operation here").  One handle
+ * = the per-task state of one reference block.  Every entry point cites the
+ * reference code it stands in for (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - rr_c32 / rr_c64 are layout-identical to num_complex::Complex<f32/f64>
+ *     (#[repr(C)] {re, im}; re-exported at src/numbers.rs:10).
+ *   - dtype: RR_F32 or RR_F64 = the reference's generic `Flt` (numbers.rs:23-42).
+ *     `in`/`out` point to rr_c32 or rr_c64 arrays accordingly.
+ *   - Every function returns an int status (RR_OK = 0).  Nothing unwinds across
+ *     the boundary.  rr_last_error_string() describes the last failure on the
+ *     calling thread.  Contract violations that `panic!`/`assert!` in the
+ *     reference return RR_ERR_CONTRACT; the Rust shim re-raises them as panics.
+ *   - A handle is used by one thread at a time (its state lives in one task
+ *     closure in the reference, e.g. transform.rs:307-310) but may move between
+ *     threads between calls: every entry point selects the handle's device.
+ *   - Input is borrowed and never written (a Chunk is a shared Arc<Vec<T>>,
+ *     bufferpool.rs:44-48); output is caller-allocated (ChunkBuf from the
+ *     block's own pool, bufferpool.rs:213-222).
+ *   - `*_process`      : host pointers, blocking (H2D, kernels, D2H, sync).
+ *     `*_enqueue`      : host pointers (ideally pinned, see rr_host_*), returns
+ *                        after queueing on the handle's stream; *n_out is final
+ *                        on return (all schedules are computed on the host),
+ *                        data is valid after rr_wait()/rr_query()==RR_OK.
+ *     `*_process_dev`  : device pointers, asynchronous on the handle's stream.
+ *   - There is no CPU fallback: with no usable HIP device every create fails
+ *     with RR_ERR_HIP.
+ */
+#ifndef RADIORUST_AMD_H
+#define RADIORUST_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float re, im; } rr_c32;
+typedef struct { double re, im; } rr_c64;
+
+enum rr_status {
+    RR_OK = 0,
+    RR_ERR_BAD_ARG = 1,   /* null pointer, unknown dtype, ...                  */
+    RR_ERR_CAPACITY = 2,  /* out_cap too small; nothing was consumed           */
+    RR_ERR_HIP = 3,       /* HIP runtime error / no device                     */
+    RR_ERR_CONTRACT = 4,  /* the reference would panic (assert!/expect)        */
+    RR_ERR_NEED_DESIGN = 5, /* Filter: (rate, chunk length) not designed yet   */
+    RR_ERR_NOT_READY = 6  /* rr_query: work still in flight                    */
+};
+
+enum rr_dtype { RR_F32 = 0, RR_F64 = 1 };
+
+/* Window trait objects stay on the host (windowing.rs:6-10).  Built-ins are
+ * described by value; anything else is sampled by the caller. */
+enum rr_window_kind { RR_WIN_RECTANGULAR = 0, RR_WIN_KAISER = 1, RR_WIN_SAMPLED = 2 };
+typedef struct {
+    int kind;      /* rr_window_kind                                            */
+    double beta;   /* Kaiser beta (windowing.rs:24-51)                          */
+} rr_window;
+
+typedef struct rr_block rr_block; /* base of every handle below */
+typedef struct rr_freqshifter rr_freqshifter;
+typedef struct rr_filter rr_filter;
+typedef struct rr_downsampler rr_downsampler;
+typedef struct rr_fourier rr_fourier;
+typedef struct rr_chain rr_chain;
+
+/* ------------------------------------------------------------------------ */
+/* library / device                                                         */
+/* ------------------------------------------------------------------------ */
+int rr_version(void);
+const char *rr_last_error_string(void);
+int rr_device_count(int *count);
+
+/* Any handle may be passed as rr_block*.  stream = hipStream_t (NULL restores
+ * the handle's own stream).  The handle never owns a caller's stream. */
+int rr_set_stream(rr_block *h, void *hip_stream);
+int rr_wait(rr_block *h);   /* block until everything queued on h is done       */
+int rr_query(rr_block *h);  /* RR_OK = idle, RR_ERR_NOT_READY = in flight       */
+
+/* bufferpool.rs:187-222 re-backed by pinned memory: page-locked allocations
+ * for ChunkBufPool, or registration of an existing Vec's storage. */
+int rr_host_alloc(size_t bytes, void **out);
+int rr_host_free(void *p);
+int rr_host_register(void *p, size_t bytes);
+int rr_host_unregister(void *p);
+
+/* ------------------------------------------------------------------------ */
+/* design math — src/math.rs:7-49, src/windowing.rs (host, f64, no GPU)     */
+/* ------------------------------------------------------------------------ */
+double rr_bessel_i0(double x);                          /* math.rs:7-20  */
+double rr_kaiser_rel_with_beta(double beta, double x);  /* math.rs:26-28 */
+double rr_kaiser_alpha_to_beta(double alpha);           /* math.rs:31-33 */
+double rr_kaiser_null_at_bin_to_beta(double n);         /* math.rs:37-39 */
+double rr_sinc(double x);                               /* math.rs:42-49 */
+/* out[i] = window.relative_value_at(2 (i + 0.5) / n - 1) for a built-in window
+ * (the sampling positions of filters.rs:209-212 and analysis.rs:93-94). */
+int rr_window_sample(const rr_window *w, size_t n, double *out);
+
+/* FreqShifter::with_precision_and_shift's `freq_to_ratio` closure + num's
+ * Ratio::new reduction (transform.rs:298-302). */
+int rr_freqshifter_ratio(double sample_rate, double precision, double shift,
+                         int64_t *numer, int64_t *denom);
+/* The phase table of transform.rs:326-340 for `Flt` = dtype; table has room for
+ * denom complex entries of that dtype. */
+int rr_freqshifter_table(int dtype, int64_t numer, int64_t denom,
+                         double start_phase, void *table);
+
+/* Filter design, filters.rs:184-225: `resp[i]` is what the reference's
+ * `response` vector holds before the division by `scale`, i.e.
+ * resp[i] = freq_resp(i, i*fs/n) for i <= (n-1)/2, resp[n-i] = freq_resp(-i,
+ * -i*fs/n), everything else 0 (the host layer evaluates the closure);
+ * `window_rel[i]` = window.relative_value_at(2(i+.5)/n-1).  Writes the n
+ * equivalent causal FIR taps g[k] = 2n*h[k] (f64): out[t] = sum_k g[k] x[t-k]. */
+int rr_filter_design_taps(size_t n, const rr_c64 *resp, const double *window_rel,
+                          rr_c64 *taps);
+
+/* Downsampler design, resampling.rs:82-99: *ir_len = L; ir (capacity ir_cap,
+ * may be NULL to query L) receives the unit-energy f64 impulse response. */
+int rr_downsampler_design(double input_rate, double output_rate, double bandwidth,
+                          double quality, size_t *ir_len, double *ir, size_t ir_cap);
+
+/* The decimation schedule of resampling.rs:110-112 run over n_in inputs starting
+ * from *pos (0.0 for a fresh block): emit[k] (capacity emit_cap, may be NULL)
+ * receives the 0-based index of the input after which output k is produced;
+ * *count the number of outputs; *pos the carried-over position. */
+int rr_downsampler_schedule(double input_rate, double output_rate, size_t n_in,
+                            double *pos, uint32_t *emit, size_t emit_cap, size_t *count);
+
+/* Fourier window, analysis.rs:88-101: values[i] = rel[i] * sqrt(n / sum rel^2). */
+int rr_fourier_design_window(size_t n, const double *window_rel, double *values);
+
+/* ------------------------------------------------------------------------ */
+/* FreqShifter — src/blocks/transform.rs:266-391                            */
+/* ------------------------------------------------------------------------ */
+/* FreqShifter::with_precision_and_shift (transform.rs:297) */
+int rr_freqshifter_create(int dtype, double precision, double shift, int device,
+                          rr_freqshifter **out);
+/* FreqShifter::set_shift (transform.rs:384-386): applies at the next process,
+ * keeping the phase continuous (transform.rs:322-325). */
+int rr_freqshifter_set_shift(rr_freqshifter *h, double shift);
+int rr_freqshifter_shift(const rr_freqshifter *h, double *shift);         /* :380 */
+int rr_freqshifter_precision(const rr_freqshifter *h, double *precision); /* :376 */
+/* One Signal::Samples message (transform.rs:314-355); n_out = n_in. */
+int rr_freqshifter_process(rr_freqshifter *h, double sample_rate, const void *in,
+                           size_t n_in, void *out, size_t out_cap, size_t *n_out);
+int rr_freqshifter_enqueue(rr_freqshifter *h, double sample_rate, const void *in,
+                           size_t n_in, void *out, size_t out_cap, size_t *n_out);
+int rr_freqshifter_process_dev(rr_freqshifter *h, double sample_rate,
+                               const void *d_in, size_t n_in, void *d_out,
+                               size_t out_cap, size_t *n_out);
+int rr_freqshifter_destroy(rr_freqshifter *h);
+
+/* ------------------------------------------------------------------------ */
+/* Filter — src/blocks/filters.rs:110-298                                   */
+/* ------------------------------------------------------------------------ */
+int rr_filter_create(int dtype, int device, rr_filter **out);
+/* 1 when the reference would `recalculate` for this message (filters.rs:178-
+ * 183): never designed, params updated, sample rate or chunk length changed. */
+int rr_filter_needs_design(const rr_filter *h, double sample_rate, size_t n,
+                           int *needed);
+/* Filter::update / update_with_window (filters.rs:279-297): marks the params
+ * as changed so that needs_design reports 1 for the next message. */
+int rr_filter_mark_params_changed(rr_filter *h);
+/* The `if recalculate { ... }` body (filters.rs:184-239); arguments as for
+ * rr_filter_design_taps.  Drops the history like `previous_chunk = None`. */
+int rr_filter_design(rr_filter *h, double sample_rate, size_t n,
+                     const rr_c64 *resp, const double *window_rel);
+/* Event::is_interrupt() handling (filters.rs:262-265). */
+int rr_filter_reset(rr_filter *h);
+/* One Signal::Samples message of exactly the designed length n
+ * (filters.rs:240-260): n_out = 0 for the first chunk after create/design/
+ * reset, n afterwards.  RR_ERR_NEED_DESIGN if (sample_rate, n_in) differ from
+ * the design. */
+int rr_filter_process(rr_filter *h, double sample_rate, const void *in, size_t n_in,
+                      void *out, size_t out_cap, size_t *n_out);
+int rr_filter_enqueue(rr_filter *h, double sample_rate, const void *in, size_t n_in,
+                      void *out, size_t out_cap, size_t *n_out);
+/* Batched form for device-resident streams: n_in = k*n consecutive chunks
+ * (what a Rechunker(n) in front of the Filter would deliver, chunks.rs:42-177);
+ * n_out = n_in - n if the history was empty, n_in otherwise. */
+int rr_filter_process_dev(rr_filter *h, double sample_rate, const void *d_in,
+                          size_t n_in, void *d_out, size_t out_cap, size_t *n_out);
+int rr_filter_destroy(rr_filter *h);
+
+/* ------------------------------------------------------------------------ */
+/* Downsampler — src/blocks/resampling.rs:14-146                            */
+/* ------------------------------------------------------------------------ */
+/* Downsampler::with_quality (resampling.rs:45-56).  `output_chunk_len` stays
+ * with the host layer, which regroups outputs into chunks (resampling.rs:121-
+ * 131); the handle produces the raw decimated stream. */
+int rr_downsampler_create(int dtype, double output_rate, double bandwidth,
+                          double quality, int device, rr_downsampler **out);
+/* Outputs this message will produce (the `pos` schedule of resampling.rs:110-
+ * 112 run ahead without consuming anything). */
+int rr_downsampler_peek(rr_downsampler *h, double input_rate, size_t n_in,
+                        size_t *n_out);
+int rr_downsampler_process(rr_downsampler *h, double input_rate, const void *in,
+                           size_t n_in, void *out, size_t out_cap, size_t *n_out);
+int rr_downsampler_enqueue(rr_downsampler *h, double input_rate, const void *in,
+                           size_t n_in, void *out, size_t out_cap, size_t *n_out);
+int rr_downsampler_process_dev(rr_downsampler *h, double input_rate,
+                               const void *d_in, size_t n_in, void *d_out,
+                               size_t out_cap, size_t *n_out);
+int rr_downsampler_ir_len(const rr_downsampler *h, size_t *ir_len);
+int rr_downsampler_destroy(rr_downsampler *h);
+
+/* ------------------------------------------------------------------------ */
+/* Fourier — src/blocks/analysis.rs:26-133                                  */
+/* ------------------------------------------------------------------------ */
+/* Fourier::new / new_center_dc / with_window / with_window_center_dc
+ * (analysis.rs:39-59).  With RR_WIN_SAMPLED the caller supplies the window via
+ * rr_fourier_set_sampled_window whenever the chunk length changes. */
+int rr_fourier_create(int dtype, const rr_window *window, int center_dc, int device,
+                      rr_fourier **out);
+int rr_fourier_set_sampled_window(rr_fourier *h, size_t n, const double *window_rel);
+/* One Signal::Samples message (analysis.rs:77-121): n_out = n_in, any n_in >= 1. */
+int rr_fourier_process(rr_fourier *h, const void *in, size_t n_in, void *out,
+                       size_t out_cap, size_t *n_out);
+int rr_fourier_enqueue(rr_fourier *h, const void *in, size_t n_in, void *out,
+                       size_t out_cap, size_t *n_out);
+/* Batched: n_in = k * chunk_len consecutive chunks, each transformed on its own. */
+int rr_fourier_process_dev(rr_fourier *h, size_t chunk_len, const void *d_in,
+                           size_t n_in, void *d_out, size_t out_cap, size_t *n_out);
+int rr_fourier_destroy(rr_fourier *h);
+
+/* ------------------------------------------------------------------------ */
+/* Chain — FreqShifter -> Filter -> Downsampler -> Fourier wired as in       */
+/* examples/bandwidth_meter/main.rs:51-72, on one device without host hops.  */
+/* The stream entering the Filter is cut into chunks of `filter_len`          */
+/* (a Rechunker(filter_len), chunks.rs:42-177); the Downsampler's             */
+/* output_chunk_len is `fft_len`.                                             */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    int dtype;              /* RR_F32 (fused fast path) or RR_F64               */
+    double precision;       /* FreqShifter precision                            */
+    double shift;           /* FreqShifter shift                                */
+    size_t filter_len;      /* Filter chunk length = tap count n                */
+    double output_rate;     /* Downsampler                                      */
+    double bandwidth;
+    double quality;
+    size_t fft_len;         /* Downsampler output_chunk_len = Fourier length    */
+    rr_window fft_window;   /* built-in kinds only                              */
+    int center_dc;
+    int allow_fused;        /* 0 forces the block-by-block path (for parity)    */
+} rr_chain_params;
+
+int rr_chain_create(const rr_chain_params *p, int device, rr_chain **out);
+int rr_chain_set_shift(rr_chain *h, double shift);
+int rr_chain_filter_needs_design(const rr_chain *h, double sample_rate, int *needed);
+int rr_chain_filter_mark_params_changed(rr_chain *h);
+int rr_chain_filter_design(rr_chain *h, double sample_rate, const rr_c64 *resp,
+                           const double *window_rel);
+/* An Event with is_interrupt() travelling down the chain: Filter drops its
+ * history (filters.rs:262-265); FreqShifter, Downsampler and Fourier keep their
+ * state (transform.rs:357-359, resampling.rs:135-137, analysis.rs:122-124). */
+int rr_chain_interrupt(rr_chain *h);
+/* Spectra this call will emit for n_in more input samples. */
+int rr_chain_peek(rr_chain *h, double sample_rate, size_t n_in, size_t *n_frames);
+/* Consumes n_in samples; writes n_frames*fft_len spectrum bins (n_out). */
+int rr_chain_process(rr_chain *h, double sample_rate, const void *in, size_t n_in,
+                     void *out, size_t out_cap, size_t *n_out);
+int rr_chain_process_dev(rr_chain *h, double sample_rate, const void *d_in,
+                         size_t n_in, void *d_out, size_t out_cap, size_t *n_out);
+/* 1 if the last process call ran the fused kernels, 0 = block-by-block. */
+int rr_chain_last_path(const rr_chain *h, int *fused);
+int rr_chain_destroy(rr_chain *h);
+
+/* Measurement aid (no reference counterpart): with timing on, every kernel the
+ * chain launches is bracketed by hipEvents on the chain's stream.  Stages:
+ * see rr_chain_timing_stage_name(); read returns the accumulated device time
+ * and launch count of one stage since the last reset and waits for the events
+ * it needs. */
+int rr_chain_timing_enable(rr_chain *h, int on);
+int rr_chain_timing_reset(rr_chain *h);
+int rr_chain_timing_read(rr_chain *h, int stage, double *total_ms, uint64_t *launches);
+const char *rr_chain_timing_stage_name(int stage); /* NULL past the last stage */
+
+/* ------------------------------------------------------------------------ */
+/* Synthetic IQ source generated on the device; the test      */
+/* harness's stand-in for an SDR source block.  d_out: n rr_c32.             */
+/* ------------------------------------------------------------------------ */
+int rr_synth_iq_dev(int device, void *hip_stream, uint64_t seed, uint64_t t0,
+                    size_t n, void *d_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RADIORUST_AMD_H */

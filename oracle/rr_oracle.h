@@ -110,7 +110,15 @@ typedef void (*rro_freq_resp_fn)(int64_t bin, double freq, double *out,
                                    size_t n, FLT *out);                       \
     size_t rro_fourier_window_##SUF(rro_fourier_##SUF *, FLT *out,            \
                                     size_t cap);                              \
-    void rro_fourier_free_##SUF(rro_fourier_##SUF *);
+    void rro_fourier_free_##SUF(rro_fourier_##SUF *);                         \
+    size_t rro_chain_run_##SUF(const FLT *x, size_t n, double fs,             \
+                               double precision, double shift,                \
+                               size_t filter_len, rro_freq_resp_fn fn,        \
+                               void *ud, const rro_window *filter_window,     \
+                               double output_rate, double bandwidth,          \
+                               double quality, size_t fft_len,                \
+                               const rro_window *fft_window, int center_dc,   \
+                               FLT *out, size_t out_cap_frames);
 
 RRO_DECL(f32, float)
 RRO_DECL(f64, double)

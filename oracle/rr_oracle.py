@@ -107,6 +107,9 @@ def lib() -> C.CDLL:
         g("rro_fourier_window").argtypes = [vp, vp, sz]
         g("rro_fourier_free").restype = None
         g("rro_fourier_free").argtypes = [vp]
+        g("rro_chain_run").restype = sz
+        g("rro_chain_run").argtypes = [vp, sz, d, d, d, sz, _RESPFN, vp, C.POINTER(_CWindow), d, d, d, sz,
+                                       C.POINTER(_CWindow), C.c_int, vp, sz]
     _lib = L
     return L
 
@@ -428,3 +431,32 @@ def run_chain(
             spectra.append(fo.process(chunk))
     cat = lambda l: np.concatenate(l) if l else np.empty(0, dtype=cdt)  # noqa: E731
     return cat(mixed), cat(filtered), cat(decimated), spectra
+
+
+def run_chain_c(x, sample_rate, *, shift, precision=1.0, filter_len, freq_resp, filter_window=None, output_rate,
+                bandwidth, quality=3.0, fft_len, fft_window=None, center_dc=False, flt=np.float32, max_frames=None):
+    """Same wiring as run_chain, but the chunk loop runs in C (rro_chain_run):
+    returns the spectra as an array [frames, fft_len].  With `max_frames` only
+    the first frames are kept (all the work is still done) — used for timing."""
+    suf, cdt, _ = _dt(flt)
+    x = _cin(x, cdt)
+    fw = filter_window if filter_window is not None else Kaiser.with_null_at_bin(2.0)
+    ffw = fft_window if fft_window is not None else Rectangular()
+
+    def tramp(bin_, freq, out, _ud):
+        v = complex(freq_resp(int(bin_), float(freq)))
+        out[0] = v.real
+        out[1] = v.imag
+
+    cfn = _RESPFN(tramp)
+    cap = max(1, x.size // int(filter_len) if max_frames is None else int(max_frames))
+    cap = min(cap, x.size // int(fft_len) + 1)
+    out = np.empty((cap, int(fft_len)), dtype=cdt)
+    cfw, cffw = fw._c(), ffw._c()
+    frames = getattr(lib(), f"rro_chain_run_{suf}")(
+        x.ctypes.data, x.size, float(sample_rate), float(precision), float(shift), int(filter_len), cfn, None,
+        C.byref(cfw), float(output_rate), float(bandwidth), float(quality), int(fft_len), C.byref(cffw),
+        int(bool(center_dc)), out.ctypes.data, cap)
+    if frames == C.c_size_t(-1).value:
+        raise AssertionError("chain contract violated")
+    return out[: min(frames, cap)], frames

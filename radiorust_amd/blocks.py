@@ -1,0 +1,384 @@
+"""Host-side mirror of the reference's hot-path blocks over the C ABI.
+
+Same constructor names, argument meaning and error behaviour as
+`radiorust::blocks::{FreqShifter, Filter, Downsampler, Fourier}`; each block's
+`process(signal)` is the body of the reference block's task loop for one
+received message (it returns the list of messages the task would `send`).
+All arithmetic happens in the HIP library; this module only evaluates the user's
+closures (frequency response, custom windows) and moves messages.
+
+Python is the test/bench harness language here (the reference's own host
+language, Rust, has no toolchain in this image): see INTEGRATION.md for the
+Rust shim a maintainer would add on top of the same C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .signal import EventSignal, Samples
+from .windowing import Kaiser, Rectangular, Window
+
+
+def _dtype_code(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return _lib.RR_F32, np.complex64
+    if dtype == np.float64:
+        return _lib.RR_F64, np.complex128
+    raise TypeError(f"Flt must be float32 or float64, not {dtype}")
+
+
+class _Block:
+    _destroy = None
+
+    def __init__(self):
+        self._h = C.c_void_p()
+
+    # -- plumbing shared by all handles ---------------------------------
+    def set_stream(self, hip_stream: int | None):
+        """Run on the caller's hipStream_t (e.g. torch's current stream)."""
+        _lib.check(_lib.lib().rr_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def wait(self):
+        _lib.check(_lib.lib().rr_wait(self._h))
+
+    def query(self) -> bool:
+        s = _lib.lib().rr_query(self._h)
+        if s == _lib.RR_ERR_NOT_READY:
+            return False
+        _lib.check(s)
+        return True
+
+    def close(self):
+        if self._h:
+            getattr(_lib.lib(), self._destroy)(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _host_call(self, fn, rate_args, chunk, cap):
+        x = np.ascontiguousarray(chunk, dtype=self._cdt)
+        out = np.empty(cap, dtype=self._cdt)
+        n_out = C.c_size_t()
+        _lib.check(fn(self._h, *rate_args, x.ctypes.data, x.size, out.ctypes.data, cap, C.byref(n_out)))
+        return out[: n_out.value]
+
+
+class FreqShifter(_Block):
+    """Complex oscillator and mixer (transform.rs:266-391)."""
+
+    _destroy = "rr_freqshifter_destroy"
+
+    def __init__(self, precision: float = 1.0, shift: float = 0.0, dtype=np.float32, device: int = 0):
+        super().__init__()
+        self._code, self._cdt = _dtype_code(dtype)
+        _lib.check(_lib.lib().rr_freqshifter_create(self._code, float(precision), float(shift), device, C.byref(self._h)))
+
+    # transform.rs:282-297
+    @classmethod
+    def new(cls, **kw):
+        return cls(1.0, 0.0, **kw)
+
+    @classmethod
+    def with_shift(cls, shift, **kw):
+        return cls(1.0, shift, **kw)
+
+    @classmethod
+    def with_precision(cls, precision, **kw):
+        return cls(precision, 0.0, **kw)
+
+    @classmethod
+    def with_precision_and_shift(cls, precision, shift, **kw):
+        return cls(precision, shift, **kw)
+
+    def precision(self) -> float:
+        v = C.c_double()
+        _lib.check(_lib.lib().rr_freqshifter_precision(self._h, C.byref(v)))
+        return v.value
+
+    def shift(self) -> float:
+        v = C.c_double()
+        _lib.check(_lib.lib().rr_freqshifter_shift(self._h, C.byref(v)))
+        return v.value
+
+    def set_shift(self, shift: float):
+        _lib.check(_lib.lib().rr_freqshifter_set_shift(self._h, float(shift)))
+
+    def update_shift(self, modify):
+        """transform.rs:388-390: `modify` maps the old shift to the new one."""
+        self.set_shift(modify(self.shift()))
+
+    def process(self, signal):
+        if signal.is_event():
+            return [signal]  # transform.rs:357-359
+        y = self._host_call(_lib.lib().rr_freqshifter_process, (float(signal.sample_rate),), signal.chunk, len(signal.chunk))
+        return [Samples(signal.sample_rate, y)]
+
+    def process_dev(self, sample_rate, d_in: int, n_in: int, d_out: int, cap: int) -> int:
+        n_out = C.c_size_t()
+        _lib.check(_lib.lib().rr_freqshifter_process_dev(self._h, float(sample_rate), d_in, n_in, d_out, cap, C.byref(n_out)))
+        return n_out.value
+
+
+def sample_freq_resp(freq_resp, n: int, sample_rate: float) -> np.ndarray:
+    """Evaluates the user's closure exactly where the reference does
+    (filters.rs:188-199): bins 0..=(n-1)/2 and their negatives; for even n the
+    Nyquist bin stays zero."""
+    resp = np.zeros(n, dtype=np.complex128)
+    step = sample_rate / n
+    for i in range((n - 1) // 2 + 1):
+        resp[i] = complex(freq_resp(i, i * step))
+        if i > 0:
+            resp[n - i] = complex(freq_resp(-i, -(i * step)))
+    return resp
+
+
+class Filter(_Block):
+    """General purpose frequency filter (filters.rs:110-298).  `freq_resp(bin,
+    freq) -> complex` stays on the host; the library gets its samples."""
+
+    _destroy = "rr_filter_destroy"
+
+    def __init__(self, freq_resp, window: Window | None = None, dtype=np.float32, device: int = 0):
+        super().__init__()
+        self._code, self._cdt = _dtype_code(dtype)
+        self._freq_resp = freq_resp
+        self._window = window if window is not None else Kaiser.with_null_at_bin(2.0)
+        _lib.check(_lib.lib().rr_filter_create(self._code, device, C.byref(self._h)))
+
+    # filters.rs:128-152
+    @classmethod
+    def new(cls, freq_resp, **kw):
+        return cls(freq_resp, Kaiser.with_null_at_bin(2.0), **kw)
+
+    @classmethod
+    def new_rectangular(cls, freq_resp, **kw):
+        return cls(freq_resp, Rectangular(), **kw)
+
+    @classmethod
+    def with_window(cls, freq_resp, window, **kw):
+        return cls(freq_resp, window, **kw)
+
+    def update(self, freq_resp):
+        self._freq_resp = freq_resp
+        _lib.check(_lib.lib().rr_filter_mark_params_changed(self._h))
+
+    def update_with_window(self, freq_resp, window):
+        self._freq_resp = freq_resp
+        self._window = window
+        _lib.check(_lib.lib().rr_filter_mark_params_changed(self._h))
+
+    def _ensure_design(self, sample_rate: float, n: int):
+        needed = C.c_int()
+        _lib.check(_lib.lib().rr_filter_needs_design(self._h, sample_rate, n, C.byref(needed)))
+        if needed.value:
+            resp = sample_freq_resp(self._freq_resp, n, sample_rate)
+            win = self._window.sample(n)
+            _lib.check(_lib.lib().rr_filter_design(self._h, sample_rate, n, resp.ctypes.data, win.ctypes.data))
+
+    def process(self, signal):
+        if signal.is_event():
+            if signal.event.is_interrupt():  # filters.rs:262-265
+                _lib.check(_lib.lib().rr_filter_reset(self._h))
+            return [signal]
+        n = len(signal.chunk)
+        self._ensure_design(float(signal.sample_rate), n)
+        y = self._host_call(_lib.lib().rr_filter_process, (float(signal.sample_rate),), signal.chunk, n)
+        return [Samples(signal.sample_rate, y)] if len(y) else []
+
+    def process_dev(self, sample_rate, chunk_len: int, d_in: int, n_in: int, d_out: int, cap: int) -> int:
+        """n_in = k * chunk_len consecutive chunks resident on the device."""
+        self._ensure_design(float(sample_rate), chunk_len)
+        n_out = C.c_size_t()
+        _lib.check(_lib.lib().rr_filter_process_dev(self._h, float(sample_rate), d_in, n_in, d_out, cap, C.byref(n_out)))
+        return n_out.value
+
+
+class Downsampler(_Block):
+    """Reduce sample rate (resampling.rs:14-146)."""
+
+    _destroy = "rr_downsampler_destroy"
+
+    def __init__(self, output_chunk_len: int, output_rate: float, bandwidth: float, quality: float = 3.0,
+                 dtype=np.float32, device: int = 0):
+        super().__init__()
+        self._code, self._cdt = _dtype_code(dtype)
+        self.output_chunk_len = int(output_chunk_len)
+        self.output_rate = float(output_rate)
+        _lib.check(_lib.lib().rr_downsampler_create(self._code, float(output_rate), float(bandwidth), float(quality), device, C.byref(self._h)))
+        self._pending = np.empty(0, dtype=self._cdt)  # the partly filled output_chunk
+
+    @classmethod
+    def new(cls, output_chunk_len, output_rate, bandwidth, **kw):
+        return cls(output_chunk_len, output_rate, bandwidth, 3.0, **kw)
+
+    @classmethod
+    def with_quality(cls, output_chunk_len, output_rate, bandwidth, quality, **kw):
+        return cls(output_chunk_len, output_rate, bandwidth, quality, **kw)
+
+    def ir_len(self) -> int:
+        v = C.c_size_t()
+        _lib.check(_lib.lib().rr_downsampler_ir_len(self._h, C.byref(v)))
+        return v.value
+
+    def process_raw(self, sample_rate, chunk) -> np.ndarray:
+        """Outputs produced by this input chunk, not yet regrouped."""
+        n_out = C.c_size_t()
+        _lib.check(_lib.lib().rr_downsampler_peek(self._h, float(sample_rate), len(chunk), C.byref(n_out)))
+        return self._host_call(_lib.lib().rr_downsampler_process, (float(sample_rate),), chunk, n_out.value)
+
+    def process(self, signal):
+        if signal.is_event():
+            return [signal]  # resampling.rs:135-137 (no reset)
+        self._pending = np.concatenate([self._pending, self.process_raw(signal.sample_rate, signal.chunk)])
+        out = []
+        L = self.output_chunk_len
+        while len(self._pending) >= L:  # resampling.rs:121-131
+            out.append(Samples(self.output_rate, self._pending[:L].copy()))
+            self._pending = self._pending[L:]
+        return out
+
+    def process_dev(self, sample_rate, d_in: int, n_in: int, d_out: int, cap: int) -> int:
+        n_out = C.c_size_t()
+        _lib.check(_lib.lib().rr_downsampler_process_dev(self._h, float(sample_rate), d_in, n_in, d_out, cap, C.byref(n_out)))
+        return n_out.value
+
+
+class Fourier(_Block):
+    """Windowed Fourier analysis (analysis.rs:26-133)."""
+
+    _destroy = "rr_fourier_destroy"
+
+    def __init__(self, window: Window | None = None, center_dc: bool = False, dtype=np.float32, device: int = 0):
+        super().__init__()
+        self._code, self._cdt = _dtype_code(dtype)
+        self._window = window if window is not None else Rectangular()
+        spec = self._window._spec()
+        self._sampled_for = None
+        if spec is None:
+            spec = _lib.Window(_lib.RR_WIN_SAMPLED, 0.0)
+        _lib.check(_lib.lib().rr_fourier_create(self._code, spec, int(bool(center_dc)), device, C.byref(self._h)))
+        self._is_sampled = spec.kind == _lib.RR_WIN_SAMPLED
+
+    # analysis.rs:39-59
+    @classmethod
+    def new(cls, **kw):
+        return cls(Rectangular(), False, **kw)
+
+    @classmethod
+    def new_center_dc(cls, **kw):
+        return cls(Rectangular(), True, **kw)
+
+    @classmethod
+    def with_window(cls, window, **kw):
+        return cls(window, False, **kw)
+
+    @classmethod
+    def with_window_center_dc(cls, window, **kw):
+        return cls(window, True, **kw)
+
+    def _ensure_window(self, n: int):
+        if self._is_sampled and self._sampled_for != n:
+            vals = self._window.sample(n)
+            _lib.check(_lib.lib().rr_fourier_set_sampled_window(self._h, n, vals.ctypes.data))
+            self._sampled_for = n
+
+    def process(self, signal):
+        if signal.is_event():
+            return [signal]  # analysis.rs:122-124
+        n = len(signal.chunk)
+        self._ensure_window(n)
+        y = self._host_call(_lib.lib().rr_fourier_process, (), signal.chunk, n)
+        return [Samples(signal.sample_rate, y)]
+
+    def process_dev(self, chunk_len: int, d_in: int, n_in: int, d_out: int, cap: int) -> int:
+        self._ensure_window(chunk_len)
+        n_out = C.c_size_t()
+        _lib.check(_lib.lib().rr_fourier_process_dev(self._h, chunk_len, d_in, n_in, d_out, cap, C.byref(n_out)))
+        return n_out.value
+
+
+class Chain(_Block):
+    """FreqShifter -> [Rechunker(filter_len)] -> Filter -> Downsampler(fft_len)
+    -> Fourier on one device without host hops (the wiring of
+    examples/bandwidth_meter/main.rs:51-72).  Emits spectra of `fft_len` bins."""
+
+    _destroy = "rr_chain_destroy"
+
+    def __init__(self, *, shift: float, precision: float = 1.0, filter_len: int, freq_resp,
+                 filter_window: Window | None = None, output_rate: float, bandwidth: float, quality: float = 3.0,
+                 fft_len: int, fft_window: Window | None = None, center_dc: bool = False, dtype=np.float32,
+                 device: int = 0, allow_fused: bool = True):
+        super().__init__()
+        self._code, self._cdt = _dtype_code(dtype)
+        self._freq_resp = freq_resp
+        self._filter_window = filter_window if filter_window is not None else Kaiser.with_null_at_bin(2.0)
+        fw = fft_window if fft_window is not None else Rectangular()
+        spec = fw._spec()
+        if spec is None:
+            raise TypeError("Chain needs a built-in fft_window (Rectangular or Kaiser)")
+        self.filter_len = int(filter_len)
+        self.fft_len = int(fft_len)
+        self.output_rate = float(output_rate)
+        p = _lib.ChainParams(self._code, float(precision), float(shift), self.filter_len, float(output_rate),
+                             float(bandwidth), float(quality), self.fft_len, spec, int(bool(center_dc)),
+                             int(bool(allow_fused)))
+        _lib.check(_lib.lib().rr_chain_create(p, device, C.byref(self._h)))
+
+    def set_shift(self, shift: float):
+        _lib.check(_lib.lib().rr_chain_set_shift(self._h, float(shift)))
+
+    def update_filter(self, freq_resp, window: Window | None = None):
+        self._freq_resp = freq_resp
+        if window is not None:
+            self._filter_window = window
+        _lib.check(_lib.lib().rr_chain_filter_mark_params_changed(self._h))
+
+    def interrupt(self):
+        _lib.check(_lib.lib().rr_chain_interrupt(self._h))
+
+    def _ensure_design(self, sample_rate: float):
+        needed = C.c_int()
+        _lib.check(_lib.lib().rr_chain_filter_needs_design(self._h, sample_rate, C.byref(needed)))
+        if needed.value:
+            resp = sample_freq_resp(self._freq_resp, self.filter_len, sample_rate)
+            win = self._filter_window.sample(self.filter_len)
+            _lib.check(_lib.lib().rr_chain_filter_design(self._h, sample_rate, resp.ctypes.data, win.ctypes.data))
+
+    def peek(self, sample_rate, n_in: int) -> int:
+        self._ensure_design(float(sample_rate))
+        v = C.c_size_t()
+        _lib.check(_lib.lib().rr_chain_peek(self._h, float(sample_rate), n_in, C.byref(v)))
+        return v.value
+
+    def last_path_fused(self) -> bool:
+        v = C.c_int()
+        _lib.check(_lib.lib().rr_chain_last_path(self._h, C.byref(v)))
+        return bool(v.value)
+
+    def process(self, signal):
+        if signal.is_event():
+            if signal.event.is_interrupt():
+                self.interrupt()
+            return [signal]
+        frames = self.peek(signal.sample_rate, len(signal.chunk))
+        y = self._host_call(_lib.lib().rr_chain_process, (float(signal.sample_rate),), signal.chunk, frames * self.fft_len)
+        return [Samples(self.output_rate, y[i * self.fft_len : (i + 1) * self.fft_len]) for i in range(frames)]
+
+    def process_dev(self, sample_rate, d_in: int, n_in: int, d_out: int, cap: int) -> int:
+        self._ensure_design(float(sample_rate))
+        n_out = C.c_size_t()
+        _lib.check(_lib.lib().rr_chain_process_dev(self._h, float(sample_rate), d_in, n_in, d_out, cap, C.byref(n_out)))
+        return n_out.value
+
+
+def synth_iq_dev(device: int, hip_stream: int | None, seed: int, t0: int, n: int, d_out: int):
+    """Fills n complex64 samples of the synthetic IQ source on the device."""
+    _lib.check(_lib.lib().rr_synth_iq_dev(device, C.c_void_p(hip_stream or 0), seed, t0, n, d_out))

@@ -1,0 +1,1070 @@
+// rr_api.hip — the extern "C" boundary (include/radiorust_amd.h) and the host
+// logic of the four blocks + the chain.  No CPU fallback anywhere: without a
+// HIP device every create returns RR_ERR_HIP.
+#include "rr_blocks.hpp"
+
+#include <cmath>
+#include <new>
+
+using namespace rr;
+
+// ---------------------------------------------------------------------------
+// base
+// ---------------------------------------------------------------------------
+rr_block::~rr_block() {
+    if (own_stream) {
+        (void)hipSetDevice(device);
+        (void)hipStreamSynchronize(own_stream);
+        (void)hipStreamDestroy(own_stream);
+    }
+}
+
+int rr_block::select() const {
+    RR_HIP(hipSetDevice(device));
+    return RR_OK;
+}
+
+int rr_block::init_base(int kind_, int dtype_, int device_) {
+    if (dtype_ != RR_F32 && dtype_ != RR_F64) RR_FAIL(RR_ERR_BAD_ARG, "unknown dtype %d", dtype_);
+    kind = kind_;
+    dtype = dtype_;
+    device = device_;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        RR_FAIL(RR_ERR_HIP, "no HIP device available (%s); this backend has no CPU fallback",
+                e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device_ < 0 || device_ >= count) RR_FAIL(RR_ERR_BAD_ARG, "device %d out of range (%d devices)", device_, count);
+    RR_HIP(hipSetDevice(device_));
+    RR_HIP(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+    stream = own_stream;
+    return RR_OK;
+}
+
+template <class T> static void cast_to(const double *src, size_t n, std::vector<unsigned char> &dst) {
+    dst.resize(n * sizeof(T));
+    T *d = reinterpret_cast<T *>(dst.data());
+    for (size_t i = 0; i < n; ++i) d[i] = static_cast<T>(src[i]);
+}
+
+static int upload(DevBuf &buf, const void *src, size_t bytes, hipStream_t s) {
+    RR_TRY(buf.reserve(bytes ? bytes : 16));
+    if (bytes) {
+        RR_HIP(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, s));
+        // the source is pageable host memory owned by the handle and may be
+        // rewritten by the next (re)design: make the copy complete here.
+        RR_HIP(hipStreamSynchronize(s));
+    }
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// FreqShifter
+// ---------------------------------------------------------------------------
+int rr_freqshifter::prepare(double sample_rate) {
+    const bool recalculate = shift_changed || !have_rate || sample_rate != prev_rate;  // transform.rs:318-319
+    have_rate = true;
+    prev_rate = sample_rate;
+    if (!recalculate) return RR_OK;
+    int64_t nu = 0, de = 0;
+    RR_TRY(freq_to_ratio(sample_rate, precision, shift, &nu, &de));
+    if (de > (int64_t(1) << 28))
+        RR_FAIL(RR_ERR_BAD_ARG, "FreqShifter: phase table of %lld entries is not supported (raise `precision`)",
+                (long long)de);
+    // phase continuity (transform.rs:322-325): arg() of the current phasor, in Flt
+    double start = 0.0;
+    const size_t esz = elem_size(dtype);
+    if (!host_table.empty()) {
+        if (dtype == RR_F32) {
+            const float *t = reinterpret_cast<const float *>(host_table.data()) + 2 * phase_idx;
+            start = atan2f(t[1], t[0]);
+        } else {
+            const double *t = reinterpret_cast<const double *>(host_table.data()) + 2 * phase_idx;
+            start = std::atan2(t[1], t[0]);
+        }
+    }
+    numer = nu;
+    denom = de;
+    phase_idx = 0;
+    shift_changed = false;
+    host_table.resize((size_t)de * esz);
+    if (dtype == RR_F32)
+        nco_table<float>(nu, de, (float)start, reinterpret_cast<float *>(host_table.data()));
+    else
+        nco_table<double>(nu, de, start, reinterpret_cast<double *>(host_table.data()));
+    return upload(d_table, host_table.data(), host_table.size(), stream);
+}
+
+int rr_freqshifter::process_dev(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap,
+                                size_t *n_out) {
+    if (n_out) *n_out = 0;
+    if (n_in > cap) RR_FAIL(RR_ERR_CAPACITY, "FreqShifter: out_cap %zu < %zu", cap, n_in);
+    RR_TRY(select());
+    RR_TRY(prepare(sample_rate));
+    RR_TRY(launch_freqshift(dtype, stream, d_in, d_out, n_in, d_table.p, (uint32_t)denom, (uint32_t)phase_idx));
+    phase_idx = (phase_idx + n_in % (uint64_t)denom) % (uint64_t)denom;
+    if (n_out) *n_out = n_in;
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Filter
+// ---------------------------------------------------------------------------
+int rr_filter::design(double sample_rate, size_t len, const rr_c64 *resp, const double *window_rel) {
+    RR_TRY(select());
+    if (len > (size_t(1) << 24)) RR_FAIL(RR_ERR_BAD_ARG, "Filter: chunk length %zu is not supported", len);
+    std::vector<cd> g(len);
+    RR_TRY(filter_design_taps(len, resp, window_rel, g.data()));
+    double max_re = 0.0, max_im = 0.0;
+    for (const cd &v : g) {
+        max_re = std::fmax(max_re, std::fabs(v.real()));
+        max_im = std::fmax(max_im, std::fabs(v.imag()));
+    }
+    // A real-even response gives taps that are real up to ~1e-17 relative
+    // rounding residue of the f64 inverse transform; carrying that residue costs
+    // 2x the flops and changes results by < 1e-12 relative, far below f32 epsilon.
+    real_taps = max_im <= 1e-12 * max_re;
+    // device order: w[j] = g[n-1-j] so that out[m] = sum_j w[j] x[e_m-(n-1)+j]
+    std::vector<double> w(real_taps ? len : 2 * len);
+    for (size_t j = 0; j < len; ++j) {
+        const cd v = g[len - 1 - j];
+        if (real_taps)
+            w[j] = v.real();
+        else {
+            w[2 * j] = v.real();
+            w[2 * j + 1] = v.imag();
+        }
+    }
+    std::vector<unsigned char> bytes;
+    if (dtype == RR_F32)
+        cast_to<float>(w.data(), w.size(), bytes);
+    else
+        cast_to<double>(w.data(), w.size(), bytes);
+    RR_TRY(upload(d_taps, bytes.data(), bytes.size(), stream));
+    const size_t hb = len * elem_size(dtype);
+    RR_TRY(hist[0].reserve(hb));
+    RR_TRY(hist[1].reserve(hb));
+    taps_f64.swap(g);
+    n = len;
+    rate = sample_rate;
+    designed = true;
+    params_changed = false;
+    hist_valid = false;  // previous_chunk = None (filters.rs:187)
+    cur = 0;
+    return RR_OK;
+}
+
+int rr_filter::process_dev(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap,
+                           size_t *n_out) {
+    if (n_out) *n_out = 0;
+    if (!designed || params_changed || sample_rate != rate)
+        RR_FAIL(RR_ERR_NEED_DESIGN, "Filter: no design for sample rate %g (filters.rs:178-183)", sample_rate);
+    if (n_in == 0) return RR_OK;
+    if (n_in % n != 0)
+        RR_FAIL(RR_ERR_NEED_DESIGN, "Filter: %zu samples is not a whole number of chunks of the designed length %zu", n_in, n);
+    const size_t produce = peek(n_in);
+    if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Filter: out_cap %zu < %zu", cap, produce);
+    RR_TRY(select());
+    if (produce) {
+        FirArgs a;
+        a.hist = hist[cur].p;
+        a.hist_len = hist_valid ? n : 0;
+        a.in = d_in;
+        a.n_in = n_in;
+        a.taps = d_taps.p;
+        a.K = (uint32_t)n;
+        a.complex_taps = !real_taps;
+        a.out = d_out;
+        a.n_out = produce;
+        a.e0 = hist_valid ? 0 : n;  // the first chunk after a reset is swallowed (filters.rs:240,260)
+        a.D = 1;
+        RR_TRY(launch_fir(dtype, stream, a));
+    }
+    // previous_chunk = Some(input_chunk): the last n samples
+    RR_TRY(launch_update_hist(dtype, stream, hist[cur].p, hist[cur ^ 1].p, n, d_in, n_in));
+    cur ^= 1;
+    hist_valid = true;
+    if (n_out) *n_out = produce;
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Downsampler
+// ---------------------------------------------------------------------------
+int rr_downsampler::prepare(double input_rate) {
+    if (have_rate && input_rate == prev_rate) return RR_OK;
+    std::vector<double> ir;
+    RR_TRY(downsampler_design(input_rate, output_rate, bandwidth, quality, ir));
+    have_rate = true;
+    prev_rate = input_rate;
+    L = ir.size();
+    std::vector<unsigned char> bytes;
+    if (dtype == RR_F32)
+        cast_to<float>(ir.data(), L, bytes);
+    else
+        cast_to<double>(ir.data(), L, bytes);
+    RR_TRY(upload(d_ir, bytes.data(), bytes.size(), stream));
+    ir_f64.swap(ir);
+    const size_t hb = L * elem_size(dtype);
+    RR_TRY(hist[0].reserve(hb));
+    RR_TRY(hist[1].reserve(hb));
+    RR_HIP(hipMemsetAsync(hist[0].p, 0, hb, stream));  // ringbuf = vec![0; ir_len]
+    cur = 0;
+    sched.configure(input_rate, output_rate);  // pos = 0
+    return RR_OK;
+}
+
+int rr_downsampler::peek(double input_rate, size_t n_in, size_t *n_out) {
+    if (have_rate && input_rate == prev_rate) {
+        *n_out = sched.count(n_in);
+        return RR_OK;
+    }
+    if (!(input_rate >= 0.0)) RR_FAIL(RR_ERR_CONTRACT, "input sample rate must be positive");
+    if (!(input_rate >= output_rate))
+        RR_FAIL(RR_ERR_CONTRACT, "input sample rate must be greater than or equal to output sample rate");
+    Schedule tmp;
+    tmp.configure(input_rate, output_rate);
+    *n_out = tmp.count(n_in);
+    return RR_OK;
+}
+
+int rr_downsampler::process_dev(double input_rate, const void *d_in, size_t n_in, void *d_out, size_t cap,
+                                size_t *n_out) {
+    if (n_out) *n_out = 0;
+    size_t produce = 0;
+    RR_TRY(peek(input_rate, n_in, &produce));
+    if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Downsampler: out_cap %zu < %zu", cap, produce);
+    if (n_in > 0xfffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: more than 2^32 samples in one call");
+    RR_TRY(select());
+    RR_TRY(prepare(input_rate));
+    if (n_in == 0) return RR_OK;
+    FirArgs a;
+    a.hist = hist[cur].p;
+    a.hist_len = L;
+    a.in = d_in;
+    a.n_in = n_in;
+    a.taps = d_ir.p;
+    a.K = (uint32_t)L;
+    a.complex_taps = false;
+    a.out = d_out;
+    a.n_out = produce;
+    if (sched.integer_ratio) {
+        a.e0 = sched.first_emit();
+        a.D = (uint32_t)sched.D;
+        if (sched.D > 0xffffffffull) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: decimation factor too large");
+        sched.advance(n_in, nullptr);
+    } else {
+        sched.advance(n_in, &emit);
+        if (produce) {
+            RR_TRY(d_emit.reserve(produce * sizeof(uint32_t)));
+            RR_HIP(hipMemcpyAsync(d_emit.p, emit.data(), produce * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            RR_HIP(hipStreamSynchronize(stream));  // `emit` is reused by the next call
+        }
+        a.emit = d_emit.as<uint32_t>();
+        a.max_step = (uint32_t)std::ceil(input_rate / output_rate) + 1;
+    }
+    if (produce) RR_TRY(launch_fir(dtype, stream, a));
+    RR_TRY(launch_update_hist(dtype, stream, hist[cur].p, hist[cur ^ 1].p, L, d_in, n_in));
+    cur ^= 1;
+    if (n_out) *n_out = produce;
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Fourier
+// ---------------------------------------------------------------------------
+int rr_fourier::prepare(size_t len) {
+    if (len == n) return RR_OK;
+    RR_TRY(fourier_supported(dtype, len));
+    std::vector<double> rel(len);
+    if (window.kind == RR_WIN_SAMPLED) {
+        if (sampled_n != len)
+            RR_FAIL(RR_ERR_NEED_DESIGN, "Fourier: sampled window has %zu values, chunk has %zu", sampled_n, len);
+        rel = sampled;
+    } else {
+        RR_TRY(window_sample(&window, len, rel.data()));
+    }
+    std::vector<double> vals(len);
+    RR_TRY(fourier_design_window(len, rel.data(), vals.data()));
+    const size_t ntw = fourier_pow2_path(dtype, len) ? len / 2 : len;
+    std::vector<double> tw(2 * ntw);
+    for (size_t k = 0; k < ntw; ++k) {
+        const double ang = -2.0 * M_PI * (double)k / (double)len;
+        tw[2 * k] = std::cos(ang);
+        tw[2 * k + 1] = std::sin(ang);
+    }
+    std::vector<unsigned char> wb, tb;
+    if (dtype == RR_F32) {
+        cast_to<float>(vals.data(), len, wb);
+        cast_to<float>(tw.data(), tw.size(), tb);
+    } else {
+        cast_to<double>(vals.data(), len, wb);
+        cast_to<double>(tw.data(), tw.size(), tb);
+    }
+    RR_TRY(upload(d_window, wb.data(), wb.size(), stream));
+    RR_TRY(upload(d_tw, tb.data(), tb.size(), stream));
+    window_f64.swap(vals);
+    n = len;
+    return RR_OK;
+}
+
+int rr_fourier::process_dev(size_t chunk_len, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out) {
+    if (n_out) *n_out = 0;
+    if (chunk_len == 0) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: chunk_len == 0");
+    if (n_in % chunk_len) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: %zu samples is not a whole number of %zu-sample chunks", n_in, chunk_len);
+    if (n_in > cap) RR_FAIL(RR_ERR_CAPACITY, "Fourier: out_cap %zu < %zu", cap, n_in);
+    if (n_in == 0) return RR_OK;
+    RR_TRY(select());
+    RR_TRY(prepare(chunk_len));
+    RR_TRY(launch_fourier(dtype, stream, d_in, d_out, chunk_len, n_in / chunk_len, d_window.p, d_tw.p, center_dc));
+    if (n_out) *n_out = n_in;
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// stage timers
+// ---------------------------------------------------------------------------
+int StageTimers::begin(int stage, hipStream_t s) {
+    if (!on) return -1;
+    if (pending.size() >= 8192 && drain() != RR_OK) return -1;
+    auto get = [&]() -> hipEvent_t {
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    };
+    Pair p{get(), get(), stage};
+    if (!p.a || !p.b) return -1;
+    (void)hipEventRecord(p.a, s);
+    pending.push_back(p);
+    return (int)pending.size() - 1;
+}
+void StageTimers::end(int idx, hipStream_t s) {
+    if (idx >= 0) (void)hipEventRecord(pending[idx].b, s);
+}
+int StageTimers::drain() {
+    for (Pair &p : pending) {
+        RR_HIP(hipEventSynchronize(p.b));
+        float ms = 0.f;
+        RR_HIP(hipEventElapsedTime(&ms, p.a, p.b));
+        total_ms[p.stage] += ms;
+        launches[p.stage] += 1;
+        pool.push_back(p.a);
+        pool.push_back(p.b);
+    }
+    pending.clear();
+    return RR_OK;
+}
+void StageTimers::reset() {
+    (void)drain();
+    for (int i = 0; i < ST_COUNT; ++i) {
+        total_ms[i] = 0;
+        launches[i] = 0;
+    }
+}
+StageTimers::~StageTimers() {
+    for (Pair &p : pending) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+}
+
+// ---------------------------------------------------------------------------
+// Chain (block-by-block path; the fused path is selected in rr_fused.hip)
+// ---------------------------------------------------------------------------
+rr_chain::~rr_chain() {
+    delete fs;
+    delete fl;
+    delete ds;
+    delete fo;
+}
+
+int rr_chain::peek(double sample_rate, size_t n_in, size_t *n_frames) {
+    const size_t nf = p.filter_len;
+    const size_t chunks = (carry_len + n_in) / nf;
+    const size_t filt = fl->peek(chunks * nf);
+    size_t dec = 0;
+    RR_TRY(ds->peek(sample_rate, filt, &dec));
+    *n_frames = (pending_len + dec) / p.fft_len;
+    return RR_OK;
+}
+
+int rr_chain::process_dev(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out) {
+    if (n_out) *n_out = 0;
+    if (fl->needs_design(sample_rate, p.filter_len))
+        RR_FAIL(RR_ERR_NEED_DESIGN, "Chain: Filter has no design for sample rate %g", sample_rate);
+    size_t frames = 0;
+    RR_TRY(peek(sample_rate, n_in, &frames));
+    if (frames * p.fft_len > cap) RR_FAIL(RR_ERR_CAPACITY, "Chain: out_cap %zu < %zu", cap, frames * p.fft_len);
+    RR_TRY(select());
+    const size_t esz = elem_size(dtype);
+    // 1. FreqShifter -> mixed[carry_len ..)
+    const size_t total = carry_len + n_in;
+    RR_TRY(mixed.reserve((total ? total : 1) * esz));
+    if (carry_len) RR_HIP(hipMemcpyAsync(mixed.p, carry.p, carry_len * esz, hipMemcpyDeviceToDevice, stream));
+    size_t got = 0;
+    int tk = timers.begin(ST_FREQSHIFT, stream);
+    RR_TRY(fs->process_dev(sample_rate, d_in, n_in, mixed.as<char>() + carry_len * esz, n_in, &got));
+    timers.end(tk, stream);
+    // 2. Filter on whole chunks
+    const size_t nf = p.filter_len;
+    const size_t whole = total / nf * nf;
+    size_t filt = fl->peek(whole);
+    RR_TRY(filtered.reserve((filt ? filt : 1) * esz));
+    tk = timers.begin(ST_FILTER, stream);
+    RR_TRY(fl->process_dev(sample_rate, mixed.p, whole, filtered.p, filt, &filt));
+    timers.end(tk, stream);
+    const size_t left = total - whole;
+    if (left) RR_HIP(hipMemcpyAsync(carry.p, mixed.as<char>() + whole * esz, left * esz, hipMemcpyDeviceToDevice, stream));
+    carry_len = left;
+    // 3. Downsampler -> decim[pending_len ..)
+    size_t dec = 0;
+    RR_TRY(ds->peek(sample_rate, filt, &dec));
+    const size_t have = pending_len + dec;
+    RR_TRY(decim.reserve((have ? have : 1) * esz));
+    if (pending_len) RR_HIP(hipMemcpyAsync(decim.p, pending.p, pending_len * esz, hipMemcpyDeviceToDevice, stream));
+    tk = timers.begin(ST_DECIM, stream);
+    RR_TRY(ds->process_dev(sample_rate, filtered.p, filt, decim.as<char>() + pending_len * esz, dec, &dec));
+    timers.end(tk, stream);
+    // 4. Fourier on whole frames
+    const size_t L = p.fft_len;
+    const size_t nfr = have / L;
+    size_t wrote = 0;
+    tk = timers.begin(ST_FOURIER, stream);
+    RR_TRY(fo->process_dev(L, decim.p, nfr * L, d_out, cap, &wrote));
+    timers.end(tk, stream);
+    const size_t rest = have - nfr * L;
+    if (rest) RR_HIP(hipMemcpyAsync(pending.p, decim.as<char>() + nfr * L * esz, rest * esz, hipMemcpyDeviceToDevice, stream));
+    pending_len = rest;
+    last_fused = 0;
+    if (n_out) *n_out = wrote;
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// host-pointer entry points: H2D -> process_dev -> D2H on the handle's stream
+// ---------------------------------------------------------------------------
+template <class F>
+static int host_io(rr_block *h, const void *in, size_t n_in, void *out, size_t need_out, bool blocking, F &&run) {
+    if (n_in && !in) RR_FAIL(RR_ERR_BAD_ARG, "null input");
+    if (need_out && !out) RR_FAIL(RR_ERR_BAD_ARG, "null output");
+    RR_TRY(h->select());
+    const size_t esz = elem_size(h->dtype);
+    RR_TRY(h->stage_in.reserve((n_in ? n_in : 1) * esz));
+    RR_TRY(h->stage_out.reserve((need_out ? need_out : 1) * esz));
+    if (n_in) RR_HIP(hipMemcpyAsync(h->stage_in.p, in, n_in * esz, hipMemcpyHostToDevice, h->stream));
+    size_t produced = 0;
+    RR_TRY(run(h->stage_in.p, h->stage_out.p, &produced));
+    if (produced) RR_HIP(hipMemcpyAsync(out, h->stage_out.p, produced * esz, hipMemcpyDeviceToHost, h->stream));
+    if (blocking) RR_HIP(hipStreamSynchronize(h->stream));
+    return RR_OK;
+}
+
+#define RR_CHECK_HANDLE(h, k)                                          \
+    do {                                                               \
+        if (!(h) || (h)->kind != (k)) RR_FAIL(RR_ERR_BAD_ARG, "bad handle"); \
+    } while (0)
+
+#define RR_GUARD_BEGIN try {
+#define RR_GUARD_END                                              \
+    }                                                             \
+    catch (const std::bad_alloc &) {                              \
+        RR_FAIL(RR_ERR_BAD_ARG, "out of host memory");            \
+    }                                                             \
+    catch (...) {                                                 \
+        RR_FAIL(RR_ERR_BAD_ARG, "unexpected C++ exception");      \
+    }
+
+extern "C" {
+
+int rr_version(void) { return 100; }
+const char *rr_last_error_string(void) { return rr::last_error(); }
+
+int rr_device_count(int *count) {
+    if (!count) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    *count = 0;
+    RR_HIP(hipGetDeviceCount(count));
+    return RR_OK;
+}
+
+int rr_set_stream(rr_block *h, void *hip_stream) {
+    if (!h) RR_FAIL(RR_ERR_BAD_ARG, "null handle");
+    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+    if (h->kind == K_CHAIN) {
+        rr_chain *c = static_cast<rr_chain *>(h);
+        c->fs->stream = c->fl->stream = c->ds->stream = c->fo->stream = h->stream;
+    }
+    return RR_OK;
+}
+
+int rr_wait(rr_block *h) {
+    if (!h) RR_FAIL(RR_ERR_BAD_ARG, "null handle");
+    RR_TRY(h->select());
+    RR_HIP(hipStreamSynchronize(h->stream));
+    return RR_OK;
+}
+
+int rr_query(rr_block *h) {
+    if (!h) RR_FAIL(RR_ERR_BAD_ARG, "null handle");
+    RR_TRY(h->select());
+    hipError_t e = hipStreamQuery(h->stream);
+    if (e == hipSuccess) return RR_OK;
+    if (e == hipErrorNotReady) return RR_ERR_NOT_READY;
+    RR_FAIL(RR_ERR_HIP, "hipStreamQuery: %s", hipGetErrorString(e));
+}
+
+int rr_host_alloc(size_t bytes, void **out) {
+    if (!out) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    RR_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return RR_OK;
+}
+int rr_host_free(void *p) {
+    if (p) RR_HIP(hipHostFree(p));
+    return RR_OK;
+}
+int rr_host_register(void *p, size_t bytes) {
+    if (!p) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    RR_HIP(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return RR_OK;
+}
+int rr_host_unregister(void *p) {
+    if (!p) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    RR_HIP(hipHostUnregister(p));
+    return RR_OK;
+}
+
+// ---- design math ------------------------------------------------------------
+double rr_bessel_i0(double x) { return rr::bessel_i0(x); }
+double rr_kaiser_rel_with_beta(double beta, double x) { return rr::kaiser_rel_with_beta(beta, x); }
+double rr_kaiser_alpha_to_beta(double alpha) { return alpha * M_PI; }
+double rr_kaiser_null_at_bin_to_beta(double n) { return std::sqrt(n * n - 1.0); }
+double rr_sinc(double x) { return rr::sinc(x); }
+int rr_window_sample(const rr_window *w, size_t n, double *out) { return rr::window_sample(w, n, out); }
+
+int rr_freqshifter_ratio(double sample_rate, double precision, double shift, int64_t *numer, int64_t *denom) {
+    if (!numer || !denom) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    return rr::freq_to_ratio(sample_rate, precision, shift, numer, denom);
+}
+
+int rr_freqshifter_table(int dtype, int64_t numer, int64_t denom, double start_phase, void *table) {
+    if (!table || denom <= 0) RR_FAIL(RR_ERR_BAD_ARG, "bad table arguments");
+    if (dtype == RR_F32)
+        nco_table<float>(numer, denom, (float)start_phase, static_cast<float *>(table));
+    else if (dtype == RR_F64)
+        nco_table<double>(numer, denom, start_phase, static_cast<double *>(table));
+    else
+        RR_FAIL(RR_ERR_BAD_ARG, "unknown dtype");
+    return RR_OK;
+}
+
+int rr_filter_design_taps(size_t n, const rr_c64 *resp, const double *window_rel, rr_c64 *taps) {
+    RR_GUARD_BEGIN
+    std::vector<cd> g(n);
+    RR_TRY(rr::filter_design_taps(n, resp, window_rel, g.data()));
+    for (size_t i = 0; i < n; ++i) {
+        taps[i].re = g[i].real();
+        taps[i].im = g[i].imag();
+    }
+    return RR_OK;
+    RR_GUARD_END
+}
+
+int rr_downsampler_design(double input_rate, double output_rate, double bandwidth, double quality, size_t *ir_len,
+                          double *ir, size_t ir_cap) {
+    RR_GUARD_BEGIN
+    if (!ir_len) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    if (!(output_rate >= 0.0)) RR_FAIL(RR_ERR_CONTRACT, "output sample rate must be positive");
+    if (!(bandwidth >= 0.0)) RR_FAIL(RR_ERR_CONTRACT, "bandwidth must be positive");
+    if (!(bandwidth < output_rate)) RR_FAIL(RR_ERR_CONTRACT, "bandwidth must be smaller than output sample rate");
+    std::vector<double> v;
+    RR_TRY(rr::downsampler_design(input_rate, output_rate, bandwidth, quality, v));
+    *ir_len = v.size();
+    if (ir) {
+        if (ir_cap < v.size()) RR_FAIL(RR_ERR_CAPACITY, "ir_cap %zu < %zu", ir_cap, v.size());
+        memcpy(ir, v.data(), v.size() * sizeof(double));
+    }
+    return RR_OK;
+    RR_GUARD_END
+}
+
+int rr_downsampler_schedule(double input_rate, double output_rate, size_t n_in, double *pos, uint32_t *emit,
+                            size_t emit_cap, size_t *count) {
+    RR_GUARD_BEGIN
+    if (!pos || !count) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    if (!(input_rate >= output_rate) || !(output_rate >= 0.0))
+        RR_FAIL(RR_ERR_CONTRACT, "input sample rate must be greater than or equal to output sample rate");
+    Schedule sc;
+    sc.configure(input_rate, output_rate);
+    // resume from *pos: replay the integer phase, or set the f64 accumulator
+    if (sc.integer_ratio) {
+        const uint64_t k = (uint64_t)(*pos / output_rate);
+        if (k >= sc.D) RR_FAIL(RR_ERR_BAD_ARG, "pos out of range");
+        sc.phase = sc.D - 1 - k;
+    }
+    sc.pos = *pos;
+    std::vector<uint32_t> e;
+    const size_t c = sc.advance(n_in, emit ? &e : nullptr);
+    if (emit) {
+        if (c > emit_cap) RR_FAIL(RR_ERR_CAPACITY, "emit_cap %zu < %zu", emit_cap, c);
+        memcpy(emit, e.data(), c * sizeof(uint32_t));
+    }
+    *count = c;
+    *pos = sc.pos;
+    return RR_OK;
+    RR_GUARD_END
+}
+
+int rr_fourier_design_window(size_t n, const double *window_rel, double *values) {
+    return rr::fourier_design_window(n, window_rel, values);
+}
+
+// ---- FreqShifter --------------------------------------------------------------
+int rr_freqshifter_create(int dtype, double precision, double shift, int device, rr_freqshifter **out) {
+    RR_GUARD_BEGIN
+    if (!out) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    *out = nullptr;
+    auto *h = new rr_freqshifter;
+    int s = h->init_base(K_FREQSHIFTER, dtype, device);
+    if (s != RR_OK) {
+        delete h;
+        return s;
+    }
+    h->precision = precision;
+    h->shift = shift;
+    *out = h;
+    return RR_OK;
+    RR_GUARD_END
+}
+
+int rr_freqshifter_set_shift(rr_freqshifter *h, double shift) {
+    RR_CHECK_HANDLE(h, K_FREQSHIFTER);
+    h->shift = shift;
+    h->shift_changed = true;
+    return RR_OK;
+}
+int rr_freqshifter_shift(const rr_freqshifter *h, double *shift) {
+    RR_CHECK_HANDLE(h, K_FREQSHIFTER);
+    *shift = h->shift;
+    return RR_OK;
+}
+int rr_freqshifter_precision(const rr_freqshifter *h, double *precision) {
+    RR_CHECK_HANDLE(h, K_FREQSHIFTER);
+    *precision = h->precision;
+    return RR_OK;
+}
+
+static int freqshifter_host(rr_freqshifter *h, double rate, const void *in, size_t n_in, void *out, size_t cap,
+                            size_t *n_out, bool blocking) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_FREQSHIFTER);
+    if (n_out) *n_out = 0;
+    if (n_in > cap) RR_FAIL(RR_ERR_CAPACITY, "FreqShifter: out_cap %zu < %zu", cap, n_in);
+    RR_TRY(host_io(h, in, n_in, out, n_in, blocking, [&](void *di, void *dout, size_t *p) {
+        return h->process_dev(rate, di, n_in, dout, n_in, p);
+    }));
+    if (n_out) *n_out = n_in;
+    return RR_OK;
+    RR_GUARD_END
+}
+int rr_freqshifter_process(rr_freqshifter *h, double rate, const void *in, size_t n_in, void *out, size_t cap,
+                           size_t *n_out) {
+    return freqshifter_host(h, rate, in, n_in, out, cap, n_out, true);
+}
+int rr_freqshifter_enqueue(rr_freqshifter *h, double rate, const void *in, size_t n_in, void *out, size_t cap,
+                           size_t *n_out) {
+    return freqshifter_host(h, rate, in, n_in, out, cap, n_out, false);
+}
+int rr_freqshifter_process_dev(rr_freqshifter *h, double rate, const void *d_in, size_t n_in, void *d_out,
+                               size_t cap, size_t *n_out) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_FREQSHIFTER);
+    return h->process_dev(rate, d_in, n_in, d_out, cap, n_out);
+    RR_GUARD_END
+}
+int rr_freqshifter_destroy(rr_freqshifter *h) {
+    if (!h) return RR_OK;
+    RR_CHECK_HANDLE(h, K_FREQSHIFTER);
+    (void)hipSetDevice(h->device);
+    delete h;
+    return RR_OK;
+}
+
+// ---- Filter -----------------------------------------------------------------------
+int rr_filter_create(int dtype, int device, rr_filter **out) {
+    RR_GUARD_BEGIN
+    if (!out) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    *out = nullptr;
+    auto *h = new rr_filter;
+    int s = h->init_base(K_FILTER, dtype, device);
+    if (s != RR_OK) {
+        delete h;
+        return s;
+    }
+    *out = h;
+    return RR_OK;
+    RR_GUARD_END
+}
+int rr_filter_needs_design(const rr_filter *h, double sample_rate, size_t n, int *needed) {
+    RR_CHECK_HANDLE(h, K_FILTER);
+    if (!needed) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    *needed = h->needs_design(sample_rate, n) ? 1 : 0;
+    return RR_OK;
+}
+int rr_filter_mark_params_changed(rr_filter *h) {
+    RR_CHECK_HANDLE(h, K_FILTER);
+    h->params_changed = true;
+    return RR_OK;
+}
+int rr_filter_design(rr_filter *h, double sample_rate, size_t n, const rr_c64 *resp, const double *window_rel) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_FILTER);
+    return h->design(sample_rate, n, resp, window_rel);
+    RR_GUARD_END
+}
+int rr_filter_reset(rr_filter *h) {
+    RR_CHECK_HANDLE(h, K_FILTER);
+    h->hist_valid = false;
+    return RR_OK;
+}
+static int filter_host(rr_filter *h, double rate, const void *in, size_t n_in, void *out, size_t cap, size_t *n_out,
+                       bool blocking) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_FILTER);
+    if (n_out) *n_out = 0;
+    if (h->needs_design(rate, n_in))
+        RR_FAIL(RR_ERR_NEED_DESIGN, "Filter: (rate %g, chunk %zu) needs a design (filters.rs:178-183)", rate, n_in);
+    const size_t produce = h->peek(n_in);
+    if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Filter: out_cap %zu < %zu", cap, produce);
+    size_t got = 0;
+    RR_TRY(host_io(h, in, n_in, out, produce, blocking, [&](void *di, void *dout, size_t *p) {
+        int s = h->process_dev(rate, di, n_in, dout, produce, p);
+        got = *p;
+        return s;
+    }));
+    if (n_out) *n_out = got;
+    return RR_OK;
+    RR_GUARD_END
+}
+int rr_filter_process(rr_filter *h, double rate, const void *in, size_t n_in, void *out, size_t cap, size_t *n_out) {
+    return filter_host(h, rate, in, n_in, out, cap, n_out, true);
+}
+int rr_filter_enqueue(rr_filter *h, double rate, const void *in, size_t n_in, void *out, size_t cap, size_t *n_out) {
+    return filter_host(h, rate, in, n_in, out, cap, n_out, false);
+}
+int rr_filter_process_dev(rr_filter *h, double rate, const void *d_in, size_t n_in, void *d_out, size_t cap,
+                          size_t *n_out) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_FILTER);
+    return h->process_dev(rate, d_in, n_in, d_out, cap, n_out);
+    RR_GUARD_END
+}
+int rr_filter_destroy(rr_filter *h) {
+    if (!h) return RR_OK;
+    RR_CHECK_HANDLE(h, K_FILTER);
+    (void)hipSetDevice(h->device);
+    delete h;
+    return RR_OK;
+}
+
+// ---- Downsampler --------------------------------------------------------------------
+int rr_downsampler_create(int dtype, double output_rate, double bandwidth, double quality, int device,
+                          rr_downsampler **out) {
+    RR_GUARD_BEGIN
+    if (!out) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    *out = nullptr;
+    // resampling.rs:51-56
+    if (!(output_rate >= 0.0)) RR_FAIL(RR_ERR_CONTRACT, "output sample rate must be positive");
+    if (!(bandwidth >= 0.0)) RR_FAIL(RR_ERR_CONTRACT, "bandwidth must be positive");
+    if (!(bandwidth < output_rate)) RR_FAIL(RR_ERR_CONTRACT, "bandwidth must be smaller than output sample rate");
+    auto *h = new rr_downsampler;
+    int s = h->init_base(K_DOWNSAMPLER, dtype, device);
+    if (s != RR_OK) {
+        delete h;
+        return s;
+    }
+    h->output_rate = output_rate;
+    h->bandwidth = bandwidth;
+    h->quality = quality;
+    *out = h;
+    return RR_OK;
+    RR_GUARD_END
+}
+int rr_downsampler_peek(rr_downsampler *h, double input_rate, size_t n_in, size_t *n_out) {
+    RR_CHECK_HANDLE(h, K_DOWNSAMPLER);
+    if (!n_out) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    return h->peek(input_rate, n_in, n_out);
+}
+static int downsampler_host(rr_downsampler *h, double rate, const void *in, size_t n_in, void *out, size_t cap,
+                            size_t *n_out, bool blocking) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_DOWNSAMPLER);
+    if (n_out) *n_out = 0;
+    size_t produce = 0;
+    RR_TRY(h->peek(rate, n_in, &produce));
+    if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Downsampler: out_cap %zu < %zu", cap, produce);
+    size_t got = 0;
+    RR_TRY(host_io(h, in, n_in, out, produce, blocking, [&](void *di, void *dout, size_t *p) {
+        int s = h->process_dev(rate, di, n_in, dout, produce, p);
+        got = *p;
+        return s;
+    }));
+    if (n_out) *n_out = got;
+    return RR_OK;
+    RR_GUARD_END
+}
+int rr_downsampler_process(rr_downsampler *h, double rate, const void *in, size_t n_in, void *out, size_t cap,
+                           size_t *n_out) {
+    return downsampler_host(h, rate, in, n_in, out, cap, n_out, true);
+}
+int rr_downsampler_enqueue(rr_downsampler *h, double rate, const void *in, size_t n_in, void *out, size_t cap,
+                           size_t *n_out) {
+    return downsampler_host(h, rate, in, n_in, out, cap, n_out, false);
+}
+int rr_downsampler_process_dev(rr_downsampler *h, double rate, const void *d_in, size_t n_in, void *d_out,
+                               size_t cap, size_t *n_out) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_DOWNSAMPLER);
+    return h->process_dev(rate, d_in, n_in, d_out, cap, n_out);
+    RR_GUARD_END
+}
+int rr_downsampler_ir_len(const rr_downsampler *h, size_t *ir_len) {
+    RR_CHECK_HANDLE(h, K_DOWNSAMPLER);
+    *ir_len = h->L;
+    return RR_OK;
+}
+int rr_downsampler_destroy(rr_downsampler *h) {
+    if (!h) return RR_OK;
+    RR_CHECK_HANDLE(h, K_DOWNSAMPLER);
+    (void)hipSetDevice(h->device);
+    delete h;
+    return RR_OK;
+}
+
+// ---- Fourier --------------------------------------------------------------------------
+int rr_fourier_create(int dtype, const rr_window *window, int center_dc, int device, rr_fourier **out) {
+    RR_GUARD_BEGIN
+    if (!out || !window) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    *out = nullptr;
+    if (window->kind < RR_WIN_RECTANGULAR || window->kind > RR_WIN_SAMPLED) RR_FAIL(RR_ERR_BAD_ARG, "unknown window kind");
+    auto *h = new rr_fourier;
+    int s = h->init_base(K_FOURIER, dtype, device);
+    if (s != RR_OK) {
+        delete h;
+        return s;
+    }
+    h->window = *window;
+    h->center_dc = center_dc != 0;
+    *out = h;
+    return RR_OK;
+    RR_GUARD_END
+}
+int rr_fourier_set_sampled_window(rr_fourier *h, size_t n, const double *window_rel) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_FOURIER);
+    if (h->window.kind != RR_WIN_SAMPLED) RR_FAIL(RR_ERR_BAD_ARG, "Fourier was not created with RR_WIN_SAMPLED");
+    if (n && !window_rel) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    h->sampled.assign(window_rel, window_rel + n);
+    h->sampled_n = n;
+    h->n = 0;  // force a redesign at the next chunk
+    return RR_OK;
+    RR_GUARD_END
+}
+static int fourier_host(rr_fourier *h, const void *in, size_t n_in, void *out, size_t cap, size_t *n_out,
+                        bool blocking) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_FOURIER);
+    if (n_out) *n_out = 0;
+    if (n_in == 0) RR_FAIL(RR_ERR_CONTRACT, "Fourier: empty chunk");
+    if (n_in > cap) RR_FAIL(RR_ERR_CAPACITY, "Fourier: out_cap %zu < %zu", cap, n_in);
+    RR_TRY(fourier_supported(h->dtype, n_in));
+    RR_TRY(host_io(h, in, n_in, out, n_in, blocking, [&](void *di, void *dout, size_t *p) {
+        return h->process_dev(n_in, di, n_in, dout, n_in, p);
+    }));
+    if (n_out) *n_out = n_in;
+    return RR_OK;
+    RR_GUARD_END
+}
+int rr_fourier_process(rr_fourier *h, const void *in, size_t n_in, void *out, size_t cap, size_t *n_out) {
+    return fourier_host(h, in, n_in, out, cap, n_out, true);
+}
+int rr_fourier_enqueue(rr_fourier *h, const void *in, size_t n_in, void *out, size_t cap, size_t *n_out) {
+    return fourier_host(h, in, n_in, out, cap, n_out, false);
+}
+int rr_fourier_process_dev(rr_fourier *h, size_t chunk_len, const void *d_in, size_t n_in, void *d_out, size_t cap,
+                           size_t *n_out) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_FOURIER);
+    return h->process_dev(chunk_len, d_in, n_in, d_out, cap, n_out);
+    RR_GUARD_END
+}
+int rr_fourier_destroy(rr_fourier *h) {
+    if (!h) return RR_OK;
+    RR_CHECK_HANDLE(h, K_FOURIER);
+    (void)hipSetDevice(h->device);
+    delete h;
+    return RR_OK;
+}
+
+// ---- Chain ------------------------------------------------------------------------------
+int rr_chain_create(const rr_chain_params *p, int device, rr_chain **out) {
+    RR_GUARD_BEGIN
+    if (!out || !p) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    *out = nullptr;
+    if (p->filter_len == 0 || p->fft_len == 0) RR_FAIL(RR_ERR_BAD_ARG, "Chain: filter_len and fft_len must be > 0");
+    if (p->fft_window.kind != RR_WIN_RECTANGULAR && p->fft_window.kind != RR_WIN_KAISER)
+        RR_FAIL(RR_ERR_BAD_ARG, "Chain: fft_window must be a built-in window");
+    if (!(p->output_rate >= 0.0)) RR_FAIL(RR_ERR_CONTRACT, "output sample rate must be positive");
+    if (!(p->bandwidth >= 0.0)) RR_FAIL(RR_ERR_CONTRACT, "bandwidth must be positive");
+    if (!(p->bandwidth < p->output_rate)) RR_FAIL(RR_ERR_CONTRACT, "bandwidth must be smaller than output sample rate");
+    RR_TRY(fourier_supported(p->dtype, p->fft_len));
+    auto *h = new rr_chain;
+    int s = h->init_base(K_CHAIN, p->dtype, device);
+    if (s != RR_OK) {
+        delete h;
+        return s;
+    }
+    h->p = *p;
+    auto sub = [&](rr_block *b, int kind) {
+        b->kind = kind;
+        b->dtype = p->dtype;
+        b->device = device;
+        b->stream = h->stream;  // shares the chain's stream; owns none
+    };
+    h->fs = new rr_freqshifter;
+    sub(h->fs, K_FREQSHIFTER);
+    h->fs->precision = p->precision;
+    h->fs->shift = p->shift;
+    h->fl = new rr_filter;
+    sub(h->fl, K_FILTER);
+    h->ds = new rr_downsampler;
+    sub(h->ds, K_DOWNSAMPLER);
+    h->ds->output_rate = p->output_rate;
+    h->ds->bandwidth = p->bandwidth;
+    h->ds->quality = p->quality;
+    h->fo = new rr_fourier;
+    sub(h->fo, K_FOURIER);
+    h->fo->window = p->fft_window;
+    h->fo->center_dc = p->center_dc != 0;
+    const size_t esz = elem_size(p->dtype);
+    s = h->carry.reserve(p->filter_len * esz);
+    if (s == RR_OK) s = h->pending.reserve(p->fft_len * esz);
+    if (s != RR_OK) {
+        delete h;
+        return s;
+    }
+    *out = h;
+    return RR_OK;
+    RR_GUARD_END
+}
+int rr_chain_set_shift(rr_chain *h, double shift) {
+    RR_CHECK_HANDLE(h, K_CHAIN);
+    h->fs->shift = shift;
+    h->fs->shift_changed = true;
+    return RR_OK;
+}
+int rr_chain_filter_needs_design(const rr_chain *h, double sample_rate, int *needed) {
+    RR_CHECK_HANDLE(h, K_CHAIN);
+    if (!needed) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    *needed = h->fl->needs_design(sample_rate, h->p.filter_len) ? 1 : 0;
+    return RR_OK;
+}
+int rr_chain_filter_mark_params_changed(rr_chain *h) {
+    RR_CHECK_HANDLE(h, K_CHAIN);
+    h->fl->params_changed = true;
+    return RR_OK;
+}
+int rr_chain_filter_design(rr_chain *h, double sample_rate, const rr_c64 *resp, const double *window_rel) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_CHAIN);
+    return h->fl->design(sample_rate, h->p.filter_len, resp, window_rel);
+    RR_GUARD_END
+}
+int rr_chain_interrupt(rr_chain *h) {
+    RR_CHECK_HANDLE(h, K_CHAIN);
+    // The Rechunker in front of the Filter drops its patchwork and the Filter
+    // its previous chunk; the other blocks only forward the event.
+    h->carry_len = 0;
+    h->fl->hist_valid = false;
+    return RR_OK;
+}
+int rr_chain_peek(rr_chain *h, double sample_rate, size_t n_in, size_t *n_frames) {
+    RR_CHECK_HANDLE(h, K_CHAIN);
+    if (!n_frames) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    return h->peek(sample_rate, n_in, n_frames);
+}
+int rr_chain_process_dev(rr_chain *h, double rate, const void *d_in, size_t n_in, void *d_out, size_t cap,
+                         size_t *n_out) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_CHAIN);
+    return h->process_dev(rate, d_in, n_in, d_out, cap, n_out);
+    RR_GUARD_END
+}
+int rr_chain_process(rr_chain *h, double rate, const void *in, size_t n_in, void *out, size_t cap, size_t *n_out) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_CHAIN);
+    if (n_out) *n_out = 0;
+    if (h->fl->needs_design(rate, h->p.filter_len))
+        RR_FAIL(RR_ERR_NEED_DESIGN, "Chain: Filter has no design for sample rate %g", rate);
+    size_t frames = 0;
+    RR_TRY(h->peek(rate, n_in, &frames));
+    const size_t need = frames * h->p.fft_len;
+    if (need > cap) RR_FAIL(RR_ERR_CAPACITY, "Chain: out_cap %zu < %zu", cap, need);
+    size_t got = 0;
+    RR_TRY(host_io(h, in, n_in, out, need, true, [&](void *di, void *dout, size_t *p) {
+        int s = h->process_dev(rate, di, n_in, dout, need, p);
+        got = *p;
+        return s;
+    }));
+    if (n_out) *n_out = got;
+    return RR_OK;
+    RR_GUARD_END
+}
+int rr_chain_last_path(const rr_chain *h, int *fused) {
+    RR_CHECK_HANDLE(h, K_CHAIN);
+    *fused = h->last_fused;
+    return RR_OK;
+}
+int rr_chain_timing_enable(rr_chain *h, int on) {
+    RR_CHECK_HANDLE(h, K_CHAIN);
+    h->timers.on = on != 0;
+    return RR_OK;
+}
+int rr_chain_timing_reset(rr_chain *h) {
+    RR_CHECK_HANDLE(h, K_CHAIN);
+    RR_TRY(h->select());
+    h->timers.reset();
+    return RR_OK;
+}
+int rr_chain_timing_read(rr_chain *h, int stage, double *total_ms, uint64_t *launches) {
+    RR_CHECK_HANDLE(h, K_CHAIN);
+    if (stage < 0 || stage >= ST_COUNT || !total_ms || !launches) RR_FAIL(RR_ERR_BAD_ARG, "bad stage");
+    RR_TRY(h->select());
+    RR_TRY(h->timers.drain());
+    *total_ms = h->timers.total_ms[stage];
+    *launches = h->timers.launches[stage];
+    return RR_OK;
+}
+const char *rr_chain_timing_stage_name(int stage) {
+    static const char *names[ST_COUNT] = {"freqshift", "filter_fir", "decim_fir", "fourier", "fused_mix_fir_decim", "fused_window_fft"};
+    return (stage >= 0 && stage < ST_COUNT) ? names[stage] : nullptr;
+}
+int rr_chain_destroy(rr_chain *h) {
+    if (!h) return RR_OK;
+    RR_CHECK_HANDLE(h, K_CHAIN);
+    (void)hipSetDevice(h->device);
+    delete h;
+    return RR_OK;
+}
+
+int rr_synth_iq_dev(int device, void *hip_stream, uint64_t seed, uint64_t t0, size_t n, void *d_out) {
+    if (n && !d_out) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    RR_HIP(hipSetDevice(device));
+    return launch_synth(static_cast<hipStream_t>(hip_stream), seed, t0, n, d_out);
+}
+
+}  // extern "C"

@@ -1,0 +1,107 @@
+// rr_blocks.hpp — handle structs = the per-task state of one reference block.
+#pragma once
+#include "rr_internal.hpp"
+#include "rr_kernels.hpp"
+
+// FreqShifter — transform.rs:306-311 (phase_vec, phase_idx, prev_sample_rate)
+struct rr_freqshifter : rr_block {
+    double precision = 1.0;
+    double shift = 0.0;
+    bool shift_changed = false;  // watch::Receiver::has_changed()
+    bool have_rate = false;
+    double prev_rate = 0.0;
+    int64_t numer = 0, denom = 0;
+    uint64_t phase_idx = 0;
+    std::vector<unsigned char> host_table;  // denom complex<T>
+    rr::DevBuf d_table;
+    int prepare(double sample_rate);  // the `if recalculate {..}` body
+    int process_dev(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
+};
+
+// Filter — filters.rs:161-170 (previous_chunk, extended_response, ...)
+struct rr_filter : rr_block {
+    bool designed = false;
+    bool params_changed = false;
+    double rate = 0.0;
+    size_t n = 0;
+    bool real_taps = false;
+    std::vector<rr::cd> taps_f64;  // g[k], causal order
+    rr::DevBuf d_taps;             // w[j] = g[n-1-j] as T or complex<T>
+    rr::DevBuf hist[2];            // previous_chunk (n samples), ping-pong
+    int cur = 0;
+    bool hist_valid = false;  // previous_chunk.is_some()
+    bool needs_design(double sample_rate, size_t len) const {
+        return !designed || params_changed || sample_rate != rate || len != n;
+    }
+    int design(double sample_rate, size_t len, const rr_c64 *resp, const double *window_rel);
+    size_t peek(size_t n_in) const { return hist_valid ? n_in : (n_in >= n ? n_in - n : 0); }
+    int process_dev(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
+};
+
+// Downsampler — resampling.rs:62-67 (ir, ringbuf, ringbuf_pos, pos)
+struct rr_downsampler : rr_block {
+    double output_rate = 0, bandwidth = 0, quality = 3.0;
+    bool have_rate = false;
+    double prev_rate = 0.0;
+    rr::Schedule sched;
+    size_t L = 0;
+    std::vector<double> ir_f64;
+    rr::DevBuf d_ir;
+    rr::DevBuf hist[2];  // the ring buffer's content in time order (L samples)
+    int cur = 0;
+    std::vector<uint32_t> emit;
+    rr::DevBuf d_emit;
+    int prepare(double input_rate);
+    int peek(double input_rate, size_t n_in, size_t *n_out);
+    int process_dev(double input_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
+};
+
+// Fourier — analysis.rs:67-73 (previous_chunk_len, fft, window_values)
+struct rr_fourier : rr_block {
+    rr_window window{RR_WIN_RECTANGULAR, 0.0};
+    bool center_dc = false;
+    size_t n = 0;  // designed chunk length (0 = none)
+    std::vector<double> sampled;  // RR_WIN_SAMPLED: relative values for sampled_n
+    size_t sampled_n = 0;
+    std::vector<double> window_f64;  // scaled window of the current design
+    rr::DevBuf d_window, d_tw;
+    int prepare(size_t len);
+    int process_dev(size_t chunk_len, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
+};
+
+// hipEvent brackets around the chain's kernels (measurement aid)
+enum Stage { ST_FREQSHIFT = 0, ST_FILTER, ST_DECIM, ST_FOURIER, ST_FUSED_FIR, ST_FUSED_FFT, ST_COUNT };
+struct StageTimers {
+    bool on = false;
+    struct Pair { hipEvent_t a, b; int stage; };
+    std::vector<Pair> pending;
+    std::vector<hipEvent_t> pool;
+    double total_ms[ST_COUNT] = {};
+    uint64_t launches[ST_COUNT] = {};
+    int begin(int stage, hipStream_t s);  // returns index into pending or -1
+    void end(int idx, hipStream_t s);
+    int drain();
+    void reset();
+    ~StageTimers();
+};
+
+// Chain — four blocks wired on one device/stream (bandwidth_meter/main.rs:51-72)
+struct rr_chain : rr_block {
+    rr_chain_params p{};
+    rr_freqshifter *fs = nullptr;
+    rr_filter *fl = nullptr;
+    rr_downsampler *ds = nullptr;
+    rr_fourier *fo = nullptr;
+    // Rechunker(filter_len) in front of the Filter: < filter_len mixed samples
+    rr::DevBuf carry;
+    size_t carry_len = 0;
+    rr::DevBuf mixed, filtered, decim;
+    // Downsampler's partly filled output chunk (resampling.rs:121-131)
+    rr::DevBuf pending;
+    size_t pending_len = 0;
+    int last_fused = 0;
+    StageTimers timers;
+    ~rr_chain() override;
+    int peek(double sample_rate, size_t n_in, size_t *n_frames);
+    int process_dev(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
+};

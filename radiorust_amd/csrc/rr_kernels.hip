@@ -1,0 +1,436 @@
+// rr_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the IQ hot path.
+//
+// This file holds the GENERIC kernels: they accept every parameter set the
+// reference blocks accept (any tap count, any resampling schedule, any chunk
+// length) and are used block-by-block.  The fused fast path for the
+// FreqShifter->Filter->Downsampler->Fourier chain lives in rr_fused.hip.
+//
+// These are vector (VALU + LDS) kernels: FIR dot products and FFT butterflies
+// over Complex<f32>/<f64>; no MFMA (not a dense contraction).
+#include "rr_kernels.hpp"
+
+namespace rr {
+
+template <class T> struct V2;
+template <> struct V2<float> { using type = float2; };
+template <> struct V2<double> { using type = double2; };
+template <class T> using v2 = typename V2<T>::type;
+
+template <class T> __device__ __forceinline__ v2<T> cmul(v2<T> a, v2<T> b) {
+    v2<T> r;
+    r.x = a.x * b.x - a.y * b.y;
+    r.y = a.x * b.y + a.y * b.x;
+    return r;
+}
+
+static int set_dyn_lds(const void *fn, size_t bytes) {
+    if (bytes > 64 * 1024) RR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// FreqShifter: y[t] = x[t] * p[(idx0 + t) mod denom]          transform.rs:341-348
+// Pure streaming: 8 B in + 8 B out per sample (16 B/lane vector accesses for f32),
+// the phase table stays in L2/MALL (it is at most a few MB for sane precisions).
+// ---------------------------------------------------------------------------
+template <class T, int VEC>
+__global__ __launch_bounds__(256) void k_freqshift(const v2<T> *__restrict__ in, v2<T> *__restrict__ out, size_t n,
+                                                   const v2<T> *__restrict__ table, uint32_t denom, uint32_t idx0) {
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    // phase index of this thread's first sample and its advance per grid stride
+    uint32_t r = (uint32_t)(((uint64_t)idx0 + i % denom) % denom);
+    const uint32_t step = (uint32_t)((nthreads * VEC) % denom);
+    for (; i + VEC <= n; i += nthreads * VEC) {
+        v2<T> x[VEC], y[VEC];
+        if constexpr (VEC == 2 && sizeof(T) == 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(in + i);
+            x[0] = make_float2(v.x, v.y);
+            x[1] = make_float2(v.z, v.w);
+        } else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) x[k] = in[i + k];
+        }
+        uint32_t rr_ = r;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            y[k] = cmul<T>(x[k], table[rr_]);
+            rr_ = rr_ + 1 == denom ? 0 : rr_ + 1;
+        }
+        if constexpr (VEC == 2 && sizeof(T) == 4) {
+            *reinterpret_cast<float4 *>(out + i) = make_float4(y[0].x, y[0].y, y[1].x, y[1].y);
+        } else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) out[i + k] = y[k];
+        }
+        r += step;
+        if (r >= denom) r -= denom;
+    }
+    // ragged tail (< VEC samples): the thread whose slot covers it
+    if (VEC > 1 && i < n) {
+        uint32_t rr_ = r;
+        for (; i < n; ++i) {
+            out[i] = cmul<T>(in[i], table[rr_]);
+            rr_ = rr_ + 1 == denom ? 0 : rr_ + 1;
+        }
+    }
+}
+
+int launch_freqshift(int dtype, hipStream_t s, const void *in, void *out, size_t n, const void *table,
+                     uint32_t denom, uint32_t idx0) {
+    if (n == 0) return RR_OK;
+    const int block = 256;
+    const bool f32 = dtype == RR_F32;
+    const bool vec = f32 && (reinterpret_cast<uintptr_t>(in) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+    const size_t per = vec ? 2 : 1;
+    size_t blocks = (n + block * per - 1) / (block * per);
+    if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 blocks per CU
+    if (f32) {
+        if (vec)
+            hipLaunchKernelGGL((k_freqshift<float, 2>), dim3(blocks), dim3(block), 0, s, (const float2 *)in,
+                               (float2 *)out, n, (const float2 *)table, denom, idx0);
+        else
+            hipLaunchKernelGGL((k_freqshift<float, 1>), dim3(blocks), dim3(block), 0, s, (const float2 *)in,
+                               (float2 *)out, n, (const float2 *)table, denom, idx0);
+    } else {
+        hipLaunchKernelGGL((k_freqshift<double, 1>), dim3(blocks), dim3(block), 0, s, (const double2 *)in,
+                           (double2 *)out, n, (const double2 *)table, denom, idx0);
+    }
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Generic gather-FIR (Filter in direct form, Downsampler):
+//   out[m] = sum_{j<K} w[j] * x[e_m - (K-1) + j]
+// One workgroup stages the input span of its outputs (plus the K-1 halo) in LDS
+// with coalesced loads; each lane then owns R outputs that share every tap load.
+// Taps are wave-uniform, read through the scalar cache.
+// ---------------------------------------------------------------------------
+template <class T, bool CT> struct TapType { using type = T; };
+template <class T> struct TapType<T, true> { using type = v2<T>; };
+
+template <class T, bool CT, bool LIST, int R>
+__global__ __launch_bounds__(256) void k_fir(const v2<T> *__restrict__ hist, long hist_len,
+                                             const v2<T> *__restrict__ in, long n_in,
+                                             const typename TapType<T, CT>::type *__restrict__ taps, int K,
+                                             v2<T> *__restrict__ out, size_t n_out, unsigned long long e0, uint32_t D,
+                                             const uint32_t *__restrict__ emit, uint32_t outs_per_block) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v2<T> *xs = reinterpret_cast<v2<T> *>(smem);
+    const size_t m0 = (size_t)blockIdx.x * outs_per_block;
+    if (m0 >= n_out) return;
+    const size_t m1 = (m0 + outs_per_block < n_out) ? m0 + outs_per_block : n_out;
+    auto e_of = [&](size_t m) -> long { return LIST ? (long)emit[m] : (long)(e0 + m * (unsigned long long)D); };
+    const long lo = e_of(m0) - (K - 1);
+    const long hi = e_of(m1 - 1);
+    for (long i = lo + threadIdx.x; i <= hi; i += blockDim.x) {
+        v2<T> v;
+        v.x = 0;
+        v.y = 0;
+        if (i >= 0) {
+            if (i < n_in) v = in[i];
+        } else if (i >= -hist_len) {
+            v = hist[hist_len + i];
+        }
+        xs[i - lo] = v;
+    }
+    __syncthreads();
+    for (size_t mb = m0 + threadIdx.x; mb < m1; mb += (size_t)blockDim.x * R) {
+        int base[R];
+        v2<T> acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const size_t m = mb + (size_t)r * blockDim.x;
+            base[r] = (m < m1) ? (int)(e_of(m) - (K - 1) - lo) : 0;
+            acc[r].x = 0;
+            acc[r].y = 0;
+        }
+        for (int j = 0; j < K; ++j) {
+            const auto w = taps[j];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const v2<T> x = xs[base[r] + j];
+                if constexpr (CT) {
+                    acc[r].x += w.x * x.x - w.y * x.y;
+                    acc[r].y += w.x * x.y + w.y * x.x;
+                } else {
+                    acc[r].x += x.x * w;
+                    acc[r].y += x.y * w;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const size_t m = mb + (size_t)r * blockDim.x;
+            if (m < m1) out[m] = acc[r];
+        }
+    }
+}
+
+template <class T, bool CT, bool LIST>
+static int launch_fir_t(hipStream_t s, const FirArgs &a) {
+    constexpr int R = 4;
+    const size_t esz = sizeof(v2<T>);
+    const size_t budget = kFirLdsBytes / esz;  // samples
+    if (a.K == 0) RR_FAIL(RR_ERR_BAD_ARG, "fir: no taps");
+    const uint64_t step = LIST ? a.max_step : a.D;
+    if ((uint64_t)a.K + 63 * step + 1 > budget)
+        RR_FAIL(RR_ERR_BAD_ARG, "fir: %u taps with step %llu exceed the LDS tile (%zu samples)", a.K,
+                (unsigned long long)step, budget);
+    uint64_t opb = (budget - a.K) / (step ? step : 1) + 1;
+    if (opb > 2048) opb = 2048;
+    // keep >= ~4 workgroups per CU when the problem is large enough
+    while (opb > 256 && (a.n_out + opb - 1) / opb < 1024) opb /= 2;
+    if (opb > 64) opb &= ~uint64_t(63);
+    const size_t span = (opb - 1) * step + a.K;
+    const size_t lds = span * esz;
+    auto fn = k_fir<T, CT, LIST, R>;
+    RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));
+    const size_t blocks = (a.n_out + opb - 1) / opb;
+    if (blocks > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fir: too many workgroups");
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), lds, s, (const v2<T> *)a.hist, (long)a.hist_len,
+                       (const v2<T> *)a.in, (long)a.n_in, (const typename TapType<T, CT>::type *)a.taps, (int)a.K,
+                       (v2<T> *)a.out, a.n_out, (unsigned long long)a.e0, a.D, a.emit, (uint32_t)opb);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+int launch_fir(int dtype, hipStream_t s, const FirArgs &a) {
+    if (a.n_out == 0) return RR_OK;
+    const bool list = a.emit != nullptr;
+    if (dtype == RR_F32) {
+        if (a.complex_taps) return list ? launch_fir_t<float, true, true>(s, a) : launch_fir_t<float, true, false>(s, a);
+        return list ? launch_fir_t<float, false, true>(s, a) : launch_fir_t<float, false, false>(s, a);
+    }
+    if (a.complex_taps) return list ? launch_fir_t<double, true, true>(s, a) : launch_fir_t<double, true, false>(s, a);
+    return list ? launch_fir_t<double, false, true>(s, a) : launch_fir_t<double, false, false>(s, a);
+}
+
+// ---------------------------------------------------------------------------
+// history carry: new_hist = last H samples of [ zeros | old_hist | in ]
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ void k_update_hist(const v2<T> *__restrict__ old_hist, v2<T> *__restrict__ new_hist, long H,
+                              const v2<T> *__restrict__ in, long n_in) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H) return;
+    const long src = n_in - H + i;  // index into `in`; negative -> old history
+    v2<T> v;
+    if (src >= 0)
+        v = in[src];
+    else
+        v = old_hist[H + src];  // src >= -H always
+    new_hist[i] = v;
+}
+
+int launch_update_hist(int dtype, hipStream_t s, const void *old_hist, void *new_hist, size_t H, const void *in,
+                       size_t n_in) {
+    if (H == 0) return RR_OK;
+    const unsigned blocks = (unsigned)((H + 255) / 256);
+    if (dtype == RR_F32)
+        hipLaunchKernelGGL(k_update_hist<float>, dim3(blocks), dim3(256), 0, s, (const float2 *)old_hist,
+                           (float2 *)new_hist, (long)H, (const float2 *)in, (long)n_in);
+    else
+        hipLaunchKernelGGL(k_update_hist<double>, dim3(blocks), dim3(256), 0, s, (const double2 *)old_hist,
+                           (double2 *)new_hist, (long)H, (const double2 *)in, (long)n_in);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Fourier, power-of-two length: window * x -> Stockham autosort radix-2 in LDS,
+// one workgroup per chunk.  center_dc is an index rotation on the store.
+// (Generic version; the radix-16 register kernel for n = 4096 is in rr_fused.hip.)
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_fft_pow2(const v2<T> *__restrict__ in, v2<T> *__restrict__ out, int n,
+                                                  const T *__restrict__ window, const v2<T> *__restrict__ tw,
+                                                  int center_dc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v2<T> *a = reinterpret_cast<v2<T> *>(smem);
+    v2<T> *b = a + n;
+    const size_t chunk = blockIdx.x;
+    const v2<T> *src = in + chunk * (size_t)n;
+    v2<T> *dst = out + chunk * (size_t)n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        v2<T> v = src[i];
+        const T w = window[i];
+        v.x *= w;
+        v.y *= w;
+        a[i] = v;
+    }
+    __syncthreads();
+    const int half = n >> 1;
+    for (int ns = 1; ns < n; ns <<= 1) {
+        const int tstride = half / ns;  // tw index step: e^{-j 2 pi k / (2 ns)} = tw[k * n / (2 ns)]
+        for (int j = threadIdx.x; j < half; j += blockDim.x) {
+            const int k = j & (ns - 1);
+            const v2<T> u = a[j];
+            const v2<T> v = cmul<T>(a[j + half], tw[k * tstride]);
+            const int j0 = ((j - k) << 1) + k;
+            v2<T> s, d;
+            s.x = u.x + v.x;
+            s.y = u.y + v.y;
+            d.x = u.x - v.x;
+            d.y = u.y - v.y;
+            b[j0] = s;
+            b[j0 + ns] = d;
+        }
+        __syncthreads();
+        v2<T> *t = a;
+        a = b;
+        b = t;
+    }
+    const int rot = center_dc ? (n >> 1) : 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        int o = i + rot;
+        if (o >= n) o -= n;
+        dst[o] = a[i];
+    }
+}
+
+// Fourier, any other length: direct DFT  X[k] = sum_j (w[j] x[j]) tw[(j k) mod n].
+// grid = (k tiles, chunks).  O(n^2) — small/odd chunk lengths only.
+template <class T>
+__global__ __launch_bounds__(256) void k_dft_direct(const v2<T> *__restrict__ in, v2<T> *__restrict__ out, int n,
+                                                    const T *__restrict__ window, const v2<T> *__restrict__ tw,
+                                                    int center_dc) {
+    __shared__ v2<T> xs[1024];
+    const size_t chunk = blockIdx.y;
+    const v2<T> *src = in + chunk * (size_t)n;
+    v2<T> *dst = out + chunk * (size_t)n;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    v2<T> acc;
+    acc.x = 0;
+    acc.y = 0;
+    for (int j0 = 0; j0 < n; j0 += 1024) {
+        const int cnt = (n - j0 < 1024) ? n - j0 : 1024;
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+            v2<T> v = src[j0 + i];
+            const T w = window[j0 + i];
+            v.x *= w;
+            v.y *= w;
+            xs[i] = v;
+        }
+        __syncthreads();
+        if (k < n) {
+            int idx = (int)(((long long)j0 * k) % n);
+            for (int i = 0; i < cnt; ++i) {
+                const v2<T> p = cmul<T>(xs[i], tw[idx]);
+                acc.x += p.x;
+                acc.y += p.y;
+                idx += k;
+                if (idx >= n) idx -= n;
+            }
+        }
+    }
+    if (k < n) {
+        int o = k + (center_dc ? n / 2 : 0);  // rotate_right(n / 2)
+        if (o >= n) o -= n;
+        dst[o] = acc;
+    }
+}
+
+static bool is_pow2(size_t n) { return n && (n & (n - 1)) == 0; }
+static size_t pow2_limit(int dtype) { return dtype == RR_F32 ? 8192 : 4096; }  // 2 LDS buffers <= 128 KiB
+constexpr size_t kDirectLimit = 16384;
+
+bool fourier_pow2_path(int dtype, size_t n) { return is_pow2(n) && n >= 2 && n <= pow2_limit(dtype); }
+
+int fourier_supported(int dtype, size_t n) {
+    if (n == 0) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: empty chunk");
+    if (fourier_pow2_path(dtype, n)) return RR_OK;
+    if (n <= kDirectLimit) return RR_OK;
+    RR_FAIL(RR_ERR_BAD_ARG, "Fourier: chunk length %zu is not supported yet (power of two <= %zu, or any length <= %zu)",
+            n, pow2_limit(dtype), kDirectLimit);
+}
+
+template <class T>
+static int launch_fourier_t(hipStream_t s, const void *in, void *out, size_t n, size_t count, const void *window,
+                            const void *twiddle, bool center_dc, int dtype) {
+    if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: too many chunks in one call");
+    if (fourier_pow2_path(dtype, n)) {
+        const size_t lds = 2 * n * sizeof(v2<T>);
+        auto fn = k_fft_pow2<T>;
+        RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));
+        int threads = (int)(n / 2);
+        if (threads > 256) threads = 256;
+        if (threads < 64) threads = 64;
+        hipLaunchKernelGGL(fn, dim3((unsigned)count), dim3(threads), lds, s, (const v2<T> *)in, (v2<T> *)out, (int)n,
+                           (const T *)window, (const v2<T> *)twiddle, (int)center_dc);
+    } else {
+        if (count > 65535) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: too many non-power-of-two chunks in one call");
+        dim3 grid((unsigned)((n + 255) / 256), (unsigned)count);
+        hipLaunchKernelGGL(k_dft_direct<T>, grid, dim3(256), 0, s, (const v2<T> *)in, (v2<T> *)out, (int)n,
+                           (const T *)window, (const v2<T> *)twiddle, (int)center_dc);
+    }
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+int launch_fourier(int dtype, hipStream_t s, const void *in, void *out, size_t n, size_t count, const void *window,
+                   const void *twiddle, bool center_dc) {
+    if (count == 0) return RR_OK;
+    RR_TRY(fourier_supported(dtype, n));
+    if (dtype == RR_F32) return launch_fourier_t<float>(s, in, out, n, count, window, twiddle, center_dc, dtype);
+    return launch_fourier_t<double>(s, in, out, n, count, window, twiddle, center_dc, dtype);
+}
+
+// ---------------------------------------------------------------------------
+// Synthetic IQ source: counter based, any sample independently.
+// ---------------------------------------------------------------------------
+struct ToneTable {
+    double re[32], im[32];
+};
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z ^= z >> 30;
+    z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27;
+    z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+
+__global__ __launch_bounds__(256) void k_synth(unsigned long long seed, unsigned long long t0, size_t n,
+                                               float2 *__restrict__ out, ToneTable tones) {
+    __shared__ double tr[32], ti[32];
+    if (threadIdx.x < 32) {
+        tr[threadIdx.x] = tones.re[threadIdx.x];
+        ti[threadIdx.x] = tones.im[threadIdx.x];
+    }
+    __syncthreads();
+    const double sc = 1.0 / 4294967296.0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const unsigned long long t = t0 + i;
+        const unsigned long long u = mix64(seed * 0x9E3779B97F4A7C15ull + t);
+        const int a = (int)(unsigned)(u >> 32);
+        const int b = (int)(unsigned)(u & 0xFFFFFFFFull);
+        float2 v;
+        v.x = (float)((double)a * sc + tr[t & 31]);
+        v.y = (float)((double)b * sc + ti[t & 31]);
+        out[i] = v;
+    }
+}
+
+int launch_synth(hipStream_t s, uint64_t seed, uint64_t t0, size_t n, void *out) {
+    if (n == 0) return RR_OK;
+    ToneTable tones;
+    for (int k = 0; k < 32; ++k) {
+        const double a1 = 2.0 * M_PI * (double)(k % 16) / 16.0;
+        const double a2 = -2.0 * M_PI * (double)((3 * k) % 32) / 32.0;
+        tones.re[k] = 0.25 * cos(a1) + 0.25 * cos(a2);
+        tones.im[k] = 0.25 * sin(a1) + 0.25 * sin(a2);
+    }
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_synth, dim3((unsigned)blocks), dim3(256), 0, s, (unsigned long long)seed,
+                       (unsigned long long)t0, n, (float2 *)out, tones);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+}  // namespace rr

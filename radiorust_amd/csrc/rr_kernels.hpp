@@ -1,0 +1,53 @@
+// rr_kernels.hpp — launchers of the gfx950 kernels (rr_kernels.hip).
+// All launchers are asynchronous on `stream` and return an rr_status.
+#pragma once
+#include "rr_internal.hpp"
+
+namespace rr {
+
+// LDS bytes a generic FIR tile may use for samples
+constexpr size_t kFirLdsBytes = 96 * 1024;
+
+// out[i] = in[i] * table[(idx0 + i) % denom]   (transform.rs:341-348)
+int launch_freqshift(int dtype, hipStream_t s, const void *in, void *out, size_t n, const void *table,
+                     uint32_t denom, uint32_t idx0);
+
+// Generic gather-FIR over the virtual stream  [ zeros | hist (hist_len) | in (n_in) ]:
+//   out[m] = sum_{j<K} w[j] * x[e_m - (K-1) + j],
+//   e_m = e0 + m*D (emit == nullptr) or emit[m]   (indices relative to in[0])
+// complex_taps: w is K complex values (Filter, direct form), else K real values
+// (Downsampler, resampling.rs:112-120, oldest sample times ir[0]).
+struct FirArgs {
+    const void *hist = nullptr;
+    size_t hist_len = 0;
+    const void *in = nullptr;
+    size_t n_in = 0;
+    const void *taps = nullptr;
+    uint32_t K = 0;
+    bool complex_taps = false;
+    void *out = nullptr;
+    size_t n_out = 0;
+    uint64_t e0 = 0;
+    uint32_t D = 1;
+    const uint32_t *emit = nullptr;
+    uint32_t max_step = 1;  // upper bound of e_{m+1} - e_m (list mode)
+};
+int launch_fir(int dtype, hipStream_t s, const FirArgs &a);
+
+// new_hist (H samples) = last H samples of [ zeros | old_hist (H) | in (n_in) ]
+int launch_update_hist(int dtype, hipStream_t s, const void *old_hist, void *new_hist, size_t H, const void *in,
+                       size_t n_in);
+
+// Windowed forward DFT of `count` consecutive chunks of n samples each
+// (analysis.rs:105-115).  twiddle = e^{-j 2 pi k / n}: n/2 entries for power-of-two
+// n (LDS Stockham kernel), n entries otherwise (direct DFT kernel).
+int fourier_supported(int dtype, size_t n);
+// true: LDS Stockham kernel (twiddle table of n/2 entries); false: direct DFT (n entries)
+bool fourier_pow2_path(int dtype, size_t n);
+int launch_fourier(int dtype, hipStream_t s, const void *in, void *out, size_t n, size_t count, const void *window,
+                   const void *twiddle, bool center_dc);
+
+// SURVEY §8(d) synthetic IQ, f32
+int launch_synth(hipStream_t s, uint64_t seed, uint64_t t0, size_t n, void *out);
+
+}  // namespace rr

@@ -1,0 +1,411 @@
+"""GPU parity of the four blocks, called through the C ABI (ctypes), against the
+CPU oracle on identical synthetic IQ.
+
+Tolerances
+  * Complex<f32> data path: relative RMS error against the f64 oracle
+        sqrt(sum |y - y_ref|^2 / sum |y_ref|^2) <= 1e-5        (north_star)
+    and, as a regression guard, within a small multiple of the error the f32
+    oracle itself makes (a wrong tap or index shows up as >> f32 rounding).
+  * Complex<f64> data path: <= 1e-12 relative RMS; the reference's own
+    known-answer test (analysis.rs:139-209) at its 1e-10.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import assert_approx
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def lowpass(cut):
+    return lambda _b, f: 1.0 if abs(f) <= cut else 0.0
+
+
+def rms_rel(a, b):
+    a = np.asarray(a, dtype=np.complex128)
+    b = np.asarray(b, dtype=np.complex128)
+    den = np.sum(np.abs(b) ** 2)
+    return float(np.sqrt(np.sum(np.abs(a - b) ** 2) / den)) if den else float(np.max(np.abs(a - b)))
+
+
+@pytest.fixture(scope="module")
+def rr():
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import radiorust_amd
+
+    radiorust_amd._lib.lib()  # the HIP library must be the thing that runs
+    return radiorust_amd
+
+
+def check(got, truth64, oracle32=None, tol=TOL):
+    err = rms_rel(got, truth64)
+    assert err <= tol, f"rms {err:g} > {tol:g}"
+    if oracle32 is not None:
+        ref_err = rms_rel(oracle32, truth64)
+        assert err <= max(4 * ref_err, 4e-7), f"gpu rms {err:g} vs cpu-f32 rms {ref_err:g}"
+    return err
+
+
+# ---------------------------------------------------------------- source
+def test_synth_source_bit_exact(rr, oracle):
+    import torch
+
+    for seed, t0, n in ((1, 0, 100000), (7, 123456789, 4097), (8, 2**40 + 5, 33)):
+        buf = torch.empty(n, dtype=torch.complex64, device="cuda")
+        rr.synth_iq_dev(0, torch.cuda.current_stream().cuda_stream, seed, t0, n, buf.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(buf.cpu().numpy(), oracle.synth_iq(seed, t0, n))
+
+
+# ---------------------------------------------------------------- FreqShifter
+@pytest.mark.parametrize("fs,prec,shift", [(48000.0, 1.0, 700.0), (200e6, 1.0, 25e6), (200e6, 1e3, 12.345e6),
+                                           (48000.0, 1.0, -1234.0), (48000.0, 1.0, 0.0)])
+def test_freqshifter_parity(rr, oracle, fs, prec, shift):
+    x = oracle.synth_iq(1, 0, 200001)
+    cuts = [0, 1, 1000, 1000, 4097, 65536, 200001]  # ragged, one empty chunk
+    o64 = oracle.FreqShifter(prec, shift, flt=np.float64)
+    o32 = oracle.FreqShifter(prec, shift, flt=np.float32)
+    g = rr.FreqShifter.with_precision_and_shift(prec, shift)
+    assert g.precision() == prec and g.shift() == shift
+    got, t64, t32 = [], [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        (s,) = g.process(rr.Samples(fs, x[a:b]))
+        assert s.sample_rate == fs and len(s.chunk) == b - a
+        got.append(s.chunk)
+        t64.append(o64.process(fs, x[a:b]))
+        t32.append(o32.process(fs, x[a:b]))
+    check(np.concatenate(got), np.concatenate(t64), np.concatenate(t32))
+    # same table, same products: agreement with the f32 oracle is at the ulp level
+    assert rms_rel(np.concatenate(got), np.concatenate(t32)) < 1e-7
+
+
+def test_freqshifter_retune_and_events(rr, oracle):
+    fs = 48000.0
+    x = oracle.synth_iq(2, 0, 3000)
+    g = rr.FreqShifter.with_shift(700.0)
+    o64 = oracle.FreqShifter(1.0, 700.0, flt=np.float64)
+    o32 = oracle.FreqShifter(1.0, 700.0, flt=np.float32)
+    outs, refs = [], []
+    outs.append(g.process(rr.Samples(fs, x[:777]))[0].chunk)
+    refs.append(o32.process(fs, x[:777]))
+    o64.process(fs, x[:777])
+    ev = rr.EventSignal(rr.Disconnection())
+    assert g.process(ev) == [ev]  # forwarded unchanged, no state change
+    g.set_shift(-2500.0)
+    o32.set_shift(-2500.0)
+    assert g.shift() == -2500.0
+    outs.append(g.process(rr.Samples(fs, x[777:2000]))[0].chunk)
+    refs.append(o32.process(fs, x[777:2000]))
+    g.update_shift(lambda s: s + 100.0)
+    o32.set_shift(-2400.0)
+    outs.append(g.process(rr.Samples(fs, x[2000:]))[0].chunk)
+    refs.append(o32.process(fs, x[2000:]))
+    # phase continuity goes through atan2f of an f32 phasor on both sides
+    assert rms_rel(np.concatenate(outs), np.concatenate(refs)) < 5e-7
+    # sample-rate change alone also rebuilds the table (transform.rs:318-319)
+    y = g.process(rr.Samples(44100.0, x[:100]))[0].chunk
+    assert rms_rel(y, o32.process(44100.0, x[:100])) < 5e-7
+
+
+def test_freqshifter_f64(rr, oracle):
+    x = oracle.synth_iq(3, 0, 50000).astype(np.complex128)
+    g = rr.FreqShifter.with_shift(700.0, dtype=np.float64)
+    o64 = oracle.FreqShifter(1.0, 700.0, flt=np.float64)
+    y = np.concatenate([g.process(rr.Samples(48000.0, x[a:b]))[0].chunk for a, b in ((0, 12345), (12345, 50000))])
+    assert y.dtype == np.complex128
+    assert rms_rel(y, o64.process(48000.0, x)) < 1e-15
+
+
+def test_freqshifter_errors(rr):
+    from radiorust_amd._lib import RR_ERR_BAD_ARG, RR_ERR_CAPACITY, BackendError, ContractViolation
+
+    g = rr.FreqShifter.with_precision_and_shift(100.0, 1.0)
+    with pytest.raises(ContractViolation):  # 10 / 100 rounds to denom 0: Ratio::new panics
+        g.process(rr.Samples(10.0, np.zeros(4, dtype=np.complex64)))
+    g2 = rr.FreqShifter.with_precision_and_shift(1e-3, 1.0)
+    with pytest.raises(BackendError) as e:  # 2e11-entry table
+        g2.process(rr.Samples(200e6, np.zeros(4, dtype=np.complex64)))
+    assert e.value.status == RR_ERR_BAD_ARG
+    L = rr._lib.lib()
+    g3 = rr.FreqShifter.with_shift(1.0)
+    x = np.zeros(8, dtype=np.complex64)
+    n = C.c_size_t(99)
+    assert L.rr_freqshifter_process(g3._h, 48000.0, x.ctypes.data, 8, x.ctypes.data, 4, C.byref(n)) == RR_ERR_CAPACITY
+    assert n.value == 0
+    with pytest.raises(TypeError):
+        rr.FreqShifter.with_shift(1.0, dtype=np.float16)
+
+
+# ---------------------------------------------------------------- Filter
+FILTER_CASES = [(64, 200e6, 20e6, 40), (1024, 2e9, 200e6, 6), (4096, 48000.0, 16e3, 3), (48, 48000.0, 4e3, 9), (33, 48000.0, 5e3, 9)]
+
+
+@pytest.mark.parametrize("n,fs,cut,chunks", FILTER_CASES)
+def test_filter_parity(rr, oracle, n, fs, cut, chunks):
+    x = oracle.synth_iq(4, 0, n * chunks)
+    g = rr.Filter.new(lowpass(cut))
+    o64 = oracle.Filter(lowpass(cut), flt=np.float64)
+    o32 = oracle.Filter(lowpass(cut), flt=np.float32)
+    got, t64, t32 = [], [], []
+    for i in range(chunks):
+        c = x[i * n : (i + 1) * n]
+        out = g.process(rr.Samples(fs, c))
+        r64, r32 = o64.process(fs, c), o32.process(fs, c)
+        if i == 0:
+            assert out == [] and r64 is None  # delay of one chunk (filters.rs:240,260)
+            continue
+        assert len(out) == 1 and len(out[0].chunk) == n
+        got.append(out[0].chunk)
+        t64.append(r64)
+        t32.append(r32)
+    check(np.concatenate(got), np.concatenate(t64), np.concatenate(t32))
+
+
+def test_filter_interrupt_update_and_rate_change(rr, oracle):
+    n, fs = 64, 200e6
+    x = oracle.synth_iq(5, 0, n * 10)
+    g = rr.Filter.new(lowpass(20e6))
+    o = oracle.Filter(lowpass(20e6), flt=np.float64)
+
+    def both(rate, c):
+        out = g.process(rr.Samples(rate, c))
+        ref = o.process(rate, c)
+        assert (out == []) == (ref is None)
+        if ref is not None:
+            check(out[0].chunk, ref)
+
+    both(fs, x[:n])
+    both(fs, x[n : 2 * n])
+    ev = rr.EventSignal(rr.SamplesLost())
+    assert g.process(ev) == [ev]
+    o.interrupt()
+    both(fs, x[2 * n : 3 * n])  # swallowed again
+    both(fs, x[3 * n : 4 * n])
+    ev2 = rr.EventSignal(rr.Event())  # not an interrupt: history survives
+    assert g.process(ev2) == [ev2]
+    both(fs, x[4 * n : 5 * n])
+    g.update(lowpass(5e6))
+    o.update(lowpass(5e6))
+    both(fs, x[5 * n : 6 * n])
+    both(fs, x[6 * n : 7 * n])
+    g.update_with_window(lowpass(5e6), rr.Rectangular())
+    o.update(lowpass(5e6), oracle.Rectangular())
+    both(fs, x[7 * n : 8 * n])
+    both(fs, x[8 * n : 9 * n])
+    both(fs / 2, x[:n])  # rate change -> redesign -> swallowed
+    both(fs / 2, x[n : 2 * n])
+    both(fs / 2, x[: n // 2])  # chunk length change -> redesign
+    both(fs / 2, x[n // 2 : n])
+
+
+def test_filter_complex_taps_and_windows(rr, oracle):
+    n, fs = 64, 48000.0
+    fr = lambda b, f: (1.0 + 0.5j) if 0 <= f <= 6000 else 0.0  # noqa: E731
+    x = oracle.synth_iq(6, 0, n * 8)
+    for gw, ow in ((rr.Rectangular(), oracle.Rectangular()), (rr.Kaiser.with_alpha(1.5), oracle.Kaiser.with_alpha(1.5)),
+                   (rr.CustomWindow(lambda v: 1 - 0.9 * v * v), oracle.CustomWindow(lambda v: 1 - 0.9 * v * v))):
+        g = rr.Filter.with_window(fr, gw)
+        o64 = oracle.Filter(fr, ow, flt=np.float64)
+        o32 = oracle.Filter(fr, ow, flt=np.float32)
+        got, t64, t32 = [], [], []
+        for i in range(8):
+            c = x[i * n : (i + 1) * n]
+            out = g.process(rr.Samples(fs, c))
+            r64, r32 = o64.process(fs, c), o32.process(fs, c)
+            if out:
+                got.append(out[0].chunk)
+                t64.append(r64)
+                t32.append(r32)
+        check(np.concatenate(got), np.concatenate(t64), np.concatenate(t32))
+
+
+def test_filter_f64(rr, oracle):
+    n, fs = 64, 200e6
+    x = oracle.synth_iq(7, 0, n * 6).astype(np.complex128)
+    g = rr.Filter.new(lowpass(20e6), dtype=np.float64)
+    o = oracle.Filter(lowpass(20e6), flt=np.float64)
+    got, ref = [], []
+    for i in range(6):
+        out = g.process(rr.Samples(fs, x[i * n : (i + 1) * n]))
+        r = o.process(fs, x[i * n : (i + 1) * n])
+        if out:
+            got.append(out[0].chunk)
+            ref.append(r)
+    assert rms_rel(np.concatenate(got), np.concatenate(ref)) < 1e-12
+
+
+def test_filter_needs_design_status(rr):
+    from radiorust_amd._lib import RR_ERR_NEED_DESIGN
+
+    L = rr._lib.lib()
+    g = rr.Filter.new(lowpass(1e3))
+    x = np.zeros(64, dtype=np.complex64)
+    n = C.c_size_t()
+    assert L.rr_filter_process(g._h, 48000.0, x.ctypes.data, 64, x.ctypes.data, 64, C.byref(n)) == RR_ERR_NEED_DESIGN
+    g.process(rr.Samples(48000.0, x))
+    assert L.rr_filter_process(g._h, 48000.0, x.ctypes.data, 32, x.ctypes.data, 64, C.byref(n)) == RR_ERR_NEED_DESIGN
+    assert L.rr_filter_process(g._h, 44100.0, x.ctypes.data, 64, x.ctypes.data, 64, C.byref(n)) == RR_ERR_NEED_DESIGN
+    assert L.rr_filter_process(g._h, 48000.0, x.ctypes.data, 64, x.ctypes.data, 64, C.byref(n)) == 0 and n.value == 64
+
+
+# ---------------------------------------------------------------- Downsampler
+DS_CASES = [(200e6, 50e6, 40e6, 3.0), (1024000.0, 384000.0, 200000.0, 3.0), (384000.0, 48000.0, 40000.0, 3.0),
+            (1024000.0, 102400.0, 60000.0, 3.0), (48000.0, 44100.5, 30000.0, 2.0), (48000.0, 48000.0, 20000.0, 1.0)]
+
+
+@pytest.mark.parametrize("fin,fout,bw,q", DS_CASES)
+def test_downsampler_parity(rr, oracle, fin, fout, bw, q):
+    n = 60000
+    x = oracle.synth_iq(8, 0, n)
+    cuts = [0, 7, 7, 2048, 2049, 30000, n]
+    g = rr.Downsampler.with_quality(1000, fout, bw, q)
+    o64 = oracle.Downsampler(1000, fout, bw, q, flt=np.float64)
+    o32 = oracle.Downsampler(1000, fout, bw, q, flt=np.float32)
+    got, t64, t32 = [], [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        y = g.process_raw(fin, x[a:b])
+        r64, r32 = o64.process(fin, x[a:b]), o32.process(fin, x[a:b])
+        assert len(y) == len(r64)  # identical emission schedule, chunk by chunk
+        got.append(y)
+        t64.append(r64)
+        t32.append(r32)
+    assert g.ir_len() == len(o64.ir())
+    check(np.concatenate(got), np.concatenate(t64), np.concatenate(t32))
+
+
+def test_downsampler_output_chunks_and_events(rr, oracle):
+    g = rr.Downsampler.new(100, 50e6, 40e6)
+    x = oracle.synth_iq(9, 0, 1200)
+    out = g.process(rr.Samples(200e6, x[:1000]))
+    assert [len(s.chunk) for s in out] == [100, 100] and all(s.sample_rate == 50e6 for s in out)
+    ev = rr.EventSignal(rr.Disconnection())
+    assert g.process(ev) == [ev]  # no reset (resampling.rs:135-137)
+    out2 = g.process(rr.Samples(200e6, x[1000:]))
+    assert [len(s.chunk) for s in out2] == [100]
+    o = oracle.Downsampler(100, 50e6, 40e6, flt=np.float64)
+    ref = o.feed(200e6, x[:1000]) + o.feed(200e6, x[1000:])
+    check(np.concatenate([s.chunk for s in out + out2]), np.concatenate(ref))
+
+
+def test_downsampler_contract(rr):
+    from radiorust_amd._lib import ContractViolation
+
+    with pytest.raises(ContractViolation):
+        rr.Downsampler.new(16, 48000.0, 48000.0)
+    with pytest.raises(ContractViolation):
+        rr.Downsampler.new(16, -1.0, -2.0)
+    g = rr.Downsampler.new(16, 48000.0, 40000.0)
+    with pytest.raises(ContractViolation):
+        g.process_raw(44100.0, np.zeros(8, dtype=np.complex64))
+
+
+def test_downsampler_rate_change_resets(rr, oracle):
+    g = rr.Downsampler.new(16, 48000.0, 40000.0)
+    o = oracle.Downsampler(16, 48000.0, 40000.0, flt=np.float64)
+    x = oracle.synth_iq(10, 0, 4000)
+    for rate, a, b in ((96000.0, 0, 1500), (192000.0, 1500, 3000), (96000.0, 3000, 4000)):
+        check(g.process_raw(rate, x[a:b]), o.process(rate, x[a:b]))
+
+
+def test_downsampler_f64(rr, oracle):
+    x = oracle.synth_iq(11, 0, 20000).astype(np.complex128)
+    g = rr.Downsampler.new(16, 50e6, 40e6, dtype=np.float64)
+    o = oracle.Downsampler(16, 50e6, 40e6, flt=np.float64)
+    assert rms_rel(g.process_raw(200e6, x), o.process(200e6, x)) < 1e-13
+
+
+# ---------------------------------------------------------------- Fourier
+def test_fourier_reference_kat_on_gpu(rr):
+    """analysis.rs:139-209 run on the device in f64 at the reference's 1e-10."""
+    f1 = rr.Fourier.new(dtype=np.float64)
+    f2 = rr.Fourier.new_center_dc(dtype=np.float64)
+    for chunk, want1, want2 in [([1.0, 1.0, 1.0], [3, 0, 0], [0, 3, 0]),
+                                ([1.0, 1.5, 1.0, 0.5], [4, -1j, 0, 1j], [0, 1j, 4, -1j])]:
+        sig = rr.Samples(48000.0, np.array(chunk, dtype=np.complex128))
+        (o1,), (o2,) = f1.process(sig), f2.process(sig)
+        for got, want in ((o1.chunk, want1), (o2.chunk, want2)):
+            for gv, wv in zip(got, want):
+                assert_approx(gv.real, complex(wv).real)
+                assert_approx(gv.imag, complex(wv).imag)
+    g1, g2 = rr.Fourier.new(), rr.Fourier.new_center_dc()  # and in f32
+    sig = rr.Samples(48000.0, np.array([1.0, 1.5, 1.0, 0.5], dtype=np.complex64))
+    np.testing.assert_allclose(g1.process(sig)[0].chunk, [4, -1j, 0, 1j], atol=1e-6)
+    np.testing.assert_allclose(g2.process(sig)[0].chunk, [0, 1j, 4, -1j], atol=1e-6)
+
+
+@pytest.mark.parametrize("n,center", [(4096, False), (4096, True), (8192, False), (256, True), (2, False), (1, True),
+                                      (1000, True), (7, True), (4095, False), (12000, False)])
+def test_fourier_parity(rr, oracle, n, center):
+    x = oracle.synth_iq(12, 0, n)
+    gw, ow = rr.Kaiser.with_null_at_bin(2.0), oracle.Kaiser.with_null_at_bin(2.0)
+    g = rr.Fourier(gw, center)
+    (out,) = g.process(rr.Samples(1e6, x))
+    t64 = oracle.Fourier(ow, center, flt=np.float64).process(x)
+    t32 = oracle.Fourier(ow, center, flt=np.float32).process(x)
+    check(out.chunk, t64, t32)
+
+
+def test_fourier_custom_window_and_length_change(rr, oracle):
+    fn = lambda v: 1 - 0.8 * v * v  # noqa: E731
+    g = rr.Fourier.with_window(rr.CustomWindow(fn))
+    o = oracle.Fourier(oracle.CustomWindow(fn), flt=np.float64)
+    for n in (512, 300, 512):
+        x = oracle.synth_iq(13, n, n)
+        check(g.process(rr.Samples(1.0, x))[0].chunk, o.process(x))
+    ev = rr.EventSignal(rr.Disconnection())
+    assert g.process(ev) == [ev]
+
+
+def test_fourier_batched_device_api(rr, oracle):
+    import torch
+
+    n, k = 4096, 9
+    x = oracle.synth_iq(14, 0, n * k)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.empty_like(d_in)
+    g = rr.Fourier.with_window(rr.Kaiser.with_null_at_bin(2.0))
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    assert g.process_dev(n, d_in.data_ptr(), n * k, d_out.data_ptr(), n * k) == n * k
+    torch.cuda.synchronize()
+    o = oracle.Fourier(oracle.Kaiser.with_null_at_bin(2.0), flt=np.float64)
+    ref = np.concatenate([o.process(x[i * n : (i + 1) * n]) for i in range(k)])
+    check(d_out.cpu().numpy(), ref)
+
+
+def test_fourier_errors(rr):
+    from radiorust_amd._lib import BackendError
+
+    g = rr.Fourier.new()
+    with pytest.raises(BackendError):
+        g.process(rr.Samples(1.0, np.zeros(0, dtype=np.complex64)))
+    with pytest.raises(BackendError):
+        g.process(rr.Samples(1.0, np.zeros(20000, dtype=np.complex64)))  # unsupported length says so
+
+
+# ---------------------------------------------------------------- async + pinned
+def test_enqueue_wait_with_pinned_buffers(rr, oracle):
+    L = rr._lib.lib()
+    n = 1 << 16
+    p_in, p_out = C.c_void_p(), C.c_void_p()
+    assert L.rr_host_alloc(n * 8, C.byref(p_in)) == 0 and L.rr_host_alloc(n * 8, C.byref(p_out)) == 0
+    x = oracle.synth_iq(15, 0, n)
+    C.memmove(p_in, x.ctypes.data, n * 8)
+    g = rr.FreqShifter.with_shift(700.0)
+    cnt = C.c_size_t()
+    assert L.rr_freqshifter_enqueue(g._h, 48000.0, p_in, n, p_out, n, C.byref(cnt)) == 0
+    assert cnt.value == n  # final at enqueue time
+    g.wait()
+    assert g.query()
+    y = np.frombuffer((C.c_char * (n * 8)).from_address(p_out.value), dtype=np.complex64).copy()
+    assert rms_rel(y, oracle.FreqShifter(1.0, 700.0, flt=np.float32).process(48000.0, x)) < 1e-7
+    # registering an existing allocation (a pooled Vec) works too
+    buf = np.zeros(n, dtype=np.complex64)
+    assert L.rr_host_register(buf.ctypes.data, buf.nbytes) == 0
+    assert L.rr_host_unregister(buf.ctypes.data) == 0
+    assert L.rr_host_free(p_in) == 0 and L.rr_host_free(p_out) == 0
