@@ -151,6 +151,15 @@ def lib() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python -m radiorust_amd.build` "
             "(or __graft_entry__.build()); radiorust_amd has no CPU fallback"
         )
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own
+    # libamdhip64 and load it by file name, so if our library pulled in the
+    # system runtime first, torch.cuda would later fail to initialise.  When
+    # torch is installed, let it load its runtime first; ours then binds to the
+    # same libamdhip64.so.7 by soname.  (Plumbing only: no torch API is used.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol

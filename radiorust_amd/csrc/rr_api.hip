@@ -151,6 +151,7 @@ int rr_filter::design(double sample_rate, size_t len, const rr_c64 *resp, const 
     params_changed = false;
     hist_valid = false;  // previous_chunk = None (filters.rs:187)
     cur = 0;
+    ++design_version;
     return RR_OK;
 }
 
@@ -211,6 +212,7 @@ int rr_downsampler::prepare(double input_rate) {
     RR_HIP(hipMemsetAsync(hist[0].p, 0, hb, stream));  // ringbuf = vec![0; ir_len]
     cur = 0;
     sched.configure(input_rate, output_rate);  // pos = 0
+    ++design_version;
     return RR_OK;
 }
 
@@ -286,7 +288,7 @@ int rr_fourier::prepare(size_t len) {
     }
     std::vector<double> vals(len);
     RR_TRY(fourier_design_window(len, rel.data(), vals.data()));
-    const size_t ntw = fourier_pow2_path(dtype, len) ? len / 2 : len;
+    const size_t ntw = len;  // the radix-2 kernel uses the first half, radix-16 and direct all of it
     std::vector<double> tw(2 * ntw);
     for (size_t k = 0; k < ntw; ++k) {
         const double ang = -2.0 * M_PI * (double)k / (double)len;
@@ -375,7 +377,12 @@ StageTimers::~StageTimers() {
 }
 
 // ---------------------------------------------------------------------------
-// Chain (block-by-block path; the fused path is selected in rr_fused.hip)
+// Chain
+//   process_generic : the four blocks one after the other (any parameters)
+//   process_fused   : k_mix_fir_decim + k_fft4096/k_fft (Complex<f32>, integer
+//                     decimation, real taps), selected per call when the whole
+//                     call is in steady state; the two paths hand their state to
+//                     each other exactly (materialize / xh history).
 // ---------------------------------------------------------------------------
 rr_chain::~rr_chain() {
     delete fs;
@@ -394,14 +401,135 @@ int rr_chain::peek(double sample_rate, size_t n_in, size_t *n_frames) {
     return RR_OK;
 }
 
-int rr_chain::process_dev(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out) {
-    if (n_out) *n_out = 0;
-    if (fl->needs_design(sample_rate, p.filter_len))
-        RR_FAIL(RR_ERR_NEED_DESIGN, "Chain: Filter has no design for sample rate %g", sample_rate);
-    size_t frames = 0;
-    RR_TRY(peek(sample_rate, n_in, &frames));
-    if (frames * p.fft_len > cap) RR_FAIL(RR_ERR_CAPACITY, "Chain: out_cap %zu < %zu", cap, frames * p.fft_len);
+// parameters for which the fused kernels exist at all (independent of stream state)
+bool rr_chain::fused_candidate(double sample_rate) const {
+    if (!p.allow_fused || dtype != RR_F32) return false;
+    if (!fl->designed || !fl->real_taps) return false;
+    if (!ds->have_rate || ds->prev_rate != sample_rate || !ds->sched.integer_ratio) return false;
+    return fused_fir_supported(ds->sched.D, ds->L + fl->n - 1);
+}
+
+int rr_chain::ensure_xh() {
+    const size_t want = ds->L + 2 * fl->n + 8;
+    if (want == HX) return RR_OK;
+    const size_t bytes = want * elem_size(dtype);
+    RR_TRY(xh[0].reserve(bytes));
+    RR_TRY(xh[1].reserve(bytes));
+    RR_HIP(hipMemsetAsync(xh[0].p, 0, bytes, stream));
+    RR_HIP(hipMemsetAsync(xh[1].p, 0, bytes, stream));
+    xh_cur = 0;
+    HX = want;
+    xh_count = 0;  // stay on the block-by-block path until the history has filled
+    return RR_OK;
+}
+
+// c = reverse(ir) (*) g in f64, cast to f32 and laid out in the step order of
+// k_mix_fir_decim: tb[t*D + p] = c[D*(Gp-1-t) + (D-1-p)], zero beyond Lc
+int rr_chain::ensure_ctaps() {
+    if (ctaps_fl == fl->design_version && ctaps_ds == ds->design_version) return RR_OK;
+    const size_t n = fl->n, L = ds->L;
+    const size_t lc = L + n - 1;
+    std::vector<double> c(lc, 0.0);
+    for (size_t j = 0; j < L; ++j) {
+        const double a = ds->ir_f64[L - 1 - j];
+        for (size_t k = 0; k < n; ++k) c[j + k] += a * fl->taps_f64[k].real();
+    }
+    const int D = (int)ds->sched.D, R = fused_fir_R(ds->sched.D);
+    const int groups = (int)((lc + D - 1) / D);
+    const int gp = (groups + R - 1) / R * R;
+    std::vector<float> tb((size_t)gp * D, 0.f);
+    for (int t = 0; t < gp; ++t)
+        for (int q = 0; q < D; ++q) {
+            const size_t i = (size_t)D * (gp - 1 - t) + (D - 1 - q);
+            if (i < lc) tb[(size_t)t * D + q] = (float)c[i];
+        }
+    RR_TRY(upload(d_ctaps, tb.data(), tb.size() * sizeof(float), stream));
+    Gp = gp;
+    Lc = lc;
+    ctaps_fl = fl->design_version;
+    ctaps_ds = ds->design_version;
+    return RR_OK;
+}
+
+// After fused calls the Filter's previous chunk and the Downsampler's ring are
+// stale; rebuild both from the mixed-sample history before anything reads them.
+int rr_chain::materialize() {
+    if (!blocks_stale) return RR_OK;
     RR_TRY(select());
+    const size_t esz = elem_size(dtype), n = fl->n, L = ds->L;
+    const size_t fed = HX - carry_len;  // xh[0 .. fed) went through the Filter, the rest is the carry
+    // previous_chunk = the last n samples the Filter saw
+    RR_HIP(hipMemcpyAsync(fl->hist[fl->cur].p, xh[xh_cur].as<char>() + (fed - n) * esz, n * esz, hipMemcpyDeviceToDevice, stream));
+    // ring buffer = the last L Filter outputs, recomputed from the same samples
+    FirArgs a;
+    a.in = xh[xh_cur].p;
+    a.n_in = HX;
+    a.taps = fl->d_taps.p;
+    a.K = (uint32_t)n;
+    a.complex_taps = !fl->real_taps;
+    a.out = ds->hist[ds->cur].p;
+    a.n_out = L;
+    a.e0 = fed - L;
+    a.D = 1;
+    RR_TRY(launch_fir(dtype, stream, a));
+    blocks_stale = false;
+    return RR_OK;
+}
+
+int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out) {
+    const size_t esz = elem_size(dtype), nf = p.filter_len, LF = p.fft_len;
+    RR_TRY(fs->prepare(sample_rate));  // picks up set_shift (transform.rs:318-340)
+    RR_TRY(ensure_ctaps());
+    const size_t total = carry_len + n_in, whole = total / nf * nf, left = total - whole;
+    const size_t dec = ds->sched.count(whole);
+    const size_t have = pending_len + dec;
+    RR_TRY(decim.reserve((have ? have : 1) * esz));
+    if (pending_len) RR_HIP(hipMemcpyAsync(decim.p, pending.p, pending_len * esz, hipMemcpyDeviceToDevice, stream));
+    FusedFirArgs a;
+    a.xh = xh[xh_cur].p;
+    a.hx = HX;
+    a.in = d_in;
+    a.n_in = n_in;
+    a.nco = fs->d_table.p;
+    a.denom = (uint32_t)fs->denom;
+    a.idx0 = (uint32_t)fs->phase_idx;
+    a.taps = d_ctaps.p;
+    a.Gp = Gp;
+    a.out = decim.as<char>() + pending_len * esz;
+    a.n_out = dec;
+    a.e0 = (int64_t)ds->sched.first_emit() - (int64_t)carry_len;
+    a.D = (uint32_t)ds->sched.D;
+    int tk = timers.begin(ST_FUSED_FIR, stream);
+    RR_TRY(launch_fused_fir(stream, a));
+    timers.end(tk, stream);
+    // mixed-sample history for the next call: mix the last HX raw samples again
+    const uint64_t den = (uint64_t)fs->denom;
+    const uint32_t tail_idx = (uint32_t)((fs->phase_idx + (n_in - HX) % den) % den);
+    RR_TRY(launch_freqshift(dtype, stream, static_cast<const char *>(d_in) + (n_in - HX) * esz, xh[xh_cur ^ 1].p, HX,
+                            fs->d_table.p, (uint32_t)fs->denom, tail_idx));
+    xh_cur ^= 1;
+    if (left) RR_HIP(hipMemcpyAsync(carry.p, xh[xh_cur].as<char>() + (HX - left) * esz, left * esz, hipMemcpyDeviceToDevice, stream));
+    fs->phase_idx = (fs->phase_idx + n_in % den) % den;
+    carry_len = left;
+    ds->sched.advance(whole, nullptr);
+    zrun += whole;
+    blocks_stale = true;
+    // Fourier on whole frames, the rest stays pending (resampling.rs:121-131)
+    const size_t nfr = have / LF;
+    size_t wrote = 0;
+    tk = timers.begin(ST_FOURIER, stream);
+    RR_TRY(fo->process_dev(LF, decim.p, nfr * LF, d_out, cap, &wrote));
+    timers.end(tk, stream);
+    const size_t rest = have - nfr * LF;
+    if (rest) RR_HIP(hipMemcpyAsync(pending.p, decim.as<char>() + nfr * LF * esz, rest * esz, hipMemcpyDeviceToDevice, stream));
+    pending_len = rest;
+    last_fused = 1;
+    if (n_out) *n_out = wrote;
+    return RR_OK;
+}
+
+int rr_chain::process_generic(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out) {
+    if (blocks_stale) RR_TRY(materialize());
     const size_t esz = elem_size(dtype);
     // 1. FreqShifter -> mixed[carry_len ..)
     const size_t total = carry_len + n_in;
@@ -419,9 +547,7 @@ int rr_chain::process_dev(double sample_rate, const void *d_in, size_t n_in, voi
     tk = timers.begin(ST_FILTER, stream);
     RR_TRY(fl->process_dev(sample_rate, mixed.p, whole, filtered.p, filt, &filt));
     timers.end(tk, stream);
-    const size_t left = total - whole;
-    if (left) RR_HIP(hipMemcpyAsync(carry.p, mixed.as<char>() + whole * esz, left * esz, hipMemcpyDeviceToDevice, stream));
-    carry_len = left;
+    zrun += filt;
     // 3. Downsampler -> decim[pending_len ..)
     size_t dec = 0;
     RR_TRY(ds->peek(sample_rate, filt, &dec));
@@ -431,6 +557,16 @@ int rr_chain::process_dev(double sample_rate, const void *d_in, size_t n_in, voi
     tk = timers.begin(ST_DECIM, stream);
     RR_TRY(ds->process_dev(sample_rate, filtered.p, filt, decim.as<char>() + pending_len * esz, dec, &dec));
     timers.end(tk, stream);
+    // keep the mixed-sample history the fused kernels start from
+    if (fused_candidate(sample_rate)) {
+        RR_TRY(ensure_xh());
+        RR_TRY(launch_update_hist(dtype, stream, xh[xh_cur].p, xh[xh_cur ^ 1].p, HX, mixed.as<char>() + carry_len * esz, n_in));
+        xh_cur ^= 1;
+        xh_count = (xh_count + n_in > HX) ? HX : xh_count + n_in;
+    }
+    const size_t left = total - whole;
+    if (left) RR_HIP(hipMemcpyAsync(carry.p, mixed.as<char>() + whole * esz, left * esz, hipMemcpyDeviceToDevice, stream));
+    carry_len = left;
     // 4. Fourier on whole frames
     const size_t L = p.fft_len;
     const size_t nfr = have / L;
@@ -444,6 +580,24 @@ int rr_chain::process_dev(double sample_rate, const void *d_in, size_t n_in, voi
     last_fused = 0;
     if (n_out) *n_out = wrote;
     return RR_OK;
+}
+
+int rr_chain::process_dev(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out) {
+    if (n_out) *n_out = 0;
+    if (fl->needs_design(sample_rate, p.filter_len))
+        RR_FAIL(RR_ERR_NEED_DESIGN, "Chain: Filter has no design for sample rate %g", sample_rate);
+    size_t frames = 0;
+    RR_TRY(peek(sample_rate, n_in, &frames));
+    if (frames * p.fft_len > cap) RR_FAIL(RR_ERR_CAPACITY, "Chain: out_cap %zu < %zu", cap, frames * p.fft_len);
+    if (n_in > 0xfffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "Chain: more than 2^32 samples in one call");
+    RR_TRY(select());
+    // The fused kernels apply when every output of this call is in steady state:
+    // the Filter has its previous chunk, the Downsampler's window holds only real
+    // Filter outputs of the current contiguous run, and the mixed history is filled.
+    const bool fused = fused_candidate(sample_rate) && HX != 0 && xh_count >= HX && fl->hist_valid &&
+                       zrun + 1 >= ds->L && n_in >= HX;
+    if (fused) return process_fused(sample_rate, d_in, n_in, d_out, cap, n_out);
+    return process_generic(sample_rate, d_in, n_in, d_out, cap, n_out);
 }
 
 // ---------------------------------------------------------------------------
@@ -981,16 +1135,31 @@ int rr_chain_filter_mark_params_changed(rr_chain *h) {
 int rr_chain_filter_design(rr_chain *h, double sample_rate, const rr_c64 *resp, const double *window_rel) {
     RR_GUARD_BEGIN
     RR_CHECK_HANDLE(h, K_CHAIN);
-    return h->fl->design(sample_rate, h->p.filter_len, resp, window_rel);
+    // the Downsampler keeps running across a Filter redesign: give it its ring back first
+    RR_TRY(h->materialize());
+    RR_TRY(h->fl->design(sample_rate, h->p.filter_len, resp, window_rel));
+    h->zrun = 0;
+    return RR_OK;
     RR_GUARD_END
 }
 int rr_chain_interrupt(rr_chain *h) {
+    RR_GUARD_BEGIN
     RR_CHECK_HANDLE(h, K_CHAIN);
-    // The Rechunker in front of the Filter drops its patchwork and the Filter
-    // its previous chunk; the other blocks only forward the event.
+    // The Rechunker in front of the Filter drops its patchwork (chunks.rs:80-88)
+    // and the Filter its previous chunk (filters.rs:262-265); the other blocks
+    // only forward the event.
+    RR_TRY(h->materialize());
+    if (h->HX && h->carry_len) {
+        RR_TRY(h->select());
+        RR_TRY(launch_drop_tail(h->stream, h->xh[h->xh_cur].p, h->xh[h->xh_cur ^ 1].p, h->HX, h->carry_len));
+        h->xh_cur ^= 1;
+        h->xh_count = h->xh_count > h->carry_len ? h->xh_count - h->carry_len : 0;
+    }
     h->carry_len = 0;
     h->fl->hist_valid = false;
+    h->zrun = 0;
     return RR_OK;
+    RR_GUARD_END
 }
 int rr_chain_peek(rr_chain *h, double sample_rate, size_t n_in, size_t *n_frames) {
     RR_CHECK_HANDLE(h, K_CHAIN);

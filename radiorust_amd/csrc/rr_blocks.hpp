@@ -30,6 +30,7 @@ struct rr_filter : rr_block {
     rr::DevBuf hist[2];            // previous_chunk (n samples), ping-pong
     int cur = 0;
     bool hist_valid = false;  // previous_chunk.is_some()
+    uint64_t design_version = 0;
     bool needs_design(double sample_rate, size_t len) const {
         return !designed || params_changed || sample_rate != rate || len != n;
     }
@@ -51,6 +52,7 @@ struct rr_downsampler : rr_block {
     int cur = 0;
     std::vector<uint32_t> emit;
     rr::DevBuf d_emit;
+    uint64_t design_version = 0;
     int prepare(double input_rate);
     int peek(double input_rate, size_t n_in, size_t *n_out);
     int process_dev(double input_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
@@ -101,6 +103,23 @@ struct rr_chain : rr_block {
     size_t pending_len = 0;
     int last_fused = 0;
     StageTimers timers;
+    // ---- fused fast path state (rr_api.hip, "fused") ----
+    rr::DevBuf xh[2];  // last HX mixed samples of the stream entering the Filter (+ carry at the tail)
+    int xh_cur = 0;
+    size_t HX = 0;
+    size_t xh_count = 0;  // mixed samples tracked in xh since it was (re)allocated, saturating at HX
+    bool blocks_stale = false;  // Filter/Downsampler histories not updated by the fused kernels
+    uint64_t zrun = 0;          // Filter outputs since the last discontinuity
+    rr::DevBuf d_ctaps;
+    int Gp = 0;
+    size_t Lc = 0;
+    uint64_t ctaps_fl = ~0ull, ctaps_ds = ~0ull;
+    bool fused_candidate(double sample_rate) const;
+    int ensure_xh();
+    int ensure_ctaps();
+    int materialize();  // bring the per-block histories up to date after fused calls
+    int process_fused(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
+    int process_generic(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
     ~rr_chain() override;
     int peek(double sample_rate, size_t n_in, size_t *n_frames);
     int process_dev(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);

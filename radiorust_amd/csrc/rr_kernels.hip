@@ -146,18 +146,34 @@ __global__ __launch_bounds__(256) void k_fir(const v2<T> *__restrict__ hist, lon
             acc[r].x = 0;
             acc[r].y = 0;
         }
-        for (int j = 0; j < K; ++j) {
-            const auto w = taps[j];
+        // two-level summation: partial sums over 64 taps keep the rounding error
+        // of long filters (n = 4096) at the level of the FFT-based reference
+        for (int j0 = 0; j0 < K; j0 += 64) {
+            v2<T> part[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const v2<T> x = xs[base[r] + j];
-                if constexpr (CT) {
-                    acc[r].x += w.x * x.x - w.y * x.y;
-                    acc[r].y += w.x * x.y + w.y * x.x;
-                } else {
-                    acc[r].x += x.x * w;
-                    acc[r].y += x.y * w;
+                part[r].x = 0;
+                part[r].y = 0;
+            }
+            const int j1 = (j0 + 64 < K) ? j0 + 64 : K;
+            for (int j = j0; j < j1; ++j) {
+                const auto w = taps[j];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const v2<T> x = xs[base[r] + j];
+                    if constexpr (CT) {
+                        part[r].x += w.x * x.x - w.y * x.y;
+                        part[r].y += w.x * x.y + w.y * x.x;
+                    } else {
+                        part[r].x += x.x * w;
+                        part[r].y += x.y * w;
+                    }
                 }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                acc[r].x += part[r].x;
+                acc[r].y += part[r].y;
             }
         }
 #pragma unroll
@@ -374,6 +390,7 @@ int launch_fourier(int dtype, hipStream_t s, const void *in, void *out, size_t n
                    const void *twiddle, bool center_dc) {
     if (count == 0) return RR_OK;
     RR_TRY(fourier_supported(dtype, n));
+    if (dtype == RR_F32 && n == 4096) return launch_fft4096(s, in, out, count, window, twiddle, center_dc);
     if (dtype == RR_F32) return launch_fourier_t<float>(s, in, out, n, count, window, twiddle, center_dc, dtype);
     return launch_fourier_t<double>(s, in, out, n, count, window, twiddle, center_dc, dtype);
 }

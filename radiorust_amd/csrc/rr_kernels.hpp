@@ -47,6 +47,33 @@ bool fourier_pow2_path(int dtype, size_t n);
 int launch_fourier(int dtype, hipStream_t s, const void *in, void *out, size_t n, size_t count, const void *window,
                    const void *twiddle, bool center_dc);
 
+// ---- fused fast path (rr_fused.hip), Complex<f32> only ------------------------
+// v[m] = sum_i c[i] xs[e0 + D m - i]; xs = NCO-mixed input.  Virtual stream:
+// positions [-hx, 0) come from `xh` (already mixed), [0, n_in) from `in` (raw,
+// mixed on load with nco[(idx0 + pos) mod denom]).  `taps`: Gp*D floats in step
+// order (see build_combined_taps).
+struct FusedFirArgs {
+    const void *xh = nullptr;
+    size_t hx = 0;
+    const void *in = nullptr;
+    size_t n_in = 0;
+    const void *nco = nullptr;
+    uint32_t denom = 1, idx0 = 0;
+    const void *taps = nullptr;
+    int Gp = 0;
+    void *out = nullptr;
+    size_t n_out = 0;
+    int64_t e0 = 0;
+    uint32_t D = 1;
+};
+bool fused_fir_supported(uint64_t D, size_t Lc);
+int fused_fir_R(uint64_t D);  // outputs per lane of the instantiation for D
+int launch_fused_fir(hipStream_t s, const FusedFirArgs &a);
+// 4096-point windowed forward DFT (radix 16 x 3); tw4096[k] = e^{-j 2 pi k / 4096}, 4096 entries
+int launch_fft4096(hipStream_t s, const void *in, void *out, size_t count, const void *window, const void *tw4096,
+                   bool center_dc);
+int launch_drop_tail(hipStream_t s, const void *oldh, void *newh, size_t H, size_t drop);
+
 // SURVEY §8(d) synthetic IQ, f32
 int launch_synth(hipStream_t s, uint64_t seed, uint64_t t0, size_t n, void *out);
 

@@ -18,7 +18,7 @@ run() { # name timeout cmd...
   return 0
 }
 rocminfo | grep -m1 gfx || true
-run pytest 900 python -m pytest tests -m gpu -q -x --timeout 300 ${PYTEST_ARGS:-}
+run pytest 900 python -m pytest tests -m gpu -q --timeout 300 ${PYTEST_ARGS:-}
 run bench 600 python bench.py "$@"
 grep -h '^{' "$OUT/bench.log" > "$OUT/bench.json" || true
 export TMPDIR=/tmp

@@ -128,7 +128,7 @@ def test_freqshifter_errors(rr):
     g = rr.FreqShifter.with_precision_and_shift(100.0, 1.0)
     with pytest.raises(ContractViolation):  # 10 / 100 rounds to denom 0: Ratio::new panics
         g.process(rr.Samples(10.0, np.zeros(4, dtype=np.complex64)))
-    g2 = rr.FreqShifter.with_precision_and_shift(1e-3, 1.0)
+    g2 = rr.FreqShifter.with_precision_and_shift(1e-3, 1.001)  # 1001 / 2e11 does not reduce
     with pytest.raises(BackendError) as e:  # 2e11-entry table
         g2.process(rr.Samples(200e6, np.zeros(4, dtype=np.complex64)))
     assert e.value.status == RR_ERR_BAD_ARG
