@@ -483,8 +483,12 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     const size_t total = carry_len + n_in, whole = total / nf * nf, left = total - whole;
     const size_t dec = ds->sched.count(whole);
     const size_t have = pending_len + dec;
-    RR_TRY(decim.reserve((have ? have : 1) * esz));
-    if (pending_len) RR_HIP(hipMemcpyAsync(decim.p, pending.p, pending_len * esz, hipMemcpyDeviceToDevice, stream));
+    // the pending outputs go in front of the new ones; shift by one sample when
+    // needed so that the kernel's 16-byte stores of the new outputs are aligned
+    const size_t off = pending_len & 1;
+    RR_TRY(decim.reserve((have + off + 1) * esz));
+    char *dbase = decim.as<char>() + off * esz;
+    if (pending_len) RR_HIP(hipMemcpyAsync(dbase, pending.p, pending_len * esz, hipMemcpyDeviceToDevice, stream));
     FusedFirArgs a;
     a.xh = xh[xh_cur].p;
     a.hx = HX;
@@ -495,7 +499,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     a.idx0 = (uint32_t)fs->phase_idx;
     a.taps = d_ctaps.p;
     a.Gp = Gp;
-    a.out = decim.as<char>() + pending_len * esz;
+    a.out = dbase + pending_len * esz;
     a.n_out = dec;
     a.e0 = (int64_t)ds->sched.first_emit() - (int64_t)carry_len;
     a.D = (uint32_t)ds->sched.D;
@@ -518,10 +522,10 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     const size_t nfr = have / LF;
     size_t wrote = 0;
     tk = timers.begin(ST_FOURIER, stream);
-    RR_TRY(fo->process_dev(LF, decim.p, nfr * LF, d_out, cap, &wrote));
+    RR_TRY(fo->process_dev(LF, dbase, nfr * LF, d_out, cap, &wrote));
     timers.end(tk, stream);
     const size_t rest = have - nfr * LF;
-    if (rest) RR_HIP(hipMemcpyAsync(pending.p, decim.as<char>() + nfr * LF * esz, rest * esz, hipMemcpyDeviceToDevice, stream));
+    if (rest) RR_HIP(hipMemcpyAsync(pending.p, dbase + nfr * LF * esz, rest * esz, hipMemcpyDeviceToDevice, stream));
     pending_len = rest;
     last_fused = 1;
     if (n_out) *n_out = wrote;

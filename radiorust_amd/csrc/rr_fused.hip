@@ -47,77 +47,114 @@ template <int D, int R> struct FirGeom {
     static constexpr int OUT_STRIDE = R * 8 + 16;          // staged outputs per lane
 };
 
+// pairs of samples each lane prefetches per tile (upper bound of the real count)
+constexpr int kNPF = 18;
+
 template <int D, int R, int T>
-__global__ __launch_bounds__(T) void k_mix_fir_decim(const float2 *__restrict__ xh, int hx,
-                                                     const float2 *__restrict__ in, long n_in, int in_aligned16,
-                                                     const float2 *__restrict__ nco, unsigned denom, unsigned idx0,
-                                                     const float *__restrict__ taps, int Gp,
-                                                     float2 *__restrict__ out, long n_out, long e0,
-                                                     unsigned ntiles) {
+__global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict__ xh, int hx,
+                                                        const float2 *__restrict__ in, long n_in, int in_aligned16,
+                                                        const float2 *__restrict__ nco, unsigned denom, unsigned idx0,
+                                                        const float *__restrict__ taps, int Gp,
+                                                        float2 *__restrict__ out, long n_out, int out_aligned16,
+                                                        long e0, unsigned ntiles, unsigned tiles_per_wg) {
     using G = FirGeom<D, R>;
     constexpr int RD = G::RD, STRIDE = G::STRIDE;
     constexpr int OUTS = T * R;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(RD == 32 && (2 * T) % RD == 0, "LDS write addresses advance by whole rows per prefetch slot");
+    constexpr int ROWS_PER_SLOT = 2 * T / RD;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    // 32 spare bytes in front: when the tile starts at an odd sample, the first lane's
+    // pair straddles the tile start and its first half (sample -1 = row -1, column 31)
+    // lands there; slack rows at the end take the pairs past the tile end
+    char *smem = smem_raw + 32;
     const int rows = T + Gp / R;
-    float *tap_lds = reinterpret_cast<float *>(smem + (size_t)rows * STRIDE);
-
-    // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (round robin), give
-    // them consecutive tiles so the halo re-read hits that XCD's L2
-    unsigned tile;
-    {
-        const unsigned b = blockIdx.x, q = ntiles >> 3, rmd = ntiles & 7, xcd = b & 7;
-        tile = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (b >> 3);
-    }
-    const long mt = (long)tile * OUTS;
-    const long tile_lo = e0 + (long)D * mt - (long)D * Gp + 1;  // oldest sample of the tile
     const int NS = rows * RD;
-
-    // ---- taps -> LDS -------------------------------------------------------
+    const int lds_rows = rows + ROWS_PER_SLOT + 1;
+    float *tap_lds = reinterpret_cast<float *>(smem + (size_t)lds_rows * STRIDE);
     for (int i = threadIdx.x; i < Gp * D; i += T) tap_lds[i] = taps[i];
 
-    // ---- load + mix --------------------------------------------------------
+    // XCD-aware work split: workgroups b, b+8, b+16.. share an XCD (round robin);
+    // give each workgroup a contiguous run of tiles and neighbouring runs to one XCD,
+    // so the halo a tile shares with its predecessor is an L2 hit.
+    unsigned chunk;
     {
-        const long lo_even = tile_lo - (tile_lo & 1);
-        const int npairs = (int)((tile_lo + NS - lo_even + 1) >> 1);
-        const unsigned step = (unsigned)((2 * T) % denom);
-        long ph = ((long)idx0 + lo_even + 2 * (long)threadIdx.x) % (long)denom;
+        const unsigned b = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, rmd = nwg & 7, xcd = b & 7;
+        chunk = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (b >> 3);
+    }
+    const unsigned tile_begin = chunk * tiles_per_wg;
+    unsigned tile_end = tile_begin + tiles_per_wg;
+    if (tile_end > ntiles) tile_end = ntiles;
+    if (tile_begin >= tile_end) return;
+
+    // per-lane constants of the load phase -------------------------------------
+    const long lo0 = e0 - (long)D * Gp + 1;            // tile_lo of tile 0
+    const int odd = (int)(lo0 & 1);                    // same for every tile (D*OUTS is even)
+    const int npairs = (NS + odd + 1) >> 1;
+    const int sfirst = 2 * (int)threadIdx.x - odd;     // LDS sample index of this lane's first prefetched sample
+    // byte address of sample s (floor division, so s = -1 is row -1, column 31 = -24)
+    auto lds_addr = [&](int s) -> int { return (s >> 5) * STRIDE + (s & 31) * 8; };
+    const int a0 = lds_addr(sfirst), a1 = lds_addr(sfirst + 1);
+    const unsigned step = (unsigned)((2 * T) % denom);
+    const unsigned tstep = (unsigned)(((long)D * OUTS) % denom);
+    const bool nco_const = (step == 0 && tstep == 0);  // phasor of a lane never changes (e.g. denom = 8)
+
+    auto tile_lo_of = [&](unsigned tile) -> long { return lo0 + (long)D * OUTS * tile; };
+    auto interior_of = [&](long tile_lo) -> bool {
+        const long le = tile_lo - odd;
+        return in_aligned16 && le >= 0 && le + 2L * kNPF * T <= n_in;  // the whole prefetch window is inside `in`
+    };
+    long tile_lo = tile_lo_of(tile_begin);
+    unsigned rbase;
+    {
+        long ph = ((long)idx0 + (tile_lo - odd) + 2 * (long)threadIdx.x) % (long)denom;
         if (ph < 0) ph += denom;
-        unsigned rr_ = (unsigned)ph;
-        auto put = [&](int s, f2 v) {
-            if (s >= 0 && s < NS) *reinterpret_cast<f2 *>(smem + (s / RD) * STRIDE + (s % RD) * 8) = v;
-        };
-        // interior tiles (all but the first and last few): every pair is a 16-B
-        // aligned load inside `in`.  U pairs per lane are requested before the
-        // first one is used, so the HBM latency is paid once per batch.
-        const bool interior = in_aligned16 && lo_even >= 0 && lo_even + 2L * npairs <= n_in;  // workgroup-uniform
-        if (interior) {
-            constexpr int U = 6;
-            const f4 *src = reinterpret_cast<const f4 *>(in + lo_even);
-            for (int pb = 0; pb < npairs; pb += U * T) {
-                f4 x[U];
-                float2 p0[U], p1[U];
+        rbase = (unsigned)ph;
+    }
+    float2 pc0 = nco[rbase], pc1 = nco[(rbase + 1 == denom) ? 0 : rbase + 1];
+
+    f4 x[kNPF];
+    auto prefetch = [&](long tlo) {
+        const f4 *src = reinterpret_cast<const f4 *>(in + (tlo - odd)) + threadIdx.x;
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    int pi = pb + u * T + (int)threadIdx.x;
-                    pi = pi < npairs ? pi : npairs - 1;  // clamp instead of branching around the load
-                    x[u] = src[pi];
-                    p0[u] = nco[rr_];
-                    p1[u] = nco[(rr_ + 1 == denom) ? 0 : rr_ + 1];
+        for (int u = 0; u < kNPF; ++u) x[u] = src[u * T];
+    };
+    bool cur_interior = interior_of(tile_lo);
+    if (cur_interior) prefetch(tile_lo);
+
+    for (unsigned tile = tile_begin; tile < tile_end; ++tile) {
+        // ---- stage: (prefetched) raw samples -> mix -> LDS ----------------------
+        if (cur_interior) {
+            if (nco_const) {
+#pragma unroll
+                for (int u = 0; u < kNPF; ++u) {
+                    const bool ok = (int)threadIdx.x + u * T < npairs;
+                    const f2 v0 = {x[u].x * pc0.x - x[u].y * pc0.y, x[u].x * pc0.y + x[u].y * pc0.x};
+                    const f2 v1 = {x[u].z * pc1.x - x[u].w * pc1.y, x[u].z * pc1.y + x[u].w * pc1.x};
+                    if (ok) {
+                        *reinterpret_cast<f2 *>(smem + a0 + u * ROWS_PER_SLOT * STRIDE) = v0;
+                        *reinterpret_cast<f2 *>(smem + a1 + u * ROWS_PER_SLOT * STRIDE) = v1;
+                    }
+                }
+            } else {
+                unsigned rr_ = rbase;
+#pragma unroll
+                for (int u = 0; u < kNPF; ++u) {
+                    const bool ok = (int)threadIdx.x + u * T < npairs;
+                    const float2 p0 = nco[rr_], p1 = nco[(rr_ + 1 == denom) ? 0 : rr_ + 1];
+                    const f2 v0 = {x[u].x * p0.x - x[u].y * p0.y, x[u].x * p0.y + x[u].y * p0.x};
+                    const f2 v1 = {x[u].z * p1.x - x[u].w * p1.y, x[u].z * p1.y + x[u].w * p1.x};
+                    if (ok) {
+                        *reinterpret_cast<f2 *>(smem + a0 + u * ROWS_PER_SLOT * STRIDE) = v0;
+                        *reinterpret_cast<f2 *>(smem + a1 + u * ROWS_PER_SLOT * STRIDE) = v1;
+                    }
                     rr_ += step;
                     if (rr_ >= denom) rr_ -= denom;
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int pi = pb + u * T + (int)threadIdx.x;
-                    if (pi < npairs) {
-                        const int s0 = (int)(lo_even - tile_lo) + 2 * pi;
-                        put(s0, (f2){x[u].x * p0[u].x - x[u].y * p0[u].y, x[u].x * p0[u].y + x[u].y * p0[u].x});
-                        put(s0 + 1, (f2){x[u].z * p1[u].x - x[u].w * p1[u].y, x[u].z * p1[u].y + x[u].w * p1[u].x});
-                    }
                 }
             }
         } else {
             // edge tiles: history (already mixed), end of input, unaligned input
+            unsigned rr_ = rbase;
+            const long lo_even = tile_lo - odd;
             for (int pi = threadIdx.x; pi < npairs; pi += T) {
                 const long pe = lo_even + 2 * (long)pi;
                 const unsigned r1 = (rr_ + 1 == denom) ? 0 : rr_ + 1;
@@ -131,100 +168,104 @@ __global__ __launch_bounds__(T) void k_mix_fir_decim(const float2 *__restrict__ 
                             v = (f2){h.x, h.y};
                         }
                     } else if (pos < n_in) {
-                        const float2 x = in[pos];
+                        const float2 xx = in[pos];
                         const float2 pp = nco[k ? r1 : rr_];
-                        v = (f2){x.x * pp.x - x.y * pp.y, x.x * pp.y + x.y * pp.x};
+                        v = (f2){xx.x * pp.x - xx.y * pp.y, xx.x * pp.y + xx.y * pp.x};
                     }
-                    put((int)(pos - tile_lo), v);
+                    const int sidx = (int)(pos - tile_lo);
+                    if (sidx >= 0 && sidx < NS) *reinterpret_cast<f2 *>(smem + lds_addr(sidx)) = v;
                 }
                 rr_ += step;
                 if (rr_ >= denom) rr_ -= denom;
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // ---- FIR: rotating register window, packed FMAs ------------------------
-    f2 acc[R];
+        // ---- prefetch the next tile while this one is filtered -------------------
+        const long next_lo = tile_lo + (long)D * OUTS;
+        const bool next_interior = (tile + 1 < tile_end) && interior_of(next_lo);
+        if (next_interior) prefetch(next_lo);
+
+        // ---- FIR: rotating register window, packed FMAs --------------------------
+        f2 acc[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = (f2){0.f, 0.f};
-    f2 W[R][D];
-    const char *lane = smem + (size_t)threadIdx.x * STRIDE;
-    // block b of this lane lives at row b / R, column block b % R
-    auto load_block = [&](const char *row0, int b_static, f2(&dst)[D]) {
-        const char *p = row0 + (b_static / R) * STRIDE + (b_static % R) * (D * 8);
-        if constexpr (D % 2 == 0) {
-#pragma unroll
-            for (int q = 0; q < D / 2; ++q) {
-                const f4 v = *reinterpret_cast<const f4 *>(p + 16 * q);
-                dst[2 * q] = (f2){v.x, v.y};
-                dst[2 * q + 1] = (f2){v.z, v.w};
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < D; ++q) dst[q] = *reinterpret_cast<const f2 *>(p + 8 * q);
-        }
-    };
-#pragma unroll
-    for (int b = 0; b < R - 1; ++b) load_block(lane, b, W[b]);
-    const int nouter = Gp / R;
-    for (int to = 0; to < nouter; ++to) {
-        const char *row0 = lane + (size_t)to * STRIDE;
-        const float *tp = tap_lds + to * RD;
-#pragma unroll
-        for (int ti = 0; ti < R; ++ti) {
-            load_block(row0, ti + R - 1, W[(ti + R - 1) % R]);
-            float c[D];
-            if constexpr (D % 4 == 0) {
-#pragma unroll
-                for (int q = 0; q < D / 4; ++q) {
-                    const f4 t4 = *reinterpret_cast<const f4 *>(tp + ti * D + 4 * q);
-                    c[4 * q] = t4.x;
-                    c[4 * q + 1] = t4.y;
-                    c[4 * q + 2] = t4.z;
-                    c[4 * q + 3] = t4.w;
-                }
-            } else if constexpr (D % 2 == 0) {
+        for (int r = 0; r < R; ++r) acc[r] = (f2){0.f, 0.f};
+        {
+            f2 W[R][D];
+            const char *lane = smem + (size_t)threadIdx.x * STRIDE;
+            // block b of this lane lives at row b / R, column block b % R
+            auto load_block = [&](const char *row0, int b_static, f2(&dst)[D]) {
+                const char *p = row0 + (b_static / R) * STRIDE + (b_static % R) * (D * 8);
 #pragma unroll
                 for (int q = 0; q < D / 2; ++q) {
-                    const f2 t2 = *reinterpret_cast<const f2 *>(tp + ti * D + 2 * q);
-                    c[2 * q] = t2.x;
-                    c[2 * q + 1] = t2.y;
+                    const f4 v = *reinterpret_cast<const f4 *>(p + 16 * q);
+                    dst[2 * q] = (f2){v.x, v.y};
+                    dst[2 * q + 1] = (f2){v.z, v.w};
                 }
+            };
+#pragma unroll
+            for (int b = 0; b < R - 1; ++b) load_block(lane, b, W[b]);
+            const int nouter = Gp / R;
+            for (int to = 0; to < nouter; ++to) {
+                const char *row0 = lane + (size_t)to * STRIDE;
+                const float *tp = tap_lds + to * RD;
+#pragma unroll
+                for (int ti = 0; ti < R; ++ti) {
+                    load_block(row0, ti + R - 1, W[(ti + R - 1) % R]);
+                    float c[D];
+                    if constexpr (D % 4 == 0) {
+#pragma unroll
+                        for (int q = 0; q < D / 4; ++q) {
+                            const f4 t4 = *reinterpret_cast<const f4 *>(tp + ti * D + 4 * q);
+                            c[4 * q] = t4.x;
+                            c[4 * q + 1] = t4.y;
+                            c[4 * q + 2] = t4.z;
+                            c[4 * q + 3] = t4.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < D / 2; ++q) {
+                            const f2 t2 = *reinterpret_cast<const f2 *>(tp + ti * D + 2 * q);
+                            c[2 * q] = t2.x;
+                            c[2 * q + 1] = t2.y;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+#pragma unroll
+                        for (int q = 0; q < D; ++q) {
+                            const f2 cc = {c[q], c[q]};
+                            acc[r] = __builtin_elementwise_fma(W[(ti + r) % R][q], cc, acc[r]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();  // every wave is done reading this tile's samples
+
+        // ---- store: R consecutive outputs per lane ---------------------------------
+        {
+            const long m0 = (long)tile * OUTS + (long)threadIdx.x * R;
+            float2 *o = out + m0;
+            if (out_aligned16 && m0 + R <= n_out) {
+#pragma unroll
+                for (int r = 0; r < R; r += 2)
+                    *reinterpret_cast<f4 *>(o + r) = (f4){acc[r].x, acc[r].y, acc[r + 1].x, acc[r + 1].y};
             } else {
 #pragma unroll
-                for (int q = 0; q < D; ++q) c[q] = tp[ti * D + q];
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-#pragma unroll
-                for (int q = 0; q < D; ++q) {
-                    const f2 cc = {c[q], c[q]};
-                    acc[r] = __builtin_elementwise_fma(W[(ti + r) % R][q], cc, acc[r]);
-                }
+                for (int r = 0; r < R; ++r)
+                    if (m0 + r < n_out) {
+                        float2 w;
+                        w.x = acc[r].x;
+                        w.y = acc[r].y;
+                        o[r] = w;
+                    }
             }
         }
-    }
-    __syncthreads();
-
-    // ---- stage the R outputs of each lane, then store coalesced --------------
-    {
-        char *o = smem + (size_t)threadIdx.x * G::OUT_STRIDE;
-#pragma unroll
-        for (int r = 0; r < R; ++r) *reinterpret_cast<f2 *>(o + 8 * r) = acc[r];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const int e = threadIdx.x + k * T;
-        const long m = mt + e;
-        if (m < n_out) {
-            const f2 v = *reinterpret_cast<const f2 *>(smem + (e / R) * G::OUT_STRIDE + (e % R) * 8);
-            float2 w;
-            w.x = v.x;
-            w.y = v.y;
-            out[m] = w;
-        }
+        tile_lo = next_lo;
+        cur_interior = next_interior;
+        rbase += tstep;
+        if (rbase >= denom) rbase -= denom;
     }
 }
 
@@ -233,23 +274,36 @@ static int launch_mfd(hipStream_t s, const FusedFirArgs &a) {
     using G = FirGeom<D, R>;
     constexpr int OUTS = T * R;
     const int rows = T + a.Gp / R;
-    const size_t lds = (size_t)rows * G::STRIDE + (size_t)a.Gp * D * sizeof(float);
+    const int lds_rows = rows + 2 * T / G::RD + 1;
+    const size_t lds = 32 + (size_t)lds_rows * G::STRIDE + (size_t)a.Gp * D * sizeof(float);
+    if ((rows * G::RD + 2) / 2 > kNPF * T) RR_FAIL(RR_ERR_BAD_ARG, "fused FIR: %d tap groups exceed the prefetch window", a.Gp);
     auto fn = k_mix_fir_decim<D, R, T>;
     if (lds > 64 * 1024)
         RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const size_t ntiles = (a.n_out + OUTS - 1) / OUTS;
     if (ntiles > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fused FIR: too many tiles");
-    const int aligned = (reinterpret_cast<uintptr_t>(a.in) % 16 == 0) ? 1 : 0;
-    hipLaunchKernelGGL(fn, dim3((unsigned)ntiles), dim3(T), lds, s, (const float2 *)a.xh, (int)a.hx,
-                       (const float2 *)a.in, (long)a.n_in, aligned, (const float2 *)a.nco, a.denom, a.idx0,
-                       (const float *)a.taps, a.Gp, (float2 *)a.out, (long)a.n_out, (long)a.e0, (unsigned)ntiles);
+    // persistent grid: 4 workgroups of 2 waves per CU (LDS-limited), 256 CUs
+    size_t nwg = 256 * 4;
+    if (nwg > ntiles) nwg = ntiles;
+    const size_t tpw = (ntiles + nwg - 1) / nwg;
+    nwg = (ntiles + tpw - 1) / tpw;
+    const int in_al = (reinterpret_cast<uintptr_t>(a.in) % 16 == 0) ? 1 : 0;
+    const int out_al = (reinterpret_cast<uintptr_t>(a.out) % 16 == 0) ? 1 : 0;
+    hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(T), lds, s, (const float2 *)a.xh, (int)a.hx, (const float2 *)a.in,
+                       (long)a.n_in, in_al, (const float2 *)a.nco, a.denom, a.idx0, (const float *)a.taps, a.Gp,
+                       (float2 *)a.out, (long)a.n_out, out_al, (long)a.e0, (unsigned)ntiles, (unsigned)tpw);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
 
 bool fused_fir_supported(uint64_t D, size_t Lc) {
-    if (Lc == 0 || Lc > 4096) return false;  // LDS rows grow with the tap count
-    return D == 2 || D == 4 || D == 8 || D == 10;
+    if (!(D == 2 || D == 4 || D == 8) || Lc == 0) return false;
+    // tap groups (padded to a multiple of R) must fit the per-lane prefetch window
+    const int R = fused_fir_R(D);
+    const size_t groups = (Lc + D - 1) / D;
+    const size_t gp = (groups + R - 1) / R * R;
+    const size_t rows = 128 + gp / R;
+    return (rows * 32 + 2) / 2 <= (size_t)kNPF * 128;
 }
 
 int fused_fir_R(uint64_t D) {
@@ -257,7 +311,6 @@ int fused_fir_R(uint64_t D) {
         case 2: return 16;
         case 4: return 8;
         case 8: return 4;
-        case 10: return 3;
     }
     return 0;
 }
@@ -268,7 +321,6 @@ int launch_fused_fir(hipStream_t s, const FusedFirArgs &a) {
         case 2: return launch_mfd<2, 16, 128>(s, a);
         case 4: return launch_mfd<4, 8, 128>(s, a);
         case 8: return launch_mfd<8, 4, 128>(s, a);
-        case 10: return launch_mfd<10, 3, 128>(s, a);
     }
     RR_FAIL(RR_ERR_BAD_ARG, "fused FIR: decimation %u not instantiated", a.D);
 }
