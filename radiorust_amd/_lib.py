@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libradiorust_amd.so")
+# RR_LIB selects a diagnostic build (ablation/stamp variants of the same sources)
+LIB_PATH = os.environ.get("RR_LIB") or os.path.join(_HERE, "lib", "libradiorust_amd.so")
 
 RR_OK, RR_ERR_BAD_ARG, RR_ERR_CAPACITY, RR_ERR_HIP, RR_ERR_CONTRACT, RR_ERR_NEED_DESIGN, RR_ERR_NOT_READY = range(7)
 RR_F32, RR_F64 = 0, 1

@@ -435,8 +435,8 @@ int rr_chain::ensure_ctaps() {
         for (size_t k = 0; k < n; ++k) c[j + k] += a * fl->taps_f64[k].real();
     }
     const int D = (int)ds->sched.D, R = fused_fir_R(ds->sched.D);
-    const int groups = (int)((lc + D - 1) / D);
-    const int gp = (groups + R - 1) / R * R;
+    const int gp = (int)((lc + D - 1) / D);  // tap groups of D; the kernel runs gp/R full rounds + a partial one
+    (void)R;
     std::vector<float> tb((size_t)gp * D, 0.f);
     for (int t = 0; t < gp; ++t)
         for (int q = 0; q < D; ++q) {
@@ -454,6 +454,12 @@ int rr_chain::ensure_ctaps() {
 // After fused calls the Filter's previous chunk and the Downsampler's ring are
 // stale; rebuild both from the mixed-sample history before anything reads them.
 int rr_chain::materialize() {
+    if (pend_ptr) {
+        RR_TRY(select());
+        if (pending_len)
+            RR_HIP(hipMemcpyAsync(pending.p, pend_ptr, pending_len * elem_size(dtype), hipMemcpyDeviceToDevice, stream));
+        pend_ptr = nullptr;
+    }
     if (!blocks_stale) return RR_OK;
     RR_TRY(select());
     const size_t esz = elem_size(dtype), n = fl->n, L = ds->L;
@@ -483,12 +489,9 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     const size_t total = carry_len + n_in, whole = total / nf * nf, left = total - whole;
     const size_t dec = ds->sched.count(whole);
     const size_t have = pending_len + dec;
-    // the pending outputs go in front of the new ones; shift by one sample when
-    // needed so that the kernel's 16-byte stores of the new outputs are aligned
-    const size_t off = pending_len & 1;
-    RR_TRY(decim.reserve((have + off + 1) * esz));
-    char *dbase = decim.as<char>() + off * esz;
-    if (pending_len) RR_HIP(hipMemcpyAsync(dbase, pending.p, pending_len * esz, hipMemcpyDeviceToDevice, stream));
+    const size_t nfr = have / LF, rest = have - nfr * LF;
+    const bool split = (LF == 4096);  // k_fft4096 reads [pending | new] from two places: no copies
+    if (!split && pend_ptr) RR_TRY(materialize());
     FusedFirArgs a;
     a.xh = xh[xh_cur].p;
     a.hx = HX;
@@ -499,41 +502,78 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     a.idx0 = (uint32_t)fs->phase_idx;
     a.taps = d_ctaps.p;
     a.Gp = Gp;
-    a.out = dbase + pending_len * esz;
     a.n_out = dec;
     a.e0 = (int64_t)ds->sched.first_emit() - (int64_t)carry_len;
     a.D = (uint32_t)ds->sched.D;
+    a.xh_out = xh[xh_cur ^ 1].p;  // written by the kernel's last workgroup
+    char *newv = nullptr;
+    char *dbase = nullptr;
+    if (split) {
+        DevBuf &buf = dec2[dec_cur ^ 1];  // never the buffer the pending samples live in
+        RR_TRY(buf.reserve((dec + 2) * esz));
+        newv = buf.as<char>();
+    } else {
+        // pending outputs in front of the new ones; shifted by one sample when needed so
+        // that the kernel's 16-byte stores of the new outputs are aligned
+        const size_t off = pending_len & 1;
+        RR_TRY(decim.reserve((have + off + 1) * esz));
+        dbase = decim.as<char>() + off * esz;
+        if (pending_len) RR_HIP(hipMemcpyAsync(dbase, pending.p, pending_len * esz, hipMemcpyDeviceToDevice, stream));
+        newv = dbase + pending_len * esz;
+    }
+    a.out = newv;
     int tk = timers.begin(ST_FUSED_FIR, stream);
     RR_TRY(launch_fused_fir(stream, a));
     timers.end(tk, stream);
-    // mixed-sample history for the next call: mix the last HX raw samples again
-    const uint64_t den = (uint64_t)fs->denom;
-    const uint32_t tail_idx = (uint32_t)((fs->phase_idx + (n_in - HX) % den) % den);
-    RR_TRY(launch_freqshift(dtype, stream, static_cast<const char *>(d_in) + (n_in - HX) * esz, xh[xh_cur ^ 1].p, HX,
-                            fs->d_table.p, (uint32_t)fs->denom, tail_idx));
     xh_cur ^= 1;
     if (left) RR_HIP(hipMemcpyAsync(carry.p, xh[xh_cur].as<char>() + (HX - left) * esz, left * esz, hipMemcpyDeviceToDevice, stream));
+    const uint64_t den = (uint64_t)fs->denom;
     fs->phase_idx = (fs->phase_idx + n_in % den) % den;
     carry_len = left;
     ds->sched.advance(whole, nullptr);
     zrun += whole;
     blocks_stale = true;
     // Fourier on whole frames, the rest stays pending (resampling.rs:121-131)
-    const size_t nfr = have / LF;
     size_t wrote = 0;
     tk = timers.begin(ST_FOURIER, stream);
-    RR_TRY(fo->process_dev(LF, dbase, nfr * LF, d_out, cap, &wrote));
+    if (split) {
+        if (nfr * LF > cap) RR_FAIL(RR_ERR_CAPACITY, "Chain: out_cap %zu < %zu", cap, nfr * LF);
+        RR_TRY(fo->prepare(LF));
+        const void *head = pend_ptr ? pend_ptr : pending.p;
+        RR_TRY(launch_fft4096(stream, head, pending_len, newv, d_out, nfr, fo->d_window.p, fo->d_tw.p, fo->center_dc));
+        wrote = nfr * LF;
+        if (nfr) {  // the leftover is the tail of the new outputs
+            pend_ptr = newv + (nfr * LF - pending_len) * esz;
+            dec_cur ^= 1;
+        } else if (dec) {
+            // no frame completed: append the new outputs to the pending chunk
+            RR_TRY(materialize_pending_append(newv, dec));
+        }
+    } else {
+        RR_TRY(fo->process_dev(LF, dbase, nfr * LF, d_out, cap, &wrote));
+        if (rest) RR_HIP(hipMemcpyAsync(pending.p, dbase + nfr * LF * esz, rest * esz, hipMemcpyDeviceToDevice, stream));
+    }
     timers.end(tk, stream);
-    const size_t rest = have - nfr * LF;
-    if (rest) RR_HIP(hipMemcpyAsync(pending.p, dbase + nfr * LF * esz, rest * esz, hipMemcpyDeviceToDevice, stream));
     pending_len = rest;
     last_fused = 1;
     if (n_out) *n_out = wrote;
     return RR_OK;
 }
 
+// fewer than fft_len outputs in total: gather [pending | new] into the `pending` buffer
+int rr_chain::materialize_pending_append(const void *newv, size_t dec) {
+    const size_t esz = elem_size(dtype);
+    if (pend_ptr) {
+        if (pending_len)
+            RR_HIP(hipMemcpyAsync(pending.p, pend_ptr, pending_len * esz, hipMemcpyDeviceToDevice, stream));
+        pend_ptr = nullptr;
+    }
+    RR_HIP(hipMemcpyAsync(pending.as<char>() + pending_len * esz, newv, dec * esz, hipMemcpyDeviceToDevice, stream));
+    return RR_OK;
+}
+
 int rr_chain::process_generic(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out) {
-    if (blocks_stale) RR_TRY(materialize());
+    if (blocks_stale || pend_ptr) RR_TRY(materialize());
     const size_t esz = elem_size(dtype);
     // 1. FreqShifter -> mixed[carry_len ..)
     const size_t total = carry_len + n_in;

@@ -111,6 +111,11 @@ struct rr_chain : rr_block {
     bool blocks_stale = false;  // Filter/Downsampler histories not updated by the fused kernels
     uint64_t zrun = 0;          // Filter outputs since the last discontinuity
     rr::DevBuf d_ctaps;
+    // fused path with fft_len 4096: the Downsampler's partly filled chunk stays where the
+    // kernel wrote it (tail of one of two output buffers) instead of being copied around
+    rr::DevBuf dec2[2];
+    int dec_cur = 0;
+    const void *pend_ptr = nullptr;  // non-null: pending samples live here, not in `pending`
     int Gp = 0;
     size_t Lc = 0;
     uint64_t ctaps_fl = ~0ull, ctaps_ds = ~0ull;
@@ -118,6 +123,7 @@ struct rr_chain : rr_block {
     int ensure_xh();
     int ensure_ctaps();
     int materialize();  // bring the per-block histories up to date after fused calls
+    int materialize_pending_append(const void *newv, size_t dec);
     int process_fused(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
     int process_generic(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
     ~rr_chain() override;

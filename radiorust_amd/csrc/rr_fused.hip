@@ -29,6 +29,7 @@
 #include "rr_blocks.hpp"
 
 #include <cmath>
+#include <utility>
 
 namespace rr {
 
@@ -50,13 +51,44 @@ template <int D, int R> struct FirGeom {
 // pairs of samples each lane prefetches per tile (upper bound of the real count)
 constexpr int kNPF = 18;
 
+#ifdef RR_STAMP
+// diagnostic build: per-phase cycle sums (s_memtime), summed over all waves
+__device__ unsigned long long g_stamp[8];
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define RR_STAMP_T(var) const unsigned long long var = stamp()
+#define RR_STAMP_ADD(i, a, b) st_acc[i] += (b) - (a)
+#else
+#define RR_STAMP_T(var)
+#define RR_STAMP_ADD(i, a, b)
+#endif
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains
+// vmcnt(0), i.e. it would wait for the next tile's prefetch and for this tile's
+// output stores; global memory is not shared between the waves here.
+__device__ __forceinline__ void lds_barrier() {
+#ifndef RR_V_RAWBARRIER  // measured on MI355X: the plain barrier (which also drains vmcnt) is 8 % FASTER here
+    __syncthreads();
+    return;
+#endif
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 template <int D, int R, int T>
 __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict__ xh, int hx,
                                                         const float2 *__restrict__ in, long n_in, int in_aligned16,
                                                         const float2 *__restrict__ nco, unsigned denom, unsigned idx0,
                                                         const float *__restrict__ taps, int Gp,
                                                         float2 *__restrict__ out, long n_out, int out_aligned16,
-                                                        long e0, unsigned ntiles, unsigned tiles_per_wg) {
+                                                        long e0, unsigned ntiles, unsigned tiles_per_wg,
+                                                        float2 *__restrict__ xh_out, int hx_out) {
     using G = FirGeom<D, R>;
     constexpr int RD = G::RD, STRIDE = G::STRIDE;
     constexpr int OUTS = T * R;
@@ -67,7 +99,7 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
     // pair straddles the tile start and its first half (sample -1 = row -1, column 31)
     // lands there; slack rows at the end take the pairs past the tile end
     char *smem = smem_raw + 32;
-    const int rows = T + Gp / R;
+    const int rows = T + (Gp + R - 2) / R;  // the last lane reads blocks up to R*(T-1) + Gp + R - 2
     const int NS = rows * RD;
     const int lds_rows = rows + ROWS_PER_SLOT + 1;
     float *tap_lds = reinterpret_cast<float *>(smem + (size_t)lds_rows * STRIDE);
@@ -84,6 +116,23 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
     const unsigned tile_begin = chunk * tiles_per_wg;
     unsigned tile_end = tile_begin + tiles_per_wg;
     if (tile_end > ntiles) tile_end = ntiles;
+    // The workgroup that owns the last run of tiles also leaves the mixed-sample
+    // history for the next call: xh_out = the last hx_out mixed samples of this call.
+    if (xh_out && chunk == gridDim.x - 1) {
+        for (int i = threadIdx.x; i < hx_out; i += T) {
+            const long pos = n_in - hx_out + i;
+            float2 v;
+            if (pos >= 0) {
+                const float2 xx = in[pos];
+                const float2 pp = nco[(unsigned)(((long)idx0 + pos) % (long)denom)];
+                v.x = xx.x * pp.x - xx.y * pp.y;
+                v.y = xx.x * pp.y + xx.y * pp.x;
+            } else {
+                v = (pos >= -(long)hx) ? xh[hx + pos] : float2{0.f, 0.f};
+            }
+            xh_out[i] = v;
+        }
+    }
     if (tile_begin >= tile_end) return;
 
     // per-lane constants of the load phase -------------------------------------
@@ -114,26 +163,57 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
 
     f4 x[kNPF];
     auto prefetch = [&](long tlo) {
+#if defined(RR_ABLATE) && (RR_ABLATE == 2 || RR_ABLATE == 3 || RR_ABLATE == 4)  // diagnostic: no global loads
+#pragma unroll
+        for (int u = 0; u < kNPF; ++u) x[u] = (f4){1.f, 2.f, 3.f, (float)tlo};
+#else
         const f4 *src = reinterpret_cast<const f4 *>(in + (tlo - odd)) + threadIdx.x;
 #pragma unroll
         for (int u = 0; u < kNPF; ++u) x[u] = src[u * T];
+#endif
     };
     bool cur_interior = interior_of(tile_lo);
     if (cur_interior) prefetch(tile_lo);
+#ifdef RR_V_STAGGER
+    // Workgroups that share a CU start a fraction of a tile period apart, so that the
+    // load/stage/store phases of one wave overlap the FIR loop of its SIMD partner
+    // instead of all waves doing the same thing at the same time.
+    {
+        const unsigned slot = (blockIdx.x >> 8) & 3;  // round-robin dispatch: b and b + 256 land on the same CU
+        for (unsigned k = 0; k < slot * RR_V_STAGGER; ++k) __builtin_amdgcn_s_sleep(64);
+    }
+#endif
 
+#ifdef RR_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (unsigned tile = tile_begin; tile < tile_end; ++tile) {
-        // ---- stage: (prefetched) raw samples -> mix -> LDS ----------------------
+        RR_STAMP_T(ts0);
+        // ---- stage: (prefetched) raw samples -> mix -> LDS; each prefetch slot is
+        //      re-issued for the next tile as soon as it has been consumed ----------
+        const long next_lo = tile_lo + (long)D * OUTS;
+        const bool next_interior = (tile + 1 < tile_end) && interior_of(next_lo);
+        const f4 *nsrc = reinterpret_cast<const f4 *>(in + (next_lo - odd)) + threadIdx.x;
+        // x * p = x.re * (p.re, p.im) + x.im * (-p.im, p.re): one packed mul + one packed fma
+        auto mix = [](f2 xv, f2 p, f2 pj) -> f2 { return __builtin_elementwise_fma(xv.yy, pj, xv.xx * p); };
+#if defined(RR_ABLATE) && RR_ABLATE == 3  // diagnostic: no stage either
+        if (false) {
+#else
         if (cur_interior) {
+#endif
             if (nco_const) {
+                const f2 q0 = {pc0.x, pc0.y}, q0j = {-pc0.y, pc0.x}, q1 = {pc1.x, pc1.y}, q1j = {-pc1.y, pc1.x};
 #pragma unroll
                 for (int u = 0; u < kNPF; ++u) {
                     const bool ok = (int)threadIdx.x + u * T < npairs;
-                    const f2 v0 = {x[u].x * pc0.x - x[u].y * pc0.y, x[u].x * pc0.y + x[u].y * pc0.x};
-                    const f2 v1 = {x[u].z * pc1.x - x[u].w * pc1.y, x[u].z * pc1.y + x[u].w * pc1.x};
+                    const f2 v0 = mix(x[u].xy, q0, q0j), v1 = mix(x[u].zw, q1, q1j);
                     if (ok) {
                         *reinterpret_cast<f2 *>(smem + a0 + u * ROWS_PER_SLOT * STRIDE) = v0;
                         *reinterpret_cast<f2 *>(smem + a1 + u * ROWS_PER_SLOT * STRIDE) = v1;
                     }
+#ifdef RR_V_REISSUE  // measured slower: re-issuing each slot inside the stage loop
+                    if (next_interior) x[u] = nsrc[u * T];
+#endif
                 }
             } else {
                 unsigned rr_ = rbase;
@@ -141,12 +221,15 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
                 for (int u = 0; u < kNPF; ++u) {
                     const bool ok = (int)threadIdx.x + u * T < npairs;
                     const float2 p0 = nco[rr_], p1 = nco[(rr_ + 1 == denom) ? 0 : rr_ + 1];
-                    const f2 v0 = {x[u].x * p0.x - x[u].y * p0.y, x[u].x * p0.y + x[u].y * p0.x};
-                    const f2 v1 = {x[u].z * p1.x - x[u].w * p1.y, x[u].z * p1.y + x[u].w * p1.x};
+                    const f2 v0 = mix(x[u].xy, (f2){p0.x, p0.y}, (f2){-p0.y, p0.x});
+                    const f2 v1 = mix(x[u].zw, (f2){p1.x, p1.y}, (f2){-p1.y, p1.x});
                     if (ok) {
                         *reinterpret_cast<f2 *>(smem + a0 + u * ROWS_PER_SLOT * STRIDE) = v0;
                         *reinterpret_cast<f2 *>(smem + a1 + u * ROWS_PER_SLOT * STRIDE) = v1;
                     }
+#ifdef RR_V_REISSUE
+                    if (next_interior) x[u] = nsrc[u * T];
+#endif
                     rr_ += step;
                     if (rr_ >= denom) rr_ -= denom;
                 }
@@ -178,13 +261,15 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
                 rr_ += step;
                 if (rr_ >= denom) rr_ -= denom;
             }
+            if (next_interior) prefetch(next_lo);
         }
-        __syncthreads();
-
-        // ---- prefetch the next tile while this one is filtered -------------------
-        const long next_lo = tile_lo + (long)D * OUTS;
-        const bool next_interior = (tile + 1 < tile_end) && interior_of(next_lo);
-        if (next_interior) prefetch(next_lo);
+        RR_STAMP_T(ts1);
+        lds_barrier();
+        RR_STAMP_T(ts2);
+#ifndef RR_V_REISSUE  // prefetch the next tile once the stage barrier is passed
+        if (cur_interior && next_interior) prefetch(next_lo);
+#endif
+        RR_STAMP_T(ts3);
 
         // ---- FIR: rotating register window, packed FMAs --------------------------
         f2 acc[R];
@@ -205,43 +290,60 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
             };
 #pragma unroll
             for (int b = 0; b < R - 1; ++b) load_block(lane, b, W[b]);
-            const int nouter = Gp / R;
+            // one tap group: read block (t + R - 1) and D taps, R*D packed FMAs
+            auto fir_step = [&](auto TI, const char *row0, const float *tp) {
+                constexpr int ti = decltype(TI)::value;
+                load_block(row0, ti + R - 1, W[(ti + R - 1) % R]);
+                float c[D];
+                if constexpr (D % 4 == 0) {
+#pragma unroll
+                    for (int q = 0; q < D / 4; ++q) {
+                        const f4 t4 = *reinterpret_cast<const f4 *>(tp + ti * D + 4 * q);
+                        c[4 * q] = t4.x;
+                        c[4 * q + 1] = t4.y;
+                        c[4 * q + 2] = t4.z;
+                        c[4 * q + 3] = t4.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < D / 2; ++q) {
+                        const f2 t2 = *reinterpret_cast<const f2 *>(tp + ti * D + 2 * q);
+                        c[2 * q] = t2.x;
+                        c[2 * q + 1] = t2.y;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+#pragma unroll
+                    for (int q = 0; q < D; ++q) {
+                        const f2 cc = {c[q], c[q]};
+                        acc[r] = __builtin_elementwise_fma(W[(ti + r) % R][q], cc, acc[r]);
+                    }
+                }
+            };
+#if defined(RR_ABLATE) && (RR_ABLATE == 1 || RR_ABLATE == 4)  // diagnostic: one round of tap groups instead of all
+            const int nouter = 1, rem = 0;
+#else
+            const int nouter = Gp / R, rem = Gp % R;
+#endif
             for (int to = 0; to < nouter; ++to) {
                 const char *row0 = lane + (size_t)to * STRIDE;
                 const float *tp = tap_lds + to * RD;
-#pragma unroll
-                for (int ti = 0; ti < R; ++ti) {
-                    load_block(row0, ti + R - 1, W[(ti + R - 1) % R]);
-                    float c[D];
-                    if constexpr (D % 4 == 0) {
-#pragma unroll
-                        for (int q = 0; q < D / 4; ++q) {
-                            const f4 t4 = *reinterpret_cast<const f4 *>(tp + ti * D + 4 * q);
-                            c[4 * q] = t4.x;
-                            c[4 * q + 1] = t4.y;
-                            c[4 * q + 2] = t4.z;
-                            c[4 * q + 3] = t4.w;
-                        }
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < D / 2; ++q) {
-                            const f2 t2 = *reinterpret_cast<const f2 *>(tp + ti * D + 2 * q);
-                            c[2 * q] = t2.x;
-                            c[2 * q + 1] = t2.y;
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-#pragma unroll
-                        for (int q = 0; q < D; ++q) {
-                            const f2 cc = {c[q], c[q]};
-                            acc[r] = __builtin_elementwise_fma(W[(ti + r) % R][q], cc, acc[r]);
-                        }
-                    }
-                }
+                [&]<int... I>(std::integer_sequence<int, I...>) {
+                    (fir_step(std::integral_constant<int, I>{}, row0, tp), ...);
+                }(std::make_integer_sequence<int, R>{});
+            }
+            if (rem) {  // the last, partial round (workgroup-uniform)
+                const char *row0 = lane + (size_t)nouter * STRIDE;
+                const float *tp = tap_lds + nouter * RD;
+                [&]<int... I>(std::integer_sequence<int, I...>) {
+                    ((I < rem ? fir_step(std::integral_constant<int, I>{}, row0, tp) : (void)0), ...);
+                }(std::make_integer_sequence<int, R - 1>{});
             }
         }
-        __syncthreads();  // every wave is done reading this tile's samples
+        RR_STAMP_T(ts4);
+        lds_barrier();  // every wave is done reading this tile's samples
+        RR_STAMP_T(ts5);
 
         // ---- store: R consecutive outputs per lane ---------------------------------
         {
@@ -262,18 +364,31 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
                     }
             }
         }
+        RR_STAMP_T(ts6);
+        RR_STAMP_ADD(0, ts0, ts1);  // stage
+        RR_STAMP_ADD(1, ts1, ts2);  // barrier after stage
+        RR_STAMP_ADD(2, ts2, ts3);  // prefetch issue
+        RR_STAMP_ADD(3, ts3, ts4);  // FIR loop
+        RR_STAMP_ADD(4, ts4, ts5);  // barrier after FIR
+        RR_STAMP_ADD(5, ts5, ts6);  // store
         tile_lo = next_lo;
         cur_interior = next_interior;
         rbase += tstep;
         if (rbase >= denom) rbase -= denom;
     }
+#ifdef RR_STAMP
+    if ((threadIdx.x & 63) == 0) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_stamp[i], st_acc[i]);
+        atomicAdd(&g_stamp[7], 1ull);
+    }
+#endif
 }
 
 template <int D, int R, int T>
 static int launch_mfd(hipStream_t s, const FusedFirArgs &a) {
     using G = FirGeom<D, R>;
     constexpr int OUTS = T * R;
-    const int rows = T + a.Gp / R;
+    const int rows = T + (a.Gp + R - 2) / R;
     const int lds_rows = rows + 2 * T / G::RD + 1;
     const size_t lds = 32 + (size_t)lds_rows * G::STRIDE + (size_t)a.Gp * D * sizeof(float);
     if ((rows * G::RD + 2) / 2 > kNPF * T) RR_FAIL(RR_ERR_BAD_ARG, "fused FIR: %d tap groups exceed the prefetch window", a.Gp);
@@ -282,8 +397,8 @@ static int launch_mfd(hipStream_t s, const FusedFirArgs &a) {
         RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const size_t ntiles = (a.n_out + OUTS - 1) / OUTS;
     if (ntiles > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fused FIR: too many tiles");
-    // persistent grid: 4 workgroups of 2 waves per CU (LDS-limited), 256 CUs
-    size_t nwg = 256 * 4;
+    // persistent grid: 8 waves per CU (LDS-limited), 256 CUs
+    size_t nwg = 256 * (512 / T);
     if (nwg > ntiles) nwg = ntiles;
     const size_t tpw = (ntiles + nwg - 1) / nwg;
     nwg = (ntiles + tpw - 1) / tpw;
@@ -291,7 +406,8 @@ static int launch_mfd(hipStream_t s, const FusedFirArgs &a) {
     const int out_al = (reinterpret_cast<uintptr_t>(a.out) % 16 == 0) ? 1 : 0;
     hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(T), lds, s, (const float2 *)a.xh, (int)a.hx, (const float2 *)a.in,
                        (long)a.n_in, in_al, (const float2 *)a.nco, a.denom, a.idx0, (const float *)a.taps, a.Gp,
-                       (float2 *)a.out, (long)a.n_out, out_al, (long)a.e0, (unsigned)ntiles, (unsigned)tpw);
+                       (float2 *)a.out, (long)a.n_out, out_al, (long)a.e0, (unsigned)ntiles, (unsigned)tpw,
+                       (float2 *)a.xh_out, (int)a.hx);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
@@ -300,10 +416,9 @@ bool fused_fir_supported(uint64_t D, size_t Lc) {
     if (!(D == 2 || D == 4 || D == 8) || Lc == 0) return false;
     // tap groups (padded to a multiple of R) must fit the per-lane prefetch window
     const int R = fused_fir_R(D);
-    const size_t groups = (Lc + D - 1) / D;
-    const size_t gp = (groups + R - 1) / R * R;
-    const size_t rows = 128 + gp / R;
-    return (rows * 32 + 2) / 2 <= (size_t)kNPF * 128;
+    const size_t gp = (Lc + D - 1) / D;
+    const size_t rows = 128 + (gp + R - 2) / R;
+    return (rows * 32 + 2) / 2 <= (size_t)kNPF * 128;  // (T = 128 geometry; T = 256 has more slack)
 }
 
 int fused_fir_R(uint64_t D) {
@@ -319,7 +434,11 @@ int launch_fused_fir(hipStream_t s, const FusedFirArgs &a) {
     if (a.n_out == 0) return RR_OK;
     switch (a.D) {
         case 2: return launch_mfd<2, 16, 128>(s, a);
+#ifdef RR_V_T256
+        case 4: return launch_mfd<4, 8, 256>(s, a);
+#else
         case 4: return launch_mfd<4, 8, 128>(s, a);
+#endif
         case 8: return launch_mfd<8, 4, 128>(s, a);
     }
     RR_FAIL(RR_ERR_BAD_ARG, "fused FIR: decimation %u not instantiated", a.D);
@@ -371,17 +490,40 @@ __device__ __forceinline__ void dft16(f2 (&v)[16]) {
 
 __device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
 
-__global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ in, float2 *__restrict__ out,
+// wp[k] = w^k, k = 1..15, every power at most 4 complex products deep
+__device__ __forceinline__ void twiddle_powers(f2 w, f2 (&wp)[16]) {
+    wp[1] = w;
+    wp[2] = cmulf(w, w);
+    wp[3] = cmulf(wp[2], w);
+    wp[4] = cmulf(wp[2], wp[2]);
+    wp[5] = cmulf(wp[4], w);
+    wp[6] = cmulf(wp[4], wp[2]);
+    wp[7] = cmulf(wp[4], wp[3]);
+    wp[8] = cmulf(wp[4], wp[4]);
+    wp[9] = cmulf(wp[8], w);
+    wp[10] = cmulf(wp[8], wp[2]);
+    wp[11] = cmulf(wp[8], wp[3]);
+    wp[12] = cmulf(wp[8], wp[4]);
+    wp[13] = cmulf(wp[8], wp[5]);
+    wp[14] = cmulf(wp[8], wp[6]);
+    wp[15] = cmulf(wp[8], wp[7]);
+}
+
+// The input stream of frames is [ head (n_head samples) | in ]: the head is the
+// Downsampler's partly filled output chunk left over by the previous call.
+__global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head, long n_head,
+                                                 const float2 *__restrict__ in, float2 *__restrict__ out,
                                                  const float *__restrict__ window, const float2 *__restrict__ tw,
                                                  int center_dc) {
     __shared__ f2 lds[4096 + 256];
     const int j = threadIdx.x;
-    const float2 *src = in + (size_t)blockIdx.x * 4096;
+    const long base = (long)blockIdx.x * 4096 - n_head;  // index into `in` of this frame's first sample
     float2 *dst = out + (size_t)blockIdx.x * 4096;
     f2 v[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const float2 x = src[j + 256 * k];
+        const long i = base + j + 256 * k;
+        const float2 x = (i >= 0) ? in[i] : head[n_head + i];
         const float w = window[j + 256 * k];
         v[k] = (f2){x.x * w, x.y * w};
     }
@@ -394,12 +536,13 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ in, 
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = lds[pad16(j + 256 * k)];
     {
-        const int jm = j & 15;
+        // e^{-j 2 pi k (j mod 16) / 256} = w^k with w = tw[16 (j mod 16)]: one
+        // table read, powers by a depth-4 product tree (error ~4 ulp, not 15)
+        f2 wp[16];
+        const float2 t = tw[16 * (j & 15)];
+        twiddle_powers((f2){t.x, t.y}, wp);
 #pragma unroll
-        for (int k = 1; k < 16; ++k) {
-            const float2 t = tw[16 * k * jm];
-            v[k] = cmulf(v[k], (f2){t.x, t.y});
-        }
+        for (int k = 1; k < 16; ++k) v[k] = cmulf(v[k], wp[k]);
     }
     dft16(v);
     __syncthreads();
@@ -412,10 +555,12 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ in, 
     // pass 2 (Ns = 256): twiddle e^{-j 2 pi k j / 4096}; out j + 256 k
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = lds[pad16(j + 256 * k)];
+    {
+        f2 wp[16];
+        const float2 t = tw[j];  // e^{-j 2 pi j / 4096}, coalesced
+        twiddle_powers((f2){t.x, t.y}, wp);
 #pragma unroll
-    for (int k = 1; k < 16; ++k) {
-        const float2 t = tw[k * j];
-        v[k] = cmulf(v[k], (f2){t.x, t.y});
+        for (int k = 1; k < 16; ++k) v[k] = cmulf(v[k], wp[k]);
     }
     dft16(v);
     const int rot = center_dc ? 2048 : 0;
@@ -429,11 +574,12 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ in, 
     }
 }
 
-int launch_fft4096(hipStream_t s, const void *in, void *out, size_t count, const void *window, const void *tw4096,
-                   bool center_dc) {
+int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
+                   const void *window, const void *tw4096, bool center_dc) {
     if (count == 0) return RR_OK;
     if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fft4096: too many frames");
-    hipLaunchKernelGGL(k_fft4096, dim3((unsigned)count), dim3(256), 0, s, (const float2 *)in, (float2 *)out,
+    hipLaunchKernelGGL(k_fft4096, dim3((unsigned)count), dim3(256), 0, s, (const float2 *)head, (long)n_head,
+                       (const float2 *)in, (float2 *)out,
                        (const float *)window, (const float2 *)tw4096, (int)center_dc);
     RR_HIP(hipGetLastError());
     return RR_OK;
@@ -449,6 +595,19 @@ __global__ void k_drop_tail(const float2 *__restrict__ oldh, float2 *__restrict_
     if (i >= drop) v = oldh[i - drop];
     newh[i] = v;
 }
+
+#ifdef RR_STAMP
+extern "C" int rr_debug_read_stamps(unsigned long long *out8, int reset) {
+    unsigned long long h[8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp), sizeof h) != hipSuccess) return 1;
+    for (int i = 0; i < 8; ++i) out8[i] = h[i];
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 int launch_drop_tail(hipStream_t s, const void *oldh, void *newh, size_t H, size_t drop) {
     if (H == 0) return RR_OK;

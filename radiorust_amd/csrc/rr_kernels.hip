@@ -390,7 +390,7 @@ int launch_fourier(int dtype, hipStream_t s, const void *in, void *out, size_t n
                    const void *twiddle, bool center_dc) {
     if (count == 0) return RR_OK;
     RR_TRY(fourier_supported(dtype, n));
-    if (dtype == RR_F32 && n == 4096) return launch_fft4096(s, in, out, count, window, twiddle, center_dc);
+    if (dtype == RR_F32 && n == 4096) return launch_fft4096(s, nullptr, 0, in, out, count, window, twiddle, center_dc);
     if (dtype == RR_F32) return launch_fourier_t<float>(s, in, out, n, count, window, twiddle, center_dc, dtype);
     return launch_fourier_t<double>(s, in, out, n, count, window, twiddle, center_dc, dtype);
 }

@@ -65,13 +65,15 @@ struct FusedFirArgs {
     size_t n_out = 0;
     int64_t e0 = 0;
     uint32_t D = 1;
+    void *xh_out = nullptr;  // receives the last hx mixed samples of this call (may be null)
 };
 bool fused_fir_supported(uint64_t D, size_t Lc);
 int fused_fir_R(uint64_t D);  // outputs per lane of the instantiation for D
 int launch_fused_fir(hipStream_t s, const FusedFirArgs &a);
 // 4096-point windowed forward DFT (radix 16 x 3); tw4096[k] = e^{-j 2 pi k / 4096}, 4096 entries
-int launch_fft4096(hipStream_t s, const void *in, void *out, size_t count, const void *window, const void *tw4096,
-                   bool center_dc);
+// frames are cut from the stream [ head (n_head samples) | in ]
+int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
+                   const void *window, const void *tw4096, bool center_dc);
 int launch_drop_tail(hipStream_t s, const void *oldh, void *newh, size_t H, size_t drop);
 
 // SURVEY §8(d) synthetic IQ, f32
