@@ -90,18 +90,13 @@ def main():
     import numpy as np
     import torch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the backend has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    from radiorust_amd.dist import Ranks, whole_job_rate
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    ranks = Ranks("nccl")
+    world, rank, local_rank = ranks.world, ranks.rank, ranks.local_rank
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world} rank(s)", file=sys.stderr)
 
@@ -114,7 +109,7 @@ def main():
                      fft_window=rr.Kaiser.with_null_at_bin(2.0), device=local_rank, allow_fused=not args.no_fused)
     chain.set_stream(stream)
     d_in = torch.empty(n, dtype=torch.complex64, device="cuda")
-    rr.synth_iq_dev(local_rank, stream, rank + 1, 0, n, d_in.data_ptr())  # one channel per rank
+    rr.synth_iq_dev(local_rank, stream, ranks.channel_seed(), 0, n, d_in.data_ptr())  # one channel per rank
     cap = (n // 4 // 4096 + 2) * 4096
     d_out = torch.empty(cap, dtype=torch.complex64, device="cuda")
 
@@ -143,10 +138,7 @@ def main():
     lib.rr_chain_timing_enable(chain._h, 1)
     lib.rr_chain_timing_reset(chain._h)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
+    barrier = ranks.barrier
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -157,10 +149,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     fused = chain.last_path_fused()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = ranks.max_over_ranks(elapsed)
 
     # per-kernel device time from the library's hipEvents
     stages = {}
@@ -176,14 +165,19 @@ def main():
         i += 1
 
     if rank == 0:
-        total_samples = float(world) * n * args.steps
-        value = total_samples / elapsed / 1e6
+        value = whole_job_rate(n, args.steps, world, elapsed)
         dom = max(stages, key=lambda k: stages[k]["avg_ms"])
         avg_s = stages[dom]["avg_ms"] * 1e-3
         achieved = ALG_BYTES_PER_SAMPLE * n / avg_s / 1e9
+        # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc
+        # passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; scripts/gpu_pmc.sh), committed
+        # under profiles/; they cannot be collected in the same run as the timing.
         traffic = None
-        if args.traffic_json and os.path.exists(args.traffic_json):
-            traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
+        tj = args.traffic_json or os.path.join(ROOT, "profiles", "traffic_fused_fir.json")
+        if fused and os.path.exists(tj):
+            t = json.load(open(tj))
+            if int(t.get("samples_per_launch", 0)) == n:
+                traffic = t.get("hbm_bytes_per_launch")
         line = {
             "metric": "MSamples/s (complex IQ) through shift->FIR->decimate->FFT chain; % HBM roofline",
             "value": round(value, 1),
@@ -224,8 +218,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
         assert first_frames >= 0
         print(json.dumps(line))
-    if dist is not None:
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":
