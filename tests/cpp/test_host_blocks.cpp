@@ -1,0 +1,262 @@
+// Tests of the C++ host layer (radiorust_amd/host/radiorust_amd.hpp), written after
+// the reference's own tests: a hand-made sender/receiver pair around the block under
+// test (src/blocks/analysis.rs:139-209, src/sync/broadcast_bp.rs:337-375,
+// src/blocks/chunks.rs:247-271).  `--cpu` runs what needs no GPU, `--gpu` the rest.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+
+#include "../../oracle/rr_oracle.h"  // test infrastructure: the checker
+#include "../../radiorust_amd/host/radiorust_amd.hpp"
+
+using namespace radiorust;
+using signal::Signal;
+template <class F> using Sig = Signal<Complex<F>>;
+
+static int g_failures = 0;
+#define CHECK(cond)                                                          \
+    do {                                                                     \
+        if (!(cond)) {                                                       \
+            std::printf("  CHECK FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+            ++g_failures;                                                    \
+        }                                                                    \
+    } while (0)
+
+// lib.rs:52-58
+static bool approx(double a, double b) { return std::fabs(a - b) <= 1e-10 || std::fabs(std::log(a / b)) <= 1e-10; }
+
+// ---- CPU -----------------------------------------------------------------------
+static void test_broadcast() {  // broadcast_bp.rs:337-375
+    auto [sender, enlister] = flow::new_sender<int>();
+    std::vector<std::thread> th;
+    std::atomic<int> ok{0};
+    for (int r = 0; r < 3; ++r) {
+        auto rx = std::make_shared<flow::InnerReceiver<int>>(enlister.subscribe());
+        th.emplace_back([rx, &ok] {
+            int got[3] = {0, 0, 0};
+            for (int i = 0; i < 3; ++i) {
+                int v = 0;
+                while (rx->recv(v, std::chrono::milliseconds(50)) == flow::RecvStatus::Timeout) {}
+                got[i] = v;
+            }
+            if (got[0] == 1 && got[1] == 5 && got[2] == 3) ok++;
+        });
+    }
+    CHECK(sender.send(1));
+    CHECK(sender.send(5));
+    CHECK(sender.send(3));
+    for (auto &t : th) t.join();
+    CHECK(ok == 3);
+}
+
+static void test_send_fails_without_receivers() {
+    auto sh = std::make_shared<flow::Shared<int>>();
+    flow::Sender<int> sender(sh);
+    { flow::SenderConnector<int> only_enlister(sh); }  // goes away; no receiver ever existed
+    CHECK(!sender.send(7));
+}
+
+static void test_reconnect_emits_disconnection() {  // flow.rs:176-189
+    using S = Sig<float>;
+    auto a = flow::new_sender<S>();
+    auto b = flow::new_sender<S>();
+    auto [receiver, connector] = flow::new_receiver<S>();
+    connector->feed_from(a.second);
+    std::thread t([&] {
+        a.first.send(S::new_event(signal::SamplesLost{}));
+    });
+    auto m1 = receiver.recv();
+    t.join();
+    CHECK(m1 && m1->is_event() && std::string(m1->event->name()) == "SamplesLost");
+    connector->feed_from(b.second);  // re-connect: the stream was interrupted
+    auto m2 = receiver.recv();
+    CHECK(m2 && m2->is_event() && m2->event->is_interrupt() && std::string(m2->event->name()) == "Disconnection");
+}
+
+// ---- GPU -----------------------------------------------------------------------
+static void test_pinned_pool_recycles() {  // bufferpool.rs:82-90,202-222
+    ChunkBufPool<Complex<float>> pool;
+    const Complex<float> *p0;
+    {
+        auto buf = pool.get_with_capacity(1024);
+        buf.push({1.f, 2.f});
+        p0 = buf.data();
+        Chunk<Complex<float>> c = buf.finalize();
+        Chunk<Complex<float>> c2 = c;  // shared like Arc<Vec<T>>
+        CHECK(c2.len() == 1 && c2[0] == Complex<float>(1.f, 2.f));
+        Chunk<Complex<float>> head = c2.separate_beginning(1);
+        CHECK(head.len() == 1 && c2.len() == 0 && head.data() == c.data());
+        CHECK(pool.spare_count() == 0);
+    }
+    CHECK(pool.spare_count() == 1);  // recycled on the last drop
+    auto again = pool.get_with_capacity(8);
+    CHECK(again.data() == p0 && again.len() == 0 && again.capacity() == 1024);
+}
+
+template <class F> static Chunk<Complex<F>> chunk_of(std::initializer_list<Complex<F>> v) {
+    return Chunk<Complex<F>>::from(std::vector<Complex<F>>(v));
+}
+
+static void test_fourier() {  // analysis.rs:139-209, verbatim structure and values
+    using S = Sig<double>;
+    auto [sender, sender_connector] = flow::new_sender<S>();
+    auto fourier1 = blocks::Fourier<double>::new_();
+    auto fourier2 = blocks::Fourier<double>::new_center_dc();
+    auto [receiver1, receiver1_connector] = flow::new_receiver<S>();
+    auto [receiver2, receiver2_connector] = flow::new_receiver<S>();
+    fourier1->feed_from(sender_connector);
+    fourier2->feed_from(sender_connector);
+    fourier1->feed_into(*receiver1_connector);
+    fourier2->feed_into(*receiver2_connector);
+    CHECK(sender.send(S::Samples(48000.0, chunk_of<double>({{1.0, 0.0}, {1.0, 0.0}, {1.0, 0.0}}))));
+    auto o1 = receiver1.recv(), o2 = receiver2.recv();
+    CHECK(o1 && o2 && !o1->is_event() && !o2->is_event());
+    const double want1[3][2] = {{3, 0}, {0, 0}, {0, 0}}, want2[3][2] = {{0, 0}, {3, 0}, {0, 0}};
+    for (int i = 0; i < 3; ++i) {
+        CHECK(approx(o1->chunk[i].real(), want1[i][0]) && approx(o1->chunk[i].imag(), want1[i][1]));
+        CHECK(approx(o2->chunk[i].real(), want2[i][0]) && approx(o2->chunk[i].imag(), want2[i][1]));
+    }
+    CHECK(sender.send(S::Samples(48000.0, chunk_of<double>({{1.0, 0.0}, {1.5, 0.0}, {1.0, 0.0}, {0.5, 0.0}}))));
+    o1 = receiver1.recv();
+    o2 = receiver2.recv();
+    const double w1[4][2] = {{4, 0}, {0, -1}, {0, 0}, {0, 1}}, w2[4][2] = {{0, 0}, {0, 1}, {4, 0}, {0, -1}};
+    for (int i = 0; i < 4; ++i) {
+        CHECK(approx(o1->chunk[i].real(), w1[i][0]) && approx(o1->chunk[i].imag(), w1[i][1]));
+        CHECK(approx(o2->chunk[i].real(), w2[i][0]) && approx(o2->chunk[i].imag(), w2[i][1]));
+    }
+}
+
+static double rms_rel(const Complex<float> *a, const float *ref, size_t n) {
+    double num = 0, den = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const double dr = a[i].real() - ref[2 * i], di = a[i].imag() - ref[2 * i + 1];
+        num += dr * dr + di * di;
+        den += (double)ref[2 * i] * ref[2 * i] + (double)ref[2 * i + 1] * ref[2 * i + 1];
+    }
+    return std::sqrt(num / den);
+}
+
+static void lowpass20(int64_t, double f, double *out, void *) {
+    out[0] = std::fabs(f) <= 20e6 ? 1.0 : 0.0;
+    out[1] = 0.0;
+}
+
+// FreqShifter -> Filter -> Downsampler -> Fourier wired like
+// examples/bandwidth_meter/main.rs:51-72, fed 64-sample chunks, against the oracle
+static void test_pipeline_vs_oracle() {
+    using S = Sig<float>;
+    const double fs = 200e6;
+    const size_t n = 64 * 600, nf = 64;
+    std::vector<float> x(2 * n);
+    rro_synth_iq_f32(1, 0, n, x.data());
+    auto [sender, sender_connector] = flow::new_sender<S>();
+    auto freq_shifter = blocks::FreqShifter<float>::with_shift(25e6);
+    auto filter = blocks::Filter<float>::new_([](long, double f) { return Complex<double>(std::fabs(f) <= 20e6 ? 1.0 : 0.0, 0.0); });
+    auto downsampler = blocks::Downsampler<float>::new_(4096, 50e6, 40e6);
+    auto fourier = blocks::Fourier<float>::with_window(windowing::Kaiser::with_null_at_bin(2.0));
+    auto [receiver, receiver_connector] = flow::new_receiver<S>();
+    freq_shifter->feed_from(sender_connector);
+    filter->feed_from(*freq_shifter);
+    downsampler->feed_from(*filter);
+    fourier->feed_from(*downsampler);
+    receiver_connector->feed_from(*fourier);
+    std::thread feeder([&, s = &sender] {
+        for (size_t off = 0; off + nf <= n; off += nf) {
+            std::vector<Complex<float>> c(nf);
+            std::memcpy(c.data(), x.data() + 2 * off, nf * sizeof(Complex<float>));
+            if (off == 64 * 300) s->send(S::new_event(signal::Event{}));  // a non-interrupt event travels through
+            s->send(S::Samples(fs, Chunk<Complex<float>>::from(c)));
+        }
+    });
+    rro_window fw{RRO_WIN_KAISER, rro_kaiser_null_at_bin_to_beta(2.0), nullptr, nullptr};
+    std::vector<float> ref(2 * 4096 * 4);
+    const size_t frames = rro_chain_run_f32(x.data(), n, fs, 1.0, 25e6, nf, lowpass20, nullptr, &fw, 50e6, 40e6, 3.0, 4096, &fw, 0,
+                                            ref.data(), 4);
+    CHECK(frames == 2);
+    size_t got_frames = 0, got_events = 0;
+    while (got_frames < frames) {
+        auto m = receiver.recv();
+        if (!m) break;
+        if (m->is_event()) {
+            ++got_events;
+            continue;
+        }
+        CHECK(m->chunk.len() == 4096 && m->sample_rate == 50e6);
+        const double e = rms_rel(m->chunk.data(), ref.data() + 2 * 4096 * got_frames, 4096);
+        CHECK(e <= 1e-5);  // north-star tolerance; the f32 oracle itself is the reference here
+        ++got_frames;
+    }
+    feeder.join();
+    CHECK(got_frames == 2 && got_events == 1);
+}
+
+static void test_filter_swallow_and_interrupt() {  // filters.rs:240,260,262-265
+    using S = Sig<float>;
+    auto [sender, sender_connector] = flow::new_sender<S>();
+    auto filter = blocks::Filter<float>::new_rectangular([](long, double f) { return Complex<double>(std::fabs(f) <= 6e3 ? 1.0 : 0.0, 0.0); });
+    auto [receiver, receiver_connector] = flow::new_receiver<S>();
+    filter->feed_from(sender_connector);
+    filter->feed_into(*receiver_connector);
+    std::vector<Complex<float>> c(64, Complex<float>(1.f, 0.f));
+    auto chunk = [&] { return S::Samples(48000.0, Chunk<Complex<float>>::from(c)); };
+    std::thread feeder([&, s = &sender] {
+        s->send(chunk());  // swallowed
+        s->send(chunk());  // -> output 1
+        s->send(S::new_event(signal::SamplesLost{}));  // interrupt: history dropped
+        s->send(chunk());  // swallowed again
+        s->send(chunk());  // -> output 2
+    });
+    auto m1 = receiver.recv();
+    CHECK(m1 && !m1->is_event() && m1->chunk.len() == 64);
+    // DC gain of the low-pass is 1: a constant input comes out constant
+    if (m1 && !m1->is_event()) CHECK(std::fabs(m1->chunk[63].real() - 1.f) < 1e-4f && std::fabs(m1->chunk[63].imag()) < 1e-5f);
+    auto m2 = receiver.recv();
+    CHECK(m2 && m2->is_event() && m2->event->is_interrupt());
+    auto m3 = receiver.recv();
+    CHECK(m3 && !m3->is_event() && m3->chunk.len() == 64);
+    feeder.join();
+}
+
+static void test_contract_violation_is_loud() {  // resampling.rs:51-56
+    bool threw = false;
+    try {
+        auto d = blocks::Downsampler<float>::new_(16, 48000.0, 48000.0);
+    } catch (const ContractViolation &) {
+        threw = true;
+    }
+    CHECK(threw);
+}
+
+int main(int argc, char **argv) {
+    const bool cpu = argc > 1 && !std::strcmp(argv[1], "--cpu");
+    const bool gpu = argc > 1 && !std::strcmp(argv[1], "--gpu");
+    struct T { const char *name; void (*fn)(); bool needs_gpu; };
+    const T tests[] = {
+        {"broadcast", test_broadcast, false},
+        {"send_fails_without_receivers", test_send_fails_without_receivers, false},
+        {"reconnect_emits_disconnection", test_reconnect_emits_disconnection, false},
+        {"pinned_pool_recycles", test_pinned_pool_recycles, true},
+        {"fourier (analysis.rs:139-209)", test_fourier, true},
+        {"filter_swallow_and_interrupt", test_filter_swallow_and_interrupt, true},
+        {"pipeline_vs_oracle", test_pipeline_vs_oracle, true},
+        {"contract_violation_is_loud", test_contract_violation_is_loud, true},
+    };
+    int ran = 0;
+    for (const T &t : tests) {
+        if ((t.needs_gpu && cpu) || (!t.needs_gpu && gpu)) continue;
+        const int before = g_failures;
+        std::printf("[ RUN  ] %s\n", t.name);
+        std::fflush(stdout);
+        try {
+            t.fn();
+        } catch (const std::exception &e) {
+            std::printf("  EXCEPTION: %s\n", e.what());
+            ++g_failures;
+        }
+        std::printf("[ %s ] %s\n", g_failures == before ? " OK " : "FAIL", t.name);
+        ++ran;
+    }
+    std::printf("%d tests, %d failures\n", ran, g_failures);
+    return g_failures ? 1 : 0;
+}
