@@ -141,6 +141,33 @@ int rr_filter::design(double sample_rate, size_t len, const rr_c64 *resp, const 
     else
         cast_to<double>(w.data(), w.size(), bytes);
     RR_TRY(upload(d_taps, bytes.data(), bytes.size(), stream));
+    use_ols = ols_supported(dtype, len);
+    if (use_ols) {
+        // the reference's extended response (filters.rs:220-238), transformed in f64 here
+        std::vector<cd> ext(2 * len, cd(0, 0));
+        for (size_t i = 0; i < len; ++i) ext[len + i] = g[i] / (2.0 * (double)len);
+        fft_f64(ext, false);
+        std::vector<double> hh(4 * len), tw(2 * len);
+        for (size_t i = 0; i < 2 * len; ++i) {
+            hh[2 * i] = ext[i].real();
+            hh[2 * i + 1] = ext[i].imag();
+        }
+        for (size_t k = 0; k < len; ++k) {
+            const double ang = -2.0 * M_PI * (double)k / (double)(2 * len);
+            tw[2 * k] = std::cos(ang);
+            tw[2 * k + 1] = std::sin(ang);
+        }
+        std::vector<unsigned char> hb2, tb2;
+        if (dtype == RR_F32) {
+            cast_to<float>(hh.data(), hh.size(), hb2);
+            cast_to<float>(tw.data(), tw.size(), tb2);
+        } else {
+            cast_to<double>(hh.data(), hh.size(), hb2);
+            cast_to<double>(tw.data(), tw.size(), tb2);
+        }
+        RR_TRY(upload(d_H, hb2.data(), hb2.size(), stream));
+        RR_TRY(upload(d_olstw, tb2.data(), tb2.size(), stream));
+    }
     const size_t hb = len * elem_size(dtype);
     RR_TRY(hist[0].reserve(hb));
     RR_TRY(hist[1].reserve(hb));
@@ -166,7 +193,9 @@ int rr_filter::process_dev(double sample_rate, const void *d_in, size_t n_in, vo
     const size_t produce = peek(n_in);
     if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Filter: out_cap %zu < %zu", cap, produce);
     RR_TRY(select());
-    if (produce) {
+    if (produce && use_ols) {
+        RR_TRY(launch_filter_ols(dtype, stream, hist[cur].p, d_in, n, produce / n, hist_valid ? 0 : 1, d_H.p, d_olstw.p, d_out));
+    } else if (produce) {
         FirArgs a;
         a.hist = hist[cur].p;
         a.hist_len = hist_valid ? n : 0;

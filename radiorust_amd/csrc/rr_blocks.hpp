@@ -27,6 +27,8 @@ struct rr_filter : rr_block {
     bool real_taps = false;
     std::vector<rr::cd> taps_f64;  // g[k], causal order
     rr::DevBuf d_taps;             // w[j] = g[n-1-j] as T or complex<T>
+    bool use_ols = false;          // long power-of-two filters: overlap-save fast convolution
+    rr::DevBuf d_H, d_olstw;       // H = FFT_2n([0 | g / 2n]) and e^{-j 2 pi k / 2n}, k < n
     rr::DevBuf hist[2];            // previous_chunk (n samples), ping-pong
     int cur = 0;
     bool hist_valid = false;  // previous_chunk.is_some()

@@ -175,12 +175,19 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
     bool cur_interior = interior_of(tile_lo);
     if (cur_interior) prefetch(tile_lo);
 #ifdef RR_V_STAGGER
-    // Workgroups that share a CU start a fraction of a tile period apart, so that the
-    // load/stage/store phases of one wave overlap the FIR loop of its SIMD partner
-    // instead of all waves doing the same thing at the same time.
+    // The two waves that share a SIMD (hardware wave slots 0 and 1) belong to two
+    // different workgroups.  Delay the workgroup whose first wave sits in an odd slot by
+    // about half a tile period, so that one wave's load/stage/store phases overlap the
+    // other's FIR loop instead of both doing the same thing at the same time.
     {
-        const unsigned slot = (blockIdx.x >> 8) & 3;  // round-robin dispatch: b and b + 256 land on the same CU
-        for (unsigned k = 0; k < slot * RR_V_STAGGER; ++k) __builtin_amdgcn_s_sleep(64);
+        __shared__ int stagger_flag;
+        if (threadIdx.x == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID
+            stagger_flag = (int)(hw & 1);                                                // wave_id[0]
+        }
+        __syncthreads();
+        if (stagger_flag)
+            for (int k = 0; k < RR_V_STAGGER; ++k) __builtin_amdgcn_s_sleep(64);  // 64 * 64 cycles each
     }
 #endif
 
@@ -266,8 +273,24 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
         RR_STAMP_T(ts1);
         lds_barrier();
         RR_STAMP_T(ts2);
-#ifndef RR_V_REISSUE  // prefetch the next tile once the stage barrier is passed
+#if !defined(RR_V_REISSUE) && !defined(RR_V_SPREAD)  // prefetch the next tile once the stage barrier is passed
         if (cur_interior && next_interior) prefetch(next_lo);
+#endif
+#ifdef RR_V_SPREAD
+        // issue the next tile's loads in slices between the rounds of the FIR loop, so
+        // that the vector-memory issue (TA ingest) overlaps the packed FMAs
+        const bool spread = cur_interior && next_interior;
+#define RR_PF(u) x[u] = nsrc[(u) * T];
+#define RR_PREFETCH_SLICE(k)                                         \
+    switch (k) {                                                     \
+        case 0: RR_PF(0) RR_PF(1) RR_PF(2) RR_PF(3) break;           \
+        case 1: RR_PF(4) RR_PF(5) RR_PF(6) RR_PF(7) break;           \
+        case 2: RR_PF(8) RR_PF(9) RR_PF(10) RR_PF(11) break;         \
+        case 3: RR_PF(12) RR_PF(13) RR_PF(14) RR_PF(15) break;       \
+        case 4: RR_PF(16) RR_PF(17) break;                           \
+        default: break;                                              \
+    }
+        static_assert(kNPF == 18, "slices are written out for 18 prefetch slots");
 #endif
         RR_STAMP_T(ts3);
 
@@ -329,10 +352,17 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
             for (int to = 0; to < nouter; ++to) {
                 const char *row0 = lane + (size_t)to * STRIDE;
                 const float *tp = tap_lds + to * RD;
+#ifdef RR_V_SPREAD
+                if (spread) { RR_PREFETCH_SLICE(to) }
+#endif
                 [&]<int... I>(std::integer_sequence<int, I...>) {
                     (fir_step(std::integral_constant<int, I>{}, row0, tp), ...);
                 }(std::make_integer_sequence<int, R>{});
             }
+#ifdef RR_V_SPREAD
+            if (spread)
+                for (int k = nouter; k < 5; ++k) { RR_PREFETCH_SLICE(k) }  // fewer rounds than slices: issue the rest now
+#endif
             if (rem) {  // the last, partial round (workgroup-uniform)
                 const char *row0 = lane + (size_t)nouter * STRIDE;
                 const float *tp = tap_lds + nouter * RD;
@@ -398,7 +428,11 @@ static int launch_mfd(hipStream_t s, const FusedFirArgs &a) {
     const size_t ntiles = (a.n_out + OUTS - 1) / OUTS;
     if (ntiles > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fused FIR: too many tiles");
     // persistent grid: 8 waves per CU (LDS-limited), 256 CUs
+#ifdef RR_V_WGPCU
+    size_t nwg = 256 * RR_V_WGPCU;
+#else
     size_t nwg = 256 * (512 / T);
+#endif
     if (nwg > ntiles) nwg = ntiles;
     const size_t tpw = (ntiles + nwg - 1) / nwg;
     nwg = (ntiles + tpw - 1) / tpw;

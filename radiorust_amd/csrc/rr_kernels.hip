@@ -23,6 +23,8 @@ template <class T> __device__ __forceinline__ v2<T> cmul(v2<T> a, v2<T> b) {
     return r;
 }
 
+static bool is_pow2_n(size_t n) { return n && (n & (n - 1)) == 0; }
+
 static int set_dyn_lds(const void *fn, size_t bytes) {
     if (bytes > 64 * 1024) RR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return RR_OK;
@@ -221,6 +223,85 @@ int launch_fir(int dtype, hipStream_t s, const FirArgs &a) {
     }
     if (a.complex_taps) return list ? launch_fir_t<double, true, true>(s, a) : launch_fir_t<double, true, false>(s, a);
     return list ? launch_fir_t<double, false, true>(s, a) : launch_fir_t<double, false, false>(s, a);
+}
+
+// ---------------------------------------------------------------------------
+// Filter, overlap-save fast convolution (filters.rs:240-259) for long filters.
+// One workgroup per output chunk: [prev | cur] (2n samples) -> Stockham radix-2 FFT in
+// LDS -> * H -> inverse (conjugate twiddles) -> the first n results.  ~20 log2(2n)
+// flop per sample instead of 8n for the direct form.
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_filter_ols(const v2<T> *__restrict__ hist, const v2<T> *__restrict__ in, int n,
+                                                    int first_chunk, const v2<T> *__restrict__ H,
+                                                    const v2<T> *__restrict__ tw, v2<T> *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = 2 * n;
+    v2<T> *a = reinterpret_cast<v2<T> *>(smem);
+    v2<T> *b = a + N;
+    const long c = (long)blockIdx.x + first_chunk;  // chunk whose filtered version this workgroup emits
+    const v2<T> *prev = (c == 0) ? hist : in + (c - 1) * (long)n;
+    const v2<T> *cur = in + c * (long)n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        a[i] = prev[i];
+        a[n + i] = cur[i];
+    }
+    __syncthreads();
+    const int half = n;  // N / 2
+    for (int dir = 0; dir < 2; ++dir) {
+        for (int ns = 1; ns < N; ns <<= 1) {
+            const int tstride = half / ns;
+            for (int j = threadIdx.x; j < half; j += blockDim.x) {
+                const int k = j & (ns - 1);
+                v2<T> w = tw[k * tstride];
+                if (dir) w.y = -w.y;
+                const v2<T> u = a[j];
+                const v2<T> v = cmul<T>(a[j + half], w);
+                const int j0 = ((j - k) << 1) + k;
+                v2<T> s, d;
+                s.x = u.x + v.x;
+                s.y = u.y + v.y;
+                d.x = u.x - v.x;
+                d.y = u.y - v.y;
+                b[j0] = s;
+                b[j0 + ns] = d;
+            }
+            __syncthreads();
+            v2<T> *t = a;
+            a = b;
+            b = t;
+        }
+        if (dir == 0) {
+            for (int i = threadIdx.x; i < N; i += blockDim.x) a[i] = cmul<T>(a[i], H[i]);
+            __syncthreads();
+        }
+    }
+    v2<T> *dst = out + (long)blockIdx.x * n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = a[i];
+}
+
+static size_t ols_max_n(int dtype) { return dtype == RR_F32 ? 4096 : 2048; }  // 2 LDS buffers of 2n <= 128 KiB
+
+bool ols_supported(int dtype, size_t n) { return is_pow2_n(n) && n >= 128 && n <= ols_max_n(dtype); }
+
+int launch_filter_ols(int dtype, hipStream_t s, const void *hist, const void *in, size_t n, size_t nchunks,
+                      int first_chunk, const void *H, const void *tw, void *out) {
+    if (nchunks == 0) return RR_OK;
+    if (nchunks > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "Filter: too many chunks in one call");
+    const size_t lds = 4 * n * elem_size(dtype);
+    if (dtype == RR_F32) {
+        auto fn = k_filter_ols<float>;
+        RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));
+        hipLaunchKernelGGL(fn, dim3((unsigned)nchunks), dim3(256), lds, s, (const float2 *)hist, (const float2 *)in,
+                           (int)n, first_chunk, (const float2 *)H, (const float2 *)tw, (float2 *)out);
+    } else {
+        auto fn = k_filter_ols<double>;
+        RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));
+        hipLaunchKernelGGL(fn, dim3((unsigned)nchunks), dim3(256), lds, s, (const double2 *)hist, (const double2 *)in,
+                           (int)n, first_chunk, (const double2 *)H, (const double2 *)tw, (double2 *)out);
+    }
+    RR_HIP(hipGetLastError());
+    return RR_OK;
 }
 
 // ---------------------------------------------------------------------------

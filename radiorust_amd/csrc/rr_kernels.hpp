@@ -34,6 +34,14 @@ struct FirArgs {
 };
 int launch_fir(int dtype, hipStream_t s, const FirArgs &a);
 
+// Filter by overlap-save fast convolution, exactly the reference's per-chunk recipe
+// (filters.rs:240-259): out_c = IFFT_2n(FFT_2n([chunk c-1 | chunk c]) * H)[0..n), n a power
+// of two.  H: 2n complex (transform of [0_n | h], h = g / 2n); tw: n entries e^{-j 2 pi k / 2n}.
+// first_chunk = 0: chunk -1 is `hist` (n samples); first_chunk = 1: chunk 0 only provides history.
+bool ols_supported(int dtype, size_t n);
+int launch_filter_ols(int dtype, hipStream_t s, const void *hist, const void *in, size_t n, size_t nchunks,
+                      int first_chunk, const void *H, const void *tw, void *out);
+
 // new_hist (H samples) = last H samples of [ zeros | old_hist (H) | in (n_in) ]
 int launch_update_hist(int dtype, hipStream_t s, const void *old_hist, void *new_hist, size_t H, const void *in,
                        size_t n_in);
