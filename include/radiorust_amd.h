@@ -284,6 +284,26 @@ int rr_chain_timing_read(rr_chain *h, int stage, double *total_ms, uint64_t *lau
 const char *rr_chain_timing_stage_name(int stage); /* NULL past the last stage */
 
 /* ------------------------------------------------------------------------ */
+/* Polyphase FFT channelizer (BASELINE configs[2]) = the reference composition */
+/*   Rechunker(bins) -> Overlapper(taps_per_branch) -> Fourier::with_window     */
+/*   -> every taps_per_branch-th bin                                             */
+/* (chunks.rs:42-242, analysis.rs:60-132) as one fold + bins-point FFT per hop. */
+/* Input: whole chunks of `bins` samples; each chunk after the first             */
+/* taps_per_branch-1 yields one frame of `bins` outputs (critically sampled).    */
+/* ------------------------------------------------------------------------ */
+typedef struct rr_channelizer rr_channelizer;
+int rr_channelizer_create(int dtype, size_t bins, size_t taps_per_branch,
+                          const rr_window *window, int device, rr_channelizer **out);
+/* Any event makes the Overlapper drop its history (chunks.rs:225-233). */
+int rr_channelizer_reset(rr_channelizer *h);
+int rr_channelizer_peek(const rr_channelizer *h, size_t n_in, size_t *n_out);
+int rr_channelizer_process(rr_channelizer *h, const void *in, size_t n_in, void *out,
+                           size_t out_cap, size_t *n_out);
+int rr_channelizer_process_dev(rr_channelizer *h, const void *d_in, size_t n_in,
+                               void *d_out, size_t out_cap, size_t *n_out);
+int rr_channelizer_destroy(rr_channelizer *h);
+
+/* ------------------------------------------------------------------------ */
 /* Synthetic IQ source generated on the device; the test      */
 /* harness's stand-in for an SDR source block.  d_out: n rr_c32.             */
 /* ------------------------------------------------------------------------ */

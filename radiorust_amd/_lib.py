@@ -135,6 +135,12 @@ SIGNATURES = {
     "rr_chain_timing_reset": (_i, [_vp]),
     "rr_chain_timing_read": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(C.c_uint64)]),
     "rr_chain_timing_stage_name": (C.c_char_p, [_i]),
+    "rr_channelizer_create": (_i, [_i, _sz, _sz, C.POINTER(Window), _i, C.POINTER(_vp)]),
+    "rr_channelizer_reset": (_i, [_vp]),
+    "rr_channelizer_peek": (_i, [_vp, _sz, _psz]),
+    "rr_channelizer_process": (_i, [_vp, _vp, _sz, _vp, _sz, _psz]),
+    "rr_channelizer_process_dev": (_i, [_vp, _vp, _sz, _vp, _sz, _psz]),
+    "rr_channelizer_destroy": (_i, [_vp]),
     "rr_synth_iq_dev": (_i, [_i, _vp, C.c_uint64, C.c_uint64, _sz, _vp]),
 }
 

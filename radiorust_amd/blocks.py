@@ -379,6 +379,45 @@ class Chain(_Block):
         return n_out.value
 
 
+class Channelizer(_Block):
+    """Polyphase FFT channelizer (BASELINE configs[2]): the reference composition
+    Rechunker(bins) -> Overlapper(taps_per_branch) -> Fourier.with_window(window) ->
+    every taps_per_branch-th bin (chunks.rs:42-242, analysis.rs:60-132) as one
+    fold + `bins`-point FFT per hop.  Input chunks must be multiples of `bins`."""
+
+    _destroy = "rr_channelizer_destroy"
+
+    def __init__(self, bins: int, taps_per_branch: int, window: Window | None = None, dtype=np.float32, device: int = 0):
+        super().__init__()
+        self._code, self._cdt = _dtype_code(dtype)
+        self.bins, self.taps_per_branch = int(bins), int(taps_per_branch)
+        w = window if window is not None else Kaiser.with_null_at_bin(float(taps_per_branch))
+        spec = w._spec()
+        if spec is None:
+            raise TypeError("Channelizer needs a built-in window (Rectangular or Kaiser)")
+        _lib.check(_lib.lib().rr_channelizer_create(self._code, self.bins, self.taps_per_branch, spec, device, C.byref(self._h)))
+
+    def process(self, signal):
+        """Each output message is one frame of `bins` channel samples; the frame rate is
+        sample_rate / bins.  Any event resets the overlap history and is preceded by
+        SamplesLost, as the Overlapper does (chunks.rs:225-233)."""
+        from .signal import SamplesLost
+
+        if signal.is_event():
+            _lib.check(_lib.lib().rr_channelizer_reset(self._h))
+            return [EventSignal(SamplesLost()), signal]
+        n_out = C.c_size_t()
+        _lib.check(_lib.lib().rr_channelizer_peek(self._h, len(signal.chunk), C.byref(n_out)))
+        y = self._host_call(_lib.lib().rr_channelizer_process, (), signal.chunk, n_out.value)
+        M = self.bins
+        return [Samples(signal.sample_rate, y[i * M : (i + 1) * M]) for i in range(len(y) // M)]
+
+    def process_dev(self, d_in: int, n_in: int, d_out: int, cap: int) -> int:
+        n_out = C.c_size_t()
+        _lib.check(_lib.lib().rr_channelizer_process_dev(self._h, d_in, n_in, d_out, cap, C.byref(n_out)))
+        return n_out.value
+
+
 def synth_iq_dev(device: int, hip_stream: int | None, seed: int, t0: int, n: int, d_out: int):
     """Fills n complex64 samples of the synthetic IQ source on the device."""
     _lib.check(_lib.lib().rr_synth_iq_dev(device, C.c_void_p(hip_stream or 0), seed, t0, n, d_out))

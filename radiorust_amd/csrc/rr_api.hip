@@ -353,6 +353,34 @@ int rr_fourier::process_dev(size_t chunk_len, const void *d_in, size_t n_in, voi
 }
 
 // ---------------------------------------------------------------------------
+// Channelizer
+// ---------------------------------------------------------------------------
+int rr_channelizer::process_dev(const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out) {
+    if (n_out) *n_out = 0;
+    if (n_in % M) RR_FAIL(RR_ERR_BAD_ARG, "Channelizer: %zu samples is not a whole number of %zu-sample chunks", n_in, M);
+    const size_t produce = peek(n_in);
+    if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Channelizer: out_cap %zu < %zu", cap, produce);
+    if (n_in == 0) return RR_OK;
+    RR_TRY(select());
+    const size_t chunks = n_in / M, H = (P - 1) * M;
+    const size_t frames = produce / M;
+    if (frames) {
+        // frame 0 ends with the chunk that completes the history: it starts (have_chunks) chunks before in[0]
+        // when the history is full, later when it is still filling
+        const size_t first_complete = (have_chunks >= P - 1) ? 0 : (P - 1 - have_chunks);  // index of the chunk that ends frame 0
+        const long base0 = ((long)first_complete - (long)(P - 1)) * (long)M;
+        RR_TRY(launch_channelizer(dtype, stream, hist[cur].p, H, d_in, base0, M, P, frames, d_window.p, d_tw.p, d_out));
+    }
+    if (H) {
+        RR_TRY(launch_update_hist(dtype, stream, hist[cur].p, hist[cur ^ 1].p, H, d_in, n_in));
+        cur ^= 1;
+    }
+    have_chunks = (have_chunks + chunks > P - 1) ? P - 1 : have_chunks + chunks;
+    if (n_out) *n_out = produce;
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
 // stage timers
 // ---------------------------------------------------------------------------
 int StageTimers::begin(int stage, hipStream_t s) {
@@ -1298,6 +1326,98 @@ const char *rr_chain_timing_stage_name(int stage) {
 int rr_chain_destroy(rr_chain *h) {
     if (!h) return RR_OK;
     RR_CHECK_HANDLE(h, K_CHAIN);
+    (void)hipSetDevice(h->device);
+    delete h;
+    return RR_OK;
+}
+
+int rr_channelizer_create(int dtype, size_t bins, size_t taps_per_branch, const rr_window *window, int device,
+                          rr_channelizer **out) {
+    RR_GUARD_BEGIN
+    if (!out || !window) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    *out = nullptr;
+    if (taps_per_branch == 0) RR_FAIL(RR_ERR_CONTRACT, "chunk count must be positive");  // chunks.rs:195
+    if (bins < 2 || (bins & (bins - 1)) || bins > (dtype == RR_F32 ? 8192u : 4096u))
+        RR_FAIL(RR_ERR_BAD_ARG, "Channelizer: bins must be a power of two in [2, %u]", dtype == RR_F32 ? 8192u : 4096u);
+    if (window->kind != RR_WIN_RECTANGULAR && window->kind != RR_WIN_KAISER)
+        RR_FAIL(RR_ERR_BAD_ARG, "Channelizer: window must be a built-in window");
+    auto *h = new rr_channelizer;
+    int st = h->init_base(K_CHANNELIZER, dtype, device);
+    if (st != RR_OK) {
+        delete h;
+        return st;
+    }
+    h->M = bins;
+    h->P = taps_per_branch;
+    const size_t n = bins * taps_per_branch;
+    std::vector<double> rel(n), vals(n), tw(bins);
+    st = window_sample(window, n, rel.data());
+    if (st == RR_OK) st = fourier_design_window(n, rel.data(), vals.data());  // analysis.rs:88-101 over the P*M span
+    for (size_t k = 0; k < bins / 2; ++k) {
+        const double ang = -2.0 * M_PI * (double)k / (double)bins;
+        tw[2 * k] = std::cos(ang);
+        tw[2 * k + 1] = std::sin(ang);
+    }
+    std::vector<unsigned char> wb, tb;
+    if (dtype == RR_F32) {
+        cast_to<float>(vals.data(), n, wb);
+        cast_to<float>(tw.data(), bins, tb);
+    } else {
+        cast_to<double>(vals.data(), n, wb);
+        cast_to<double>(tw.data(), bins, tb);
+    }
+    if (st == RR_OK) st = upload(h->d_window, wb.data(), wb.size(), h->stream);
+    if (st == RR_OK) st = upload(h->d_tw, tb.data(), tb.size(), h->stream);
+    const size_t hb = (taps_per_branch - 1) * bins * elem_size(dtype);
+    if (st == RR_OK) st = h->hist[0].reserve(hb ? hb : 16);
+    if (st == RR_OK) st = h->hist[1].reserve(hb ? hb : 16);
+    if (st != RR_OK) {
+        delete h;
+        return st;
+    }
+    *out = h;
+    return RR_OK;
+    RR_GUARD_END
+}
+int rr_channelizer_reset(rr_channelizer *h) {
+    RR_CHECK_HANDLE(h, K_CHANNELIZER);
+    h->have_chunks = 0;
+    return RR_OK;
+}
+int rr_channelizer_peek(const rr_channelizer *h, size_t n_in, size_t *n_out) {
+    RR_CHECK_HANDLE(h, K_CHANNELIZER);
+    if (!n_out) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    if (n_in % h->M) RR_FAIL(RR_ERR_BAD_ARG, "Channelizer: input must be whole chunks of %zu samples", h->M);
+    *n_out = h->peek(n_in);
+    return RR_OK;
+}
+int rr_channelizer_process_dev(rr_channelizer *h, const void *d_in, size_t n_in, void *d_out, size_t cap,
+                               size_t *n_out) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_CHANNELIZER);
+    return h->process_dev(d_in, n_in, d_out, cap, n_out);
+    RR_GUARD_END
+}
+int rr_channelizer_process(rr_channelizer *h, const void *in, size_t n_in, void *out, size_t cap, size_t *n_out) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_CHANNELIZER);
+    if (n_out) *n_out = 0;
+    if (n_in % h->M) RR_FAIL(RR_ERR_BAD_ARG, "Channelizer: input must be whole chunks of %zu samples", h->M);
+    const size_t produce = h->peek(n_in);
+    if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Channelizer: out_cap %zu < %zu", cap, produce);
+    size_t got = 0;
+    RR_TRY(host_io(h, in, n_in, out, produce, true, [&](void *di, void *dout, size_t *p) {
+        int s = h->process_dev(di, n_in, dout, produce, p);
+        got = *p;
+        return s;
+    }));
+    if (n_out) *n_out = got;
+    return RR_OK;
+    RR_GUARD_END
+}
+int rr_channelizer_destroy(rr_channelizer *h) {
+    if (!h) return RR_OK;
+    RR_CHECK_HANDLE(h, K_CHANNELIZER);
     (void)hipSetDevice(h->device);
     delete h;
     return RR_OK;

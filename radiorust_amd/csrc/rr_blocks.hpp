@@ -73,6 +73,20 @@ struct rr_fourier : rr_block {
     int process_dev(size_t chunk_len, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
 };
 
+// Channelizer — Overlapper's history (chunks.rs:200-223) + Fourier's window (analysis.rs:67-73)
+struct rr_channelizer : rr_block {
+    size_t M = 0, P = 0;
+    size_t have_chunks = 0;  // chunks in the Overlapper's history, < P
+    rr::DevBuf hist[2];      // the last (P-1)*M samples
+    int cur = 0;
+    rr::DevBuf d_window, d_tw;
+    size_t peek(size_t n_in) const {
+        const size_t chunks = n_in / M, total = have_chunks + chunks;
+        return total >= P ? (total - (P - 1)) * M : 0;
+    }
+    int process_dev(const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
+};
+
 // hipEvent brackets around the chain's kernels (measurement aid)
 enum Stage { ST_FREQSHIFT = 0, ST_FILTER, ST_DECIM, ST_FOURIER, ST_FUSED_FIR, ST_FUSED_FFT, ST_COUNT };
 struct StageTimers {

@@ -101,7 +101,7 @@ struct Schedule {
 };
 
 // ---- block base ------------------------------------------------------------
-enum Kind { K_FREQSHIFTER = 1, K_FILTER, K_DOWNSAMPLER, K_FOURIER, K_CHAIN };
+enum Kind { K_FREQSHIFTER = 1, K_FILTER, K_DOWNSAMPLER, K_FOURIER, K_CHAIN, K_CHANNELIZER };
 
 }  // namespace rr
 

@@ -84,6 +84,12 @@ int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *i
                    const void *window, const void *tw4096, bool center_dc);
 int launch_drop_tail(hipStream_t s, const void *oldh, void *newh, size_t H, size_t drop);
 
+// Polyphase channelizer: frame f = FFT_M( sum_{p<P} w[r + M p] x[M (f0 + f) + r + M p] ), r < M,
+// over the virtual stream [ hist (hist_len samples, ends right before in[0]) | in ].
+// base0 = index (relative to in[0], may be negative) of the first sample of frame 0.
+int launch_channelizer(int dtype, hipStream_t s, const void *hist, size_t hist_len, const void *in, long base0,
+                       size_t M, size_t P, size_t nframes, const void *window, const void *tw, void *out);
+
 // SURVEY §8(d) synthetic IQ, f32
 int launch_synth(hipStream_t s, uint64_t seed, uint64_t t0, size_t n, void *out);
 

@@ -1,0 +1,102 @@
+"""GPU parity of the polyphase FFT channelizer (BASELINE configs[2]: 256 bins, 4 taps
+per branch) against the reference composition it is defined by:
+Rechunker(M) -> Overlapper(P) -> Fourier::with_window(Kaiser null-at-bin P) over P*M
+samples -> every P-th bin (chunks.rs:42-242, analysis.rs:60-132), built from the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rms_rel(a, b):
+    a = np.asarray(a, dtype=np.complex128)
+    b = np.asarray(b, dtype=np.complex128)
+    return float(np.sqrt(np.sum(np.abs(a - b) ** 2) / np.sum(np.abs(b) ** 2)))
+
+
+@pytest.fixture(scope="module")
+def rr():
+    import torch
+
+    assert torch.cuda.is_available()
+    import radiorust_amd
+
+    return radiorust_amd
+
+
+def reference_frames(oracle, chunks, M, P, flt, history=None):
+    """Overlapper(P) + Fourier + bin selection, chunk by chunk."""
+    hist = [] if history is None else history
+    fo = oracle.Fourier(oracle.Kaiser.with_null_at_bin(float(P)), flt=flt)
+    out = []
+    for c in chunks:
+        hist.append(c)
+        if len(hist) >= P:
+            X = fo.process(np.concatenate(hist[-P:]))
+            out.append(X[::P])
+            del hist[: len(hist) - (P - 1)]
+    return out, hist
+
+
+@pytest.mark.parametrize("M,P,dtype,tol", [(256, 4, np.float32, 1e-5), (64, 3, np.float32, 1e-5), (256, 1, np.float32, 1e-5),
+                                           (128, 4, np.float64, 1e-12)])
+def test_channelizer_parity(rr, oracle, M, P, dtype, tol):
+    nchunks = 37
+    x = oracle.synth_iq(21, 0, M * nchunks)
+    if dtype == np.float64:
+        x = x.astype(np.complex128)
+    chunks = [x[i * M : (i + 1) * M] for i in range(nchunks)]
+    ref, _ = reference_frames(oracle, chunks, M, P, np.float64)
+    g = rr.Channelizer(M, P, dtype=dtype)
+    got = []
+    # ragged multiples of M per call, including one call that is too short to emit anything
+    cuts = [0, 1, 2, 10, 11, 30, nchunks]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        got += g.process(rr.Samples(1e9, x[a * M : b * M]))
+    assert len(got) == len(ref) == nchunks - (P - 1)
+    assert all(len(s.chunk) == M for s in got)
+    for a, b in zip(got, ref):
+        assert rms_rel(a.chunk, b) <= tol
+
+
+def test_channelizer_event_resets_history(rr, oracle):
+    M, P = 256, 4
+    x = oracle.synth_iq(22, 0, M * 12)
+    g = rr.Channelizer(M, P)
+    out1 = g.process(rr.Samples(1e9, x[: M * 6]))
+    assert len(out1) == 3
+    ev = rr.EventSignal(rr.Event())
+    res = g.process(ev)
+    assert len(res) == 2 and res[0].event.is_interrupt() and res[1] is ev  # SamplesLost first (chunks.rs:225-233)
+    out2 = g.process(rr.Samples(1e9, x[M * 6 :]))
+    assert len(out2) == 3  # the history starts again from empty
+    ref, _ = reference_frames(oracle, [x[i * M : (i + 1) * M] for i in range(6, 12)], M, P, np.float64)
+    for a, b in zip(out2, ref):
+        assert rms_rel(a.chunk, b) <= 1e-5
+
+
+def test_channelizer_device_batch_and_errors(rr, oracle):
+    import torch
+
+    from radiorust_amd._lib import BackendError
+
+    M, P, k = 256, 4, 4096
+    n = M * k
+    d_in = torch.empty(n, dtype=torch.complex64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    rr.synth_iq_dev(0, st, 23, 0, n, d_in.data_ptr())
+    d_out = torch.empty(n, dtype=torch.complex64, device="cuda")
+    g = rr.Channelizer(M, P)
+    g.set_stream(st)
+    wrote = g.process_dev(d_in.data_ptr(), n, d_out.data_ptr(), n)
+    assert wrote == (k - (P - 1)) * M
+    torch.cuda.synchronize()
+    x = oracle.synth_iq(23, 0, n)
+    got = d_out.cpu().numpy()[:wrote].reshape(-1, M)
+    ref, _ = reference_frames(oracle, [x[i * M : (i + 1) * M] for i in range(40)], M, P, np.float64)
+    for j in (0, 1, 17, 36):
+        assert rms_rel(got[j], ref[j]) <= 1e-5
+    with pytest.raises(BackendError):
+        g.process(rr.Samples(1e9, x[: M + 1]))  # not whole chunks
+    with pytest.raises(BackendError):
+        rr.Channelizer(100, 4)  # bins must be a power of two
