@@ -304,6 +304,31 @@ int rr_channelizer_process_dev(rr_channelizer *h, const void *d_in, size_t n_in,
 int rr_channelizer_destroy(rr_channelizer *h);
 
 /* ------------------------------------------------------------------------ */
+/* Consumers of the chain output, over batches of frames   */
+/* of n samples so that spectra need not leave the device.  `_dev`: device       */
+/* pointers, asynchronous on `hip_stream`; the others: host pointers, blocking.  */
+/* ------------------------------------------------------------------------ */
+/* metering::level (src/metering.rs:21-30): mean |x|^2, f64; out[count] */
+int rr_level_dev(int dtype, int device, void *hip_stream, const void *d_frames, size_t n,
+                 size_t count, double *d_out);
+int rr_level(int dtype, int device, const void *chunk, size_t n, double *out);
+/* metering::bandwidth (src/metering.rs:41-80) */
+int rr_bandwidth_dev(int dtype, int device, void *hip_stream, double double_percentile,
+                     double sample_rate, const void *d_frames, size_t n, size_t count,
+                     double *d_out);
+int rr_bandwidth(int dtype, int device, double double_percentile, double sample_rate,
+                 const void *bins, size_t n, double *out);
+/* metering::rescale_energy (src/metering.rs:89-109): out = count x resolution Flt */
+int rr_rescale_energy_dev(int dtype, int device, void *hip_stream, const void *d_frames,
+                          size_t n, size_t count, size_t resolution, void *d_out);
+int rr_rescale_energy(int dtype, int device, const void *input, size_t n, size_t resolution,
+                      void *output);
+/* GainControl's `sample * gain` (src/blocks/transform.rs:62-72), gain cast to Flt */
+int rr_gain_dev(int dtype, int device, void *hip_stream, double gain, const void *d_in,
+                size_t n, void *d_out);
+int rr_gain(int dtype, int device, double gain, const void *in, size_t n, void *out);
+
+/* ------------------------------------------------------------------------ */
 /* Synthetic IQ source generated on the device; the test      */
 /* harness's stand-in for an SDR source block.  d_out: n rr_c32.             */
 /* ------------------------------------------------------------------------ */

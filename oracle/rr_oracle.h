@@ -118,7 +118,13 @@ typedef void (*rro_freq_resp_fn)(int64_t bin, double freq, double *out,
                                double output_rate, double bandwidth,          \
                                double quality, size_t fft_len,                \
                                const rro_window *fft_window, int center_dc,   \
-                               FLT *out, size_t out_cap_frames);
+                               FLT *out, size_t out_cap_frames);           \
+    double rro_level_##SUF(const FLT *chunk, size_t n);                       \
+    double rro_bandwidth_##SUF(double double_percentile, double sample_rate,  \
+                               const FLT *bins, size_t n);                    \
+    int rro_rescale_energy_##SUF(FLT *output, size_t resolution,              \
+                                 const FLT *input, size_t n);                 \
+    void rro_gain_##SUF(double gain, const FLT *in, size_t n, FLT *out);
 
 RRO_DECL(f32, float)
 RRO_DECL(f64, double)

@@ -107,6 +107,14 @@ def lib() -> C.CDLL:
         g("rro_fourier_window").argtypes = [vp, vp, sz]
         g("rro_fourier_free").restype = None
         g("rro_fourier_free").argtypes = [vp]
+        g("rro_level").restype = d
+        g("rro_level").argtypes = [vp, sz]
+        g("rro_bandwidth").restype = d
+        g("rro_bandwidth").argtypes = [d, d, vp, sz]
+        g("rro_rescale_energy").restype = C.c_int
+        g("rro_rescale_energy").argtypes = [vp, sz, vp, sz]
+        g("rro_gain").restype = None
+        g("rro_gain").argtypes = [d, vp, sz, vp]
         g("rro_chain_run").restype = sz
         g("rro_chain_run").argtypes = [vp, sz, d, d, d, sz, _RESPFN, vp, C.POINTER(_CWindow), d, d, d, sz,
                                        C.POINTER(_CWindow), C.c_int, vp, sz]
@@ -460,3 +468,35 @@ def run_chain_c(x, sample_rate, *, shift, precision=1.0, filter_len, freq_resp, 
     if frames == C.c_size_t(-1).value:
         raise AssertionError("chain contract violated")
     return out[: min(frames, cap)], frames
+
+
+# --------------------------------------------------------------------------
+# metering (metering.rs) and GainControl (transform.rs:29-92)
+# --------------------------------------------------------------------------
+def level(chunk, flt=np.float64) -> float:
+    suf, cdt, _ = _dt(flt)
+    x = _cin(chunk, cdt)
+    return getattr(lib(), f"rro_level_{suf}")(x.ctypes.data, x.size)
+
+
+def bandwidth(double_percentile, sample_rate, bins, flt=np.float64) -> float:
+    suf, cdt, _ = _dt(flt)
+    x = _cin(bins, cdt)
+    return getattr(lib(), f"rro_bandwidth_{suf}")(float(double_percentile), float(sample_rate), x.ctypes.data, x.size)
+
+
+def rescale_energy(resolution, input_, flt=np.float64):
+    suf, cdt, rdt = _dt(flt)
+    x = _cin(input_, cdt)
+    out = np.empty(int(resolution), dtype=rdt)
+    if getattr(lib(), f"rro_rescale_energy_{suf}")(out.ctypes.data, int(resolution), x.ctypes.data, x.size) != 0:
+        raise AssertionError("assert!(n > 0)")
+    return out
+
+
+def gain(g, chunk, flt=np.float32):
+    suf, cdt, _ = _dt(flt)
+    x = _cin(chunk, cdt)
+    y = np.empty_like(x)
+    getattr(lib(), f"rro_gain_{suf}")(float(g), x.ctypes.data, x.size, y.ctypes.data)
+    return y

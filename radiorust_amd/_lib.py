@@ -141,6 +141,14 @@ SIGNATURES = {
     "rr_channelizer_process": (_i, [_vp, _vp, _sz, _vp, _sz, _psz]),
     "rr_channelizer_process_dev": (_i, [_vp, _vp, _sz, _vp, _sz, _psz]),
     "rr_channelizer_destroy": (_i, [_vp]),
+    "rr_level_dev": (_i, [_i, _i, _vp, _vp, _sz, _sz, _vp]),
+    "rr_level": (_i, [_i, _i, _vp, _sz, C.POINTER(_d)]),
+    "rr_bandwidth_dev": (_i, [_i, _i, _vp, _d, _d, _vp, _sz, _sz, _vp]),
+    "rr_bandwidth": (_i, [_i, _i, _d, _d, _vp, _sz, C.POINTER(_d)]),
+    "rr_rescale_energy_dev": (_i, [_i, _i, _vp, _vp, _sz, _sz, _sz, _vp]),
+    "rr_rescale_energy": (_i, [_i, _i, _vp, _sz, _sz, _vp]),
+    "rr_gain_dev": (_i, [_i, _i, _vp, _d, _vp, _sz, _vp]),
+    "rr_gain": (_i, [_i, _i, _d, _vp, _sz, _vp]),
     "rr_synth_iq_dev": (_i, [_i, _vp, C.c_uint64, C.c_uint64, _sz, _vp]),
 }
 

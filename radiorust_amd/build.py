@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libradiorust_amd.so")
-SOURCES = ["rr_design.cpp", "rr_kernels.hip", "rr_fused.hip", "rr_api.hip"]
+SOURCES = ["rr_design.cpp", "rr_kernels.hip", "rr_fused.hip", "rr_metering.hip", "rr_api.hip"]
 ARCH = "gfx950"
 
 
@@ -47,6 +47,10 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(LIBDIR, src + ".o")
         if force or not os.path.exists(obj) or _obj_stale(obj):
             cmd = [_hipcc(), *flags, "-c", path, "-o", obj]
+            if src == "rr_metering.hip":
+                # the reference accumulates these reductions without a*b+c contraction; HIP's
+                # __fmul_rn/__fadd_rn are plain operators, so contraction is switched off per file
+                cmd[1:1] = ["-ffp-contract=off"]
             if src.endswith(".cpp"):
                 # host-only design math: no a*b+c contraction, like the reference's Rust
                 cmd[1:1] = ["-x", "hip", "-ffp-contract=off"]

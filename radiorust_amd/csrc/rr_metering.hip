@@ -1,0 +1,223 @@
+// rr_metering.hip — consumers of the chain's output that the reference computes on the
+// host per spectrum: metering::{level, bandwidth, rescale_energy} (src/metering.rs:21-109)
+// and the GainControl block's multiply (src/blocks/transform.rs:62-72), as device
+// functions over batches of frames so that spectra need not leave the GPU.
+//
+// The reference accumulates in f64 in index order (and `bandwidth` scans with an early
+// exit), so one lane per frame does the sequential part over energies staged in LDS by
+// the whole workgroup; no a*b+c contraction anywhere (the reference is Rust).
+#include "rr_kernels.hpp"
+
+namespace rr {
+
+template <class T> struct V2m;
+template <> struct V2m<float> { using type = float2; };
+template <> struct V2m<double> { using type = double2; };
+
+__device__ __forceinline__ float norm_sqr_rn(float2 v) { return __fadd_rn(__fmul_rn(v.x, v.x), __fmul_rn(v.y, v.y)); }
+__device__ __forceinline__ double norm_sqr_rn(double2 v) { return __dadd_rn(__dmul_rn(v.x, v.x), __dmul_rn(v.y, v.y)); }
+
+constexpr int kMeterMaxN = 8192;  // energies of one frame in LDS as f64
+
+// mode 0: level (metering.rs:21-30); mode 1: bandwidth (metering.rs:41-80)
+template <class T>
+__global__ __launch_bounds__(256) void k_meter(const typename V2m<T>::type *__restrict__ frames, int n, int mode,
+                                               double double_percentile, double sample_rate,
+                                               double *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *e = reinterpret_cast<double *>(smem);
+    const typename V2m<T>::type *src = frames + (size_t)blockIdx.x * n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) e[i] = (double)norm_sqr_rn(src[i]);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double total = 0.0;
+    for (int i = 0; i < n; ++i) total = __dadd_rn(total, e[i]);
+    if (mode == 0) {
+        out[blockIdx.x] = total / (double)n;
+        return;
+    }
+    const double limit = __dmul_rn(total, double_percentile) / 2.0;
+    const int wrap = (n + 1) / 2;
+    double used_bins = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {
+        double old_e = 0.0, used = 0.0;
+        for (int k = 0; k < n; ++k) {
+            const int pos = pass == 0 ? k : n - 1 - k;
+            const int idx = pos < n - wrap ? wrap + pos : pos - (n - wrap);
+            const double new_e = __dadd_rn(old_e, e[idx]);
+            if (new_e > limit) {
+                used = __dadd_rn(used, __dsub_rn(limit, old_e) / __dsub_rn(new_e, old_e));
+                break;
+            }
+            used = __dadd_rn(used, 1.0);
+            old_e = new_e;
+        }
+        used_bins = __dadd_rn(used_bins, used);
+    }
+    const double bw = __dmul_rn(__dsub_rn((double)n, used_bins), sample_rate) / (double)n;
+    out[blockIdx.x] = bw > 0.0 ? bw : 0.0;
+}
+
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(a, b); }
+__device__ __forceinline__ float div_rn(float a, float b) { return __fdiv_rn(a, b); }
+__device__ __forceinline__ double div_rn(double a, double b) { return __ddiv_rn(a, b); }
+__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ double sub_rn(double a, double b) { return __dsub_rn(a, b); }
+
+// metering.rs:89-109, one lane per output value, all arithmetic in Flt
+template <class T>
+__global__ __launch_bounds__(256) void k_rescale_energy(const typename V2m<T>::type *__restrict__ frames, int n,
+                                                        int resolution, T *__restrict__ out) {
+    const int oi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (oi >= resolution) return;
+    const typename V2m<T>::type *src = frames + (size_t)blockIdx.y * n;
+    const T left = mul_rn(div_rn((T)oi, (T)resolution), (T)n);
+    const T right = mul_rn(div_rn(add_rn((T)oi, (T)1), (T)resolution), (T)n);
+    long lf = (long)floor((double)left);
+    if (lf > n - 1) lf = n - 1;
+    long rc = (long)ceil((double)right);
+    if (rc > n) rc = n;
+    T acc = 0;
+    for (long ii = lf; ii < rc; ++ii) {
+        const T lb = (T)ii > left ? (T)ii : left;
+        const T up = add_rn((T)ii, (T)1);
+        const T rb = up < right ? up : right;
+        acc = add_rn(acc, mul_rn(norm_sqr_rn(src[ii]), sub_rn(rb, lb)));
+    }
+    out[(size_t)blockIdx.y * resolution + oi] = acc;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_gain(const T *__restrict__ in, T *__restrict__ out, size_t n2, T g) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) out[i] = mul_rn(in[i], g);
+}
+
+int launch_meter(int dtype, hipStream_t s, int mode, double double_percentile, double sample_rate, const void *frames,
+                 size_t n, size_t count, double *out) {
+    if (count == 0) return RR_OK;
+    if (n == 0) RR_FAIL(RR_ERR_CONTRACT, "metering: empty chunk");
+    if (n > (size_t)kMeterMaxN) RR_FAIL(RR_ERR_BAD_ARG, "metering: frames longer than %d bins are not supported yet", kMeterMaxN);
+    if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "metering: too many frames");
+    const size_t lds = n * sizeof(double);
+    if (dtype == RR_F32) {
+        auto fn = k_meter<float>;
+        if (lds > 64 * 1024) RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fn, dim3((unsigned)count), dim3(256), lds, s, (const float2 *)frames, (int)n, mode,
+                           double_percentile, sample_rate, out);
+    } else {
+        auto fn = k_meter<double>;
+        if (lds > 64 * 1024) RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fn, dim3((unsigned)count), dim3(256), lds, s, (const double2 *)frames, (int)n, mode,
+                           double_percentile, sample_rate, out);
+    }
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+int launch_rescale_energy(int dtype, hipStream_t s, const void *frames, size_t n, size_t count, size_t resolution,
+                          void *out) {
+    if (count == 0 || resolution == 0) return RR_OK;
+    if (n == 0) RR_FAIL(RR_ERR_CONTRACT, "rescale_energy: assert!(n > 0)");
+    if (count > 65535 || n > 0x7fffffffull || resolution > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "rescale_energy: size out of range");
+    dim3 grid((unsigned)((resolution + 255) / 256), (unsigned)count);
+    if (dtype == RR_F32)
+        hipLaunchKernelGGL(k_rescale_energy<float>, grid, dim3(256), 0, s, (const float2 *)frames, (int)n, (int)resolution, (float *)out);
+    else
+        hipLaunchKernelGGL(k_rescale_energy<double>, grid, dim3(256), 0, s, (const double2 *)frames, (int)n, (int)resolution, (double *)out);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+int launch_gain(int dtype, hipStream_t s, double gain, const void *in, size_t n, void *out) {
+    if (n == 0) return RR_OK;
+    size_t blocks = (2 * n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == RR_F32)
+        hipLaunchKernelGGL(k_gain<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float *)in, (float *)out, 2 * n, (float)gain);
+    else
+        hipLaunchKernelGGL(k_gain<double>, dim3((unsigned)blocks), dim3(256), 0, s, (const double *)in, (double *)out, 2 * n, gain);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+}  // namespace rr
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+using namespace rr;
+
+static int dev_check(int dtype, int device) {
+    if (dtype != RR_F32 && dtype != RR_F64) RR_FAIL(RR_ERR_BAD_ARG, "unknown dtype %d", dtype);
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) RR_FAIL(RR_ERR_HIP, "no HIP device available; this backend has no CPU fallback");
+    if (device < 0 || device >= count) RR_FAIL(RR_ERR_BAD_ARG, "device %d out of range", device);
+    RR_HIP(hipSetDevice(device));
+    return RR_OK;
+}
+
+// host-pointer convenience: copy in, run, copy out, blocking
+template <class F>
+static int host_roundtrip(int dtype, int device, const void *in, size_t in_bytes, void *out, size_t out_bytes, F &&run) {
+    RR_TRY(dev_check(dtype, device));
+    DevBuf din, dout;
+    RR_TRY(din.reserve(in_bytes ? in_bytes : 16));
+    RR_TRY(dout.reserve(out_bytes ? out_bytes : 16));
+    if (in_bytes) RR_HIP(hipMemcpy(din.p, in, in_bytes, hipMemcpyHostToDevice));
+    RR_TRY(run(din.p, dout.p));
+    RR_HIP(hipStreamSynchronize(nullptr));
+    if (out_bytes) RR_HIP(hipMemcpy(out, dout.p, out_bytes, hipMemcpyDeviceToHost));
+    return RR_OK;
+}
+
+extern "C" {
+
+int rr_level_dev(int dtype, int device, void *stream, const void *d_frames, size_t n, size_t count, double *d_out) {
+    RR_TRY(dev_check(dtype, device));
+    return launch_meter(dtype, (hipStream_t)stream, 0, 0.0, 0.0, d_frames, n, count, d_out);
+}
+int rr_bandwidth_dev(int dtype, int device, void *stream, double double_percentile, double sample_rate,
+                     const void *d_frames, size_t n, size_t count, double *d_out) {
+    RR_TRY(dev_check(dtype, device));
+    return launch_meter(dtype, (hipStream_t)stream, 1, double_percentile, sample_rate, d_frames, n, count, d_out);
+}
+int rr_rescale_energy_dev(int dtype, int device, void *stream, const void *d_frames, size_t n, size_t count,
+                          size_t resolution, void *d_out) {
+    RR_TRY(dev_check(dtype, device));
+    return launch_rescale_energy(dtype, (hipStream_t)stream, d_frames, n, count, resolution, d_out);
+}
+int rr_gain_dev(int dtype, int device, void *stream, double gain, const void *d_in, size_t n, void *d_out) {
+    RR_TRY(dev_check(dtype, device));
+    return launch_gain(dtype, (hipStream_t)stream, gain, d_in, n, d_out);
+}
+
+int rr_level(int dtype, int device, const void *chunk, size_t n, double *out) {
+    if (!out || (n && !chunk)) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    return host_roundtrip(dtype, device, chunk, n * elem_size(dtype), out, sizeof(double), [&](void *di, void *dout) {
+        return launch_meter(dtype, nullptr, 0, 0.0, 0.0, di, n, 1, (double *)dout);
+    });
+}
+int rr_bandwidth(int dtype, int device, double double_percentile, double sample_rate, const void *bins, size_t n,
+                 double *out) {
+    if (!out || (n && !bins)) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    return host_roundtrip(dtype, device, bins, n * elem_size(dtype), out, sizeof(double), [&](void *di, void *dout) {
+        return launch_meter(dtype, nullptr, 1, double_percentile, sample_rate, di, n, 1, (double *)dout);
+    });
+}
+int rr_rescale_energy(int dtype, int device, const void *input, size_t n, size_t resolution, void *output) {
+    if ((resolution && !output) || (n && !input)) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    return host_roundtrip(dtype, device, input, n * elem_size(dtype), output, resolution * (elem_size(dtype) / 2),
+                          [&](void *di, void *dout) { return launch_rescale_energy(dtype, nullptr, di, n, 1, resolution, dout); });
+}
+int rr_gain(int dtype, int device, double gain, const void *in, size_t n, void *out) {
+    if (n && (!in || !out)) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    return host_roundtrip(dtype, device, in, n * elem_size(dtype), out, n * elem_size(dtype),
+                          [&](void *di, void *dout) { return launch_gain(dtype, nullptr, gain, di, n, dout); });
+}
+
+}  // extern "C"
