@@ -135,7 +135,12 @@ struct rr_chain : rr_block {
     int Gp = 0;
     size_t Lc = 0;
     uint64_t ctaps_fl = ~0ull, ctaps_ds = ~0ull;
+    // overlap-save variant of the fused FIR (k_ols_decim4)
+    bool use_ols = false;
+    int ols_V = 0;
+    rr::DevBuf d_olsH, d_tw4096;
     bool fused_candidate(double sample_rate) const;
+    static bool ols_wanted();
     int ensure_xh();
     int ensure_ctaps();
     int materialize();  // bring the per-block histories up to date after fused calls

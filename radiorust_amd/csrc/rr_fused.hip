@@ -49,7 +49,9 @@ template <int D, int R> struct FirGeom {
 };
 
 // pairs of samples each lane prefetches per tile (upper bound of the real count)
-constexpr int kNPF = 18;
+constexpr int kNPF = 18;  // R*D = 32 samples per lane row
+// generic: enough 16-B pairs per lane for a tile of T rows of RD samples plus up to 16 halo rows
+constexpr int npf_for(int RD) { return RD * 9 / 16; }
 
 #ifdef RR_STAMP
 // diagnostic build: per-phase cycle sums (s_memtime), summed over all waves
@@ -92,8 +94,10 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
     using G = FirGeom<D, R>;
     constexpr int RD = G::RD, STRIDE = G::STRIDE;
     constexpr int OUTS = T * R;
-    static_assert(RD == 32 && (2 * T) % RD == 0, "LDS write addresses advance by whole rows per prefetch slot");
+    static_assert((RD == 32 || RD == 16) && (2 * T) % RD == 0, "LDS write addresses advance by whole rows per prefetch slot");
     constexpr int ROWS_PER_SLOT = 2 * T / RD;
+    constexpr int NPF = npf_for(RD);        // 18 for RD = 32, 9 for RD = 16
+    constexpr int LOG2_RD = RD == 32 ? 5 : 4;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // 32 spare bytes in front: when the tile starts at an odd sample, the first lane's
     // pair straddles the tile start and its first half (sample -1 = row -1, column 31)
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
     const int npairs = (NS + odd + 1) >> 1;
     const int sfirst = 2 * (int)threadIdx.x - odd;     // LDS sample index of this lane's first prefetched sample
     // byte address of sample s (floor division, so s = -1 is row -1, column 31 = -24)
-    auto lds_addr = [&](int s) -> int { return (s >> 5) * STRIDE + (s & 31) * 8; };
+    auto lds_addr = [&](int s) -> int { return (s >> LOG2_RD) * STRIDE + (s & (RD - 1)) * 8; };
     const int a0 = lds_addr(sfirst), a1 = lds_addr(sfirst + 1);
     const unsigned step = (unsigned)((2 * T) % denom);
     const unsigned tstep = (unsigned)(((long)D * OUTS) % denom);
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
     auto tile_lo_of = [&](unsigned tile) -> long { return lo0 + (long)D * OUTS * tile; };
     auto interior_of = [&](long tile_lo) -> bool {
         const long le = tile_lo - odd;
-        return in_aligned16 && le >= 0 && le + 2L * kNPF * T <= n_in;  // the whole prefetch window is inside `in`
+        return in_aligned16 && le >= 0 && le + 2L * NPF * T <= n_in;  // the whole prefetch window is inside `in`
     };
     long tile_lo = tile_lo_of(tile_begin);
     unsigned rbase;
@@ -161,15 +165,15 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
     }
     float2 pc0 = nco[rbase], pc1 = nco[(rbase + 1 == denom) ? 0 : rbase + 1];
 
-    f4 x[kNPF];
+    f4 x[NPF];
     auto prefetch = [&](long tlo) {
 #if defined(RR_ABLATE) && (RR_ABLATE == 2 || RR_ABLATE == 3 || RR_ABLATE == 4)  // diagnostic: no global loads
 #pragma unroll
-        for (int u = 0; u < kNPF; ++u) x[u] = (f4){1.f, 2.f, 3.f, (float)tlo};
+        for (int u = 0; u < NPF; ++u) x[u] = (f4){1.f, 2.f, 3.f, (float)tlo};
 #else
         const f4 *src = reinterpret_cast<const f4 *>(in + (tlo - odd)) + threadIdx.x;
 #pragma unroll
-        for (int u = 0; u < kNPF; ++u) x[u] = src[u * T];
+        for (int u = 0; u < NPF; ++u) x[u] = src[u * T];
 #endif
     };
     bool cur_interior = interior_of(tile_lo);
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
             if (nco_const) {
                 const f2 q0 = {pc0.x, pc0.y}, q0j = {-pc0.y, pc0.x}, q1 = {pc1.x, pc1.y}, q1j = {-pc1.y, pc1.x};
 #pragma unroll
-                for (int u = 0; u < kNPF; ++u) {
+                for (int u = 0; u < NPF; ++u) {
                     const bool ok = (int)threadIdx.x + u * T < npairs;
                     const f2 v0 = mix(x[u].xy, q0, q0j), v1 = mix(x[u].zw, q1, q1j);
                     if (ok) {
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
             } else {
                 unsigned rr_ = rbase;
 #pragma unroll
-                for (int u = 0; u < kNPF; ++u) {
+                for (int u = 0; u < NPF; ++u) {
                     const bool ok = (int)threadIdx.x + u * T < npairs;
                     const float2 p0 = nco[rr_], p1 = nco[(rr_ + 1 == denom) ? 0 : rr_ + 1];
                     const f2 v0 = mix(x[u].xy, (f2){p0.x, p0.y}, (f2){-p0.y, p0.x});
@@ -421,7 +425,7 @@ static int launch_mfd(hipStream_t s, const FusedFirArgs &a) {
     const int rows = T + (a.Gp + R - 2) / R;
     const int lds_rows = rows + 2 * T / G::RD + 1;
     const size_t lds = 32 + (size_t)lds_rows * G::STRIDE + (size_t)a.Gp * D * sizeof(float);
-    if ((rows * G::RD + 2) / 2 > kNPF * T) RR_FAIL(RR_ERR_BAD_ARG, "fused FIR: %d tap groups exceed the prefetch window", a.Gp);
+    if ((rows * G::RD + 2) / 2 > npf_for(G::RD) * T) RR_FAIL(RR_ERR_BAD_ARG, "fused FIR: %d tap groups exceed the prefetch window", a.Gp);
     auto fn = k_mix_fir_decim<D, R, T>;
     if (lds > 64 * 1024)
         RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -431,7 +435,7 @@ static int launch_mfd(hipStream_t s, const FusedFirArgs &a) {
 #ifdef RR_V_WGPCU
     size_t nwg = 256 * RR_V_WGPCU;
 #else
-    size_t nwg = 256 * (512 / T);
+    size_t nwg = 256 * (512 / T) * (32 / G::RD);  // LDS-limited: 8 waves/CU at 32 samples per lane, 12-16 at 16
 #endif
     if (nwg > ntiles) nwg = ntiles;
     const size_t tpw = (ntiles + nwg - 1) / nwg;
@@ -458,7 +462,11 @@ bool fused_fir_supported(uint64_t D, size_t Lc) {
 int fused_fir_R(uint64_t D) {
     switch (D) {
         case 2: return 16;
+#ifdef RR_V_R4
+        case 4: return 4;
+#else
         case 4: return 8;
+#endif
         case 8: return 4;
     }
     return 0;
@@ -468,7 +476,9 @@ int launch_fused_fir(hipStream_t s, const FusedFirArgs &a) {
     if (a.n_out == 0) return RR_OK;
     switch (a.D) {
         case 2: return launch_mfd<2, 16, 128>(s, a);
-#ifdef RR_V_T256
+#if defined(RR_V_R4)
+        case 4: return launch_mfd<4, 4, 128>(s, a);
+#elif defined(RR_V_T256)
         case 4: return launch_mfd<4, 8, 256>(s, a);
 #else
         case 4: return launch_mfd<4, 8, 128>(s, a);
@@ -615,6 +625,219 @@ int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *i
     hipLaunchKernelGGL(k_fft4096, dim3((unsigned)count), dim3(256), 0, s, (const float2 *)head, (long)n_head,
                        (const float2 *)in, (float2 *)out,
                        (const float *)window, (const float2 *)tw4096, (int)center_dc);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Kernel 3  k_ols_decim4: the same mix + combined FIR + 4x decimation as
+// k_mix_fir_decim, computed by overlap-save fast convolution:
+//   block of 4096 mixed samples -> forward DFT (radix 16 x 3, as k_fft4096)
+//   -> * H  (H = DFT_4096(c) / 4096, c = reverse(ir) (*) g, real or complex)
+//   -> fold the four 1024-bin quarters (decimation by 4 in time = aliasing in frequency)
+//   -> inverse DFT_1024 (radix 4 x 5) -> the last (4096 - V)/4 results are valid.
+// ~30 packed VALU ops per input sample instead of ~49 for the direct form, and the
+// occupancy/LDS profile of k_fft4096 (34.8 KiB, 16 waves/CU).  Blocks start at
+// e0 - V + b * (4096 - V), so output m of the call is sample (V/4 + i) of block b.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ f2 mul_pj(f2 a) { return (f2){-a.y, a.x}; }  // * (+j)
+
+// inverse 4-point DFT (kernel e^{+j 2 pi n k / 4})
+__device__ __forceinline__ void idft4(f2 &a, f2 &b, f2 &c, f2 &d) {
+    const f2 s0 = a + c, s1 = a - c, s2 = b + d, s3 = mul_pj(b - d);
+    a = s0 + s2;
+    b = s1 + s3;
+    c = s0 - s2;
+    d = s1 - s3;
+}
+
+__global__ __launch_bounds__(256) void k_ols_decim4(const float2 *__restrict__ xh, int hx,
+                                                    const float2 *__restrict__ in, long n_in,
+                                                    const float2 *__restrict__ nco, unsigned denom, unsigned idx0,
+                                                    const float2 *__restrict__ H, const float2 *__restrict__ tw,
+                                                    int V, float2 *__restrict__ out, long n_out, long e0,
+                                                    float2 *__restrict__ xh_out, int hx_out) {
+    __shared__ f2 lds[4096 + 256];
+    const int j = threadIdx.x;
+    const int hop = 4096 - V, per_block = hop >> 2;
+    const long b0 = e0 - V + (long)blockIdx.x * hop;  // position of the block's first sample
+
+    // the last workgroup also leaves the mixed-sample history for the next call
+    if (xh_out && blockIdx.x == gridDim.x - 1) {
+        for (int i = j; i < hx_out; i += 256) {
+            const long pos = n_in - hx_out + i;
+            float2 v;
+            if (pos >= 0) {
+                const float2 xx = in[pos];
+                const float2 pp = nco[(unsigned)(((long)idx0 + pos) % (long)denom)];
+                v.x = xx.x * pp.x - xx.y * pp.y;
+                v.y = xx.x * pp.y + xx.y * pp.x;
+            } else {
+                v = (pos >= -(long)hx) ? xh[hx + pos] : float2{0.f, 0.f};
+            }
+            xh_out[i] = v;
+        }
+    }
+
+    // ---- load + mix: v[k] = xs[b0 + j + 256 k] ----------------------------------
+    f2 v[16];
+    {
+        const unsigned kstep = 256u % denom;
+        long ph = ((long)idx0 + b0 + j) % (long)denom;
+        if (ph < 0) ph += denom;
+        unsigned r = (unsigned)ph;
+        const bool interior = b0 >= 0 && b0 + 4096 <= n_in;
+        if (interior) {
+            const float2 *src = in + b0 + j;
+            float2 x[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) x[k] = src[256 * k];
+            if (kstep == 0) {  // the phasor of a lane does not change (e.g. denom = 8)
+                const float2 p = nco[r];
+                const f2 pp = {p.x, p.y}, pj = {-p.y, p.x};
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const f2 xv = {x[k].x, x[k].y};
+                    v[k] = __builtin_elementwise_fma(xv.yy, pj, xv.xx * pp);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float2 p = nco[r];
+                    const f2 xv = {x[k].x, x[k].y};
+                    v[k] = __builtin_elementwise_fma(xv.yy, (f2){-p.y, p.x}, xv.xx * (f2){p.x, p.y});
+                    r += kstep;
+                    if (r >= denom) r -= denom;
+                }
+            }
+        } else {  // edges: history (already mixed) in front, nothing behind the input
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const long pos = b0 + j + 256 * k;
+                f2 t = {0.f, 0.f};
+                if (pos < 0) {
+                    if (pos >= -(long)hx) {
+                        const float2 h = xh[hx + pos];
+                        t = (f2){h.x, h.y};
+                    }
+                } else if (pos < n_in) {
+                    const float2 xx = in[pos];
+                    const float2 p = nco[r];
+                    t = (f2){xx.x * p.x - xx.y * p.y, xx.x * p.y + xx.y * p.x};
+                }
+                v[k] = t;
+                r += kstep;
+                if (r >= denom) r -= denom;
+            }
+        }
+    }
+    // ---- forward DFT_4096 (identical to k_fft4096) --------------------------------
+    dft16(v);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[pad16(16 * j + k)] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = lds[pad16(j + 256 * k)];
+    {
+        f2 wp[16];
+        const float2 t = tw[16 * (j & 15)];
+        twiddle_powers((f2){t.x, t.y}, wp);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v[k] = cmulf(v[k], wp[k]);
+    }
+    dft16(v);
+    __syncthreads();
+    {
+        const int base = (j >> 4) * 256 + (j & 15);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lds[pad16(base + 16 * k)] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = lds[pad16(j + 256 * k)];
+    {
+        f2 wp[16];
+        const float2 t = tw[j];
+        twiddle_powers((f2){t.x, t.y}, wp);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v[k] = cmulf(v[k], wp[k]);
+    }
+    dft16(v);  // v[k] = X[j + 256 k]
+    // ---- * H and fold: Y[j + 256 c] = sum_q X[j + 256 (c + 4 q)] H[...] -----------
+    f2 y[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        f2 acc = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float2 h = H[j + 256 * (c + 4 * q)];
+            const f2 xv = v[c + 4 * q];
+            acc = __builtin_elementwise_fma(xv.yy, (f2){-h.y, h.x}, __builtin_elementwise_fma(xv.xx, (f2){h.x, h.y}, acc));
+        }
+        y[c] = acc;
+    }
+    // ---- inverse DFT_1024, Stockham radix 4 x 5 ---------------------------------------
+#pragma unroll
+    for (int pass = 0; pass < 5; ++pass) {
+        const int ns = 1 << (2 * pass);
+        if (pass > 0) {
+            __syncthreads();  // previous use of the LDS image is over
+            // (for pass 0 the forward transform's last reads were followed by a barrier-free
+            //  register phase; the barrier below orders them before the first writes)
+        }
+        if (pass > 0) {
+            // twiddles e^{+j 2 pi c (j mod ns) / (4 ns)} = conj(tw[(j mod ns) * 1024 / ns])^c
+            const float2 t = tw[(j & (ns - 1)) * (1024 / ns)];
+            const f2 w1 = {t.x, -t.y};
+            const f2 w2 = cmulf(w1, w1);
+            const f2 w3 = cmulf(w2, w1);
+            y[1] = cmulf(y[1], w1);
+            y[2] = cmulf(y[2], w2);
+            y[3] = cmulf(y[3], w3);
+        }
+        idft4(y[0], y[1], y[2], y[3]);
+        if (pass == 4) break;  // natural order: y[c] = result[j + 256 c]
+        const int k = j & (ns - 1);
+        const int o = ((j - k) << 2) + k;  // (j / ns) * 4 ns + j mod ns
+        if (pass == 0) __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) lds[pad16(o + c * ns)] = y[c];
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) y[c] = lds[pad16(j + 256 * c)];
+    }
+    // ---- store the valid part --------------------------------------------------------
+    const long mbase = (long)blockIdx.x * per_block;
+    const int first = V >> 2;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int tau = j + 256 * c;
+        const long m = mbase + (tau - first);
+        if (tau >= first && m < n_out) {
+            float2 w;
+            w.x = y[c].x;
+            w.y = y[c].y;
+            out[m] = w;
+        }
+    }
+}
+
+int ols_decim_overlap(size_t Lc) {  // V: multiple of 256 covering the Lc - 1 wrapped samples
+    const size_t v = (Lc - 1 + 255) / 256 * 256;
+    return v == 0 ? 256 : (int)v;
+}
+
+bool ols_decim_supported(uint64_t D, size_t Lc) { return D == 4 && Lc >= 1 && Lc - 1 <= 2048; }
+
+int launch_ols_decim(hipStream_t s, const FusedFirArgs &a) {
+    if (a.n_out == 0) return RR_OK;
+    const int per_block = (4096 - a.V) / 4;
+    const size_t nblocks = (a.n_out + per_block - 1) / per_block;
+    if (nblocks > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS: too many blocks");
+    hipLaunchKernelGGL(k_ols_decim4, dim3((unsigned)nblocks), dim3(256), 0, s, (const float2 *)a.xh, (int)a.hx,
+                       (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0,
+                       (const float2 *)a.H, (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out, (long)a.e0,
+                       (float2 *)a.xh_out, (int)a.hx);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }

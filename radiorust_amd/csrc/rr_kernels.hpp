@@ -74,7 +74,14 @@ struct FusedFirArgs {
     int64_t e0 = 0;
     uint32_t D = 1;
     void *xh_out = nullptr;  // receives the last hx mixed samples of this call (may be null)
+    // overlap-save variant (k_ols_decim4)
+    const void *H = nullptr;       // DFT_4096(c) / 4096, complex f32
+    const void *tw4096 = nullptr;  // e^{-j 2 pi k / 4096}
+    int V = 0;                     // overlap (samples), multiple of 256
 };
+bool ols_decim_supported(uint64_t D, size_t Lc);
+int ols_decim_overlap(size_t Lc);
+int launch_ols_decim(hipStream_t s, const FusedFirArgs &a);
 bool fused_fir_supported(uint64_t D, size_t Lc);
 int fused_fir_R(uint64_t D);  // outputs per lane of the instantiation for D
 int launch_fused_fir(hipStream_t s, const FusedFirArgs &a);

@@ -184,3 +184,36 @@ def test_chain_device_api_and_capacity(rr, oracle):
     g2.process_dev(fs, d_in2.data_ptr(), n, d_out2.data_ptr(), d_out2.numel())
     torch.cuda.synchronize()
     assert torch.allclose(d_out2, d_out * 2, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("allow_fused", [False, True])
+def test_chain_complex_response(rr, oracle, allow_fused):
+    """A one-sided (not even) frequency response gives genuinely complex taps: the fused
+    path then runs the overlap-save kernel (k_ols_decim4)."""
+    fs, n = 200e6, 1 << 18
+    resp = lambda b, f: (1.0 + 0.25j) if 0 <= f <= 20e6 else 0.0  # noqa: E731
+    params = dict(shift=25e6, filter_len=64, freq_resp=resp, output_rate=50e6, bandwidth=40e6, fft_len=4096)
+    x = oracle.synth_iq(6, 0, n)
+    t64 = oracle_spectra(oracle, x, fs, params, np.float64)
+    g = make(rr, oracle, params, allow_fused)
+    out = g.process(rr.Samples(fs, x[:100000])) + g.process(rr.Samples(fs, x[100000:]))
+    assert len(out) == len(t64) == 15
+    for a, b in zip(out, t64):
+        assert rms_rel(a.chunk, b) <= 1e-5
+    if allow_fused:
+        assert g.last_path_fused()
+
+
+def test_chain_overlap_save_kernel_forced(rr, oracle, monkeypatch):
+    """RR_FUSED_KERNEL=ols runs cfg2 through the overlap-save fused kernel."""
+    monkeypatch.setenv("RR_FUSED_KERNEL", "ols")
+    fs, n = 200e6, 1 << 18
+    x = oracle.synth_iq(1, 0, n)
+    t64 = oracle_spectra(oracle, x, fs, CFG2, np.float64)
+    g = make(rr, oracle, CFG2, True)
+    out = []
+    for a, b in ((0, 70001), (70001, 200000), (200000, n)):
+        out += g.process(rr.Samples(fs, x[a:b]))
+    assert g.last_path_fused() and len(out) == 15
+    for a, b in zip(out, t64):
+        assert rms_rel(a.chunk, b) <= 1e-5
