@@ -151,6 +151,24 @@ def main():
     fused = chain.last_path_fused()
     elapsed = ranks.max_over_ranks(elapsed)
 
+    # Full-size consistency check (not timed): replay the same calls through the block-by-block
+    # kernels and compare the last step's spectra; together with the first-spectrum check against
+    # the f64 oracle above this ties the fused kernels to the oracle at the benchmark size.
+    fused_vs_blocks = None
+    if rank == 0 and fused and not args.no_fused:
+        ref_chain = rr.Chain(shift=25e6, filter_len=64, freq_resp=lowpass20, output_rate=50e6, bandwidth=40e6,
+                             fft_len=4096, fft_window=rr.Kaiser.with_null_at_bin(2.0), device=local_rank,
+                             allow_fused=False)
+        ref_chain.set_stream(stream)
+        d_ref = torch.empty(cap, dtype=torch.complex64, device="cuda")
+        wrote = 0
+        for _ in range(1 + max(args.warmup - 1, 0) + args.steps):
+            wrote = ref_chain.process_dev(fs, d_in.data_ptr(), n, d_ref.data_ptr(), cap)
+        torch.cuda.synchronize()
+        a, b = d_out[:wrote], d_ref[:wrote]
+        fused_vs_blocks = float((torch.linalg.vector_norm(a - b) / torch.linalg.vector_norm(b)).item())
+        del ref_chain, d_ref
+
     # per-kernel device time from the library's hipEvents
     stages = {}
     i = 0
@@ -213,6 +231,7 @@ def main():
             },
             "kernels": {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 5)} for k, v in stages.items()},
             "parity_first_spectrum_rms": parity,
+            "parity_fused_vs_block_by_block_last_step_rms": fused_vs_blocks,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

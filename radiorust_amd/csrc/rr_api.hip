@@ -143,7 +143,23 @@ int rr_filter::design(double sample_rate, size_t len, const rr_c64 *resp, const 
     else
         cast_to<double>(w.data(), w.size(), bytes);
     RR_TRY(upload(d_taps, bytes.data(), bytes.size(), stream));
-    use_ols = ols_supported(dtype, len);
+    use_ols4096 = filter_ols4096_supported(dtype, len);
+    if (use_ols4096) {
+        std::vector<cd> gg(4096, cd(0, 0));
+        for (size_t i = 0; i < len; ++i) gg[i] = g[i];
+        fft_f64(gg, false);
+        std::vector<float> gb(2 * 4096), twb(2 * 4096);
+        for (size_t i = 0; i < 4096; ++i) {
+            gb[2 * i] = (float)(gg[i].real() / 4096.0);
+            gb[2 * i + 1] = (float)(gg[i].imag() / 4096.0);
+            const double ang = -2.0 * M_PI * (double)i / 4096.0;
+            twb[2 * i] = (float)std::cos(ang);
+            twb[2 * i + 1] = (float)std::sin(ang);
+        }
+        RR_TRY(upload(d_G4096, gb.data(), gb.size() * sizeof(float), stream));
+        RR_TRY(upload(d_tw4096, twb.data(), twb.size() * sizeof(float), stream));
+    }
+    use_ols = !use_ols4096 && ols_supported(dtype, len);
     if (use_ols) {
         // the reference's extended response (filters.rs:220-238), transformed in f64 here
         std::vector<cd> ext(2 * len, cd(0, 0));
@@ -195,7 +211,10 @@ int rr_filter::process_dev(double sample_rate, const void *d_in, size_t n_in, vo
     const size_t produce = peek(n_in);
     if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Filter: out_cap %zu < %zu", cap, produce);
     RR_TRY(select());
-    if (produce && use_ols) {
+    if (produce && use_ols4096) {
+        RR_TRY(launch_filter_ols4096(stream, hist[cur].p, hist_valid ? n : 0, d_in, n_in, d_G4096.p, d_tw4096.p, n, d_out,
+                                     produce, hist_valid ? 0 : (long)n));
+    } else if (produce && use_ols) {
         RR_TRY(launch_filter_ols(dtype, stream, hist[cur].p, d_in, n, produce / n, hist_valid ? 0 : 1, d_H.p, d_olstw.p, d_out));
     } else if (produce) {
         FirArgs a;

@@ -29,6 +29,8 @@ struct rr_filter : rr_block {
     rr::DevBuf d_taps;             // w[j] = g[n-1-j] as T or complex<T>
     bool use_ols = false;          // long power-of-two filters: overlap-save fast convolution
     rr::DevBuf d_H, d_olstw;       // H = FFT_2n([0 | g / 2n]) and e^{-j 2 pi k / 2n}, k < n
+    bool use_ols4096 = false;      // f32, n in {256..2048}: 4096-point blocks, radix-16 kernel
+    rr::DevBuf d_G4096, d_tw4096;
     rr::DevBuf hist[2];            // previous_chunk (n samples), ping-pong
     int cur = 0;
     bool hist_valid = false;  // previous_chunk.is_some()

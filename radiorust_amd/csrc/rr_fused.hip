@@ -842,6 +842,112 @@ int launch_ols_decim(hipStream_t s, const FusedFirArgs &a) {
     return RR_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Kernel 4  k_filter_ols4096: the Filter block's fast convolution (filters.rs:240-259)
+// for n in {256, 512, 1024, 2048}, Complex<f32>, with 4096-point blocks:
+//   y = IDFT_4096(DFT_4096(x_block) * G),  G = DFT_4096(g) / 4096, overlap V >= n - 1,
+// i.e. the same linear convolution as the reference's 2n-point transforms (it differs by
+// rounding only), three 1024-sample chunks per block instead of one per 2048-point pair.
+// Forward and inverse transforms share one radix-16 x 3 routine (inverse = conj o DFT o conj).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void fft4096_regs(f2 (&v)[16], f2 *lds, const float2 *__restrict__ tw, int j) {
+    // in: v[k] = x[j + 256 k]; out: v[k] = X[j + 256 k]
+    dft16(v);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[pad16(16 * j + k)] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = lds[pad16(j + 256 * k)];
+    {
+        f2 wp[16];
+        const float2 t = tw[16 * (j & 15)];
+        twiddle_powers((f2){t.x, t.y}, wp);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v[k] = cmulf(v[k], wp[k]);
+    }
+    dft16(v);
+    __syncthreads();
+    {
+        const int base = (j >> 4) * 256 + (j & 15);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lds[pad16(base + 16 * k)] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = lds[pad16(j + 256 * k)];
+    {
+        f2 wp[16];
+        const float2 t = tw[j];
+        twiddle_powers((f2){t.x, t.y}, wp);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v[k] = cmulf(v[k], wp[k]);
+    }
+    dft16(v);
+}
+
+__global__ __launch_bounds__(256) void k_filter_ols4096(const float2 *__restrict__ hist, int hist_len,
+                                                        const float2 *__restrict__ in, long n_in,
+                                                        const float2 *__restrict__ G, const float2 *__restrict__ tw,
+                                                        int V, float2 *__restrict__ out, long n_out, long e0) {
+    __shared__ f2 lds[4096 + 256];
+    const int j = threadIdx.x;
+    const int hop = 4096 - V;
+    const long b0 = e0 - V + (long)blockIdx.x * hop;
+    f2 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const long pos = b0 + j + 256 * k;
+        float2 x;
+        x.x = 0.f;
+        x.y = 0.f;
+        if (pos >= 0) {
+            if (pos < n_in) x = in[pos];
+        } else if (pos >= -(long)hist_len) {
+            x = hist[hist_len + pos];
+        }
+        v[k] = (f2){x.x, x.y};
+    }
+    fft4096_regs(v, lds, tw, j);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float2 g = G[j + 256 * k];
+        const f2 p = cmulf(v[k], (f2){g.x, g.y});
+        v[k] = (f2){p.x, -p.y};  // conj: the inverse transform is conj(DFT(conj(.)))
+    }
+    __syncthreads();  // the forward transform's last LDS reads are done
+    fft4096_regs(v, lds, tw, j);
+    const long mbase = (long)blockIdx.x * hop;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int t = j + 256 * k;
+        const long m = mbase + (t - V);
+        if (t >= V && m < n_out) {
+            float2 w;
+            w.x = v[k].x;
+            w.y = -v[k].y;
+            out[m] = w;
+        }
+    }
+}
+
+bool filter_ols4096_supported(int dtype, size_t n) {
+    return dtype == RR_F32 && (n == 256 || n == 512 || n == 1024 || n == 2048);
+}
+
+int launch_filter_ols4096(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *G,
+                          const void *tw4096, size_t n, void *out, size_t n_out, long e0) {
+    if (n_out == 0) return RR_OK;
+    const int V = (int)n;  // n is a multiple of 256 here, V >= n - 1
+    const size_t hop = 4096 - V;
+    const size_t nblocks = (n_out + hop - 1) / hop;
+    if (nblocks > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "Filter: too many blocks");
+    hipLaunchKernelGGL(k_filter_ols4096, dim3((unsigned)nblocks), dim3(256), 0, s, (const float2 *)hist, (int)hist_len,
+                       (const float2 *)in, (long)n_in, (const float2 *)G, (const float2 *)tw4096, V, (float2 *)out,
+                       (long)n_out, e0);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
 // tail drop on an interrupt: new[i] = old[i - drop] (zeros shifted in at the front)
 __global__ void k_drop_tail(const float2 *__restrict__ oldh, float2 *__restrict__ newh, int H, int drop) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -42,6 +42,12 @@ bool ols_supported(int dtype, size_t n);
 int launch_filter_ols(int dtype, hipStream_t s, const void *hist, const void *in, size_t n, size_t nchunks,
                       int first_chunk, const void *H, const void *tw, void *out);
 
+// Filter fast convolution with 4096-point blocks (rr_fused.hip), Complex<f32>, n in {256..2048}:
+// out[m] = sum_k g[k] x[e0 + m - k] over [ hist | in ]; G = DFT_4096(g)/4096, tw4096 as above.
+bool filter_ols4096_supported(int dtype, size_t n);
+int launch_filter_ols4096(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *G,
+                          const void *tw4096, size_t n, void *out, size_t n_out, long e0);
+
 // new_hist (H samples) = last H samples of [ zeros | old_hist (H) | in (n_in) ]
 int launch_update_hist(int dtype, hipStream_t s, const void *old_hist, void *new_hist, size_t H, const void *in,
                        size_t n_in);
