@@ -39,7 +39,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     objs = []
-    flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+    flags = ["-O3", "-std=c++20", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
     for src in SOURCES:
         path = os.path.join(CSRC, src)
         if not os.path.exists(path):

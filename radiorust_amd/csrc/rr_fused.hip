@@ -70,17 +70,10 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define RR_STAMP_ADD(i, a, b)
 #endif
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains
-// vmcnt(0), i.e. it would wait for the next tile's prefetch and for this tile's
-// output stores; global memory is not shared between the waves here.
 __device__ __forceinline__ void lds_barrier() {
-#ifndef RR_V_RAWBARRIER  // measured on MI355X: the plain barrier (which also drains vmcnt) is 8 % FASTER here
+    // Measured on MI355X: the plain barrier, which also drains vmcnt, is 8 % FASTER here than
+    // a raw s_barrier + lgkmcnt(0) that lets the prefetch and the stores stay in flight.
     __syncthreads();
-    return;
-#endif
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
 }
 
 template <int D, int R, int T>
@@ -167,7 +160,7 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
 
     f4 x[NPF];
     auto prefetch = [&](long tlo) {
-#if defined(RR_ABLATE) && (RR_ABLATE == 2 || RR_ABLATE == 3 || RR_ABLATE == 4)  // diagnostic: no global loads
+#if defined(RR_ABLATE) && (RR_ABLATE == 2 || RR_ABLATE == 4)  // diagnostic: no global loads
 #pragma unroll
         for (int u = 0; u < NPF; ++u) x[u] = (f4){1.f, 2.f, 3.f, (float)tlo};
 #else
@@ -204,14 +197,9 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
         //      re-issued for the next tile as soon as it has been consumed ----------
         const long next_lo = tile_lo + (long)D * OUTS;
         const bool next_interior = (tile + 1 < tile_end) && interior_of(next_lo);
-        const f4 *nsrc = reinterpret_cast<const f4 *>(in + (next_lo - odd)) + threadIdx.x;
         // x * p = x.re * (p.re, p.im) + x.im * (-p.im, p.re): one packed mul + one packed fma
         auto mix = [](f2 xv, f2 p, f2 pj) -> f2 { return __builtin_elementwise_fma(xv.yy, pj, xv.xx * p); };
-#if defined(RR_ABLATE) && RR_ABLATE == 3  // diagnostic: no stage either
-        if (false) {
-#else
         if (cur_interior) {
-#endif
             if (nco_const) {
                 const f2 q0 = {pc0.x, pc0.y}, q0j = {-pc0.y, pc0.x}, q1 = {pc1.x, pc1.y}, q1j = {-pc1.y, pc1.x};
 #pragma unroll
@@ -222,9 +210,6 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
                         *reinterpret_cast<f2 *>(smem + a0 + u * ROWS_PER_SLOT * STRIDE) = v0;
                         *reinterpret_cast<f2 *>(smem + a1 + u * ROWS_PER_SLOT * STRIDE) = v1;
                     }
-#ifdef RR_V_REISSUE  // measured slower: re-issuing each slot inside the stage loop
-                    if (next_interior) x[u] = nsrc[u * T];
-#endif
                 }
             } else {
                 unsigned rr_ = rbase;
@@ -238,9 +223,6 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
                         *reinterpret_cast<f2 *>(smem + a0 + u * ROWS_PER_SLOT * STRIDE) = v0;
                         *reinterpret_cast<f2 *>(smem + a1 + u * ROWS_PER_SLOT * STRIDE) = v1;
                     }
-#ifdef RR_V_REISSUE
-                    if (next_interior) x[u] = nsrc[u * T];
-#endif
                     rr_ += step;
                     if (rr_ >= denom) rr_ -= denom;
                 }
@@ -277,25 +259,9 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
         RR_STAMP_T(ts1);
         lds_barrier();
         RR_STAMP_T(ts2);
-#if !defined(RR_V_REISSUE) && !defined(RR_V_SPREAD)  // prefetch the next tile once the stage barrier is passed
+        // prefetch the next tile once the stage barrier is passed (re-issuing each slot inside
+        // the stage loop, or in slices between FIR rounds, measured 4-14 % slower)
         if (cur_interior && next_interior) prefetch(next_lo);
-#endif
-#ifdef RR_V_SPREAD
-        // issue the next tile's loads in slices between the rounds of the FIR loop, so
-        // that the vector-memory issue (TA ingest) overlaps the packed FMAs
-        const bool spread = cur_interior && next_interior;
-#define RR_PF(u) x[u] = nsrc[(u) * T];
-#define RR_PREFETCH_SLICE(k)                                         \
-    switch (k) {                                                     \
-        case 0: RR_PF(0) RR_PF(1) RR_PF(2) RR_PF(3) break;           \
-        case 1: RR_PF(4) RR_PF(5) RR_PF(6) RR_PF(7) break;           \
-        case 2: RR_PF(8) RR_PF(9) RR_PF(10) RR_PF(11) break;         \
-        case 3: RR_PF(12) RR_PF(13) RR_PF(14) RR_PF(15) break;       \
-        case 4: RR_PF(16) RR_PF(17) break;                           \
-        default: break;                                              \
-    }
-        static_assert(kNPF == 18, "slices are written out for 18 prefetch slots");
-#endif
         RR_STAMP_T(ts3);
 
         // ---- FIR: rotating register window, packed FMAs --------------------------
@@ -356,17 +322,10 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
             for (int to = 0; to < nouter; ++to) {
                 const char *row0 = lane + (size_t)to * STRIDE;
                 const float *tp = tap_lds + to * RD;
-#ifdef RR_V_SPREAD
-                if (spread) { RR_PREFETCH_SLICE(to) }
-#endif
                 [&]<int... I>(std::integer_sequence<int, I...>) {
                     (fir_step(std::integral_constant<int, I>{}, row0, tp), ...);
                 }(std::make_integer_sequence<int, R>{});
             }
-#ifdef RR_V_SPREAD
-            if (spread)
-                for (int k = nouter; k < 5; ++k) { RR_PREFETCH_SLICE(k) }  // fewer rounds than slices: issue the rest now
-#endif
             if (rem) {  // the last, partial round (workgroup-uniform)
                 const char *row0 = lane + (size_t)nouter * STRIDE;
                 const float *tp = tap_lds + nouter * RD;
