@@ -171,6 +171,16 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
     };
     bool cur_interior = interior_of(tile_lo);
     if (cur_interior) prefetch(tile_lo);
+#ifdef RR_V_CUSTAG
+    // All CUs start their tiles at the same time, so the HBM sees one burst per tile period
+    // and idles in between.  Offset the workgroups of each CU by a CU-dependent fraction of
+    // the period (hardware CU id) to turn the bursts into a steady stream.
+    {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID
+        const unsigned cu = (hw >> 8) & 7;
+        for (unsigned k = 0; k < cu; ++k) __builtin_amdgcn_s_sleep(RR_V_CUSTAG);
+    }
+#endif
 #ifdef RR_V_STAGGER
     // The two waves that share a SIMD (hardware wave slots 0 and 1) belong to two
     // different workgroups.  Delay the workgroup whose first wave sits in an odd slot by
@@ -282,34 +292,37 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
                 }
             };
 #pragma unroll
-            for (int b = 0; b < R - 1; ++b) load_block(lane, b, W[b]);
+            for (int b = 0; b < R; ++b) load_block(lane, b, W[b]);
             // one tap group: read block (t + R - 1) and D taps, R*D packed FMAs
-            auto fir_step = [&](auto TI, const char *row0, const float *tp) {
-                constexpr int ti = decltype(TI)::value;
-                load_block(row0, ti + R - 1, W[(ti + R - 1) % R]);
-                float c[D];
-                if constexpr (D % 4 == 0) {
+            // taps are read half a round (R/2 groups of D) ahead into registers
+            constexpr int HT = (R / 2) * D;  // floats per half round
+            auto load_taps = [&](const float *tp, float(&ct)[HT]) {
 #pragma unroll
-                    for (int q = 0; q < D / 4; ++q) {
-                        const f4 t4 = *reinterpret_cast<const f4 *>(tp + ti * D + 4 * q);
-                        c[4 * q] = t4.x;
-                        c[4 * q + 1] = t4.y;
-                        c[4 * q + 2] = t4.z;
-                        c[4 * q + 3] = t4.w;
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < D / 2; ++q) {
-                        const f2 t2 = *reinterpret_cast<const f2 *>(tp + ti * D + 2 * q);
-                        c[2 * q] = t2.x;
-                        c[2 * q + 1] = t2.y;
-                    }
+                for (int q = 0; q < HT / 4; ++q) {
+                    const f4 t4 = *reinterpret_cast<const f4 *>(tp + 4 * q);
+                    ct[4 * q] = t4.x;
+                    ct[4 * q + 1] = t4.y;
+                    ct[4 * q + 2] = t4.z;
+                    ct[4 * q + 3] = t4.w;
                 }
+            };
+            // one tap group: D taps, R*D packed FMAs; output 0 is the last user of block t
+            // (slot ti): once it is done the slot takes block t + R, which is not needed before
+            // output R-1 of the NEXT step -- two steps of FMAs cover the LDS latency
+            auto fir_step = [&](auto TI, const char *row0, const float(&ct)[HT]) {
+                constexpr int ti = decltype(TI)::value;
+                constexpr int tl = ti % (R / 2);
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
+                for (int q = 0; q < D; ++q) {
+                    const f2 cc = {ct[tl * D + q], ct[tl * D + q]};
+                    acc[0] = __builtin_elementwise_fma(W[ti][q], cc, acc[0]);
+                }
+                load_block(row0, ti + R, W[ti]);
+#pragma unroll
+                for (int r = 1; r < R; ++r) {
 #pragma unroll
                     for (int q = 0; q < D; ++q) {
-                        const f2 cc = {c[q], c[q]};
+                        const f2 cc = {ct[tl * D + q], ct[tl * D + q]};
                         acc[r] = __builtin_elementwise_fma(W[(ti + r) % R][q], cc, acc[r]);
                     }
                 }
@@ -319,19 +332,30 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
 #else
             const int nouter = Gp / R, rem = Gp % R;
 #endif
+            float ca[HT], cb[HT];
+            load_taps(tap_lds, ca);
             for (int to = 0; to < nouter; ++to) {
                 const char *row0 = lane + (size_t)to * STRIDE;
                 const float *tp = tap_lds + to * RD;
+                load_taps(tp + HT, cb);
                 [&]<int... I>(std::integer_sequence<int, I...>) {
-                    (fir_step(std::integral_constant<int, I>{}, row0, tp), ...);
-                }(std::make_integer_sequence<int, R>{});
+                    (fir_step(std::integral_constant<int, I>{}, row0, ca), ...);
+                }(std::make_integer_sequence<int, R / 2>{});
+                load_taps(tp + 2 * HT, ca);  // first half of the next round (a spare round of taps is allocated)
+                [&]<int... I>(std::integer_sequence<int, I...>) {
+                    (fir_step(std::integral_constant<int, I + R / 2>{}, row0, cb), ...);
+                }(std::make_integer_sequence<int, R / 2>{});
             }
             if (rem) {  // the last, partial round (workgroup-uniform)
                 const char *row0 = lane + (size_t)nouter * STRIDE;
                 const float *tp = tap_lds + nouter * RD;
+                load_taps(tp + HT, cb);
                 [&]<int... I>(std::integer_sequence<int, I...>) {
-                    ((I < rem ? fir_step(std::integral_constant<int, I>{}, row0, tp) : (void)0), ...);
-                }(std::make_integer_sequence<int, R - 1>{});
+                    ((I < rem ? fir_step(std::integral_constant<int, I>{}, row0, ca) : (void)0), ...);
+                }(std::make_integer_sequence<int, R / 2>{});
+                [&]<int... I>(std::integer_sequence<int, I...>) {
+                    ((I + R / 2 < rem ? fir_step(std::integral_constant<int, I + R / 2>{}, row0, cb) : (void)0), ...);
+                }(std::make_integer_sequence<int, R / 2 - 1>{});
             }
         }
         RR_STAMP_T(ts4);
@@ -383,7 +407,7 @@ static int launch_mfd(hipStream_t s, const FusedFirArgs &a) {
     constexpr int OUTS = T * R;
     const int rows = T + (a.Gp + R - 2) / R;
     const int lds_rows = rows + 2 * T / G::RD + 1;
-    const size_t lds = 32 + (size_t)lds_rows * G::STRIDE + (size_t)a.Gp * D * sizeof(float);
+    const size_t lds = 32 + (size_t)lds_rows * G::STRIDE + ((size_t)a.Gp * D + 3 * G::RD) * sizeof(float);
     if ((rows * G::RD + 2) / 2 > npf_for(G::RD) * T) RR_FAIL(RR_ERR_BAD_ARG, "fused FIR: %d tap groups exceed the prefetch window", a.Gp);
     auto fn = k_mix_fir_decim<D, R, T>;
     if (lds > 64 * 1024)
