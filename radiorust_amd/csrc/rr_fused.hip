@@ -474,16 +474,56 @@ int launch_fused_fir(hipStream_t s, const FusedFirArgs &a) {
 // ---------------------------------------------------------------------------
 // 4096-point windowed FFT, radix 16 x 3
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ f2 cmulf(f2 a, f2 b) { return (f2){a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-__device__ __forceinline__ f2 mul_mj(f2 a) { return (f2){a.y, -a.x}; }  // * (-j)
+// ---- packed complex arithmetic -------------------------------------------------
+// A complex f32 lives in one 64-bit VGPR pair (re = low, im = high).  Multiplying by
+// +-j is a swap with one sign flip; VOP3P packed adds take that for free through
+// their op_sel / neg modifiers, so butterflies need no moves.  hipcc does not find
+// these forms on its own (it emitted ~340 v_mov per 4096-point transform), hence the
+// four one-instruction helpers below.
+__device__ __forceinline__ f2 add_mj(f2 a, f2 t) {  // a + (-j) t = (a.x + t.y, a.y - t.x)
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(t));
+    return r;
+}
+__device__ __forceinline__ f2 add_pj(f2 a, f2 t) {  // a + (+j) t = (a.x - t.y, a.y + t.x)
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(t));
+    return r;
+}
+__device__ __forceinline__ f2 mul_mj(f2 a) {  // (-j) a = (a.y, -a.x)
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, 0 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ f2 mul_pj(f2 a) {  // (+j) a = (-a.y, a.x)
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, 0 op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[1,0]" : "=v"(r) : "v"(a));
+    return r;
+}
+// a * w with the pre-rotated partner wj = (+j) w = (-w.y, w.x): two packed ops
+__device__ __forceinline__ f2 cmul2(f2 a, f2 w, f2 wj) { return __builtin_elementwise_fma(a.yy, wj, a.xx * w); }
+__device__ __forceinline__ f2 cmulf(f2 a, f2 b) { return cmul2(a, b, mul_pj(b)); }
 
-// forward 4-point DFT (kernel e^{-j 2 pi n k / 4})
+// forward 4-point DFT (kernel e^{-j 2 pi n k / 4}): 8 packed adds
 __device__ __forceinline__ void dft4(f2 &a, f2 &b, f2 &c, f2 &d) {
-    const f2 s0 = a + c, s1 = a - c, s2 = b + d, s3 = mul_mj(b - d);
+    const f2 s0 = a + c, s1 = a - c, s2 = b + d, t = b - d;
     a = s0 + s2;
-    b = s1 + s3;
     c = s0 - s2;
-    d = s1 - s3;
+    b = add_mj(s1, t);
+    d = add_pj(s1, t);
+}
+// inverse 4-point DFT (kernel e^{+j 2 pi n k / 4})
+__device__ __forceinline__ void idft4(f2 &a, f2 &b, f2 &c, f2 &d) {
+    const f2 s0 = a + c, s1 = a - c, s2 = b + d, t = b - d;
+    a = s0 + s2;
+    c = s0 - s2;
+    b = add_pj(s1, t);
+    d = add_mj(s1, t);
+}
+
+// multiply by a compile-time constant (wr, wi): two packed ops on constant pairs
+__device__ __forceinline__ f2 cmulc(f2 v, float wr, float wi) {
+    return __builtin_elementwise_fma(v.yy, (f2){-wi, wr}, v.xx * (f2){wr, wi});
 }
 
 // in-register forward 16-point DFT, natural order in and out
@@ -493,19 +533,19 @@ __device__ __forceinline__ void dft16(f2 (&v)[16]) {
 #pragma unroll
     for (int a = 0; a < 4; ++a) dft4(v[a], v[a + 4], v[a + 8], v[a + 12]);  // v[a + 4b] now holds t[a][b]
     // twiddle W16^(a b)
-    v[1 + 4] = cmulf(v[1 + 4], (f2){C1, -S1});   // a=1,b=1: W^1
-    v[1 + 8] = cmulf(v[1 + 8], (f2){H, -H});     // a=1,b=2: W^2
-    v[1 + 12] = cmulf(v[1 + 12], (f2){S1, -C1}); // a=1,b=3: W^3
-    v[2 + 4] = cmulf(v[2 + 4], (f2){H, -H});     // a=2,b=1: W^2
-    v[2 + 8] = mul_mj(v[2 + 8]);                 // a=2,b=2: W^4 = -j
-    v[2 + 12] = cmulf(v[2 + 12], (f2){-H, -H});  // a=2,b=3: W^6
-    v[3 + 4] = cmulf(v[3 + 4], (f2){S1, -C1});   // a=3,b=1: W^3
-    v[3 + 8] = cmulf(v[3 + 8], (f2){-H, -H});    // a=3,b=2: W^6
-    v[3 + 12] = cmulf(v[3 + 12], (f2){-C1, S1}); // a=3,b=3: W^9
+    v[1 + 4] = cmulc(v[1 + 4], C1, -S1);   // a=1,b=1: W^1
+    v[1 + 8] = cmulc(v[1 + 8], H, -H);     // a=1,b=2: W^2
+    v[1 + 12] = cmulc(v[1 + 12], S1, -C1); // a=1,b=3: W^3
+    v[2 + 4] = cmulc(v[2 + 4], H, -H);     // a=2,b=1: W^2
+    v[2 + 8] = mul_mj(v[2 + 8]);           // a=2,b=2: W^4 = -j
+    v[2 + 12] = cmulc(v[2 + 12], -H, -H);  // a=2,b=3: W^6
+    v[3 + 4] = cmulc(v[3 + 4], S1, -C1);   // a=3,b=1: W^3
+    v[3 + 8] = cmulc(v[3 + 8], -H, -H);    // a=3,b=2: W^6
+    v[3 + 12] = cmulc(v[3 + 12], -C1, S1); // a=3,b=3: W^9
     // X[b + 4c] = DFT4 over a of t[a][b]; t[a][b] sits in v[a + 4b]
 #pragma unroll
     for (int b = 0; b < 4; ++b) dft4(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]);  // v[4b + c] = X[b + 4c]
-    // reorder to natural order: X[k], k = b + 4c  <-  v[4b + c]
+    // natural order: X[k], k = b + 4c  <-  v[4b + c]  (register renaming, no instructions)
     f2 t[16];
 #pragma unroll
     for (int b = 0; b < 4; ++b)
@@ -517,23 +557,32 @@ __device__ __forceinline__ void dft16(f2 (&v)[16]) {
 
 __device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
 
-// wp[k] = w^k, k = 1..15, every power at most 4 complex products deep
-__device__ __forceinline__ void twiddle_powers(f2 w, f2 (&wp)[16]) {
-    wp[1] = w;
-    wp[2] = cmulf(w, w);
-    wp[3] = cmulf(wp[2], w);
-    wp[4] = cmulf(wp[2], wp[2]);
-    wp[5] = cmulf(wp[4], w);
-    wp[6] = cmulf(wp[4], wp[2]);
-    wp[7] = cmulf(wp[4], wp[3]);
-    wp[8] = cmulf(wp[4], wp[4]);
-    wp[9] = cmulf(wp[8], w);
-    wp[10] = cmulf(wp[8], wp[2]);
-    wp[11] = cmulf(wp[8], wp[3]);
-    wp[12] = cmulf(wp[8], wp[4]);
-    wp[13] = cmulf(wp[8], wp[5]);
-    wp[14] = cmulf(wp[8], wp[6]);
-    wp[15] = cmulf(wp[8], wp[7]);
+// v[k] *= w^k, k = 1..15.  Powers by a product tree at most 4 deep (error ~4 ulp, not 15);
+// every power is kept with its rotated partner (+j) w^k so that each product is two packed ops.
+__device__ __forceinline__ void apply_twiddle_powers(f2 (&v)[16], f2 w) {
+    f2 p[16], q[16];  // p[k] = w^k, q[k] = (+j) w^k
+    p[1] = w;
+    q[1] = mul_pj(w);
+#define RR_TWP(k, a, b)          \
+    p[k] = cmul2(p[a], p[b], q[b]); \
+    q[k] = mul_pj(p[k]);
+    RR_TWP(2, 1, 1)
+    RR_TWP(3, 2, 1)
+    RR_TWP(4, 2, 2)
+    RR_TWP(5, 4, 1)
+    RR_TWP(6, 4, 2)
+    RR_TWP(7, 4, 3)
+    RR_TWP(8, 4, 4)
+    RR_TWP(9, 8, 1)
+    RR_TWP(10, 8, 2)
+    RR_TWP(11, 8, 3)
+    RR_TWP(12, 8, 4)
+    RR_TWP(13, 8, 5)
+    RR_TWP(14, 8, 6)
+    RR_TWP(15, 8, 7)
+#undef RR_TWP
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v[k] = cmul2(v[k], p[k], q[k]);
 }
 
 // The input stream of frames is [ head (n_head samples) | in ]: the head is the
@@ -565,11 +614,8 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
     {
         // e^{-j 2 pi k (j mod 16) / 256} = w^k with w = tw[16 (j mod 16)]: one
         // table read, powers by a depth-4 product tree (error ~4 ulp, not 15)
-        f2 wp[16];
         const float2 t = tw[16 * (j & 15)];
-        twiddle_powers((f2){t.x, t.y}, wp);
-#pragma unroll
-        for (int k = 1; k < 16; ++k) v[k] = cmulf(v[k], wp[k]);
+        apply_twiddle_powers(v, (f2){t.x, t.y});
     }
     dft16(v);
     __syncthreads();
@@ -583,11 +629,8 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = lds[pad16(j + 256 * k)];
     {
-        f2 wp[16];
         const float2 t = tw[j];  // e^{-j 2 pi j / 4096}, coalesced
-        twiddle_powers((f2){t.x, t.y}, wp);
-#pragma unroll
-        for (int k = 1; k < 16; ++k) v[k] = cmulf(v[k], wp[k]);
+        apply_twiddle_powers(v, (f2){t.x, t.y});
     }
     dft16(v);
     const int rot = center_dc ? 2048 : 0;
@@ -612,6 +655,36 @@ int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *i
     return RR_OK;
 }
 
+// forward 4096-point DFT in registers + one padded LDS image (radix 16 x 3, Stockham)
+__device__ __forceinline__ void fft4096_regs(f2 (&v)[16], f2 *lds, const float2 *__restrict__ tw, int j) {
+    // in: v[k] = x[j + 256 k]; out: v[k] = X[j + 256 k]
+    dft16(v);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[pad16(16 * j + k)] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = lds[pad16(j + 256 * k)];
+    {
+        const float2 t = tw[16 * (j & 15)];
+        apply_twiddle_powers(v, (f2){t.x, t.y});
+    }
+    dft16(v);
+    __syncthreads();
+    {
+        const int base = (j >> 4) * 256 + (j & 15);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lds[pad16(base + 16 * k)] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = lds[pad16(j + 256 * k)];
+    {
+        const float2 t = tw[j];
+        apply_twiddle_powers(v, (f2){t.x, t.y});
+    }
+    dft16(v);
+}
+
 // ---------------------------------------------------------------------------
 // Kernel 3  k_ols_decim4: the same mix + combined FIR + 4x decimation as
 // k_mix_fir_decim, computed by overlap-save fast convolution:
@@ -623,16 +696,6 @@ int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *i
 // occupancy/LDS profile of k_fft4096 (34.8 KiB, 16 waves/CU).  Blocks start at
 // e0 - V + b * (4096 - V), so output m of the call is sample (V/4 + i) of block b.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ f2 mul_pj(f2 a) { return (f2){-a.y, a.x}; }  // * (+j)
-
-// inverse 4-point DFT (kernel e^{+j 2 pi n k / 4})
-__device__ __forceinline__ void idft4(f2 &a, f2 &b, f2 &c, f2 &d) {
-    const f2 s0 = a + c, s1 = a - c, s2 = b + d, s3 = mul_pj(b - d);
-    a = s0 + s2;
-    b = s1 + s3;
-    c = s0 - s2;
-    d = s1 - s3;
-}
 
 __global__ __launch_bounds__(256) void k_ols_decim4(const float2 *__restrict__ xh, int hx,
                                                     const float2 *__restrict__ in, long n_in,
@@ -714,38 +777,8 @@ __global__ __launch_bounds__(256) void k_ols_decim4(const float2 *__restrict__ x
             }
         }
     }
-    // ---- forward DFT_4096 (identical to k_fft4096) --------------------------------
-    dft16(v);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) lds[pad16(16 * j + k)] = v[k];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = lds[pad16(j + 256 * k)];
-    {
-        f2 wp[16];
-        const float2 t = tw[16 * (j & 15)];
-        twiddle_powers((f2){t.x, t.y}, wp);
-#pragma unroll
-        for (int k = 1; k < 16; ++k) v[k] = cmulf(v[k], wp[k]);
-    }
-    dft16(v);
-    __syncthreads();
-    {
-        const int base = (j >> 4) * 256 + (j & 15);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) lds[pad16(base + 16 * k)] = v[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = lds[pad16(j + 256 * k)];
-    {
-        f2 wp[16];
-        const float2 t = tw[j];
-        twiddle_powers((f2){t.x, t.y}, wp);
-#pragma unroll
-        for (int k = 1; k < 16; ++k) v[k] = cmulf(v[k], wp[k]);
-    }
-    dft16(v);  // v[k] = X[j + 256 k]
+    // ---- forward DFT_4096: v[k] = X[j + 256 k] -------------------------------------
+    fft4096_regs(v, lds, tw, j);
     // ---- * H and fold: Y[j + 256 c] = sum_q X[j + 256 (c + 4 q)] H[...] -----------
     f2 y[4];
 #pragma unroll
@@ -771,12 +804,12 @@ __global__ __launch_bounds__(256) void k_ols_decim4(const float2 *__restrict__ x
         if (pass > 0) {
             // twiddles e^{+j 2 pi c (j mod ns) / (4 ns)} = conj(tw[(j mod ns) * 1024 / ns])^c
             const float2 t = tw[(j & (ns - 1)) * (1024 / ns)];
-            const f2 w1 = {t.x, -t.y};
-            const f2 w2 = cmulf(w1, w1);
-            const f2 w3 = cmulf(w2, w1);
-            y[1] = cmulf(y[1], w1);
-            y[2] = cmulf(y[2], w2);
-            y[3] = cmulf(y[3], w3);
+            const f2 w1 = {t.x, -t.y}, q1 = mul_pj(w1);
+            const f2 w2 = cmul2(w1, w1, q1), q2 = mul_pj(w2);
+            const f2 w3 = cmul2(w2, w1, q1), q3 = mul_pj(w3);
+            y[1] = cmul2(y[1], w1, q1);
+            y[2] = cmul2(y[2], w2, q2);
+            y[3] = cmul2(y[3], w3, q3);
         }
         idft4(y[0], y[1], y[2], y[3]);
         if (pass == 4) break;  // natural order: y[c] = result[j + 256 c]
@@ -833,41 +866,6 @@ int launch_ols_decim(hipStream_t s, const FusedFirArgs &a) {
 // rounding only), three 1024-sample chunks per block instead of one per 2048-point pair.
 // Forward and inverse transforms share one radix-16 x 3 routine (inverse = conj o DFT o conj).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void fft4096_regs(f2 (&v)[16], f2 *lds, const float2 *__restrict__ tw, int j) {
-    // in: v[k] = x[j + 256 k]; out: v[k] = X[j + 256 k]
-    dft16(v);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) lds[pad16(16 * j + k)] = v[k];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = lds[pad16(j + 256 * k)];
-    {
-        f2 wp[16];
-        const float2 t = tw[16 * (j & 15)];
-        twiddle_powers((f2){t.x, t.y}, wp);
-#pragma unroll
-        for (int k = 1; k < 16; ++k) v[k] = cmulf(v[k], wp[k]);
-    }
-    dft16(v);
-    __syncthreads();
-    {
-        const int base = (j >> 4) * 256 + (j & 15);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) lds[pad16(base + 16 * k)] = v[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = lds[pad16(j + 256 * k)];
-    {
-        f2 wp[16];
-        const float2 t = tw[j];
-        twiddle_powers((f2){t.x, t.y}, wp);
-#pragma unroll
-        for (int k = 1; k < 16; ++k) v[k] = cmulf(v[k], wp[k]);
-    }
-    dft16(v);
-}
-
 __global__ __launch_bounds__(256) void k_filter_ols4096(const float2 *__restrict__ hist, int hist_len,
                                                         const float2 *__restrict__ in, long n_in,
                                                         const float2 *__restrict__ G, const float2 *__restrict__ tw,
