@@ -510,6 +510,10 @@ bool rr_chain::ols_wanted() {
     const char *e = std::getenv("RR_FUSED_KERNEL");
     return e && std::strcmp(e, "ols") == 0;
 }
+bool rr_chain::ols_wave_wanted() {
+    const char *e = std::getenv("RR_FUSED_KERNEL");
+    return e && std::strcmp(e, "olsw") == 0;
+}
 
 // c = reverse(ir) (*) g in f64, cast to f32 and laid out in the step order of
 // k_mix_fir_decim: tb[t*D + p] = c[D*(Gp-1-t) + (D-1-p)], zero beyond Lc
@@ -526,23 +530,27 @@ int rr_chain::ensure_ctaps() {
             cc[j + k] += a * (fl->real_taps ? cd(fl->taps_f64[k].real(), 0.0) : fl->taps_f64[k]);
         }
     }
-    use_ols = ols_decim_supported(ds->sched.D, lc) && (ols_wanted() || !(fl->real_taps && fused_fir_supported(ds->sched.D, lc)));
+    const bool wave = ols_wave_wanted() && ols_wave_supported(ds->sched.D, lc);
+    use_ols = wave || (ols_decim_supported(ds->sched.D, lc) &&
+                       (ols_wanted() || !(fl->real_taps && fused_fir_supported(ds->sched.D, lc))));
     if (use_ols) {
-        // H = DFT_4096(c) / 4096 (the inverse transform in the kernel is unnormalised)
-        std::vector<cd> h(4096, cd(0, 0));
+        // H = DFT_N(c) / N (the inverse transform in the kernel is unnormalised)
+        const size_t N = wave ? 1024 : 4096;
+        std::vector<cd> h(N, cd(0, 0));
         for (size_t i = 0; i < lc; ++i) h[i] = cc[i];
         fft_f64(h, false);
-        std::vector<float> hb(2 * 4096), twb(2 * 4096);
-        for (size_t i = 0; i < 4096; ++i) {
-            hb[2 * i] = (float)(h[i].real() / 4096.0);
-            hb[2 * i + 1] = (float)(h[i].imag() / 4096.0);
-            const double ang = -2.0 * M_PI * (double)i / 4096.0;
+        std::vector<float> hb(2 * N), twb(2 * N);
+        for (size_t i = 0; i < N; ++i) {
+            hb[2 * i] = (float)(h[i].real() / (double)N);
+            hb[2 * i + 1] = (float)(h[i].imag() / (double)N);
+            const double ang = -2.0 * M_PI * (double)i / (double)N;
             twb[2 * i] = (float)std::cos(ang);
             twb[2 * i + 1] = (float)std::sin(ang);
         }
         RR_TRY(upload(d_olsH, hb.data(), hb.size() * sizeof(float), stream));
         RR_TRY(upload(d_tw4096, twb.data(), twb.size() * sizeof(float), stream));
-        ols_V = ols_decim_overlap(lc);
+        ols_V = wave ? ols_wave_overlap(lc) : ols_decim_overlap(lc);
+        ols_N = (int)N;
         Lc = lc;
         ctaps_fl = fl->design_version;
         ctaps_ds = ds->design_version;
@@ -640,7 +648,9 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     a.tw4096 = d_tw4096.p;
     a.V = ols_V;
     int tk = timers.begin(ST_FUSED_FIR, stream);
-    if (use_ols)
+    if (use_ols && ols_N == 1024)
+        RR_TRY(launch_ols_wave(stream, a));
+    else if (use_ols)
         RR_TRY(launch_ols_decim(stream, a));
     else
         RR_TRY(launch_fused_fir(stream, a));

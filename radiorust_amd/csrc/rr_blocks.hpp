@@ -140,9 +140,11 @@ struct rr_chain : rr_block {
     // overlap-save variant of the fused FIR (k_ols_decim4)
     bool use_ols = false;
     int ols_V = 0;
+    int ols_N = 4096;  // 4096: k_ols_decim4 (workgroup per block), 1024: k_ols_wave (wave per block)
     rr::DevBuf d_olsH, d_tw4096;
     bool fused_candidate(double sample_rate) const;
     static bool ols_wanted();
+    static bool ols_wave_wanted();
     int ensure_xh();
     int ensure_ctaps();
     int materialize();  // bring the per-block histories up to date after fused calls

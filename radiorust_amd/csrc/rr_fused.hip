@@ -838,6 +838,309 @@ __global__ __launch_bounds__(256) void k_ols_decim4(const float2 *__restrict__ x
     }
 }
 
+// ---------------------------------------------------------------------------
+// Kernel 3w  k_ols_wave: overlap-save with 1024-sample blocks, ONE WAVE per block.
+// k_ols_decim4 spends most of its time at the ~11 workgroup barriers of a block (its
+// transform phases were measured purely additive to the load/store floor); with one
+// wave per block every exchange is wave-local: LDS ordering inside a wave needs no
+// s_barrier, the 16 waves of a CU run independent blocks, and H / twiddle tables are
+// 8 KiB each (L1-resident).  Forward DFT_1024 = radix 16 x 16 x 4 (16 values per lane),
+// * H, fold 4 -> 1 in the lane, inverse DFT_256 = radix 4 x 4 x 4 x 4 (one butterfly per
+// lane and pass).  V = overlap (multiple of 64, >= Lc - 1), hop = 1024 - V; the overlap
+// re-reads come from L2 because neighbouring blocks run on the same XCD.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ f2 cmul(f2 a, f2 w) {  // a * w, two packed ops, no rotated copy of w
+    f2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r)
+        : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+__device__ __forceinline__ f2 cmul_conj(f2 a, f2 w) {  // a * conj(w)
+    f2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// acc + a * w
+__device__ __forceinline__ f2 cmac(f2 acc, f2 a, f2 w) {
+    f2 t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(t) : "v"(a), "v"(w), "v"(acc));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r)
+        : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+
+// v[k] *= w^k, k = 1..15, product tree at most 4 deep
+__device__ __forceinline__ void twiddle16(f2 (&v)[16], f2 w) {
+    f2 p[16];
+    p[1] = w;
+    p[2] = cmul(p[1], p[1]);
+    p[3] = cmul(p[2], p[1]);
+    p[4] = cmul(p[2], p[2]);
+    p[5] = cmul(p[4], p[1]);
+    p[6] = cmul(p[4], p[2]);
+    p[7] = cmul(p[4], p[3]);
+    p[8] = cmul(p[4], p[4]);
+#pragma unroll
+    for (int k = 9; k < 16; ++k) p[k] = cmul(p[8], p[k - 8]);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], p[k]);
+}
+
+// LDS images of one wave (element = 8 bytes).  Image A holds the 1024-point intermediate of
+// the forward transform at  A(i) = i + 2 (i >> 4) + 16 (i >> 8):  rows of 16 elements at a
+// stride of 18 (16-byte aligned for ds_write_b128, and an odd multiple of 16 bytes so that the
+// 16 rows a half-wave touches fall on distinct banks), plus 16 per 256 so that the four lane
+// groups of a radix-16 pass do not collide.  Image B (256-point inverse) uses B(i) = i + 4 (i >> 4).
+// Every access pattern below is (lane term) + (compile-time offset), spelled out so that the
+// offsets land in the instructions' immediate fields instead of per-access address arithmetic.
+constexpr int kWaveLds = 1200;  // A(1023) + 1 = 1198, rounded
+
+__device__ __forceinline__ void wave_sync() {
+    // all 64 lanes of the only wave: order LDS writes before the following reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(64) void k_ols_wave(const float2 *__restrict__ xh, int hx,
+                                                 const float2 *__restrict__ in, long n_in,
+                                                 const float2 *__restrict__ nco, unsigned denom, unsigned idx0,
+                                                 const float2 *__restrict__ H, const float2 *__restrict__ tw,
+                                                 int V, float2 *__restrict__ out, long n_out, long e0,
+                                                 float2 *__restrict__ xh_out, int hx_out, unsigned nblocks,
+                                                 unsigned ph0, unsigned hopm, unsigned kstep, double inv_denom) {
+    __shared__ __attribute__((aligned(16))) f2 lds[kWaveLds];
+    const int l = threadIdx.x;
+    // workgroups b, b+8, .. share an XCD: give each XCD one contiguous run of blocks, so
+    // that the V samples two neighbouring blocks share are read from HBM once
+    const unsigned per_xcd = (nblocks + 7) >> 3;
+    const unsigned blk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (blk >= nblocks) return;
+    const int hop = 1024 - V, per_block = hop >> 2;
+    const long b0 = e0 - V + (long)blk * hop;
+
+    if (xh_out && blk == nblocks - 1) {  // mixed-sample history for the next call
+        for (int i = l; i < hx_out; i += 64) {
+            const long pos = n_in - hx_out + i;
+            float2 v;
+            if (pos >= 0) {
+                const float2 xx = in[pos];
+                const float2 pp = nco[(unsigned)(((long)idx0 + pos) % (long)denom)];
+                v.x = xx.x * pp.x - xx.y * pp.y;
+                v.y = xx.x * pp.y + xx.y * pp.x;
+            } else {
+                v = (pos >= -(long)hx) ? xh[hx + pos] : float2{0.f, 0.f};
+            }
+            xh_out[i] = v;
+        }
+    }
+
+    // ---- NCO phase of the lane's first sample: (idx0 + b0 + l) mod denom ------------------
+    // ph0 = (idx0 + e0 - V) mod denom and hopm = hop mod denom come from the host; the block's
+    // term blk * hopm < 2^53 is reduced in f64 (exact) instead of a 64-bit integer division.
+    unsigned r;
+    {
+        unsigned base = ph0;
+        if (hopm != 0) {
+            const double dn = (double)denom;
+            const double prod = __builtin_fma((double)blk, (double)hopm, (double)ph0);
+            const double qd = __builtin_floor(prod * inv_denom);
+            double rd = __builtin_fma(-qd, dn, prod);
+            if (rd < 0.0) rd += dn;
+            if (rd >= dn) rd -= dn;
+            base = (unsigned)rd;
+        }
+        r = base + (unsigned)l;
+        if (denom >= 64u) {
+            if (r >= denom) r -= denom;
+        } else if ((denom & (denom - 1u)) == 0u) {
+            r &= denom - 1u;
+        } else {
+            r %= denom;
+        }
+    }
+
+    // Lane constants of the transforms, requested before anything waits: the wave-level fences
+    // below would otherwise pin each of these (L2-latency) loads right in front of its use.
+    const int g = l >> 4, q = l & 15;
+    const float2 t_p1 = tw[4 * q];
+    float2 t_p2[4], t_inv[3];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) t_p2[m] = tw[l + 64 * m];
+    t_inv[0] = tw[(l & 3) * 64];
+    t_inv[1] = tw[q * 16];
+    t_inv[2] = tw[l * 4];
+
+    // ---- load + mix: v[k] = xs[b0 + l + 64 k] -----------------------------------------------
+    f2 v[16];
+    if (b0 >= 0 && b0 + 1024 <= n_in) {
+        const float2 *src = in + b0 + l;
+        float2 x[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = src[64 * k];
+        if (kstep == 0) {  // one phasor per lane (denom divides 64)
+            const float2 p = nco[r];
+            const f2 pp = {p.x, p.y};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = cmul((f2){x[k].x, x[k].y}, pp);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float2 p = nco[r];
+                v[k] = cmul((f2){x[k].x, x[k].y}, (f2){p.x, p.y});
+                r += kstep;
+                if (r >= denom) r -= denom;
+            }
+        }
+    } else {  // edges: history (already mixed) in front, nothing behind the input
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const long pos = b0 + l + 64 * k;
+            f2 t = {0.f, 0.f};
+            if (pos < 0) {
+                if (pos >= -(long)hx) {
+                    const float2 h = xh[hx + pos];
+                    t = (f2){h.x, h.y};
+                }
+            } else if (pos < n_in) {
+                const float2 xx = in[pos];
+                const float2 p = nco[r];
+                t = cmul((f2){xx.x, xx.y}, (f2){p.x, p.y});
+            }
+            v[k] = t;
+            r += kstep;
+            if (r >= denom) r -= denom;
+        }
+    }
+    f2 *const a_rd = lds + (l + 2 * g);  // A(l + 64 m + 256 c) = a_rd + 72 m + 304 c
+    // ---- forward DFT_1024 --------------------------------------------------------------------
+    // pass 0 (Ns = 1): butterfly l over x[l + 64 k]; out 16 l + k: A = 18 l + 16 g + k
+    dft16(v);
+    {
+        f2 *row = lds + (18 * l + 16 * g);
+#pragma unroll
+        for (int k = 0; k < 16; k += 2)
+            *reinterpret_cast<float4 *>(row + k) = (float4){v[k].x, v[k].y, v[k + 1].x, v[k + 1].y};
+    }
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = a_rd[72 * (k & 3) + 304 * (k >> 2)];  // in[l + 64 k]
+    // pass 1 (Ns = 16): twiddle e^{-j 2 pi k (l mod 16) / 256}; out 256 g + q + 16 k: A = 304 g + q + 18 k
+    twiddle16(v, (f2){t_p1.x, t_p1.y});
+    // the 16 H values of the lane: requested here, used after the next exchange
+    float2 hv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) hv[k] = H[l + 64 * k];
+    dft16(v);
+    wave_sync();
+    {
+        f2 *col = lds + (304 * g + q);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) col[18 * k] = v[k];
+    }
+    wave_sync();
+    // pass 2 (Ns = 256, radix 4): butterflies t = l + 64 m over in[t + 256 c]; out X[t + 256 c]
+    f2 y[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        f2 a0 = a_rd[72 * m], a1 = a_rd[72 * m + 304], a2 = a_rd[72 * m + 608], a3 = a_rd[72 * m + 912];
+        const f2 w1 = {t_p2[m].x, t_p2[m].y};
+        const f2 w2 = cmul(w1, w1);
+        const f2 w3 = cmul(w2, w1);
+        a1 = cmul(a1, w1);
+        a2 = cmul(a2, w2);
+        a3 = cmul(a3, w3);
+        dft4(a0, a1, a2, a3);
+        // * H and fold the four 256-bin quarters: Y[t] = sum_c X[t + 256 c] H[t + 256 c]
+        const float2 h0 = hv[m], h1 = hv[m + 4], h2 = hv[m + 8], h3 = hv[m + 12];
+        f2 acc = cmul(a0, (f2){h0.x, h0.y});
+        acc = cmac(acc, a1, (f2){h1.x, h1.y});
+        acc = cmac(acc, a2, (f2){h2.x, h2.y});
+        acc = cmac(acc, a3, (f2){h3.x, h3.y});
+        y[m] = acc;
+    }
+    // ---- inverse DFT_256, Stockham radix 4 x 4: butterfly l reads in[l + 64 c] -----------------
+    f2 *const b_rd = lds + (l + 4 * g);  // B(l + 64 c) = b_rd + 80 c
+    // pass 0 (Ns = 1): no twiddle; out 4 l + c: B = 4 l + 4 (l >> 2) + c
+    idft4(y[0], y[1], y[2], y[3]);
+    wave_sync();  // the forward image has been read
+    {
+        f2 *row = lds + (4 * l + 4 * (l >> 2));
+        *reinterpret_cast<float4 *>(row) = (float4){y[0].x, y[0].y, y[1].x, y[1].y};
+        *reinterpret_cast<float4 *>(row + 2) = (float4){y[2].x, y[2].y, y[3].x, y[3].y};
+    }
+    wave_sync();
+#pragma unroll
+    for (int pass = 1; pass < 4; ++pass) {
+        const int ns = 1 << (2 * pass);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) y[c] = b_rd[80 * c];
+        // twiddles e^{+j 2 pi c (l mod ns) / (4 ns)} = conj(tw[(l mod ns) 256 / ns])^c
+        const f2 w1 = {t_inv[pass - 1].x, t_inv[pass - 1].y};
+        const f2 w2 = cmul(w1, w1);
+        const f2 w3 = cmul(w2, w1);
+        y[1] = cmul_conj(y[1], w1);
+        y[2] = cmul_conj(y[2], w2);
+        y[3] = cmul_conj(y[3], w3);
+        idft4(y[0], y[1], y[2], y[3]);
+        if (pass == 3) break;  // natural order: y[c] = result[l + 64 c]
+        wave_sync();
+        if (pass == 1) {  // out 16 (l >> 2) + (l & 3) + 4 c: B = 20 (l >> 2) + (l & 3) + 4 c
+            f2 *col = lds + (20 * (l >> 2) + (l & 3));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) col[4 * c] = y[c];
+        } else {  // out 64 g + q + 16 c: B = 80 g + q + 20 c
+            f2 *col = lds + (80 * g + q);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) col[20 * c] = y[c];
+        }
+        wave_sync();
+    }
+    // ---- store the valid part ---------------------------------------------------------------
+    const long mbase = (long)blk * per_block;
+    const int first = V >> 2;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int tau = l + 64 * c;
+        const long m = mbase + (tau - first);
+        if (tau >= first && m < n_out) {
+            float2 w;
+            w.x = y[c].x;
+            w.y = y[c].y;
+            out[m] = w;
+        }
+    }
+}
+
+int ols_wave_overlap(size_t Lc) {  // V: multiple of 64 covering the Lc - 1 wrapped samples
+    const size_t v = (Lc - 1 + 63) / 64 * 64;
+    return v == 0 ? 64 : (int)v;
+}
+
+bool ols_wave_supported(uint64_t D, size_t Lc) { return D == 4 && Lc >= 1 && Lc - 1 <= 512; }
+
+int launch_ols_wave(hipStream_t s, const FusedFirArgs &a) {
+    if (a.n_out == 0) return RR_OK;
+    const int per_block = (1024 - a.V) / 4;
+    const size_t nblocks = (a.n_out + per_block - 1) / per_block;
+    if (nblocks > 0x7ffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS: too many blocks");
+    const unsigned grid = (unsigned)((nblocks + 7) / 8 * 8);
+    const int64_t den = (int64_t)a.denom;
+    int64_t ph = ((int64_t)a.idx0 + a.e0 - a.V) % den;
+    if (ph < 0) ph += den;
+    const unsigned hopm = (unsigned)((int64_t)(1024 - a.V) % den), kstep = (unsigned)(64 % den);
+    hipLaunchKernelGGL(k_ols_wave, dim3(grid), dim3(64), 0, s, (const float2 *)a.xh, (int)a.hx,
+                       (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0,
+                       (const float2 *)a.H, (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out, (long)a.e0,
+                       (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, kstep, 1.0 / (double)den);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
 int ols_decim_overlap(size_t Lc) {  // V: multiple of 256 covering the Lc - 1 wrapped samples
     const size_t v = (Lc - 1 + 255) / 256 * 256;
     return v == 0 ? 256 : (int)v;

@@ -88,6 +88,11 @@ struct FusedFirArgs {
 bool ols_decim_supported(uint64_t D, size_t Lc);
 int ols_decim_overlap(size_t Lc);
 int launch_ols_decim(hipStream_t s, const FusedFirArgs &a);
+// one-wave-per-block variant (k_ols_wave): H = DFT_1024(c) / 1024 and tw = e^{-j 2 pi k / 1024}
+// go in the H / tw4096 fields, V = ols_wave_overlap(Lc)
+bool ols_wave_supported(uint64_t D, size_t Lc);
+int ols_wave_overlap(size_t Lc);
+int launch_ols_wave(hipStream_t s, const FusedFirArgs &a);
 bool fused_fir_supported(uint64_t D, size_t Lc);
 int fused_fir_R(uint64_t D);  // outputs per lane of the instantiation for D
 int launch_fused_fir(hipStream_t s, const FusedFirArgs &a);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B of library variants in ONE GPU session: interleaved rounds of bench.py,
-one subprocess per run (usage: ab_bench.py rounds lib1 lib2 ...; '-' = product)."""
+one subprocess per run (usage: ab_bench.py rounds lib1 lib2 ...; '-' = product;
+'lib@kernel' also sets RR_FUSED_KERNEL=kernel, e.g. '-@olsw')."""
 import json
 import os
 import statistics
@@ -13,8 +14,11 @@ res = {l: {"fir": [], "fft": [], "step": []} for l in libs}
 for r in range(rounds):
     for l in libs:
         env = dict(os.environ)
-        if l != "-":
-            env["RR_LIB"] = os.path.abspath(l)
+        lib, _, kern = l.partition("@")
+        if kern:
+            env["RR_FUSED_KERNEL"] = kern
+        if lib != "-":
+            env["RR_LIB"] = os.path.abspath(lib)
         else:
             env.pop("RR_LIB", None)
         out = subprocess.run([sys.executable, "bench.py", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"],

@@ -204,9 +204,11 @@ def test_chain_complex_response(rr, oracle, allow_fused):
         assert g.last_path_fused()
 
 
-def test_chain_overlap_save_kernel_forced(rr, oracle, monkeypatch):
-    """RR_FUSED_KERNEL=ols runs cfg2 through the overlap-save fused kernel."""
-    monkeypatch.setenv("RR_FUSED_KERNEL", "ols")
+@pytest.mark.parametrize("kernel", ["ols", "olsw", "direct"])
+def test_chain_overlap_save_kernel_forced(rr, oracle, monkeypatch, kernel):
+    """RR_FUSED_KERNEL selects the fused FIR implementation: overlap-save with a workgroup per
+    4096-block (ols), with a wave per 1024-block (olsw), or the direct form (direct)."""
+    monkeypatch.setenv("RR_FUSED_KERNEL", kernel)
     fs, n = 200e6, 1 << 18
     x = oracle.synth_iq(1, 0, n)
     t64 = oracle_spectra(oracle, x, fs, CFG2, np.float64)
