@@ -547,6 +547,17 @@ int rr_chain::ensure_ctaps() {
             twb[2 * i] = (float)std::cos(ang);
             twb[2 * i + 1] = (float)std::sin(ang);
         }
+        if (wave) {  // k_ols_wave reads H as Hp[kp][l] = {H[l + 128 kp], H[l + 128 kp + 64]}, kp < 8, l < 64
+            std::vector<float> hp(2 * N);
+            for (size_t kp = 0; kp < 8; ++kp)
+                for (size_t l = 0; l < 64; ++l)
+                    for (size_t j = 0; j < 2; ++j) {
+                        const size_t src = l + 128 * kp + 64 * j, dst = (kp * 64 + l) * 2 + j;
+                        hp[2 * dst] = hb[2 * src];
+                        hp[2 * dst + 1] = hb[2 * src + 1];
+                    }
+            hb.swap(hp);
+        }
         RR_TRY(upload(d_olsH, hb.data(), hb.size() * sizeof(float), stream));
         RR_TRY(upload(d_tw4096, twb.data(), twb.size() * sizeof(float), stream));
         ols_V = wave ? ols_wave_overlap(lc) : ols_decim_overlap(lc);

@@ -65,6 +65,8 @@ __device__ __forceinline__ unsigned long long stamp() {
 }
 #define RR_STAMP_T(var) const unsigned long long var = stamp()
 #define RR_STAMP_ADD(i, a, b) st_acc[i] += (b) - (a)
+constexpr unsigned kWaveStampBlocks = 90000;
+__device__ unsigned g_wstamp[8 * kWaveStampBlocks];  // k_ols_wave: one record per block
 #else
 #define RR_STAMP_T(var)
 #define RR_STAMP_ADD(i, a, b)
@@ -897,7 +899,10 @@ __device__ __forceinline__ void twiddle16(f2 (&v)[16], f2 w) {
 // groups of a radix-16 pass do not collide.  Image B (256-point inverse) uses B(i) = i + 4 (i >> 4).
 // Every access pattern below is (lane term) + (compile-time offset), spelled out so that the
 // offsets land in the instructions' immediate fields instead of per-access address arithmetic.
-constexpr int kWaveLds = 1200;  // A(1023) + 1 = 1198, rounded
+#ifndef RR_V_WAVELDS
+#define RR_V_WAVELDS 1200
+#endif
+constexpr int kWaveLds = RR_V_WAVELDS;  // A(1023) + 1 = 1198, rounded
 
 __device__ __forceinline__ void wave_sync() {
     // all 64 lanes of the only wave: order LDS writes before the following reads
@@ -906,24 +911,82 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(64) void k_ols_wave(const float2 *__restrict__ xh, int hx,
-                                                 const float2 *__restrict__ in, long n_in,
-                                                 const float2 *__restrict__ nco, unsigned denom, unsigned idx0,
-                                                 const float2 *__restrict__ H, const float2 *__restrict__ tw,
-                                                 int V, float2 *__restrict__ out, long n_out, long e0,
-                                                 float2 *__restrict__ xh_out, int hx_out, unsigned nblocks,
-                                                 unsigned ph0, unsigned hopm, unsigned kstep, double inv_denom) {
-    __shared__ __attribute__((aligned(16))) f2 lds[kWaveLds];
-    const int l = threadIdx.x;
-    // workgroups b, b+8, .. share an XCD: give each XCD one contiguous run of blocks, so
-    // that the V samples two neighbouring blocks share are read from HBM once
-    const unsigned per_xcd = (nblocks + 7) >> 3;
-    const unsigned blk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (blk >= nblocks) return;
+#ifndef RR_V_WAVEWG
+#define RR_V_WAVEWG 1  // independent waves (blocks) per workgroup (LOOP = false only)
+#endif
+#ifndef RR_V_WAVEOCCL
+#define RR_V_WAVEOCCL 3  // waves per SIMD of the persistent form (register budget 512 / n)
+#endif
+#ifndef RR_WAVE_ABLATE
+#define RR_WAVE_ABLATE 0  // measurement builds: 1 = load/mix/store only, 2 = no inverse, 3 = no forward
+#endif
+// Stamps (RR_STAMP build, LOOP = false) showed a block at 14.0k cycles of which 7.3k are the wait
+// for its own 8 KiB of samples (HBM latency under load ~3 us) and 5.6k the transforms.
+// LOOP = true: persistent waves, each a contiguous run of blocks; the next block's samples are
+// requested as soon as the current ones have been mixed, so that latency runs under the
+// transforms.  That costs 32 registers through the whole block: 3 waves per SIMD instead of 4.
+// The sample stream passes through once: with the streaming hint it does not displace the
+// 16 KiB of H / twiddle tables from the CU's 32 KiB L1.
+#ifndef RR_V_WAVENT
+#define RR_V_WAVENT 1
+#endif
+#if RR_V_WAVENT
+__device__ __forceinline__ float2 ld_stream(const float2 *p) {
+    const f2 t = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(p));
+    float2 r;
+    r.x = t.x;
+    r.y = t.y;
+    return r;
+}
+__device__ __forceinline__ void st_stream(float2 *p, float2 v) {
+    __builtin_nontemporal_store((f2){v.x, v.y}, reinterpret_cast<f2 *>(p));
+}
+#define RR_WAVE_LDX(p) ld_stream(p)
+#define RR_WAVE_STY(p, v) st_stream(p, v)
+#else
+#define RR_WAVE_LDX(p) (*(p))
+#define RR_WAVE_STY(p, v) (*(p) = (v))
+#endif
+template <bool LOOP>
+__global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
+    __attribute__((amdgpu_waves_per_eu(LOOP ? RR_V_WAVEOCCL : 4, LOOP ? RR_V_WAVEOCCL : 4))) void k_ols_wave(
+        const float2 *__restrict__ xh, int hx, const float2 *__restrict__ in, long n_in, const float2 *__restrict__ nco,
+        unsigned denom, unsigned idx0, const float2 *__restrict__ H, const float2 *__restrict__ tw, int V,
+        float2 *__restrict__ out, long n_out, long e0, float2 *__restrict__ xh_out, int hx_out, unsigned nblocks,
+        unsigned ph0, unsigned hopm, unsigned hopm_run, unsigned kstep, double inv_denom) {
+    __shared__ __attribute__((aligned(16))) f2 lds_all[LOOP ? 1 : RR_V_WAVEWG][kWaveLds];
+    f2 *const lds = lds_all[LOOP ? 0 : (threadIdx.x >> 6)];
+    const int l = threadIdx.x & 63;
+    // Workgroups b, b+8, .. share an XCD.  Blocks are dealt so that neighbouring blocks run on one
+    // XCD (and, with LOOP, in one wave): the V samples two neighbours share come from HBM once.
+    unsigned blk, cnt, bstride;
+    if constexpr (LOOP) {
+        // XCD x owns the contiguous range of blocks [x * per_xcd, (x + 1) * per_xcd); its waves take
+        // them round robin (wave i: i, i + wpx, ..), so that the blocks in flight at any moment are
+        // neighbours in memory, as with one block per wave.  Contiguous runs per wave were measured
+        // slower (0.146 vs 0.128 ms for the bare load/store loop): 3072 separate streams.
+        const unsigned wpx = gridDim.x >> 3, xcd = blockIdx.x & 7, i = blockIdx.x >> 3;  // grid: multiple of 8
+        const unsigned per_xcd = (nblocks + 7) >> 3;
+        const unsigned lo = xcd * per_xcd, hi = lo + per_xcd < nblocks ? lo + per_xcd : nblocks;
+        blk = lo + i;
+        bstride = wpx;
+        if (blk >= hi) return;
+        cnt = (hi - blk + wpx - 1) / wpx;
+    } else {
+        const unsigned per_xcd = (nblocks + 7) >> 3;
+        const unsigned within = (blockIdx.x >> 3) * RR_V_WAVEWG + (threadIdx.x >> 6);
+        blk = (blockIdx.x & 7) * per_xcd + within;
+        cnt = 1;
+        bstride = 1;
+        if (blk >= nblocks || within >= per_xcd) return;
+    }
     const int hop = 1024 - V, per_block = hop >> 2;
-    const long b0 = e0 - V + (long)blk * hop;
+    const long bhop = (long)bstride * hop;  // distance between two blocks of this wave
+    long b0 = e0 - V + (long)blk * hop;
+    float2 x[16];
+    RR_STAMP_T(ws0);
 
-    if (xh_out && blk == nblocks - 1) {  // mixed-sample history for the next call
+    if (xh_out && blk + (cnt - 1) * bstride == nblocks - 1) {  // mixed-sample history for the next call
         for (int i = l; i < hx_out; i += 64) {
             const long pos = n_in - hx_out + i;
             float2 v;
@@ -939,22 +1002,53 @@ __global__ __launch_bounds__(64) void k_ols_wave(const float2 *__restrict__ xh, 
         }
     }
 
-    // ---- NCO phase of the lane's first sample: (idx0 + b0 + l) mod denom ------------------
+    // ---- NCO phase of the run's first sample: (idx0 + b0) mod denom ---------------------------
     // ph0 = (idx0 + e0 - V) mod denom and hopm = hop mod denom come from the host; the block's
     // term blk * hopm < 2^53 is reduced in f64 (exact) instead of a 64-bit integer division.
-    unsigned r;
-    {
-        unsigned base = ph0;
-        if (hopm != 0) {
-            const double dn = (double)denom;
-            const double prod = __builtin_fma((double)blk, (double)hopm, (double)ph0);
-            const double qd = __builtin_floor(prod * inv_denom);
-            double rd = __builtin_fma(-qd, dn, prod);
-            if (rd < 0.0) rd += dn;
-            if (rd >= dn) rd -= dn;
-            base = (unsigned)rd;
+    unsigned base = ph0;
+    if (hopm != 0) {
+        const double dn = (double)denom;
+        const double prod = __builtin_fma((double)blk, (double)hopm, (double)ph0);
+        const double qd = __builtin_floor(prod * inv_denom);
+        double rd = __builtin_fma(-qd, dn, prod);
+        if (rd < 0.0) rd += dn;
+        if (rd >= dn) rd -= dn;
+        base = (unsigned)rd;
+    }
+
+    // The block's samples first, then the lane constants of the transforms: all requested before
+    // anything waits (the wave-level fences below would otherwise pin each of these L2-latency
+    // loads right in front of its use).
+    if (LOOP || (b0 >= 0 && b0 + 1024 <= n_in)) {
+        const long bs = !LOOP ? b0 : (b0 < 0 ? 0 : (b0 > n_in - 1024 ? n_in - 1024 : b0));
+        const float2 *src = in + bs + l;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = RR_WAVE_LDX(src + 64 * k);
+    }
+    const int g = l >> 4, q = l & 15;
+    float2 t_p1 = tw[4 * q];
+    float2 t_p2[4], t_inv[3];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) t_p2[m] = tw[l + 64 * m];
+    t_inv[0] = tw[(l & 3) * 64];
+    t_inv[1] = tw[q * 16];
+    t_inv[2] = tw[l * 4];
+    f2 *const a_rd = lds + (l + 2 * g);  // A(l + 64 m + 256 c) = a_rd + 72 m + 304 c
+    f2 *const b_rd = lds + (l + 4 * g);  // B(l + 64 c) = b_rd + 80 c
+    size_t zoff = 0;
+
+    for (unsigned it = 0; it < cnt; ++it, blk += bstride, b0 += bhop) {
+        RR_STAMP_T(wt0);
+        if constexpr (LOOP) {
+            // What stays in registers across blocks is decided here, not by invariant-code motion
+            // (which would hoist the 60 derived twiddles and the 16 H values, and then spill): the
+            // 8 twiddle seeds stay, their powers and H (L1/L2 hits) are redone per block.
+            asm volatile("" : "+v"(t_p1), "+v"(t_p2[0]), "+v"(t_p2[1]), "+v"(t_p2[2]), "+v"(t_p2[3]), "+v"(t_inv[0]),
+                         "+v"(t_inv[1]), "+v"(t_inv[2]));
+            asm volatile("" : "+s"(zoff));  // an opaque 0 added to H below
         }
-        r = base + (unsigned)l;
+        // ---- phase of the lane's first sample -------------------------------------------------
+        unsigned r = base + (unsigned)l;
         if (denom >= 64u) {
             if (r >= denom) r -= denom;
         } else if ((denom & (denom - 1u)) == 0u) {
@@ -962,157 +1056,213 @@ __global__ __launch_bounds__(64) void k_ols_wave(const float2 *__restrict__ xh, 
         } else {
             r %= denom;
         }
-    }
-
-    // Lane constants of the transforms, requested before anything waits: the wave-level fences
-    // below would otherwise pin each of these (L2-latency) loads right in front of its use.
-    const int g = l >> 4, q = l & 15;
-    const float2 t_p1 = tw[4 * q];
-    float2 t_p2[4], t_inv[3];
+        base += hopm_run;  // (bstride * hop) mod denom
+        if (base >= denom) base -= denom;
+        // ---- mix: v[k] = xs[b0 + l + 64 k] ------------------------------------------------------
+        f2 v[16];
+        if (b0 >= 0 && b0 + 1024 <= n_in) {
+            if (kstep == 0) {  // one phasor per lane (denom divides 64)
+                const float2 p = nco[r];
+                const f2 pp = {p.x, p.y};
 #pragma unroll
-    for (int m = 0; m < 4; ++m) t_p2[m] = tw[l + 64 * m];
-    t_inv[0] = tw[(l & 3) * 64];
-    t_inv[1] = tw[q * 16];
-    t_inv[2] = tw[l * 4];
-
-    // ---- load + mix: v[k] = xs[b0 + l + 64 k] -----------------------------------------------
-    f2 v[16];
-    if (b0 >= 0 && b0 + 1024 <= n_in) {
-        const float2 *src = in + b0 + l;
-        float2 x[16];
+                for (int k = 0; k < 16; ++k) v[k] = cmul((f2){x[k].x, x[k].y}, pp);
+            } else {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = src[64 * k];
-        if (kstep == 0) {  // one phasor per lane (denom divides 64)
-            const float2 p = nco[r];
-            const f2 pp = {p.x, p.y};
-#pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = cmul((f2){x[k].x, x[k].y}, pp);
+                for (int k = 0; k < 16; ++k) {
+                    const float2 p = nco[r];
+                    v[k] = cmul((f2){x[k].x, x[k].y}, (f2){p.x, p.y});
+                    r += kstep;
+                    if (r >= denom) r -= denom;
+                }
+            }
         } else {
+            // edges: history (already mixed) in front, nothing behind the input.  Every lane reads
+            // some valid address and selects afterwards.
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
+                const long pos = b0 + l + 64 * k;
+                const bool inr = pos >= 0 && pos < n_in;
+                const bool hst = pos < 0 && pos >= -(long)hx;
+                const float2 *ptr = inr ? in + pos : xh + (hst ? hx + pos : 0);
+                const float2 xx = *ptr;
                 const float2 p = nco[r];
-                v[k] = cmul((f2){x[k].x, x[k].y}, (f2){p.x, p.y});
+                const f2 pk = {inr ? p.x : (hst ? 1.f : 0.f), inr ? p.y : 0.f};
+                const f2 xv = {(inr || hst) ? xx.x : 0.f, (inr || hst) ? xx.y : 0.f};
+                v[k] = cmul(xv, pk);
                 r += kstep;
                 if (r >= denom) r -= denom;
             }
         }
-    } else {  // edges: history (already mixed) in front, nothing behind the input
+        // the 16 H values of the lane, used in pass 2.  Requested BEFORE the next block's samples:
+        // loads complete in order (vmcnt), so waiting for a load issued after the prefetch would
+        // wait for the prefetch as well.
+        float2 hv[16];
+        // (H arrives pair-interleaved from the host, Hp[kp][l] = {H[l + 128 kp], H[l + 128 kp + 64]}:
+        //  8 loads of 16 bytes per lane; measured cost of vector-memory traffic here is per
+        //  instruction, not per byte)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const long pos = b0 + l + 64 * k;
-            f2 t = {0.f, 0.f};
-            if (pos < 0) {
-                if (pos >= -(long)hx) {
-                    const float2 h = xh[hx + pos];
-                    t = (f2){h.x, h.y};
-                }
-            } else if (pos < n_in) {
-                const float2 xx = in[pos];
-                const float2 p = nco[r];
-                t = cmul((f2){xx.x, xx.y}, (f2){p.x, p.y});
-            }
-            v[k] = t;
-            r += kstep;
-            if (r >= denom) r -= denom;
+        for (int kp = 0; kp < 8; ++kp) {
+            const float4 h4 = reinterpret_cast<const float4 *>(H + zoff)[l + 64 * kp];
+            hv[2 * kp] = float2{h4.x, h4.y};
+            hv[2 * kp + 1] = float2{h4.z, h4.w};
         }
-    }
-    f2 *const a_rd = lds + (l + 2 * g);  // A(l + 64 m + 256 c) = a_rd + 72 m + 304 c
-    // ---- forward DFT_1024 --------------------------------------------------------------------
-    // pass 0 (Ns = 1): butterfly l over x[l + 64 k]; out 16 l + k: A = 18 l + 16 g + k
-    dft16(v);
-    {
-        f2 *row = lds + (18 * l + 16 * g);
+        // ---- request the next block ---------------------------------------------------------------
+        // Unconditional (the position is clamped into the input, n_in >= 1024 is the launcher's
+        // duty): with the loads under a condition, the compiler must assume at every later wait
+        // that they were NOT issued, and then each wait for an H value also waits for them.
+        if constexpr (LOOP) {
+            __builtin_amdgcn_sched_barrier(0);
+            long nb = b0 + bhop;
+            nb = nb < 0 ? 0 : (nb > n_in - 1024 ? n_in - 1024 : nb);
+            const float2 *src = in + nb + l;
 #pragma unroll
-        for (int k = 0; k < 16; k += 2)
-            *reinterpret_cast<float4 *>(row + k) = (float4){v[k].x, v[k].y, v[k + 1].x, v[k + 1].y};
-    }
-    wave_sync();
+            for (int k = 0; k < 16; ++k) x[k] = RR_WAVE_LDX(src + 64 * k);
+        }
+        RR_STAMP_T(ws1);
+        f2 y[4];
+#if RR_WAVE_ABLATE == 1 || RR_WAVE_ABLATE == 3 || RR_WAVE_ABLATE == 7 || RR_WAVE_ABLATE == 8
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = a_rd[72 * (k & 3) + 304 * (k >> 2)];  // in[l + 64 k]
-    // pass 1 (Ns = 16): twiddle e^{-j 2 pi k (l mod 16) / 256}; out 256 g + q + 16 k: A = 304 g + q + 18 k
-    twiddle16(v, (f2){t_p1.x, t_p1.y});
-    // the 16 H values of the lane: requested here, used after the next exchange
-    float2 hv[16];
+        for (int m = 0; m < 4; ++m) y[m] = v[m] + v[m + 4] + v[m + 8] + v[m + 12];
+#if RR_WAVE_ABLATE == 7  // + the 16 H loads (8 bytes per lane each)
 #pragma unroll
-    for (int k = 0; k < 16; ++k) hv[k] = H[l + 64 * k];
-    dft16(v);
-    wave_sync();
-    {
-        f2 *col = lds + (304 * g + q);
+        for (int k = 0; k < 16; ++k) y[k & 3] += (f2){hv[k].x, hv[k].y};
+#elif RR_WAVE_ABLATE == 8  // + the same H bytes as 8 loads of 16 bytes per lane
 #pragma unroll
-        for (int k = 0; k < 16; ++k) col[18 * k] = v[k];
-    }
-    wave_sync();
-    // pass 2 (Ns = 256, radix 4): butterflies t = l + 64 m over in[t + 256 c]; out X[t + 256 c]
-    f2 y[4];
+        for (int k = 0; k < 8; ++k) {
+            const float4 h4 = reinterpret_cast<const float4 *>(H + zoff)[l + 64 * k];
+            y[k & 3] += (f2){h4.x + h4.z, h4.y + h4.w};
+        }
+#endif
+#else
+        // ---- forward DFT_1024 -------------------------------------------------------------------
+        // pass 0 (Ns = 1): butterfly l over x[l + 64 k]; out 16 l + k: A = 18 l + 16 g + k
+        dft16(v);
+        if constexpr (LOOP) wave_sync();  // the previous block's last reads of image B are done
+#if RR_WAVE_ABLATE != 4
+        {
+            f2 *row = lds + (18 * l + 16 * g);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        f2 a0 = a_rd[72 * m], a1 = a_rd[72 * m + 304], a2 = a_rd[72 * m + 608], a3 = a_rd[72 * m + 912];
-        const f2 w1 = {t_p2[m].x, t_p2[m].y};
-        const f2 w2 = cmul(w1, w1);
-        const f2 w3 = cmul(w2, w1);
-        a1 = cmul(a1, w1);
-        a2 = cmul(a2, w2);
-        a3 = cmul(a3, w3);
-        dft4(a0, a1, a2, a3);
-        // * H and fold the four 256-bin quarters: Y[t] = sum_c X[t + 256 c] H[t + 256 c]
-        const float2 h0 = hv[m], h1 = hv[m + 4], h2 = hv[m + 8], h3 = hv[m + 12];
-        f2 acc = cmul(a0, (f2){h0.x, h0.y});
-        acc = cmac(acc, a1, (f2){h1.x, h1.y});
-        acc = cmac(acc, a2, (f2){h2.x, h2.y});
-        acc = cmac(acc, a3, (f2){h3.x, h3.y});
-        y[m] = acc;
-    }
-    // ---- inverse DFT_256, Stockham radix 4 x 4: butterfly l reads in[l + 64 c] -----------------
-    f2 *const b_rd = lds + (l + 4 * g);  // B(l + 64 c) = b_rd + 80 c
-    // pass 0 (Ns = 1): no twiddle; out 4 l + c: B = 4 l + 4 (l >> 2) + c
-    idft4(y[0], y[1], y[2], y[3]);
-    wave_sync();  // the forward image has been read
-    {
-        f2 *row = lds + (4 * l + 4 * (l >> 2));
-        *reinterpret_cast<float4 *>(row) = (float4){y[0].x, y[0].y, y[1].x, y[1].y};
-        *reinterpret_cast<float4 *>(row + 2) = (float4){y[2].x, y[2].y, y[3].x, y[3].y};
-    }
-    wave_sync();
+            for (int k = 0; k < 16; k += 2)
+                *reinterpret_cast<float4 *>(row + k) = (float4){v[k].x, v[k].y, v[k + 1].x, v[k + 1].y};
+        }
+        wave_sync();
 #pragma unroll
-    for (int pass = 1; pass < 4; ++pass) {
-        const int ns = 1 << (2 * pass);
+        for (int k = 0; k < 16; ++k) v[k] = a_rd[72 * (k & 3) + 304 * (k >> 2)];  // in[l + 64 k]
+#endif
+        RR_STAMP_T(ws2);
+        // pass 1 (Ns = 16): twiddle e^{-j 2 pi k (l mod 16) / 256}; out 256 g + q + 16 k: A = 304 g + q + 18 k
+#if RR_WAVE_ABLATE != 5
+        twiddle16(v, (f2){t_p1.x, t_p1.y});
+#endif
+        dft16(v);
+        RR_STAMP_T(ws3);
+#if RR_WAVE_ABLATE != 4
+        wave_sync();
+        {
+            f2 *col = lds + (304 * g + q);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) y[c] = b_rd[80 * c];
-        // twiddles e^{+j 2 pi c (l mod ns) / (4 ns)} = conj(tw[(l mod ns) 256 / ns])^c
-        const f2 w1 = {t_inv[pass - 1].x, t_inv[pass - 1].y};
-        const f2 w2 = cmul(w1, w1);
-        const f2 w3 = cmul(w2, w1);
-        y[1] = cmul_conj(y[1], w1);
-        y[2] = cmul_conj(y[2], w2);
-        y[3] = cmul_conj(y[3], w3);
+            for (int k = 0; k < 16; ++k) col[18 * k] = v[k];
+        }
+        wave_sync();
+#endif
+        // pass 2 (Ns = 256, radix 4): butterflies t = l + 64 m over in[t + 256 c]; out X[t + 256 c]
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#if RR_WAVE_ABLATE == 4
+            f2 a0 = v[m], a1 = v[m + 4], a2 = v[m + 8], a3 = v[m + 12];
+#else
+            f2 a0 = a_rd[72 * m], a1 = a_rd[72 * m + 304], a2 = a_rd[72 * m + 608], a3 = a_rd[72 * m + 912];
+#endif
+#if RR_WAVE_ABLATE != 5
+            const f2 w1 = {t_p2[m].x, t_p2[m].y};
+            const f2 w2 = cmul(w1, w1);
+            const f2 w3 = cmul(w2, w1);
+            a1 = cmul(a1, w1);
+            a2 = cmul(a2, w2);
+            a3 = cmul(a3, w3);
+#endif
+            dft4(a0, a1, a2, a3);
+            // * H and fold the four 256-bin quarters: Y[t] = sum_c X[t + 256 c] H[t + 256 c]
+            const float2 h0 = hv[m], h1 = hv[m + 4], h2 = hv[m + 8], h3 = hv[m + 12];
+            f2 acc = cmul(a0, (f2){h0.x, h0.y});
+            acc = cmac(acc, a1, (f2){h1.x, h1.y});
+            acc = cmac(acc, a2, (f2){h2.x, h2.y});
+            acc = cmac(acc, a3, (f2){h3.x, h3.y});
+            y[m] = acc;
+        }
+#endif
+        RR_STAMP_T(ws4);
+#if RR_WAVE_ABLATE == 0 || (RR_WAVE_ABLATE >= 3 && RR_WAVE_ABLATE < 7)
+        // ---- inverse DFT_256, Stockham radix 4 x 4: butterfly l reads in[l + 64 c] ------------------
+        // pass 0 (Ns = 1): no twiddle; out 4 l + c: B = 4 l + 4 (l >> 2) + c
         idft4(y[0], y[1], y[2], y[3]);
-        if (pass == 3) break;  // natural order: y[c] = result[l + 64 c]
-        wave_sync();
-        if (pass == 1) {  // out 16 (l >> 2) + (l & 3) + 4 c: B = 20 (l >> 2) + (l & 3) + 4 c
-            f2 *col = lds + (20 * (l >> 2) + (l & 3));
-#pragma unroll
-            for (int c = 0; c < 4; ++c) col[4 * c] = y[c];
-        } else {  // out 64 g + q + 16 c: B = 80 g + q + 20 c
-            f2 *col = lds + (80 * g + q);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) col[20 * c] = y[c];
+        wave_sync();  // the forward image has been read
+        {
+            f2 *row = lds + (4 * l + 4 * (l >> 2));
+            *reinterpret_cast<float4 *>(row) = (float4){y[0].x, y[0].y, y[1].x, y[1].y};
+            *reinterpret_cast<float4 *>(row + 2) = (float4){y[2].x, y[2].y, y[3].x, y[3].y};
         }
         wave_sync();
-    }
-    // ---- store the valid part ---------------------------------------------------------------
-    const long mbase = (long)blk * per_block;
-    const int first = V >> 2;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int tau = l + 64 * c;
-        const long m = mbase + (tau - first);
-        if (tau >= first && m < n_out) {
-            float2 w;
-            w.x = y[c].x;
-            w.y = y[c].y;
-            out[m] = w;
+        for (int pass = 1; pass < 4; ++pass) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) y[c] = b_rd[80 * c];
+            // twiddles e^{+j 2 pi c (l mod ns) / (4 ns)} = conj(tw[(l mod ns) 256 / ns])^c, ns = 4^pass
+            const f2 w1 = {t_inv[pass - 1].x, t_inv[pass - 1].y};
+            const f2 w2 = cmul(w1, w1);
+            const f2 w3 = cmul(w2, w1);
+            y[1] = cmul_conj(y[1], w1);
+            y[2] = cmul_conj(y[2], w2);
+            y[3] = cmul_conj(y[3], w3);
+            idft4(y[0], y[1], y[2], y[3]);
+            if (pass == 3) break;  // natural order: y[c] = result[l + 64 c]
+            wave_sync();
+            if (pass == 1) {  // out 16 (l >> 2) + (l & 3) + 4 c: B = 20 (l >> 2) + (l & 3) + 4 c
+                f2 *col = lds + (20 * (l >> 2) + (l & 3));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) col[4 * c] = y[c];
+            } else {  // out 64 g + q + 16 c: B = 80 g + q + 20 c
+                f2 *col = lds + (80 * g + q);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) col[20 * c] = y[c];
+            }
+            wave_sync();
         }
+#endif
+        RR_STAMP_T(ws5);
+        // ---- store the valid part -----------------------------------------------------------------
+        const long mbase = (long)blk * per_block;
+        const int first = V >> 2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int tau = l + 64 * c;
+            const long m = mbase + (tau - first);
+            if (tau >= first && m < n_out) {
+                float2 w;
+                w.x = y[c].x;
+                w.y = y[c].y;
+                RR_WAVE_STY(out + m, w);
+            }
+        }
+#if defined(RR_STAMP) && RR_WAVE_ABLATE == 0
+        {
+            RR_STAMP_T(ws6);
+            // one record per block, no atomics (80k waves x 7 atomics on 7 addresses distort everything)
+            if (l == 0 && b0 >= 0 && b0 + 1024 <= n_in && blk < kWaveStampBlocks) {
+                unsigned *rec = g_wstamp + 8 * (size_t)blk;
+                rec[0] = (unsigned)(ws1 - (LOOP ? wt0 : ws0));  // (prologue,) wait for the samples, mix
+                rec[1] = (unsigned)(ws2 - ws1);  // pass 0 + exchange 1
+                rec[2] = (unsigned)(ws3 - ws2);  // pass 1 (twiddles + radix 16)
+                rec[3] = (unsigned)(ws4 - ws3);  // exchange 2 + pass 2 + H
+                rec[4] = (unsigned)(ws5 - ws4);  // inverse
+                rec[5] = (unsigned)(ws6 - ws5);  // store
+                rec[6] = (unsigned)ws1;          // time (low bits)
+                unsigned hwid;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+                rec[7] = hwid;
+            }
+        }
+#endif
     }
 }
 
@@ -1128,15 +1278,33 @@ int launch_ols_wave(hipStream_t s, const FusedFirArgs &a) {
     const int per_block = (1024 - a.V) / 4;
     const size_t nblocks = (a.n_out + per_block - 1) / per_block;
     if (nblocks > 0x7ffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS: too many blocks");
-    const unsigned grid = (unsigned)((nblocks + 7) / 8 * 8);
     const int64_t den = (int64_t)a.denom;
     int64_t ph = ((int64_t)a.idx0 + a.e0 - a.V) % den;
     if (ph < 0) ph += den;
     const unsigned hopm = (unsigned)((int64_t)(1024 - a.V) % den), kstep = (unsigned)(64 % den);
-    hipLaunchKernelGGL(k_ols_wave, dim3(grid), dim3(64), 0, s, (const float2 *)a.xh, (int)a.hx,
+#ifndef RR_V_WAVELOOP
+#define RR_V_WAVELOOP 1  // 0: one block per wave; G > 0: persistent waves, G resident sets
+#endif
+#if RR_V_WAVELOOP > 0
+    // one resident set = 256 CUs x 4 SIMDs x RR_V_WAVEOCCL waves; the grid must be a multiple of 8
+    const size_t cap = (size_t)1024 * RR_V_WAVEOCCL * RR_V_WAVELOOP;
+    unsigned grid = (unsigned)(nblocks < cap ? (nblocks + 7) / 8 * 8 : cap), threads = 64;
+    auto kern = k_ols_wave<true>;
+    if (a.n_in < 1024) {  // the persistent form prefetches whole blocks from inside the input
+        kern = k_ols_wave<false>;
+        grid = (unsigned)((nblocks + 7) / 8 * 8);
+    }
+#else
+    const size_t per_xcd = (nblocks + 7) / 8;
+    const unsigned grid = (unsigned)((per_xcd + RR_V_WAVEWG - 1) / RR_V_WAVEWG * 8), threads = 64 * RR_V_WAVEWG;
+    auto kern = k_ols_wave<false>;
+#endif
+    const bool looped = kern == k_ols_wave<true>;
+    const unsigned hopm_run = looped ? (unsigned)((int64_t)(grid / 8) * (1024 - a.V) % den) : hopm;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, s, (const float2 *)a.xh, (int)a.hx,
                        (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0,
                        (const float2 *)a.H, (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out, (long)a.e0,
-                       (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, kstep, 1.0 / (double)den);
+                       (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, hopm_run, kstep, 1.0 / (double)den);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
@@ -1244,6 +1412,10 @@ __global__ void k_drop_tail(const float2 *__restrict__ oldh, float2 *__restrict_
 }
 
 #ifdef RR_STAMP
+extern "C" int rr_debug_read_wave_stamps(unsigned *out, unsigned nblocks) {
+    if (nblocks > kWaveStampBlocks) nblocks = kWaveStampBlocks;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wstamp), (size_t)nblocks * 8 * sizeof(unsigned)) != hipSuccess;
+}
 extern "C" int rr_debug_read_stamps(unsigned long long *out8, int reset) {
     unsigned long long h[8];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp), sizeof h) != hipSuccess) return 1;
