@@ -89,11 +89,13 @@ int rr_freqshifter::prepare(double sample_rate) {
     denom = de;
     phase_idx = 0;
     shift_changed = false;
-    host_table.resize((size_t)de * esz);
+    // denom entries + entry 0 once more behind them: k_ols_wave reads the pair (r, r + 1) in one piece
+    host_table.resize(((size_t)de + 1) * esz);
     if (dtype == RR_F32)
         nco_table<float>(nu, de, (float)start, reinterpret_cast<float *>(host_table.data()));
     else
         nco_table<double>(nu, de, start, reinterpret_cast<double *>(host_table.data()));
+    std::memcpy(host_table.data() + (size_t)de * esz, host_table.data(), esz);
     return upload(d_table, host_table.data(), host_table.size(), stream);
 }
 
@@ -485,8 +487,7 @@ bool rr_chain::fused_candidate(double sample_rate) const {
     if (!fl->designed) return false;
     if (!ds->have_rate || ds->prev_rate != sample_rate || !ds->sched.integer_ratio) return false;
     const size_t lc = ds->L + fl->n - 1;
-    if (fl->real_taps && fused_fir_supported(ds->sched.D, lc)) return true;
-    return ols_decim_supported(ds->sched.D, lc);  // also serves complex taps
+    return pick_fused_kernel(ds->sched.D, lc, fl->real_taps) != FK_NONE;
 }
 
 int rr_chain::ensure_xh() {
@@ -503,16 +504,26 @@ int rr_chain::ensure_xh() {
     return RR_OK;
 }
 
-// Two fused FIR implementations: the direct form (k_mix_fir_decim: real taps, measured
-// faster: 0.227 vs 0.241 ms per 2^26 samples) and overlap-save (k_ols_decim4: also complex
-// taps).  RR_FUSED_KERNEL=ols forces the latter where it applies (A/B and tests).
-bool rr_chain::ols_wanted() {
+// Three fused mix + FIR + decimate implementations (measured on cfg2, 2^26 samples, Lc = 183):
+//   direct  k_mix_fir_decim  direct form, real taps, D in {2, 4, 8}; cost ~ Lc           0.222 ms
+//   ols     k_ols_decim4     overlap-save, workgroup per 4096-block, D = 4, any taps       0.21 ms
+//   olsw    k_ols_wave       overlap-save, wave per 1024-block, D = 4, any taps, Lc <= 513 0.144 ms
+// Unforced, olsw runs where it applies unless the filter is so short (Lc < 112) that the direct
+// form is at its load/store floor anyway.  RR_FUSED_KERNEL = direct | ols | olsw forces one of
+// them where it applies (A/B runs and tests).
+int rr_chain::pick_fused_kernel(uint64_t D, size_t lc, bool real_taps) {
+    const bool can_direct = real_taps && fused_fir_supported(D, lc);
+    const bool can_ols = ols_decim_supported(D, lc), can_wave = ols_wave_supported(D, lc);
     const char *e = std::getenv("RR_FUSED_KERNEL");
-    return e && std::strcmp(e, "ols") == 0;
-}
-bool rr_chain::ols_wave_wanted() {
-    const char *e = std::getenv("RR_FUSED_KERNEL");
-    return e && std::strcmp(e, "olsw") == 0;
+    if (e) {
+        if (!std::strcmp(e, "direct") && can_direct) return FK_DIRECT;
+        if (!std::strcmp(e, "ols") && can_ols) return FK_OLS;
+        if (!std::strcmp(e, "olsw") && can_wave) return FK_OLSW;
+    }
+    if (can_wave && (lc >= 112 || !can_direct)) return FK_OLSW;
+    if (can_direct) return FK_DIRECT;
+    if (can_ols) return FK_OLS;
+    return FK_NONE;
 }
 
 // c = reverse(ir) (*) g in f64, cast to f32 and laid out in the step order of
@@ -530,9 +541,9 @@ int rr_chain::ensure_ctaps() {
             cc[j + k] += a * (fl->real_taps ? cd(fl->taps_f64[k].real(), 0.0) : fl->taps_f64[k]);
         }
     }
-    const bool wave = ols_wave_wanted() && ols_wave_supported(ds->sched.D, lc);
-    use_ols = wave || (ols_decim_supported(ds->sched.D, lc) &&
-                       (ols_wanted() || !(fl->real_taps && fused_fir_supported(ds->sched.D, lc))));
+    const int fk = pick_fused_kernel(ds->sched.D, lc, fl->real_taps);
+    const bool wave = fk == FK_OLSW;
+    use_ols = wave || fk == FK_OLS;
     if (use_ols) {
         // H = DFT_N(c) / N (the inverse transform in the kernel is unnormalised)
         const size_t N = wave ? 1024 : 4096;
@@ -557,6 +568,21 @@ int rr_chain::ensure_ctaps() {
                         hp[2 * dst + 1] = hb[2 * src + 1];
                     }
             hb.swap(hp);
+            // lane seeds of the transforms behind the table: 3 entries of two twiddles per lane
+            auto twv = [&](size_t i, float *dst) {
+                dst[0] = twb[2 * i];
+                dst[1] = twb[2 * i + 1];
+            };
+            twb.resize(2 * (N + 2 * 3 * 64));
+            for (size_t l = 0; l < 64; ++l) {
+                float *e0 = &twb[2 * N + 4 * l], *e1 = e0 + 4 * 64, *e2 = e1 + 4 * 64;
+                twv(8 * (l & 7), e0);         // pass 1
+                twv(l, e0 + 2);               // pass 2, m = 0
+                twv(l + 64, e1);              // pass 2, m = 1
+                twv(64 * (l & 3), e1 + 2);    // inverse pass 1
+                twv(16 * (l & 15), e2);       // inverse pass 2
+                twv(4 * l, e2 + 2);           // inverse pass 3
+            }
         }
         RR_TRY(upload(d_olsH, hb.data(), hb.size() * sizeof(float), stream));
         RR_TRY(upload(d_tw4096, twb.data(), twb.size() * sizeof(float), stream));

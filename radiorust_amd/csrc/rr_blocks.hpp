@@ -143,8 +143,8 @@ struct rr_chain : rr_block {
     int ols_N = 4096;  // 4096: k_ols_decim4 (workgroup per block), 1024: k_ols_wave (wave per block)
     rr::DevBuf d_olsH, d_tw4096;
     bool fused_candidate(double sample_rate) const;
-    static bool ols_wanted();
-    static bool ols_wave_wanted();
+    enum { FK_NONE = 0, FK_DIRECT, FK_OLS, FK_OLSW };
+    static int pick_fused_kernel(uint64_t D, size_t lc, bool real_taps);
     int ensure_xh();
     int ensure_ctaps();
     int materialize();  // bring the per-block histories up to date after fused calls

@@ -557,6 +557,26 @@ __device__ __forceinline__ void dft16(f2 (&v)[16]) {
     for (int k = 0; k < 16; ++k) v[k] = t[k];
 }
 
+// in-register forward 8-point DFT, natural order in and out (29 packed ops)
+__device__ __forceinline__ void dft8(f2 (&v)[8]) {
+    constexpr float H = 0.70710678118654752440f;
+    f2 a0 = v[0] + v[4], a1 = v[1] + v[5], a2 = v[2] + v[6], a3 = v[3] + v[7];
+    f2 b0 = v[0] - v[4], b1 = v[1] - v[5], b2 = v[2] - v[6], b3 = v[3] - v[7];
+    b1 = cmulc(b1, H, -H);   // W8^1
+    b2 = mul_mj(b2);         // W8^2 = -j
+    b3 = cmulc(b3, -H, -H);  // W8^3
+    dft4(a0, a1, a2, a3);    // X[0], X[2], X[4], X[6]
+    dft4(b0, b1, b2, b3);    // X[1], X[3], X[5], X[7]
+    v[0] = a0;
+    v[2] = a1;
+    v[4] = a2;
+    v[6] = a3;
+    v[1] = b0;
+    v[3] = b1;
+    v[5] = b2;
+    v[7] = b3;
+}
+
 __device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
 
 // v[k] *= w^k, k = 1..15.  Powers by a product tree at most 4 deep (error ~4 ulp, not 15);
@@ -931,13 +951,8 @@ __device__ __forceinline__ void wave_sync() {
 #define RR_V_WAVENT 1
 #endif
 #if RR_V_WAVENT
-__device__ __forceinline__ float2 ld_stream(const float2 *p) {
-    const f2 t = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(p));
-    float2 r;
-    r.x = t.x;
-    r.y = t.y;
-    return r;
-}
+typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));  // two complex samples, 8-byte aligned
+__device__ __forceinline__ f4u ld_stream(const f4u *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void st_stream(float2 *p, float2 v) {
     __builtin_nontemporal_store((f2){v.x, v.y}, reinterpret_cast<f2 *>(p));
 }
@@ -983,7 +998,6 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
     const int hop = 1024 - V, per_block = hop >> 2;
     const long bhop = (long)bstride * hop;  // distance between two blocks of this wave
     long b0 = e0 - V + (long)blk * hop;
-    float2 x[16];
     RR_STAMP_T(ws0);
 
     if (xh_out && blk + (cnt - 1) * bstride == nblocks - 1) {  // mixed-sample history for the next call
@@ -1018,21 +1032,29 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
 
     // The block's samples first, then the lane constants of the transforms: all requested before
     // anything waits (the wave-level fences below would otherwise pin each of these L2-latency
-    // loads right in front of its use).
+    // loads right in front of its use).  Vector memory costs per instruction here, not per byte
+    // (measured), so everything comes in 16-byte pieces: lane l takes the sample pairs
+    // x[2 l + 128 k' .. + 1], k' < 8, and its 6 twiddle seeds as 3 packed entries.
+    f4u x[8];
     if (LOOP || (b0 >= 0 && b0 + 1024 <= n_in)) {
         const long bs = !LOOP ? b0 : (b0 < 0 ? 0 : (b0 > n_in - 1024 ? n_in - 1024 : b0));
-        const float2 *src = in + bs + l;
+        const f4u *src = reinterpret_cast<const f4u *>(in + bs) + l;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = RR_WAVE_LDX(src + 64 * k);
+        for (int k = 0; k < 8; ++k) x[k] = RR_WAVE_LDX(src + 64 * k);
     }
     const int g = l >> 4, q = l & 15;
-    float2 t_p1 = tw[4 * q];
-    float2 t_p2[4], t_inv[3];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) t_p2[m] = tw[l + 64 * m];
-    t_inv[0] = tw[(l & 3) * 64];
-    t_inv[1] = tw[q * 16];
-    t_inv[2] = tw[l * 4];
+    // seeds: pass 1 tw[8 (l mod 8)]; pass 2 tw[l], tw[l + 64]; inverse tw[64 (l mod 4)], tw[16 (l mod 16)], tw[4 l]
+    f2 t_p1, t_p2[2], t_inv[3];
+    {
+        const float4 *tl = reinterpret_cast<const float4 *>(tw + 1024) + l;
+        const float4 s0 = tl[0], s1 = tl[64], s2 = tl[128];
+        t_p1 = (f2){s0.x, s0.y};
+        t_p2[0] = (f2){s0.z, s0.w};
+        t_p2[1] = (f2){s1.x, s1.y};
+        t_inv[0] = (f2){s1.z, s1.w};
+        t_inv[1] = (f2){s2.x, s2.y};
+        t_inv[2] = (f2){s2.z, s2.w};
+    }
     f2 *const a_rd = lds + (l + 2 * g);  // A(l + 64 m + 256 c) = a_rd + 72 m + 304 c
     f2 *const b_rd = lds + (l + 4 * g);  // B(l + 64 c) = b_rd + 80 c
     size_t zoff = 0;
@@ -1042,14 +1064,13 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
         if constexpr (LOOP) {
             // What stays in registers across blocks is decided here, not by invariant-code motion
             // (which would hoist the 60 derived twiddles and the 16 H values, and then spill): the
-            // 8 twiddle seeds stay, their powers and H (L1/L2 hits) are redone per block.
-            asm volatile("" : "+v"(t_p1), "+v"(t_p2[0]), "+v"(t_p2[1]), "+v"(t_p2[2]), "+v"(t_p2[3]), "+v"(t_inv[0]),
-                         "+v"(t_inv[1]), "+v"(t_inv[2]));
+            // 6 twiddle seeds stay, their powers and H (L1/L2 hits) are redone per block.
+            asm volatile("" : "+v"(t_p1), "+v"(t_p2[0]), "+v"(t_p2[1]), "+v"(t_inv[0]), "+v"(t_inv[1]), "+v"(t_inv[2]));
             asm volatile("" : "+s"(zoff));  // an opaque 0 added to H below
         }
-        // ---- phase of the lane's first sample -------------------------------------------------
-        unsigned r = base + (unsigned)l;
-        if (denom >= 64u) {
+        // ---- phase of the lane's first sample (2 l into the block) -------------------------------
+        unsigned r = base + 2u * (unsigned)l;
+        if (denom >= 128u) {
             if (r >= denom) r -= denom;
         } else if ((denom & (denom - 1u)) == 0u) {
             r &= denom - 1u;
@@ -1058,19 +1079,23 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
         }
         base += hopm_run;  // (bstride * hop) mod denom
         if (base >= denom) base -= denom;
-        // ---- mix: v[k] = xs[b0 + l + 64 k] ------------------------------------------------------
+        // ---- mix: v[2 k' + j] = xs[b0 + 2 l + j + 128 k'] ------------------------------------------
+        // (the NCO table holds 2 * denom entries, so the pair r, r + 1 is one 16-byte read)
         f2 v[16];
         if (b0 >= 0 && b0 + 1024 <= n_in) {
-            if (kstep == 0) {  // one phasor per lane (denom divides 64)
-                const float2 p = nco[r];
-                const f2 pp = {p.x, p.y};
+            if (kstep == 0) {  // the period divides 128: one pair of phasors per lane
+                const f4u pp = *reinterpret_cast<const f4u *>(nco + r);
 #pragma unroll
-                for (int k = 0; k < 16; ++k) v[k] = cmul((f2){x[k].x, x[k].y}, pp);
+                for (int k = 0; k < 8; ++k) {
+                    v[2 * k] = cmul((f2){x[k].x, x[k].y}, (f2){pp.x, pp.y});
+                    v[2 * k + 1] = cmul((f2){x[k].z, x[k].w}, (f2){pp.z, pp.w});
+                }
             } else {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const float2 p = nco[r];
-                    v[k] = cmul((f2){x[k].x, x[k].y}, (f2){p.x, p.y});
+                for (int k = 0; k < 8; ++k) {
+                    const f4u pp = *reinterpret_cast<const f4u *>(nco + r);
+                    v[2 * k] = cmul((f2){x[k].x, x[k].y}, (f2){pp.x, pp.y});
+                    v[2 * k + 1] = cmul((f2){x[k].z, x[k].w}, (f2){pp.z, pp.w});
                     r += kstep;
                     if (r >= denom) r -= denom;
                 }
@@ -1079,16 +1104,20 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
             // edges: history (already mixed) in front, nothing behind the input.  Every lane reads
             // some valid address and selects afterwards.
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const long pos = b0 + l + 64 * k;
-                const bool inr = pos >= 0 && pos < n_in;
-                const bool hst = pos < 0 && pos >= -(long)hx;
-                const float2 *ptr = inr ? in + pos : xh + (hst ? hx + pos : 0);
-                const float2 xx = *ptr;
-                const float2 p = nco[r];
-                const f2 pk = {inr ? p.x : (hst ? 1.f : 0.f), inr ? p.y : 0.f};
-                const f2 xv = {(inr || hst) ? xx.x : 0.f, (inr || hst) ? xx.y : 0.f};
-                v[k] = cmul(xv, pk);
+            for (int k = 0; k < 8; ++k) {
+                const f4u pp = *reinterpret_cast<const f4u *>(nco + r);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const long pos = b0 + 2 * l + j + 128 * k;
+                    const bool inr = pos >= 0 && pos < n_in;
+                    const bool hst = pos < 0 && pos >= -(long)hx;
+                    const float2 *ptr = inr ? in + pos : xh + (hst ? hx + pos : 0);
+                    const float2 xx = *ptr;
+                    const f2 p = j ? (f2){pp.z, pp.w} : (f2){pp.x, pp.y};
+                    const f2 pk = {inr ? p.x : (hst ? 1.f : 0.f), inr ? p.y : 0.f};
+                    const f2 xv = {(inr || hst) ? xx.x : 0.f, (inr || hst) ? xx.y : 0.f};
+                    v[2 * k + j] = cmul(xv, pk);
+                }
                 r += kstep;
                 if (r >= denom) r -= denom;
             }
@@ -1114,9 +1143,9 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
             __builtin_amdgcn_sched_barrier(0);
             long nb = b0 + bhop;
             nb = nb < 0 ? 0 : (nb > n_in - 1024 ? n_in - 1024 : nb);
-            const float2 *src = in + nb + l;
+            const f4u *src = reinterpret_cast<const f4u *>(in + nb) + l;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) x[k] = RR_WAVE_LDX(src + 64 * k);
+            for (int k = 0; k < 8; ++k) x[k] = RR_WAVE_LDX(src + 64 * k);
         }
         RR_STAMP_T(ws1);
         f2 y[4];
@@ -1134,13 +1163,27 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
         }
 #endif
 #else
-        // ---- forward DFT_1024 -------------------------------------------------------------------
-        // pass 0 (Ns = 1): butterfly l over x[l + 64 k]; out 16 l + k: A = 18 l + 16 g + k
-        dft16(v);
+        // ---- forward DFT_1024 = radix 8 x 16 x 8 (Stockham) -------------------------------------------
+        // pass 0 (Ns = 1): butterflies 2 l + j over x[2 l + j + 128 k']; out 8 (2 l + j) + r = 16 l + 8 j + r
+        {
+            f2 e0[8], e1[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                e0[k] = v[2 * k];
+                e1[k] = v[2 * k + 1];
+            }
+            dft8(e0);
+            dft8(e1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                v[k] = e0[k];
+                v[8 + k] = e1[k];
+            }
+        }
         if constexpr (LOOP) wave_sync();  // the previous block's last reads of image B are done
 #if RR_WAVE_ABLATE != 4
         {
-            f2 *row = lds + (18 * l + 16 * g);
+            f2 *row = lds + (18 * l + 16 * g);  // A(16 l + e) = 18 l + 16 g + e
 #pragma unroll
             for (int k = 0; k < 16; k += 2)
                 *reinterpret_cast<float4 *>(row + k) = (float4){v[k].x, v[k].y, v[k + 1].x, v[k + 1].y};
@@ -1150,44 +1193,60 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
         for (int k = 0; k < 16; ++k) v[k] = a_rd[72 * (k & 3) + 304 * (k >> 2)];  // in[l + 64 k]
 #endif
         RR_STAMP_T(ws2);
-        // pass 1 (Ns = 16): twiddle e^{-j 2 pi k (l mod 16) / 256}; out 256 g + q + 16 k: A = 304 g + q + 18 k
+        // pass 1 (Ns = 8, radix 16): twiddle e^{-j 2 pi k (l mod 8) / 128}; out 128 (l / 8) + l % 8 + 8 k
 #if RR_WAVE_ABLATE != 5
-        twiddle16(v, (f2){t_p1.x, t_p1.y});
+        twiddle16(v, t_p1);
 #endif
         dft16(v);
         RR_STAMP_T(ws3);
 #if RR_WAVE_ABLATE != 4
         wave_sync();
         {
-            f2 *col = lds + (304 * g + q);
+            // A(128 h + p + 8 k), h = l / 8, p = l % 8: 144 h + 16 (h / 2) + p + 8 k + 2 (k / 2)
+            f2 *col = lds + (144 * (l >> 3) + 16 * (l >> 4) + (l & 7));
 #pragma unroll
-            for (int k = 0; k < 16; ++k) col[18 * k] = v[k];
+            for (int k = 0; k < 16; ++k) col[8 * k + 2 * (k >> 1)] = v[k];
         }
         wave_sync();
 #endif
-        // pass 2 (Ns = 256, radix 4): butterflies t = l + 64 m over in[t + 256 c]; out X[t + 256 c]
+        // pass 2 (Ns = 128, radix 8): butterflies t = l + 64 m over in[t + 128 c]; out X[t + 128 r],
+        // i.e. X[l + 64 k] with k = m + 2 r
+        f2 X[16];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < 2; ++m) {
+            f2 a[8];
 #if RR_WAVE_ABLATE == 4
-            f2 a0 = v[m], a1 = v[m + 4], a2 = v[m + 8], a3 = v[m + 12];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) a[c] = v[m + 2 * c];
 #else
-            f2 a0 = a_rd[72 * m], a1 = a_rd[72 * m + 304], a2 = a_rd[72 * m + 608], a3 = a_rd[72 * m + 912];
+            // A(l + 64 m + 128 c) = a_rd + 72 m + 144 c + 16 (c / 2)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) a[c] = a_rd[72 * m + 144 * c + 16 * (c >> 1)];
 #endif
 #if RR_WAVE_ABLATE != 5
-            const f2 w1 = {t_p2[m].x, t_p2[m].y};
+            const f2 w1 = t_p2[m];
             const f2 w2 = cmul(w1, w1);
             const f2 w3 = cmul(w2, w1);
-            a1 = cmul(a1, w1);
-            a2 = cmul(a2, w2);
-            a3 = cmul(a3, w3);
+            const f2 w4 = cmul(w2, w2);
+            a[1] = cmul(a[1], w1);
+            a[2] = cmul(a[2], w2);
+            a[3] = cmul(a[3], w3);
+            a[4] = cmul(a[4], w4);
+            a[5] = cmul(a[5], cmul(w4, w1));
+            a[6] = cmul(a[6], cmul(w4, w2));
+            a[7] = cmul(a[7], cmul(w4, w3));
 #endif
-            dft4(a0, a1, a2, a3);
-            // * H and fold the four 256-bin quarters: Y[t] = sum_c X[t + 256 c] H[t + 256 c]
-            const float2 h0 = hv[m], h1 = hv[m + 4], h2 = hv[m + 8], h3 = hv[m + 12];
-            f2 acc = cmul(a0, (f2){h0.x, h0.y});
-            acc = cmac(acc, a1, (f2){h1.x, h1.y});
-            acc = cmac(acc, a2, (f2){h2.x, h2.y});
-            acc = cmac(acc, a3, (f2){h3.x, h3.y});
+            dft8(a);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) X[m + 2 * c] = a[c];
+        }
+        // * H and fold the four 256-bin quarters: Y[l + 64 m] = sum_q X[l + 64 (m + 4 q)] H[l + 64 (m + 4 q)]
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            f2 acc = cmul(X[m], (f2){hv[m].x, hv[m].y});
+            acc = cmac(acc, X[m + 4], (f2){hv[m + 4].x, hv[m + 4].y});
+            acc = cmac(acc, X[m + 8], (f2){hv[m + 8].x, hv[m + 8].y});
+            acc = cmac(acc, X[m + 12], (f2){hv[m + 12].x, hv[m + 12].y});
             y[m] = acc;
         }
 #endif
@@ -1208,7 +1267,7 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
 #pragma unroll
             for (int c = 0; c < 4; ++c) y[c] = b_rd[80 * c];
             // twiddles e^{+j 2 pi c (l mod ns) / (4 ns)} = conj(tw[(l mod ns) 256 / ns])^c, ns = 4^pass
-            const f2 w1 = {t_inv[pass - 1].x, t_inv[pass - 1].y};
+            const f2 w1 = t_inv[pass - 1];
             const f2 w2 = cmul(w1, w1);
             const f2 w3 = cmul(w2, w1);
             y[1] = cmul_conj(y[1], w1);
@@ -1281,9 +1340,9 @@ int launch_ols_wave(hipStream_t s, const FusedFirArgs &a) {
     const int64_t den = (int64_t)a.denom;
     int64_t ph = ((int64_t)a.idx0 + a.e0 - a.V) % den;
     if (ph < 0) ph += den;
-    const unsigned hopm = (unsigned)((int64_t)(1024 - a.V) % den), kstep = (unsigned)(64 % den);
+    const unsigned hopm = (unsigned)((int64_t)(1024 - a.V) % den), kstep = (unsigned)(128 % den);
 #ifndef RR_V_WAVELOOP
-#define RR_V_WAVELOOP 1  // 0: one block per wave; G > 0: persistent waves, G resident sets
+#define RR_V_WAVELOOP 0  // 0: one block per wave (measured faster: 0.144 vs 0.168 ms); G > 0: persistent waves, G resident sets
 #endif
 #if RR_V_WAVELOOP > 0
     // one resident set = 256 CUs x 4 SIMDs x RR_V_WAVEOCCL waves; the grid must be a multiple of 8
