@@ -269,7 +269,9 @@ int rr_chain_process(rr_chain *h, double sample_rate, const void *in, size_t n_i
                      void *out, size_t out_cap, size_t *n_out);
 int rr_chain_process_dev(rr_chain *h, double sample_rate, const void *d_in,
                          size_t n_in, void *d_out, size_t out_cap, size_t *n_out);
-/* 1 if the last process call ran the fused kernels, 0 = block-by-block. */
+/* Which kernels the last process call ran: 0 = block-by-block; non-zero = fused
+ * (1 direct-form k_mix_fir_decim, 2 overlap-save k_ols_decim4, 3 overlap-save
+ * k_ols_wave) + k_fft4096. */
 int rr_chain_last_path(const rr_chain *h, int *fused);
 int rr_chain_destroy(rr_chain *h);
 
@@ -302,6 +304,55 @@ int rr_channelizer_process(rr_channelizer *h, const void *in, size_t n_in, void 
 int rr_channelizer_process_dev(rr_channelizer *h, const void *d_in, size_t n_in,
                                void *d_out, size_t out_cap, size_t *n_out);
 int rr_channelizer_destroy(rr_channelizer *h);
+
+/* ------------------------------------------------------------------------ */
+/* Upsampler — src/blocks/resampling.rs:147-280.          */
+/* The reference adds every input, scaled by the impulse response, into a ring  */
+/* buffer and releases output_rate / input_rate outputs per input (:237-267);   */
+/* here each output gathers its inputs in the same order with the same         */
+/* roundings (f32 results are bit-equal to the reference's algorithm).  The     */
+/* impulse response is redesigned and the ring cleared when the input rate      */
+/* changes (:203-236); events pass (:269-271).  Regrouping into chunks of       */
+/* output_chunk_len (:251-261) is the caller's, as for the Downsampler.         */
+/* ------------------------------------------------------------------------ */
+typedef struct rr_upsampler rr_upsampler;
+/* Upsampler::with_quality (resampling.rs:179-186); asserts -> RR_ERR_CONTRACT */
+int rr_upsampler_create(int dtype, double output_rate, double bandwidth, double quality,
+                        int device, rr_upsampler **out);
+/* Outputs the next n_in input samples at input_rate will release. */
+int rr_upsampler_peek(rr_upsampler *h, double input_rate, size_t n_in, size_t *n_out);
+int rr_upsampler_process(rr_upsampler *h, double input_rate, const void *in, size_t n_in,
+                         void *out, size_t out_cap, size_t *n_out);
+int rr_upsampler_enqueue(rr_upsampler *h, double input_rate, const void *in, size_t n_in,
+                         void *out, size_t out_cap, size_t *n_out);
+int rr_upsampler_process_dev(rr_upsampler *h, double input_rate, const void *d_in,
+                             size_t n_in, void *d_out, size_t out_cap, size_t *n_out);
+int rr_upsampler_ir_len(const rr_upsampler *h, size_t *ir_len);
+int rr_upsampler_destroy(rr_upsampler *h);
+/* The f64 impulse response of resampling.rs:215-234 (ir may be null to query the length). */
+int rr_upsampler_design(double input_rate, double output_rate, double bandwidth,
+                        double quality, size_t *ir_len, double *ir, size_t cap);
+
+/* ------------------------------------------------------------------------ */
+/* FmDemod — src/blocks/modulation.rs:83-158.             */
+/* out[t] = (arg(x[t] * conj(x[t-1])) * sample_rate / deviation / TAU, 0); the  */
+/* previous sample carries over from call to call; without one (first call, or  */
+/* after rr_fmdemod_reset = an interrupting event, :145-149) the first output   */
+/* repeats the last output (zero initially, :107).                             */
+/* ------------------------------------------------------------------------ */
+typedef struct rr_fmdemod rr_fmdemod;
+int rr_fmdemod_create(int dtype, double deviation, int device, rr_fmdemod **out);
+/* set_deviation / deviation (modulation.rs:163-170); effective from the next process call */
+int rr_fmdemod_set_deviation(rr_fmdemod *h, double deviation);
+int rr_fmdemod_deviation(const rr_fmdemod *h, double *deviation);
+int rr_fmdemod_reset(rr_fmdemod *h);
+int rr_fmdemod_process(rr_fmdemod *h, double sample_rate, const void *in, size_t n_in,
+                       void *out, size_t out_cap, size_t *n_out);
+int rr_fmdemod_enqueue(rr_fmdemod *h, double sample_rate, const void *in, size_t n_in,
+                       void *out, size_t out_cap, size_t *n_out);
+int rr_fmdemod_process_dev(rr_fmdemod *h, double sample_rate, const void *d_in, size_t n_in,
+                           void *d_out, size_t out_cap, size_t *n_out);
+int rr_fmdemod_destroy(rr_fmdemod *h);
 
 /* ------------------------------------------------------------------------ */
 /* Consumers of the chain output, over batches of frames   */

@@ -124,7 +124,27 @@ typedef void (*rro_freq_resp_fn)(int64_t bin, double freq, double *out,
                                const FLT *bins, size_t n);                    \
     int rro_rescale_energy_##SUF(FLT *output, size_t resolution,              \
                                  const FLT *input, size_t n);                 \
-    void rro_gain_##SUF(double gain, const FLT *in, size_t n, FLT *out);
+    void rro_gain_##SUF(double gain, const FLT *in, size_t n, FLT *out);      \
+    /* Upsampler (resampling.rs:147-280); process returns the output count,   \
+     * (size_t)-1 for a contract violation, (size_t)-2 if cap is too small */  \
+    typedef struct rro_upsampler_##SUF rro_upsampler_##SUF;                   \
+    rro_upsampler_##SUF *rro_upsampler_new_##SUF(double output_rate,          \
+                                                 double bandwidth,            \
+                                                 double quality);             \
+    size_t rro_upsampler_process_##SUF(rro_upsampler_##SUF *,                 \
+                                       double input_rate, const FLT *in,      \
+                                       size_t n, FLT *out, size_t cap);       \
+    size_t rro_upsampler_ir_##SUF(rro_upsampler_##SUF *, FLT *out,            \
+                                  size_t cap);                                \
+    void rro_upsampler_free_##SUF(rro_upsampler_##SUF *);                     \
+    /* FmDemod (modulation.rs:83-158) */                                      \
+    typedef struct rro_fmdemod_##SUF rro_fmdemod_##SUF;                       \
+    rro_fmdemod_##SUF *rro_fmdemod_new_##SUF(double deviation);               \
+    void rro_fmdemod_set_deviation_##SUF(rro_fmdemod_##SUF *, double);        \
+    void rro_fmdemod_interrupt_##SUF(rro_fmdemod_##SUF *);                    \
+    void rro_fmdemod_process_##SUF(rro_fmdemod_##SUF *, double sample_rate,   \
+                                   const FLT *in, size_t n, FLT *out);        \
+    void rro_fmdemod_free_##SUF(rro_fmdemod_##SUF *);
 
 RRO_DECL(f32, float)
 RRO_DECL(f64, double)

@@ -115,6 +115,24 @@ def lib() -> C.CDLL:
         g("rro_rescale_energy").argtypes = [vp, sz, vp, sz]
         g("rro_gain").restype = None
         g("rro_gain").argtypes = [d, vp, sz, vp]
+        g("rro_upsampler_new").restype = vp
+        g("rro_upsampler_new").argtypes = [d, d, d]
+        g("rro_upsampler_process").restype = sz
+        g("rro_upsampler_process").argtypes = [vp, d, vp, sz, vp, sz]
+        g("rro_upsampler_ir").restype = sz
+        g("rro_upsampler_ir").argtypes = [vp, vp, sz]
+        g("rro_upsampler_free").restype = None
+        g("rro_upsampler_free").argtypes = [vp]
+        g("rro_fmdemod_new").restype = vp
+        g("rro_fmdemod_new").argtypes = [d]
+        g("rro_fmdemod_set_deviation").restype = None
+        g("rro_fmdemod_set_deviation").argtypes = [vp, d]
+        g("rro_fmdemod_interrupt").restype = None
+        g("rro_fmdemod_interrupt").argtypes = [vp]
+        g("rro_fmdemod_process").restype = None
+        g("rro_fmdemod_process").argtypes = [vp, d, vp, sz, vp]
+        g("rro_fmdemod_free").restype = None
+        g("rro_fmdemod_free").argtypes = [vp]
         g("rro_chain_run").restype = sz
         g("rro_chain_run").argtypes = [vp, sz, d, d, d, sz, _RESPFN, vp, C.POINTER(_CWindow), d, d, d, sz,
                                        C.POINTER(_CWindow), C.c_int, vp, sz]
@@ -364,6 +382,79 @@ class Downsampler:
     def __del__(self):
         if getattr(self, "_h", None):
             getattr(lib(), f"rro_downsampler_free_{self._suf}")(self._h)
+            self._h = None
+
+
+class Upsampler:
+    """resampling.rs:147-280.  `process` returns the outputs produced by this input chunk;
+    regrouping into `output_chunk_len` chunks is `feed`."""
+
+    def __init__(self, output_chunk_len, output_rate, bandwidth, quality=3.0, flt=np.float32):
+        self._suf, self._cdt, self._rdt = _dt(flt)
+        self.output_chunk_len = int(output_chunk_len)
+        self.output_rate = float(output_rate)
+        self._h = getattr(lib(), f"rro_upsampler_new_{self._suf}")(float(output_rate), float(bandwidth), float(quality))
+        if not self._h:
+            raise AssertionError("Upsampler contract violated (resampling.rs:185-186)")
+        self._pending = np.empty(0, dtype=self._cdt)
+
+    def process(self, input_rate, chunk):
+        x = _cin(chunk, self._cdt)
+        ratio = self.output_rate / float(input_rate) if input_rate > 0 else 1.0
+        cap = int(x.size * ratio) + 8
+        y = np.empty(cap, dtype=self._cdt)
+        n = getattr(lib(), f"rro_upsampler_process_{self._suf}")(
+            self._h, float(input_rate), x.ctypes.data, x.size, y.ctypes.data, cap
+        )
+        if n == C.c_size_t(-1).value:
+            raise AssertionError("Upsampler contract violated (resampling.rs:205-214)")
+        assert n <= cap
+        return y[:n].copy()
+
+    def feed(self, input_rate, chunk):
+        self._pending = np.concatenate([self._pending, self.process(input_rate, chunk)])
+        out = []
+        L = self.output_chunk_len
+        while self._pending.size >= L:
+            out.append(self._pending[:L].copy())
+            self._pending = self._pending[L:]
+        return out
+
+    def ir(self):
+        f = getattr(lib(), f"rro_upsampler_ir_{self._suf}")
+        n = f(self._h, None, 0)
+        out = np.empty(n, dtype=self._rdt)
+        f(self._h, out.ctypes.data, n)
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            getattr(lib(), f"rro_upsampler_free_{self._suf}")(self._h)
+            self._h = None
+
+
+class FmDemod:
+    """modulation.rs:83-158."""
+
+    def __init__(self, deviation, flt=np.float32):
+        self._suf, self._cdt, self._rdt = _dt(flt)
+        self._h = getattr(lib(), f"rro_fmdemod_new_{self._suf}")(float(deviation))
+
+    def set_deviation(self, deviation):
+        getattr(lib(), f"rro_fmdemod_set_deviation_{self._suf}")(self._h, float(deviation))
+
+    def interrupt(self):
+        getattr(lib(), f"rro_fmdemod_interrupt_{self._suf}")(self._h)
+
+    def process(self, sample_rate, chunk):
+        x = _cin(chunk, self._cdt)
+        y = np.empty_like(x)
+        getattr(lib(), f"rro_fmdemod_process_{self._suf}")(self._h, float(sample_rate), x.ctypes.data, x.size, y.ctypes.data)
+        return y
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            getattr(lib(), f"rro_fmdemod_free_{self._suf}")(self._h)
             self._h = None
 
 

@@ -141,6 +141,22 @@ SIGNATURES = {
     "rr_channelizer_process": (_i, [_vp, _vp, _sz, _vp, _sz, _psz]),
     "rr_channelizer_process_dev": (_i, [_vp, _vp, _sz, _vp, _sz, _psz]),
     "rr_channelizer_destroy": (_i, [_vp]),
+    "rr_upsampler_create": (_i, [_i, _d, _d, _d, _i, C.POINTER(_vp)]),
+    "rr_upsampler_peek": (_i, [_vp, _d, _sz, _psz]),
+    "rr_upsampler_process": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
+    "rr_upsampler_enqueue": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
+    "rr_upsampler_process_dev": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
+    "rr_upsampler_ir_len": (_i, [_vp, _psz]),
+    "rr_upsampler_destroy": (_i, [_vp]),
+    "rr_upsampler_design": (_i, [_d, _d, _d, _d, _psz, _vp, _sz]),
+    "rr_fmdemod_create": (_i, [_i, _d, _i, C.POINTER(_vp)]),
+    "rr_fmdemod_set_deviation": (_i, [_vp, _d]),
+    "rr_fmdemod_deviation": (_i, [_vp, C.POINTER(_d)]),
+    "rr_fmdemod_reset": (_i, [_vp]),
+    "rr_fmdemod_process": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
+    "rr_fmdemod_enqueue": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
+    "rr_fmdemod_process_dev": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
+    "rr_fmdemod_destroy": (_i, [_vp]),
     "rr_level_dev": (_i, [_i, _i, _vp, _vp, _sz, _sz, _vp]),
     "rr_level": (_i, [_i, _i, _vp, _sz, C.POINTER(_d)]),
     "rr_bandwidth_dev": (_i, [_i, _i, _vp, _d, _d, _vp, _sz, _sz, _vp]),

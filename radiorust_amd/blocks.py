@@ -251,6 +251,91 @@ class Downsampler(_Block):
         return n_out.value
 
 
+class Upsampler(_Block):
+    """Increase sample rate (resampling.rs:147-280)."""
+
+    _destroy = "rr_upsampler_destroy"
+
+    def __init__(self, output_chunk_len: int, output_rate: float, bandwidth: float, quality: float = 3.0,
+                 dtype=np.float32, device: int = 0):
+        super().__init__()
+        self._code, self._cdt = _dtype_code(dtype)
+        self.output_chunk_len = int(output_chunk_len)
+        self.output_rate = float(output_rate)
+        _lib.check(_lib.lib().rr_upsampler_create(self._code, float(output_rate), float(bandwidth), float(quality), device, C.byref(self._h)))
+        self._pending = np.empty(0, dtype=self._cdt)  # the partly filled output_chunk
+
+    @classmethod
+    def new(cls, output_chunk_len, output_rate, bandwidth, **kw):
+        return cls(output_chunk_len, output_rate, bandwidth, 3.0, **kw)
+
+    @classmethod
+    def with_quality(cls, output_chunk_len, output_rate, bandwidth, quality, **kw):
+        return cls(output_chunk_len, output_rate, bandwidth, quality, **kw)
+
+    def ir_len(self) -> int:
+        v = C.c_size_t()
+        _lib.check(_lib.lib().rr_upsampler_ir_len(self._h, C.byref(v)))
+        return v.value
+
+    def process_raw(self, sample_rate, chunk) -> np.ndarray:
+        """Outputs released by this input chunk, not yet regrouped."""
+        n_out = C.c_size_t()
+        _lib.check(_lib.lib().rr_upsampler_peek(self._h, float(sample_rate), len(chunk), C.byref(n_out)))
+        return self._host_call(_lib.lib().rr_upsampler_process, (float(sample_rate),), chunk, n_out.value)
+
+    def process(self, signal):
+        if signal.is_event():
+            return [signal]  # resampling.rs:269-271
+        self._pending = np.concatenate([self._pending, self.process_raw(signal.sample_rate, signal.chunk)])
+        out = []
+        L = self.output_chunk_len
+        while len(self._pending) >= L:  # resampling.rs:251-261
+            out.append(Samples(self.output_rate, self._pending[:L].copy()))
+            self._pending = self._pending[L:]
+        return out
+
+    def process_dev(self, sample_rate, d_in: int, n_in: int, d_out: int, cap: int) -> int:
+        n_out = C.c_size_t()
+        _lib.check(_lib.lib().rr_upsampler_process_dev(self._h, float(sample_rate), d_in, n_in, d_out, cap, C.byref(n_out)))
+        return n_out.value
+
+
+class FmDemod(_Block):
+    """FM demodulator (modulation.rs:83-158)."""
+
+    _destroy = "rr_fmdemod_destroy"
+
+    def __init__(self, deviation: float, dtype=np.float32, device: int = 0):
+        super().__init__()
+        self._code, self._cdt = _dtype_code(dtype)
+        _lib.check(_lib.lib().rr_fmdemod_create(self._code, float(deviation), device, C.byref(self._h)))
+
+    def deviation(self) -> float:
+        v = C.c_double()
+        _lib.check(_lib.lib().rr_fmdemod_deviation(self._h, C.byref(v)))
+        return v.value
+
+    def set_deviation(self, deviation: float):
+        _lib.check(_lib.lib().rr_fmdemod_set_deviation(self._h, float(deviation)))
+        return self
+
+    def process_raw(self, sample_rate, chunk) -> np.ndarray:
+        return self._host_call(_lib.lib().rr_fmdemod_process, (float(sample_rate),), chunk, len(chunk))
+
+    def process(self, signal):
+        if signal.is_event():
+            if signal.event.is_interrupt():  # modulation.rs:145-149
+                _lib.check(_lib.lib().rr_fmdemod_reset(self._h))
+            return [signal]
+        return [Samples(signal.sample_rate, self.process_raw(signal.sample_rate, signal.chunk))]
+
+    def process_dev(self, sample_rate, d_in: int, n_in: int, d_out: int, cap: int) -> int:
+        n_out = C.c_size_t()
+        _lib.check(_lib.lib().rr_fmdemod_process_dev(self._h, float(sample_rate), d_in, n_in, d_out, cap, C.byref(n_out)))
+        return n_out.value
+
+
 class Fourier(_Block):
     """Windowed Fourier analysis (analysis.rs:26-133)."""
 
@@ -362,6 +447,12 @@ class Chain(_Block):
         v = C.c_int()
         _lib.check(_lib.lib().rr_chain_last_path(self._h, C.byref(v)))
         return bool(v.value)
+
+    def last_path_kernel(self) -> str:
+        """Name of the mix + FIR + decimate kernel the last call ran ("" = block-by-block)."""
+        v = C.c_int()
+        _lib.check(_lib.lib().rr_chain_last_path(self._h, C.byref(v)))
+        return ["", "k_mix_fir_decim", "k_ols_decim4", "k_ols_wave"][v.value]
 
     def process(self, signal):
         if signal.is_event():

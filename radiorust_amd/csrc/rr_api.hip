@@ -325,6 +325,112 @@ int rr_downsampler::process_dev(double input_rate, const void *d_in, size_t n_in
 }
 
 // ---------------------------------------------------------------------------
+// Upsampler (resampling.rs:147-280)
+// ---------------------------------------------------------------------------
+int rr_upsampler::prepare(double input_rate) {
+    if (have_rate && input_rate == prev_rate) return RR_OK;
+    std::vector<double> ir;
+    RR_TRY(upsampler_design(input_rate, output_rate, bandwidth, quality, ir));
+    have_rate = true;
+    prev_rate = input_rate;
+    L = ir.size();
+    std::vector<unsigned char> bytes;
+    if (dtype == RR_F32)
+        cast_to<float>(ir.data(), L, bytes);
+    else
+        cast_to<double>(ir.data(), L, bytes);
+    RR_TRY(upload(d_ir, bytes.data(), bytes.size(), stream));
+    ir_f64.swap(ir);
+    sched.configure(input_rate, output_rate);  // pos = 0
+    // an output gathers from at most ceil(L / U) inputs (integer ratio), or L (every input releases
+    // at least one output)
+    Hn = sched.integer_ratio ? (L + sched.U - 1) / sched.U : L;
+    const size_t hb = Hn * elem_size(dtype);
+    RR_TRY(hist[0].reserve(hb));
+    RR_TRY(hist[1].reserve(hb));
+    RR_HIP(hipMemsetAsync(hist[0].p, 0, hb, stream));  // ringbuf = vec![0; ir_len]: nothing before the first input
+    cur = 0;
+    before_hist.assign(Hn, -(int32_t(1) << 30));  // far outside every output's window
+    return RR_OK;
+}
+
+int rr_upsampler::peek(double input_rate, size_t n_in, size_t *n_out) {
+    if (have_rate && input_rate == prev_rate) {
+        *n_out = sched.count(n_in);
+        return RR_OK;
+    }
+    if (!(input_rate >= 0.0)) RR_FAIL(RR_ERR_CONTRACT, "input sample rate must be positive");
+    if (!(input_rate <= output_rate))
+        RR_FAIL(RR_ERR_CONTRACT, "input sample rate must be smaller than or equal to output sample rate");
+    if (!(bandwidth < input_rate)) RR_FAIL(RR_ERR_CONTRACT, "bandwidth must be smaller than input sample rate");
+    UpSchedule tmp;
+    tmp.configure(input_rate, output_rate);
+    *n_out = tmp.count(n_in);
+    return RR_OK;
+}
+
+int rr_upsampler::process_dev(double input_rate, const void *d_in, size_t n_in, void *d_out, size_t cap,
+                              size_t *n_out) {
+    if (n_out) *n_out = 0;
+    size_t produce = 0;
+    RR_TRY(peek(input_rate, n_in, &produce));
+    if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Upsampler: out_cap %zu < %zu", cap, produce);
+    if (n_in > 0x3fffffffull || produce > 0x3fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "Upsampler: more than 2^30 samples in one call");
+    RR_TRY(select());
+    RR_TRY(prepare(input_rate));
+    if (n_in == 0) return RR_OK;
+    const int32_t *d_bef = nullptr;
+    if (sched.integer_ratio) {
+        sched.advance(n_in, nullptr);
+    } else {
+        sched.advance(n_in, &before);
+        std::vector<int32_t> all(Hn + n_in);
+        std::copy(before_hist.begin(), before_hist.end(), all.begin());
+        std::copy(before.begin(), before.end(), all.begin() + Hn);
+        RR_TRY(d_before.reserve(all.size() * sizeof(int32_t)));
+        RR_HIP(hipMemcpyAsync(d_before.p, all.data(), all.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        RR_HIP(hipStreamSynchronize(stream));  // `all` dies here
+        d_bef = d_before.as<int32_t>();
+        // the kept inputs of the next call, relative to its first output
+        for (size_t i = 0; i < Hn; ++i) {
+            const int64_t v = (int64_t)all[n_in + i] - (int64_t)produce;
+            before_hist[i] = (int32_t)std::max<int64_t>(v, -(int64_t(1) << 30));
+        }
+    }
+    RR_TRY(launch_upsample(dtype, stream, hist[cur].p, Hn, d_in, n_in, d_ir.p, L, sched.integer_ratio ? sched.U : 0, d_bef,
+                           d_out, produce));
+    RR_TRY(launch_update_hist(dtype, stream, hist[cur].p, hist[cur ^ 1].p, Hn, d_in, n_in));
+    cur ^= 1;
+    if (n_out) *n_out = produce;
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// FmDemod (modulation.rs:83-158)
+// ---------------------------------------------------------------------------
+int rr_fmdemod::process_dev(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out) {
+    if (n_out) *n_out = 0;
+    if (n_in > cap) RR_FAIL(RR_ERR_CAPACITY, "FmDemod: out_cap %zu < %zu", cap, n_in);
+    RR_TRY(select());
+    if (!state_init) {
+        const size_t sb = 2 * elem_size(dtype);
+        RR_TRY(state[0].reserve(sb));
+        RR_TRY(state[1].reserve(sb));
+        RR_HIP(hipMemsetAsync(state[0].p, 0, sb, stream));  // output_sample = 0 (modulation.rs:107)
+        cur = 0;
+        state_init = true;
+    }
+    if (n_in == 0) return RR_OK;
+    const double TAU = 6.283185307179586476925286766559;
+    const double factor = sample_rate / deviation / TAU;  // modulation.rs:119, cast to Flt by the launcher
+    RR_TRY(launch_fmdemod(dtype, stream, d_in, n_in, d_out, state[cur].p, state[cur ^ 1].p, have_prev ? 1 : 0, factor));
+    cur ^= 1;
+    have_prev = true;
+    if (n_out) *n_out = n_in;
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
 // Fourier
 // ---------------------------------------------------------------------------
 int rr_fourier::prepare(size_t len) {
@@ -722,7 +828,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     }
     timers.end(tk, stream);
     pending_len = rest;
-    last_fused = 1;
+    last_fused = use_ols ? (ols_N == 1024 ? FK_OLSW : FK_OLS) : FK_DIRECT;
     if (n_out) *n_out = wrote;
     return RR_OK;
 }
@@ -1205,6 +1311,158 @@ int rr_downsampler_ir_len(const rr_downsampler *h, size_t *ir_len) {
 int rr_downsampler_destroy(rr_downsampler *h) {
     if (!h) return RR_OK;
     RR_CHECK_HANDLE(h, K_DOWNSAMPLER);
+    (void)hipSetDevice(h->device);
+    delete h;
+    return RR_OK;
+}
+
+// ---- Upsampler ----------------------------------------------------------------------------
+int rr_upsampler_create(int dtype, double output_rate, double bandwidth, double quality, int device,
+                        rr_upsampler **out) {
+    RR_GUARD_BEGIN
+    if (!out) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    *out = nullptr;
+    // resampling.rs:185-186
+    if (!(output_rate >= 0.0)) RR_FAIL(RR_ERR_CONTRACT, "output sample rate must be positive");
+    if (!(bandwidth >= 0.0)) RR_FAIL(RR_ERR_CONTRACT, "bandwidth must be positive");
+    auto *h = new rr_upsampler;
+    int s = h->init_base(K_UPSAMPLER, dtype, device);
+    if (s != RR_OK) {
+        delete h;
+        return s;
+    }
+    h->output_rate = output_rate;
+    h->bandwidth = bandwidth;
+    h->quality = quality;
+    *out = h;
+    return RR_OK;
+    RR_GUARD_END
+}
+int rr_upsampler_peek(rr_upsampler *h, double input_rate, size_t n_in, size_t *n_out) {
+    RR_CHECK_HANDLE(h, K_UPSAMPLER);
+    if (!n_out) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    return h->peek(input_rate, n_in, n_out);
+}
+static int upsampler_host(rr_upsampler *h, double rate, const void *in, size_t n_in, void *out, size_t cap,
+                          size_t *n_out, bool blocking) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_UPSAMPLER);
+    if (n_out) *n_out = 0;
+    size_t produce = 0;
+    RR_TRY(h->peek(rate, n_in, &produce));
+    if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Upsampler: out_cap %zu < %zu", cap, produce);
+    size_t got = 0;
+    RR_TRY(host_io(h, in, n_in, out, produce, blocking, [&](void *di, void *dout, size_t *p) {
+        int s = h->process_dev(rate, di, n_in, dout, produce, p);
+        got = *p;
+        return s;
+    }));
+    if (n_out) *n_out = got;
+    return RR_OK;
+    RR_GUARD_END
+}
+int rr_upsampler_process(rr_upsampler *h, double rate, const void *in, size_t n_in, void *out, size_t cap,
+                         size_t *n_out) {
+    return upsampler_host(h, rate, in, n_in, out, cap, n_out, true);
+}
+int rr_upsampler_enqueue(rr_upsampler *h, double rate, const void *in, size_t n_in, void *out, size_t cap,
+                         size_t *n_out) {
+    return upsampler_host(h, rate, in, n_in, out, cap, n_out, false);
+}
+int rr_upsampler_process_dev(rr_upsampler *h, double rate, const void *d_in, size_t n_in, void *d_out, size_t cap,
+                             size_t *n_out) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_UPSAMPLER);
+    return h->process_dev(rate, d_in, n_in, d_out, cap, n_out);
+    RR_GUARD_END
+}
+int rr_upsampler_ir_len(const rr_upsampler *h, size_t *ir_len) {
+    RR_CHECK_HANDLE(h, K_UPSAMPLER);
+    *ir_len = h->L;
+    return RR_OK;
+}
+int rr_upsampler_destroy(rr_upsampler *h) {
+    if (!h) return RR_OK;
+    RR_CHECK_HANDLE(h, K_UPSAMPLER);
+    (void)hipSetDevice(h->device);
+    delete h;
+    return RR_OK;
+}
+int rr_upsampler_design(double input_rate, double output_rate, double bandwidth, double quality, size_t *ir_len,
+                        double *ir, size_t cap) {
+    RR_GUARD_BEGIN
+    if (!ir_len) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    std::vector<double> v;
+    RR_TRY(upsampler_design(input_rate, output_rate, bandwidth, quality, v));
+    *ir_len = v.size();
+    if (ir) {
+        if (cap < v.size()) RR_FAIL(RR_ERR_CAPACITY, "rr_upsampler_design: cap %zu < %zu", cap, v.size());
+        std::memcpy(ir, v.data(), v.size() * sizeof(double));
+    }
+    return RR_OK;
+    RR_GUARD_END
+}
+
+// ---- FmDemod ------------------------------------------------------------------------------
+int rr_fmdemod_create(int dtype, double deviation, int device, rr_fmdemod **out) {
+    RR_GUARD_BEGIN
+    if (!out) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    *out = nullptr;
+    auto *h = new rr_fmdemod;
+    int s = h->init_base(K_FMDEMOD, dtype, device);
+    if (s != RR_OK) {
+        delete h;
+        return s;
+    }
+    h->deviation = deviation;
+    *out = h;
+    return RR_OK;
+    RR_GUARD_END
+}
+int rr_fmdemod_set_deviation(rr_fmdemod *h, double deviation) {
+    RR_CHECK_HANDLE(h, K_FMDEMOD);
+    h->deviation = deviation;
+    return RR_OK;
+}
+int rr_fmdemod_deviation(const rr_fmdemod *h, double *deviation) {
+    RR_CHECK_HANDLE(h, K_FMDEMOD);
+    *deviation = h->deviation;
+    return RR_OK;
+}
+int rr_fmdemod_reset(rr_fmdemod *h) {
+    RR_CHECK_HANDLE(h, K_FMDEMOD);
+    h->have_prev = false;  // modulation.rs:145-149
+    return RR_OK;
+}
+static int fmdemod_host(rr_fmdemod *h, double rate, const void *in, size_t n_in, void *out, size_t cap, size_t *n_out,
+                        bool blocking) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_FMDEMOD);
+    if (n_out) *n_out = 0;
+    if (n_in > cap) RR_FAIL(RR_ERR_CAPACITY, "FmDemod: out_cap %zu < %zu", cap, n_in);
+    RR_TRY(host_io(h, in, n_in, out, n_in, blocking, [&](void *di, void *dout, size_t *p) {
+        return h->process_dev(rate, di, n_in, dout, n_in, p);
+    }));
+    if (n_out) *n_out = n_in;
+    return RR_OK;
+    RR_GUARD_END
+}
+int rr_fmdemod_process(rr_fmdemod *h, double rate, const void *in, size_t n_in, void *out, size_t cap, size_t *n_out) {
+    return fmdemod_host(h, rate, in, n_in, out, cap, n_out, true);
+}
+int rr_fmdemod_enqueue(rr_fmdemod *h, double rate, const void *in, size_t n_in, void *out, size_t cap, size_t *n_out) {
+    return fmdemod_host(h, rate, in, n_in, out, cap, n_out, false);
+}
+int rr_fmdemod_process_dev(rr_fmdemod *h, double rate, const void *d_in, size_t n_in, void *d_out, size_t cap,
+                           size_t *n_out) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_FMDEMOD);
+    return h->process_dev(rate, d_in, n_in, d_out, cap, n_out);
+    RR_GUARD_END
+}
+int rr_fmdemod_destroy(rr_fmdemod *h) {
+    if (!h) return RR_OK;
+    RR_CHECK_HANDLE(h, K_FMDEMOD);
     (void)hipSetDevice(h->device);
     delete h;
     return RR_OK;

@@ -63,6 +63,32 @@ struct rr_downsampler : rr_block {
 };
 
 // Fourier — analysis.rs:67-73 (previous_chunk_len, fft, window_values)
+struct rr_upsampler : rr_block {
+    double output_rate = 0, bandwidth = 0, quality = 3.0;
+    bool have_rate = false;
+    double prev_rate = 0.0;
+    rr::UpSchedule sched;
+    size_t L = 0, Hn = 0;  // taps; inputs kept from call to call
+    std::vector<double> ir_f64;
+    rr::DevBuf d_ir;
+    rr::DevBuf hist[2];  // the last Hn inputs in time order
+    int cur = 0;
+    std::vector<int32_t> before_hist, before;  // generic ratio: outputs released before each kept / new input
+    rr::DevBuf d_before;
+    int prepare(double input_rate);
+    int peek(double input_rate, size_t n_in, size_t *n_out);
+    int process_dev(double input_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
+};
+
+struct rr_fmdemod : rr_block {
+    double deviation = 0;
+    bool have_prev = false;
+    rr::DevBuf state[2];  // {previous sample, last output}, ping-pong
+    int cur = 0;
+    bool state_init = false;
+    int process_dev(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
+};
+
 struct rr_fourier : rr_block {
     rr_window window{RR_WIN_RECTANGULAR, 0.0};
     bool center_dc = false;

@@ -228,6 +228,34 @@ int downsampler_design(double input_rate, double output_rate, double bandwidth, 
     return RR_OK;
 }
 
+// ---- Upsampler (resampling.rs:203-236) --------------------------------------------------------
+int upsampler_design(double input_rate, double output_rate, double bandwidth, double quality,
+                     std::vector<double> &ir) {
+    if (!(input_rate >= 0.0)) RR_FAIL(RR_ERR_CONTRACT, "input sample rate must be positive");
+    if (!(input_rate <= output_rate))
+        RR_FAIL(RR_ERR_CONTRACT, "input sample rate must be smaller than or equal to output sample rate");
+    if (!(bandwidth < input_rate)) RR_FAIL(RR_ERR_CONTRACT, "bandwidth must be smaller than input sample rate");
+    const double margin = (input_rate - bandwidth) / 2.0;
+    const int64_t len = saturating_i64(std::ceil(output_rate / margin * quality));
+    if (len <= 0) RR_FAIL(RR_ERR_CONTRACT, "Upsampler: ir_len must be > 0");
+    if (len > (int64_t(1) << 24)) RR_FAIL(RR_ERR_BAD_ARG, "Upsampler: impulse response of %lld taps is not supported", (long long)len);
+    const size_t L = static_cast<size_t>(len);
+    const double Lf = static_cast<double>(L);
+    const double nulls = Lf * margin / output_rate;
+    const double beta = std::sqrt(nulls * nulls - 1.0);  // Kaiser::with_null_at_bin
+    ir.assign(L, 0.0);
+    double energy = 0.0;
+    for (size_t i = 0; i < L; ++i) {
+        const double x = (static_cast<double>(i) + 0.5) - Lf / 2.0;
+        const double y = sinc(x * input_rate / output_rate) * kaiser_rel_with_beta(beta, x * 2.0 / Lf);
+        ir[i] = y;
+        energy += y * y;
+    }
+    const double gain = 1.0 / std::sqrt(energy);
+    for (double &y : ir) y *= gain;
+    return RR_OK;
+}
+
 // ---- Fourier ----------------------------------------------------------------------------
 int fourier_design_window(size_t n, const double *window_rel, double *values) {
     if (n && (!window_rel || !values)) RR_FAIL(RR_ERR_BAD_ARG, "fourier_design_window: null argument");
@@ -294,6 +322,55 @@ size_t Schedule::advance(size_t n_in, std::vector<uint32_t> *emit) {
             if (emit) emit->push_back(static_cast<uint32_t>(t));
             ++c;
         }
+    }
+    return c;
+}
+
+// ---- interpolation schedule -------------------------------------------------------------------
+void UpSchedule::configure(double in_rate, double out_rate) {
+    input_rate = in_rate;
+    output_rate = out_rate;
+    pos = 0.0;
+    integer_ratio = false;
+    U = 0;
+    if (is_integral(in_rate) && is_integral(out_rate) && in_rate >= 1.0) {
+        const uint64_t a = static_cast<uint64_t>(in_rate), b = static_cast<uint64_t>(out_rate);
+        if (b % a == 0) {
+            integer_ratio = true;  // pos returns to 0 after every input
+            U = b / a;
+        }
+    }
+}
+
+size_t UpSchedule::count(size_t n_in) const {
+    if (integer_ratio) return n_in * U;
+    double p = pos;
+    size_t c = 0;
+    for (size_t t = 0; t < n_in; ++t) {
+        while (p < output_rate) {
+            ++c;
+            p += input_rate;
+        }
+        p -= output_rate;
+    }
+    return c;
+}
+
+size_t UpSchedule::advance(size_t n_in, std::vector<int32_t> *before) {
+    if (before) before->resize(n_in);
+    if (integer_ratio) {
+        if (before)
+            for (size_t t = 0; t < n_in; ++t) (*before)[t] = static_cast<int32_t>(t * U);
+        return n_in * U;
+    }
+    size_t c = 0;
+    for (size_t t = 0; t < n_in; ++t) {  // resampling.rs:248-265, verbatim arithmetic
+        if (before) (*before)[t] = static_cast<int32_t>(c);
+        while (pos < output_rate) {
+            ++c;
+            pos += input_rate;
+        }
+        pos -= output_rate;
     }
     return c;
 }

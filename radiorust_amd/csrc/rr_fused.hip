@@ -913,10 +913,11 @@ __device__ __forceinline__ void twiddle16(f2 (&v)[16], f2 w) {
 }
 
 // LDS images of one wave (element = 8 bytes).  Image A holds the 1024-point intermediate of
-// the forward transform at  A(i) = i + 2 (i >> 4) + 16 (i >> 8):  rows of 16 elements at a
+// the forward transform at  A(i) = i + 2 (i >> 4) + 8 (i >> 8):  rows of 16 elements at a
 // stride of 18 (16-byte aligned for ds_write_b128, and an odd multiple of 16 bytes so that the
-// 16 rows a half-wave touches fall on distinct banks), plus 16 per 256 so that the four lane
-// groups of a radix-16 pass do not collide.  Image B (256-point inverse) uses B(i) = i + 4 (i >> 4).
+// 16 rows a quarter-wave touches fall on distinct banks), plus 8 per 256 (the best of the
+// paddings i + a (i >> 4) + b (i >> 7) + c (i >> 8) under a 64-bank model of the four access
+// patterns of the radix 8 x 16 x 8 transform).  Image B (256-point inverse) uses B(i) = i + 4 (i >> 4).
 // Every access pattern below is (lane term) + (compile-time offset), spelled out so that the
 // offsets land in the instructions' immediate fields instead of per-access address arithmetic.
 #ifndef RR_V_WAVELDS
@@ -1055,7 +1056,7 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
         t_inv[1] = (f2){s2.x, s2.y};
         t_inv[2] = (f2){s2.z, s2.w};
     }
-    f2 *const a_rd = lds + (l + 2 * g);  // A(l + 64 m + 256 c) = a_rd + 72 m + 304 c
+    f2 *const a_rd = lds + (l + 2 * g);  // A(l + 64 m + 256 c) = a_rd + 72 m + 296 c
     f2 *const b_rd = lds + (l + 4 * g);  // B(l + 64 c) = b_rd + 80 c
     size_t zoff = 0;
 
@@ -1183,14 +1184,14 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
         if constexpr (LOOP) wave_sync();  // the previous block's last reads of image B are done
 #if RR_WAVE_ABLATE != 4
         {
-            f2 *row = lds + (18 * l + 16 * g);  // A(16 l + e) = 18 l + 16 g + e
+            f2 *row = lds + (18 * l + 8 * g);  // A(16 l + e) = 18 l + 8 g + e
 #pragma unroll
             for (int k = 0; k < 16; k += 2)
                 *reinterpret_cast<float4 *>(row + k) = (float4){v[k].x, v[k].y, v[k + 1].x, v[k + 1].y};
         }
         wave_sync();
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = a_rd[72 * (k & 3) + 304 * (k >> 2)];  // in[l + 64 k]
+        for (int k = 0; k < 16; ++k) v[k] = a_rd[72 * (k & 3) + 296 * (k >> 2)];  // in[l + 64 k]
 #endif
         RR_STAMP_T(ws2);
         // pass 1 (Ns = 8, radix 16): twiddle e^{-j 2 pi k (l mod 8) / 128}; out 128 (l / 8) + l % 8 + 8 k
@@ -1202,8 +1203,8 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
 #if RR_WAVE_ABLATE != 4
         wave_sync();
         {
-            // A(128 h + p + 8 k), h = l / 8, p = l % 8: 144 h + 16 (h / 2) + p + 8 k + 2 (k / 2)
-            f2 *col = lds + (144 * (l >> 3) + 16 * (l >> 4) + (l & 7));
+            // A(128 h + p + 8 k), h = l / 8, p = l % 8: 144 h + 8 (h / 2) + p + 8 k + 2 (k / 2)
+            f2 *col = lds + (144 * (l >> 3) + 8 * (l >> 4) + (l & 7));
 #pragma unroll
             for (int k = 0; k < 16; ++k) col[8 * k + 2 * (k >> 1)] = v[k];
         }
@@ -1219,9 +1220,9 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
 #pragma unroll
             for (int c = 0; c < 8; ++c) a[c] = v[m + 2 * c];
 #else
-            // A(l + 64 m + 128 c) = a_rd + 72 m + 144 c + 16 (c / 2)
+            // A(l + 64 m + 128 c) = a_rd + 72 m + 144 c + 8 (c / 2)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) a[c] = a_rd[72 * m + 144 * c + 16 * (c >> 1)];
+            for (int c = 0; c < 8; ++c) a[c] = a_rd[72 * m + 144 * c + 8 * (c >> 1)];
 #endif
 #if RR_WAVE_ABLATE != 5
             const f2 w1 = t_p2[m];

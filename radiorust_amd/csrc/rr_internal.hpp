@@ -82,6 +82,8 @@ int filter_design_taps(size_t n, const rr_c64 *resp, const double *window_rel, c
 int downsampler_design(double input_rate, double output_rate, double bandwidth, double quality,
                        std::vector<double> &ir);
 int fourier_design_window(size_t n, const double *window_rel, double *values);
+int upsampler_design(double input_rate, double output_rate, double bandwidth, double quality,
+                     std::vector<double> &ir);
 
 // The decimation schedule of resampling.rs:110-112, run on the host.
 struct Schedule {
@@ -100,8 +102,22 @@ struct Schedule {
     uint64_t first_emit() const { return phase; }
 };
 
+// The interpolation schedule of resampling.rs:248-265, run on the host: how many outputs each
+// input sample releases.
+struct UpSchedule {
+    double input_rate = 0, output_rate = 0;
+    double pos = 0;
+    bool integer_ratio = false;  // both rates integral and output_rate % input_rate == 0
+    uint64_t U = 0;              // output_rate / input_rate
+    void configure(double in_rate, double out_rate);
+    size_t count(size_t n_in) const;
+    // Advances over n_in inputs; if `before` is non-null it receives, per input, the number of
+    // outputs of this call released before that input was added.  Returns the output count.
+    size_t advance(size_t n_in, std::vector<int32_t> *before);
+};
+
 // ---- block base ------------------------------------------------------------
-enum Kind { K_FREQSHIFTER = 1, K_FILTER, K_DOWNSAMPLER, K_FOURIER, K_CHAIN, K_CHANNELIZER };
+enum Kind { K_FREQSHIFTER = 1, K_FILTER, K_DOWNSAMPLER, K_FOURIER, K_CHAIN, K_CHANNELIZER, K_UPSAMPLER, K_FMDEMOD };
 
 }  // namespace rr
 

@@ -108,6 +108,18 @@ int launch_drop_tail(hipStream_t s, const void *oldh, void *newh, size_t H, size
 int launch_channelizer(int dtype, hipStream_t s, const void *hist, size_t hist_len, const void *in, long base0,
                        size_t M, size_t P, size_t nframes, const void *window, const void *tw, void *out);
 
+// Upsampler (resampling.rs:237-267) as a gather: out[m] = sum over the inputs t with
+// 0 <= m - before[t] < L, ascending t, of x[t] * ir[m - before[t]], rounded like the reference's
+// `ringbuf[i] += sample * ir` (product, then sum).  The virtual input stream is [hist (hn) | in];
+// integer ratio: before[t] = U * t, `before` may be null; otherwise before[] has hn + n_in entries.
+// (rr_metering.hip: built without a*b+c contraction)
+int launch_upsample(int dtype, hipStream_t s, const void *hist, size_t hn, const void *in, size_t n_in,
+                    const void *ir, size_t L, uint64_t U, const int32_t *before, void *out, size_t n_out);
+// FmDemod (modulation.rs:121-130): out[t] = (arg(x[t] * conj(x[t-1])) * factor, 0); st_in / st_out:
+// {previous sample, last output}; without a previous sample the first output repeats the last one.
+int launch_fmdemod(int dtype, hipStream_t s, const void *in, size_t n, void *out, const void *st_in, void *st_out,
+                   int have_prev, double factor);
+
 // SURVEY §8(d) synthetic IQ, f32
 int launch_synth(hipStream_t s, uint64_t seed, uint64_t t0, size_t n, void *out);
 

@@ -132,6 +132,127 @@ int launch_rescale_energy(int dtype, hipStream_t s, const void *frames, size_t n
     return RR_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Upsampler (resampling.rs:237-267), gather form, one output per lane.  The sums run in the
+// reference's order (ascending input index; product rounded, then added), so f32 results are
+// bit-equal to the scatter-add ring buffer of the reference.
+// ---------------------------------------------------------------------------
+template <class T, class CT>
+__global__ __launch_bounds__(256) void k_upsample(const CT *__restrict__ hist, long hn, const CT *__restrict__ in,
+                                                  long n_in, const T *__restrict__ ir, int L, long U,
+                                                  const int *__restrict__ before, CT *__restrict__ out,
+                                                  long n_out) {
+    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_out) return;
+    T ar = 0, ai = 0;
+    if (U > 0) {
+        const long t_hi = m / U;  // the input that releases output m
+        const int off0 = (int)(m - t_hi * U);
+        const int jmax = (L - 1 - off0) / (int)U;  // contributions t_hi - jmax .. t_hi
+        for (int j = jmax; j >= 0; --j) {
+            const long t = t_hi - j;
+            CT x;
+            x.x = 0;
+            x.y = 0;
+            if (t >= 0)
+                x = in[t];
+            else if (t >= -hn)
+                x = hist[hn + t];
+            const T c = ir[off0 + (int)U * j];
+            ar = add_rn(ar, mul_rn(x.x, c));
+            ai = add_rn(ai, mul_rn(x.y, c));
+        }
+    } else {
+        // largest virtual index v (0 .. hn + n_in - 1) with before[v] <= m
+        long lo = 0, hi = hn + n_in - 1;
+        while (lo < hi) {
+            const long mid = (lo + hi + 1) >> 1;
+            if ((long)before[mid] <= m)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        long v0 = lo;
+        while (v0 > 0 && m - (long)before[v0 - 1] < L) --v0;
+        for (long v = v0; v <= lo; ++v) {
+            const long off = m - (long)before[v];
+            if (off < 0 || off >= L) continue;
+            const CT x = v >= hn ? in[v - hn] : hist[v];
+            const T c = ir[off];
+            ar = add_rn(ar, mul_rn(x.x, c));
+            ai = add_rn(ai, mul_rn(x.y, c));
+        }
+    }
+    CT o;
+    o.x = ar;
+    o.y = ai;
+    out[m] = o;
+}
+
+int launch_upsample(int dtype, hipStream_t s, const void *hist, size_t hn, const void *in, size_t n_in,
+                    const void *ir, size_t L, uint64_t U, const int32_t *before, void *out, size_t n_out) {
+    if (n_out == 0) return RR_OK;
+    if (L > 0x7fffffffull || n_out > 0x7fffffffull * 256) RR_FAIL(RR_ERR_BAD_ARG, "Upsampler: size out of range");
+    if (U == 0 && !before) RR_FAIL(RR_ERR_BAD_ARG, "Upsampler: schedule missing");
+    const unsigned blocks = (unsigned)((n_out + 255) / 256);
+    if (dtype == RR_F32)
+        hipLaunchKernelGGL((k_upsample<float, float2>), dim3(blocks), dim3(256), 0, s, (const float2 *)hist, (long)hn,
+                           (const float2 *)in, (long)n_in, (const float *)ir, (int)L, (long)U, before, (float2 *)out,
+                           (long)n_out);
+    else
+        hipLaunchKernelGGL((k_upsample<double, double2>), dim3(blocks), dim3(256), 0, s, (const double2 *)hist, (long)hn,
+                           (const double2 *)in, (long)n_in, (const double *)ir, (int)L, (long)U, before, (double2 *)out,
+                           (long)n_out);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// FmDemod (modulation.rs:121-130)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float atan2_t(float y, float x) { return atan2f(y, x); }
+__device__ __forceinline__ double atan2_t(double y, double x) { return atan2(y, x); }
+
+template <class T, class CT>
+__global__ __launch_bounds__(256) void k_fmdemod(const CT *__restrict__ in, long n, CT *__restrict__ out,
+                                                 const CT *__restrict__ st_in, CT *__restrict__ st_out,
+                                                 int have_prev, T factor) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const CT cur = in[t];
+    CT o;
+    if (t == 0 && !have_prev) {
+        o = st_in[1];  // output_sample keeps its value (zero before the first pair)
+    } else {
+        const CT pv = t ? in[t - 1] : st_in[0];
+        // sample * previous.conj() as num-complex multiplies: (a.re b.re - a.im b.im, a.re b.im + a.im b.re)
+        const T cr = pv.x, ci = -pv.y;
+        const T re = sub_rn(mul_rn(cur.x, cr), mul_rn(cur.y, ci));
+        const T im = add_rn(mul_rn(cur.x, ci), mul_rn(cur.y, cr));
+        o.x = mul_rn(atan2_t(im, re), factor);
+        o.y = 0;
+    }
+    out[t] = o;
+    if (t == n - 1) {
+        st_out[0] = cur;
+        st_out[1] = o;
+    }
+}
+
+int launch_fmdemod(int dtype, hipStream_t s, const void *in, size_t n, void *out, const void *st_in, void *st_out,
+                   int have_prev, double factor) {
+    if (n == 0) return RR_OK;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (dtype == RR_F32)
+        hipLaunchKernelGGL((k_fmdemod<float, float2>), dim3(blocks), dim3(256), 0, s, (const float2 *)in, (long)n,
+                           (float2 *)out, (const float2 *)st_in, (float2 *)st_out, have_prev, (float)factor);
+    else
+        hipLaunchKernelGGL((k_fmdemod<double, double2>), dim3(blocks), dim3(256), 0, s, (const double2 *)in, (long)n,
+                           (double2 *)out, (const double2 *)st_in, (double2 *)st_out, have_prev, factor);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
 int launch_gain(int dtype, hipStream_t s, double gain, const void *in, size_t n, void *out) {
     if (n == 0) return RR_OK;
     size_t blocks = (2 * n + 255) / 256;

@@ -217,5 +217,6 @@ def test_chain_overlap_save_kernel_forced(rr, oracle, monkeypatch, kernel):
     for a, b in ((0, 70001), (70001, 200000), (200000, n)):
         out += g.process(rr.Samples(fs, x[a:b]))
     assert g.last_path_fused() and len(out) == 15
+    assert g.last_path_kernel() == {"ols": "k_ols_decim4", "olsw": "k_ols_wave", "direct": "k_mix_fir_decim"}[kernel]
     for a, b in zip(out, t64):
         assert rms_rel(a.chunk, b) <= 1e-5

@@ -1,0 +1,108 @@
+"""GPU parity of the Upsampler (resampling.rs:147-280) and FmDemod (modulation.rs:83-158)
+through the C ABI against the CPU oracle.
+
+Upsampler: the gather kernel performs the reference's products and sums in the reference's
+order without a*b+c contraction, so Complex<f32> and Complex<f64> outputs are compared
+BIT-EXACTLY with the oracle of the same type.
+FmDemod: everything but atan2 is exact; the device atan2f and glibc's differ by an ulp or
+two, so the f32 comparison allows 4 ulp of pi * factor absolute."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rr():
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import radiorust_amd
+
+    radiorust_amd._lib.lib()
+    return radiorust_amd
+
+
+CUTS = [0, 1, 1, 7, 2048, 2049, 9000, 20000]
+
+
+@pytest.mark.parametrize("flt", [np.float32, np.float64])
+@pytest.mark.parametrize("fi,fo,bw,q", [(48000.0, 384000.0, 40000.0, 3.0), (102400.0, 1024000.0, 60000.0, 3.0),
+                                        (44100.0, 48000.0, 30000.0, 3.0), (48000.0, 48000.0, 20000.0, 1.0),
+                                        (50e6, 200e6, 40e6, 3.0), (3.0, 7.0, 1.0, 2.0)])
+def test_upsampler_bit_exact(rr, oracle, fi, fo, bw, q, flt):
+    cdt = np.complex64 if flt == np.float32 else np.complex128
+    x = oracle.synth_iq(12, 0, CUTS[-1]).astype(cdt)
+    g = rr.Upsampler.with_quality(1000, fo, bw, q, dtype=flt)
+    o = oracle.Upsampler(1000, fo, bw, q, flt=flt)
+    for a, b in zip(CUTS[:-1], CUTS[1:]):
+        y, r = g.process_raw(fi, x[a:b]), o.process(fi, x[a:b])
+        assert len(y) == len(r)  # identical release schedule, chunk by chunk
+        assert np.array_equal(y.view(flt), r.view(flt)), (a, b)
+    assert g.ir_len() == len(o.ir())
+
+
+def test_upsampler_rate_change_chunks_and_events(rr, oracle):
+    g = rr.Upsampler.new(500, 384000.0, 20000.0)
+    o = oracle.Upsampler(500, 384000.0, 20000.0, flt=np.float32)
+    x = oracle.synth_iq(13, 0, 3000)
+    out, ref = [], []
+    for rate, a, b in ((48000.0, 0, 1000), (96000.0, 1000, 2200), (48000.0, 2200, 3000)):
+        out += g.process(rr.Samples(rate, x[a:b]))
+        ref += o.feed(rate, x[a:b])
+        ev = rr.EventSignal(rr.Disconnection())
+        assert g.process(ev) == [ev]  # resampling.rs:269-271
+    assert len(out) == len(ref) and all(len(s.chunk) == 500 and s.sample_rate == 384000.0 for s in out)
+    assert np.array_equal(np.concatenate([s.chunk for s in out]).view(np.float32), np.concatenate(ref).view(np.float32))
+
+
+def test_upsampler_contract(rr):
+    from radiorust_amd._lib import ContractViolation
+
+    with pytest.raises(ContractViolation):
+        rr.Upsampler.new(16, -1.0, 10.0)
+    g = rr.Upsampler.new(16, 48000.0, 20000.0)
+    with pytest.raises(ContractViolation):
+        g.process_raw(96000.0, np.zeros(8, dtype=np.complex64))
+    with pytest.raises(ContractViolation):
+        g.process_raw(16000.0, np.zeros(8, dtype=np.complex64))
+
+
+@pytest.mark.parametrize("flt,tol_ulp", [(np.float32, 4), (np.float64, 4)])
+def test_fmdemod_parity(rr, oracle, flt, tol_ulp):
+    cdt = np.complex64 if flt == np.float32 else np.complex128
+    fs, dev = 384000.0, 75000.0
+    n = 50000
+    t = np.arange(n)
+    msg = 0.7 * np.sin(2 * np.pi * 1000 * t / fs) + 0.2 * np.sin(2 * np.pi * 19000 * t / fs)
+    x = (np.exp(1j * np.cumsum(msg * dev / fs * 2 * np.pi)) * (1 + 0.01 * oracle.synth_iq(14, 0, n))).astype(cdt)
+    g, o = rr.FmDemod(dev, dtype=flt), oracle.FmDemod(dev, flt=flt)
+    factor = fs / dev / (2 * np.pi)
+    atol = tol_ulp * np.finfo(flt).eps * np.pi * factor
+    for a, b in ((0, 1), (1, 2), (2, 4097), (4097, 4097), (4097, n)):
+        y, r = g.process_raw(fs, x[a:b]), o.process(fs, x[a:b])
+        assert y.shape == r.shape and not np.any(y.imag)
+        assert np.max(np.abs(y.real - r.real), initial=0.0) <= atol
+    assert np.max(np.abs(y.real[-1000:] - msg[-1000:])) < 0.05  # and it demodulates
+
+
+def test_fmdemod_interrupt_deviation_events(rr, oracle):
+    fs = 48000.0
+    x = oracle.synth_iq(15, 0, 96)
+    g, o = rr.FmDemod(2500.0), oracle.FmDemod(2500.0, flt=np.float32)
+    (s1,) = g.process(rr.Samples(fs, x[:32]))
+    r1 = o.process(fs, x[:32])
+    ev = rr.EventSignal(rr.SamplesLost())  # an interrupting event (signal.rs)
+    assert g.process(ev) == [ev]
+    o.interrupt()
+    (s2,) = g.process(rr.Samples(fs, x[32:64]))
+    r2 = o.process(fs, x[32:64])
+    assert s2.chunk[0] == s1.chunk[-1]  # output_sample repeats (modulation.rs:121-127)
+    g.set_deviation(5000.0)
+    o.set_deviation(5000.0)
+    assert g.deviation() == 5000.0
+    (s3,) = g.process(rr.Samples(fs, x[64:]))
+    r3 = o.process(fs, x[64:])
+    atol = 4 * np.finfo(np.float32).eps * np.pi * fs / 2500.0 / (2 * np.pi)
+    for s, r in ((s1, r1), (s2, r2), (s3, r3)):
+        assert np.max(np.abs(s.chunk - r)) <= atol
