@@ -201,6 +201,16 @@ class Filter(_Block):
         return n_out.value
 
 
+    def process_dev_f16(self, sample_rate, chunk_len: int, d_in: int, n_in: int, d_out_f16: int, cap: int,
+                        response_f16: bool = False) -> int:
+        """As process_dev with half-precision output pairs (and optionally a half-precision response table)."""
+        self._ensure_design(float(sample_rate), int(chunk_len))
+        n_out = C.c_size_t()
+        _lib.check(_lib.lib().rr_filter_process_dev_f16(self._h, float(sample_rate), d_in, n_in, d_out_f16, cap,
+                                                         C.byref(n_out), int(bool(response_f16))))
+        return n_out.value
+
+
 class Downsampler(_Block):
     """Reduce sample rate (resampling.rs:14-146)."""
 

@@ -114,6 +114,28 @@ int rr_freqshifter::process_dev(double sample_rate, const void *d_in, size_t n_i
 // ---------------------------------------------------------------------------
 // Filter
 // ---------------------------------------------------------------------------
+// round-to-nearest-even conversion of a finite float to IEEE binary16 bits (host side)
+static uint16_t f32_to_f16_bits(float f) {
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x47800000u) return (uint16_t)(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));  // overflow / nan
+    if (x < 0x38800000u) {  // subnormal half or zero
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const int shift = 126 - (int)(x >> 23);  // 14 .. 24
+        const uint32_t mant = (x & 0x7fffffu) | 0x800000u;
+        uint32_t h = mant >> shift;
+        const uint32_t rem = mant & ((1u << shift) - 1), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (h & 1))) ++h;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((x - 0x38000000u) >> 13);
+    const uint32_t rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) ++h;
+    return (uint16_t)(sign | h);
+}
+
 int rr_filter::design(double sample_rate, size_t len, const rr_c64 *resp, const double *window_rel) {
     RR_TRY(select());
     if (len > (size_t(1) << 24)) RR_FAIL(RR_ERR_BAD_ARG, "Filter: chunk length %zu is not supported", len);
@@ -152,14 +174,19 @@ int rr_filter::design(double sample_rate, size_t len, const rr_c64 *resp, const 
         fft_f64(gg, false);
         std::vector<float> gb(2 * 4096), twb(2 * 4096);
         for (size_t i = 0; i < 4096; ++i) {
-            gb[2 * i] = (float)(gg[i].real() / 4096.0);
-            gb[2 * i + 1] = (float)(gg[i].imag() / 4096.0);
+            // pair-interleaved for 16-byte reads: Gp[kp][j] = {G[j + 512 kp], G[j + 512 kp + 256]}, j < 256
+            const size_t kp = i / 512, r = i % 512, dst = (kp * 256 + r % 256) * 2 + r / 256;
+            gb[2 * dst] = (float)(gg[i].real() / 4096.0);
+            gb[2 * dst + 1] = (float)(gg[i].imag() / 4096.0);
             const double ang = -2.0 * M_PI * (double)i / 4096.0;
             twb[2 * i] = (float)std::cos(ang);
             twb[2 * i + 1] = (float)std::sin(ang);
         }
         RR_TRY(upload(d_G4096, gb.data(), gb.size() * sizeof(float), stream));
         RR_TRY(upload(d_tw4096, twb.data(), twb.size() * sizeof(float), stream));
+        std::vector<uint16_t> gh(gb.size());
+        for (size_t i = 0; i < gb.size(); ++i) gh[i] = f32_to_f16_bits(gb[i]);
+        RR_TRY(upload(d_G4096h, gh.data(), gh.size() * sizeof(uint16_t), stream));
     }
     use_ols = !use_ols4096 && ols_supported(dtype, len);
     if (use_ols) {
@@ -203,8 +230,10 @@ int rr_filter::design(double sample_rate, size_t len, const rr_c64 *resp, const 
 }
 
 int rr_filter::process_dev(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap,
-                           size_t *n_out) {
+                           size_t *n_out, bool out_f16, bool g_f16) {
     if (n_out) *n_out = 0;
+    if ((out_f16 || g_f16) && !(designed && use_ols4096))
+        RR_FAIL(RR_ERR_BAD_ARG, "Filter: half-precision output/response exists for Complex<f32>, n in {256, 512, 1024, 2048}");
     if (!designed || params_changed || sample_rate != rate)
         RR_FAIL(RR_ERR_NEED_DESIGN, "Filter: no design for sample rate %g (filters.rs:178-183)", sample_rate);
     if (n_in == 0) return RR_OK;
@@ -214,8 +243,8 @@ int rr_filter::process_dev(double sample_rate, const void *d_in, size_t n_in, vo
     if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Filter: out_cap %zu < %zu", cap, produce);
     RR_TRY(select());
     if (produce && use_ols4096) {
-        RR_TRY(launch_filter_ols4096(stream, hist[cur].p, hist_valid ? n : 0, d_in, n_in, d_G4096.p, d_tw4096.p, n, d_out,
-                                     produce, hist_valid ? 0 : (long)n));
+        RR_TRY(launch_filter_ols4096(stream, hist[cur].p, hist_valid ? n : 0, d_in, n_in, g_f16 ? d_G4096h.p : d_G4096.p,
+                                     d_tw4096.p, n, d_out, produce, hist_valid ? 0 : (long)n, out_f16, g_f16));
     } else if (produce && use_ols) {
         RR_TRY(launch_filter_ols(dtype, stream, hist[cur].p, d_in, n, produce / n, hist_valid ? 0 : 1, d_H.p, d_olstw.p, d_out));
     } else if (produce) {
@@ -1232,6 +1261,13 @@ int rr_filter_process_dev(rr_filter *h, double rate, const void *d_in, size_t n_
     RR_GUARD_BEGIN
     RR_CHECK_HANDLE(h, K_FILTER);
     return h->process_dev(rate, d_in, n_in, d_out, cap, n_out);
+    RR_GUARD_END
+}
+int rr_filter_process_dev_f16(rr_filter *h, double sample_rate, const void *d_in, size_t n_in, void *d_out_f16,
+                              size_t cap, size_t *n_out, int response_f16) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_FILTER);
+    return h->process_dev(sample_rate, d_in, n_in, d_out_f16, cap, n_out, true, response_f16 != 0);
     RR_GUARD_END
 }
 int rr_filter_destroy(rr_filter *h) {

@@ -31,6 +31,7 @@ struct rr_filter : rr_block {
     rr::DevBuf d_H, d_olstw;       // H = FFT_2n([0 | g / 2n]) and e^{-j 2 pi k / 2n}, k < n
     bool use_ols4096 = false;      // f32, n in {256..2048}: 4096-point blocks, radix-16 kernel
     rr::DevBuf d_G4096, d_tw4096;
+    rr::DevBuf d_G4096h;           // the same table rounded to IEEE half (rr_filter_process_dev_f16's option)
     rr::DevBuf hist[2];            // previous_chunk (n samples), ping-pong
     int cur = 0;
     bool hist_valid = false;  // previous_chunk.is_some()
@@ -40,7 +41,8 @@ struct rr_filter : rr_block {
     }
     int design(double sample_rate, size_t len, const rr_c64 *resp, const double *window_rel);
     size_t peek(size_t n_in) const { return hist_valid ? n_in : (n_in >= n ? n_in - n : 0); }
-    int process_dev(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
+    int process_dev(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out,
+                    bool out_f16 = false, bool g_f16 = false);
 };
 
 // Downsampler — resampling.rs:62-67 (ir, ringbuf, ringbuf_pos, pos)

@@ -28,6 +28,8 @@
 //   rotation on the store.
 #include "rr_blocks.hpp"
 
+#include <hip/hip_fp16.h>
+
 #include <cmath>
 #include <utility>
 
@@ -1397,10 +1399,13 @@ int launch_ols_decim(hipStream_t s, const FusedFirArgs &a) {
 // rounding only), three 1024-sample chunks per block instead of one per 2048-point pair.
 // Forward and inverse transforms share one radix-16 x 3 routine (inverse = conj o DFT o conj).
 // ---------------------------------------------------------------------------
+// OUT16: outputs rounded to IEEE half (re, im) - 12 instead of 16 algorithmic bytes per sample;
+// G16: the response table held as halves (SURVEY 8(d) cfg5's second and third points).
+template <bool OUT16, bool G16>
 __global__ __launch_bounds__(256) void k_filter_ols4096(const float2 *__restrict__ hist, int hist_len,
                                                         const float2 *__restrict__ in, long n_in,
-                                                        const float2 *__restrict__ G, const float2 *__restrict__ tw,
-                                                        int V, float2 *__restrict__ out, long n_out, long e0) {
+                                                        const void *__restrict__ Gv, const float2 *__restrict__ tw,
+                                                        int V, void *__restrict__ outv, long n_out, long e0) {
     __shared__ f2 lds[4096 + 256];
     const int j = threadIdx.x;
     const int hop = 4096 - V;
@@ -1420,11 +1425,21 @@ __global__ __launch_bounds__(256) void k_filter_ols4096(const float2 *__restrict
         v[k] = (f2){x.x, x.y};
     }
     fft4096_regs(v, lds, tw, j);
+    // G arrives pair-interleaved (Gp[kp][j] = {G[j + 512 kp], G[j + 512 kp + 256]}): 8 reads of 16 (8) bytes
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const float2 g = G[j + 256 * k];
-        const f2 p = cmulf(v[k], (f2){g.x, g.y});
-        v[k] = (f2){p.x, -p.y};  // conj: the inverse transform is conj(DFT(conj(.)))
+    for (int kp = 0; kp < 8; ++kp) {
+        float4 g4;
+        if constexpr (G16) {
+            const uint2 raw = reinterpret_cast<const uint2 *>(Gv)[j + 256 * kp];
+            const __half2 a = *reinterpret_cast<const __half2 *>(&raw.x), b = *reinterpret_cast<const __half2 *>(&raw.y);
+            const float2 fa = __half22float2(a), fb = __half22float2(b);
+            g4 = float4{fa.x, fa.y, fb.x, fb.y};
+        } else {
+            g4 = reinterpret_cast<const float4 *>(Gv)[j + 256 * kp];
+        }
+        const f2 p0 = cmulf(v[2 * kp], (f2){g4.x, g4.y}), p1 = cmulf(v[2 * kp + 1], (f2){g4.z, g4.w});
+        v[2 * kp] = (f2){p0.x, -p0.y};  // conj: the inverse transform is conj(DFT(conj(.)))
+        v[2 * kp + 1] = (f2){p1.x, -p1.y};
     }
     __syncthreads();  // the forward transform's last LDS reads are done
     fft4096_regs(v, lds, tw, j);
@@ -1434,10 +1449,14 @@ __global__ __launch_bounds__(256) void k_filter_ols4096(const float2 *__restrict
         const int t = j + 256 * k;
         const long m = mbase + (t - V);
         if (t >= V && m < n_out) {
-            float2 w;
-            w.x = v[k].x;
-            w.y = -v[k].y;
-            out[m] = w;
+            if constexpr (OUT16) {
+                reinterpret_cast<__half2 *>(outv)[m] = __floats2half2_rn(v[k].x, -v[k].y);
+            } else {
+                float2 w;
+                w.x = v[k].x;
+                w.y = -v[k].y;
+                reinterpret_cast<float2 *>(outv)[m] = w;
+            }
         }
     }
 }
@@ -1447,15 +1466,16 @@ bool filter_ols4096_supported(int dtype, size_t n) {
 }
 
 int launch_filter_ols4096(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *G,
-                          const void *tw4096, size_t n, void *out, size_t n_out, long e0) {
+                          const void *tw4096, size_t n, void *out, size_t n_out, long e0, bool out_f16, bool g_f16) {
     if (n_out == 0) return RR_OK;
     const int V = (int)n;  // n is a multiple of 256 here, V >= n - 1
     const size_t hop = 4096 - V;
     const size_t nblocks = (n_out + hop - 1) / hop;
     if (nblocks > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "Filter: too many blocks");
-    hipLaunchKernelGGL(k_filter_ols4096, dim3((unsigned)nblocks), dim3(256), 0, s, (const float2 *)hist, (int)hist_len,
-                       (const float2 *)in, (long)n_in, (const float2 *)G, (const float2 *)tw4096, V, (float2 *)out,
-                       (long)n_out, e0);
+    auto kern = out_f16 ? (g_f16 ? k_filter_ols4096<true, true> : k_filter_ols4096<true, false>)
+                        : (g_f16 ? k_filter_ols4096<false, true> : k_filter_ols4096<false, false>);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), 0, s, (const float2 *)hist, (int)hist_len,
+                       (const float2 *)in, (long)n_in, G, (const float2 *)tw4096, V, out, (long)n_out, e0);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }

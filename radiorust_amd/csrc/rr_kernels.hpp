@@ -46,7 +46,8 @@ int launch_filter_ols(int dtype, hipStream_t s, const void *hist, const void *in
 // out[m] = sum_k g[k] x[e0 + m - k] over [ hist | in ]; G = DFT_4096(g)/4096, tw4096 as above.
 bool filter_ols4096_supported(int dtype, size_t n);
 int launch_filter_ols4096(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *G,
-                          const void *tw4096, size_t n, void *out, size_t n_out, long e0);
+                          const void *tw4096, size_t n, void *out, size_t n_out, long e0, bool out_f16 = false,
+                          bool g_f16 = false);
 
 // new_hist (H samples) = last H samples of [ zeros | old_hist (H) | in (n_in) ]
 int launch_update_hist(int dtype, hipStream_t s, const void *old_hist, void *new_hist, size_t H, const void *in,

@@ -22,3 +22,32 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / K
 print(f"cfg5 Filter n=1024 f32: {dt*1e3:.3f} ms per 2^26 samples = {N/dt/1e6:.0f} MSamples/s, "
       f"{16*N/dt/1e9:.0f} GB/s algorithmic (16 B/sample) = {100*16*N/dt/8e12:.1f} % of HBM roofline")
+
+# the half-precision points of SURVEY 8(d): f16 output, and f16 output + f16 response table
+import numpy as np
+from oracle import rr_oracle as o
+M = 1 << 16
+xh = o.synth_iq(1, 0, M)
+of = o.Filter(lambda b, fr: 1.0 if abs(fr) <= 200e6 else 0.0, flt=np.float64)
+ref = [of.process(fs, xh[a:a + n].astype(np.complex128)) for a in range(0, M, n)]
+ref = np.concatenate([r for r in ref if r is not None])
+d_h = torch.empty(2 * N, dtype=torch.float16, device="cuda")
+for resp16 in (False, True):
+    g = rr.Filter.new(lambda b, fr: 1.0 if abs(fr) <= 200e6 else 0.0)
+    g.set_stream(st)
+    got = g.process_dev_f16(fs, n, d_in.data_ptr(), M, d_h.data_ptr(), N, response_f16=resp16)
+    torch.cuda.synchronize()
+    y = d_h[: 2 * got].cpu().numpy().astype(np.float64)
+    y = y[0::2] + 1j * y[1::2]
+    err = float(np.sqrt(np.sum(np.abs(y - ref) ** 2) / np.sum(np.abs(ref) ** 2)))
+    for _ in range(3):
+        g.process_dev_f16(fs, n, d_in.data_ptr(), N, d_h.data_ptr(), N, response_f16=resp16)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(K):
+        g.process_dev_f16(fs, n, d_in.data_ptr(), N, d_h.data_ptr(), N, response_f16=resp16)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / K
+    print(f"cfg5 Filter n=1024 f16 out{' + f16 response' if resp16 else ''}: {dt*1e3:.3f} ms = {N/dt/1e6:.0f} MSamples/s, "
+          f"{12*N/dt/1e9:.0f} GB/s algorithmic (12 B/sample) = {100*12*N/dt/8e12:.1f} % of HBM roofline, "
+          f"rms error vs f64 oracle {err:.2e}")

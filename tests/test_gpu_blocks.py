@@ -443,3 +443,43 @@ def test_enqueue_wait_with_pinned_buffers(rr, oracle):
     assert L.rr_host_register(buf.ctypes.data, buf.nbytes) == 0
     assert L.rr_host_unregister(buf.ctypes.data) == 0
     assert L.rr_host_free(p_in) == 0 and L.rr_host_free(p_out) == 0
+
+
+# ---------------------------------------------------------------- Filter, half-precision points (cfg5)
+@pytest.mark.parametrize("resp16", [False, True])
+def test_filter_f16_output(rr, oracle, resp16):
+    """rr_filter_process_dev_f16: the 1024-tap overlap-save Filter with IEEE-half output pairs (and,
+    second case, a half-precision response table).  Tolerances are the formats' own: half has an
+    11-bit significand, so rounding the output alone gives a relative RMS error of about
+    2^-11 / sqrt(3) = 2.8e-4; rounding the response adds about as much again."""
+    import torch
+
+    n, N, fs = 1024, 1 << 16, 2e9
+    x = oracle.synth_iq(21, 0, N)
+    f = rr.Filter.new(lowpass(200e6))
+    st = torch.cuda.current_stream().cuda_stream
+    f.set_stream(st)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.zeros(2 * N, dtype=torch.float16, device="cuda")
+    got = f.process_dev_f16(fs, n, d_in.data_ptr(), N, d_out.data_ptr(), N, response_f16=resp16)
+    torch.cuda.synchronize()
+    assert got == N - n  # first chunk swallowed
+    y = d_out[: 2 * got].cpu().numpy().astype(np.float64)
+    y = y[0::2] + 1j * y[1::2]
+    o = oracle.Filter(lowpass(200e6), flt=np.float64)
+    ref = [o.process(fs, x[a:a + n].astype(np.complex128)) for a in range(0, N, n)]
+    ref = np.concatenate([r for r in ref if r is not None])
+    assert len(ref) == got
+    err = rms_rel(y, ref)
+    assert 5e-5 < err < (8e-4 if resp16 else 4e-4), err
+
+
+def test_filter_f16_unsupported(rr):
+    import torch
+    from radiorust_amd._lib import BackendError
+
+    f = rr.Filter.new(lowpass(10e6))
+    d = torch.zeros(128, dtype=torch.complex64, device="cuda")
+    o = torch.zeros(256, dtype=torch.float16, device="cuda")
+    with pytest.raises(BackendError):
+        f.process_dev_f16(200e6, 64, d.data_ptr(), 128, o.data_ptr(), 128)  # 64 taps: direct-form kernel
