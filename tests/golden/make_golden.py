@@ -115,11 +115,52 @@ def blocks_fixture():
                         filtered_head=y[:1024], filtered_tail=y[-1024:])
 
 
+def resample_demod_fixture():
+    """Upsampler (resampling.rs:147-280) 48 kS/s -> 384 kS/s (L = 288) and 44.1 -> 48 kS/s (L = 21), and
+    FmDemod (modulation.rs:83-158), in f32 (the Upsampler's f32 arithmetic order is part of the contract:
+    the GPU kernel is compared bit for bit) and f64.  Cross-check: the numpy scatter-add formulation."""
+    x = o.synth_iq(4, 0, 2048)
+    d = {"seed_t0_n": np.array([4, 0, 2048], dtype=np.int64)}
+    for name, fi, fo, bw in (("int8", 48000.0, 384000.0, 40000.0), ("frac", 44100.0, 48000.0, 30000.0)):
+        for flt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+            u = o.Upsampler(1024, fo, bw, 3.0, flt=flt)
+            y = np.concatenate([u.process(fi, x[:1000].astype(np.complex64 if flt == np.float32 else np.complex128)),
+                                u.process(fi, x[1000:].astype(np.complex64 if flt == np.float32 else np.complex128))])
+            if flt == np.float64:
+                ir, L = u.ir(), len(u.ir())
+                pos, cnt, ref = 0.0, 0, np.zeros(len(y) + L, dtype=np.complex128)
+                for xv in x.astype(np.complex128):
+                    ref[cnt:cnt + L] += xv * ir
+                    while pos < fo:
+                        cnt += 1
+                        pos += fi
+                    pos -= fo
+                assert cnt == len(y) and np.array_equal(ref[:cnt], y)
+                d[f"upsampler_ir_{name}"] = ir
+            d[f"upsampler_{name}_{tag}_head"] = y[:1024]
+            d[f"upsampler_{name}_{tag}_tail"] = y[-1024:]
+            d[f"upsampler_{name}_{tag}_count"] = np.array([len(y)], dtype=np.int64)
+        d[f"upsampler_params_{name}"] = np.array([fi, fo, bw, 3.0])
+    fs, dev = 384000.0, 75000.0
+    t = np.arange(2048)
+    msg = 0.7 * np.sin(2 * np.pi * 1000 * t / fs)
+    xm = (np.exp(1j * np.cumsum(msg * dev / fs * 2 * np.pi)) * (1 + 0.01 * x)).astype(np.complex64)
+    dm = o.FmDemod(dev, flt=np.float64)
+    y = dm.process(fs, xm.astype(np.complex128))
+    ref = np.concatenate([[0.0], np.angle(xm[1:].astype(np.complex128) * np.conj(xm[:-1].astype(np.complex128))) * (fs / dev / (2 * np.pi))])
+    assert np.max(np.abs(y.real - ref)) < 1e-12 and not np.any(y.imag)
+    d["fmdemod_params"] = np.array([fs, dev])
+    d["fmdemod_input_f32"] = xm
+    d["fmdemod_output_f64"] = y.real
+    np.savez_compressed(os.path.join(OUT, "resample_demod.npz"), **d)
+
+
 if __name__ == "__main__":
     o.build()
     design_fixture()
     chain_fixture()
     blocks_fixture()
+    resample_demod_fixture()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

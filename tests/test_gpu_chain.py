@@ -220,3 +220,33 @@ def test_chain_overlap_save_kernel_forced(rr, oracle, monkeypatch, kernel):
     assert g.last_path_kernel() == {"ols": "k_ols_decim4", "olsw": "k_ols_wave", "direct": "k_mix_fir_decim"}[kernel]
     for a, b in zip(out, t64):
         assert rms_rel(a.chunk, b) <= 1e-5
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_chain_wave_kernel_randomised(rr, oracle, seed):
+    """k_ols_wave (the default fused kernel for 4x decimation) under random parameters: shifts whose
+    NCO period does and does not divide 128 (one phasor pair per lane vs the general table walk),
+    filter lengths and transition widths that move the combined tap count Lc between 112 and 513,
+    random ragged call sizes (edge blocks, carry, odd block alignment), real and complex responses."""
+    rng = np.random.default_rng(100 + seed)
+    fs = 200e6
+    filter_len = int(rng.choice([64, 128, 256]))
+    bw = float(rng.choice([30e6, 40e6, 44e6]))  # L = ceil(200e6 / ((50e6 - bw) / 2) * 3): 60, 120, 200
+    shift, precision = [(25e6, 1.0), (12.5e6, 1.0), (12.345e6, 1e3), (-3.7e6, 1e5), (1.5625e6, 1.0), (31e6, 1e6)][seed]
+    cut = float(rng.choice([10e6, 20e6]))
+    resp = lowpass(cut) if seed % 2 == 0 else (lambda _b, f, c=cut: 1.0 if 0 <= f <= c else 0.0)
+    params = dict(shift=shift, filter_len=filter_len, freq_resp=resp, output_rate=50e6, bandwidth=bw, fft_len=4096)
+    n = 1 << 17
+    x = oracle.synth_iq(30 + seed, 0, n)
+    t64 = oracle.run_chain(x, fs, flt=np.float64, fft_window=oracle.Kaiser.with_null_at_bin(2.0), precision=precision, **params)[3]
+    g = rr.Chain(**params, precision=precision, fft_window=rr.Kaiser.with_null_at_bin(2.0))
+    cuts = sorted({0, n, *(int(v) for v in rng.integers(1, n, size=6))})
+    out = []
+    fused_calls = 0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        out += g.process(rr.Samples(fs, x[a:b]))
+        fused_calls += g.last_path_kernel() == "k_ols_wave"
+    assert len(out) == len(t64) and len(out) >= 7
+    assert fused_calls >= 2, (cuts, fused_calls)
+    for a, b in zip(out, t64):
+        assert rms_rel(a.chunk, b) <= 1e-5
