@@ -142,6 +142,12 @@ SIGNATURES = {
     "rr_channelizer_process": (_i, [_vp, _vp, _sz, _vp, _sz, _psz]),
     "rr_channelizer_process_dev": (_i, [_vp, _vp, _sz, _vp, _sz, _psz]),
     "rr_channelizer_destroy": (_i, [_vp]),
+    "rr_stft_create": (_i, [_i, _sz, _sz, C.POINTER(Window), _i, _i, C.POINTER(_vp)]),
+    "rr_stft_reset": (_i, [_vp]),
+    "rr_stft_peek": (_i, [_vp, _sz, _psz]),
+    "rr_stft_process": (_i, [_vp, _vp, _sz, _vp, _sz, _psz]),
+    "rr_stft_process_dev": (_i, [_vp, _vp, _sz, _vp, _sz, _psz]),
+    "rr_stft_destroy": (_i, [_vp]),
     "rr_upsampler_create": (_i, [_i, _d, _d, _d, _i, C.POINTER(_vp)]),
     "rr_upsampler_peek": (_i, [_vp, _d, _sz, _psz]),
     "rr_upsampler_process": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),

@@ -519,6 +519,45 @@ class Channelizer(_Block):
         return n_out.value
 
 
+class Stft(_Block):
+    """Overlapped Fourier analysis: Rechunker(chunk_len) -> Overlapper(chunk_count) ->
+    Fourier.with_window(window) (chunks.rs:42-242, analysis.rs:26-133; the wiring of
+    examples/bandwidth_meter/main.rs:66-69).  Input chunks must be multiples of chunk_len."""
+
+    _destroy = "rr_stft_destroy"
+
+    def __init__(self, chunk_len: int, chunk_count: int, window: Window | None = None, center_dc: bool = False,
+                 dtype=np.float32, device: int = 0):
+        super().__init__()
+        self._code, self._cdt = _dtype_code(dtype)
+        self.chunk_len, self.chunk_count = int(chunk_len), int(chunk_count)
+        w = window if window is not None else Rectangular()
+        spec = w._spec()
+        if spec is None:
+            raise TypeError("Stft needs a built-in window (Rectangular or Kaiser)")
+        _lib.check(_lib.lib().rr_stft_create(self._code, self.chunk_len, self.chunk_count, spec, int(bool(center_dc)),
+                                             device, C.byref(self._h)))
+
+    def process(self, signal):
+        """One output message per overlapped chunk (chunk_len * chunk_count bins).  Any event resets the
+        overlap history and is preceded by SamplesLost, as the Overlapper does (chunks.rs:225-233)."""
+        from .signal import SamplesLost
+
+        if signal.is_event():
+            _lib.check(_lib.lib().rr_stft_reset(self._h))
+            return [EventSignal(SamplesLost()), signal]
+        n_out = C.c_size_t()
+        _lib.check(_lib.lib().rr_stft_peek(self._h, len(signal.chunk), C.byref(n_out)))
+        y = self._host_call(_lib.lib().rr_stft_process, (), signal.chunk, n_out.value)
+        N = self.chunk_len * self.chunk_count
+        return [Samples(signal.sample_rate, y[i * N : (i + 1) * N]) for i in range(len(y) // N)]
+
+    def process_dev(self, d_in: int, n_in: int, d_out: int, cap: int) -> int:
+        n_out = C.c_size_t()
+        _lib.check(_lib.lib().rr_stft_process_dev(self._h, d_in, n_in, d_out, cap, C.byref(n_out)))
+        return n_out.value
+
+
 def synth_iq_dev(device: int, hip_stream: int | None, seed: int, t0: int, n: int, d_out: int):
     """Fills n complex64 samples of the synthetic IQ source on the device."""
     _lib.check(_lib.lib().rr_synth_iq_dev(device, C.c_void_p(hip_stream or 0), seed, t0, n, d_out))

@@ -354,6 +354,41 @@ int rr_downsampler::process_dev(double input_rate, const void *d_in, size_t n_in
 }
 
 // ---------------------------------------------------------------------------
+// Overlapped Fourier analysis: Rechunker -> Overlapper -> Fourier
+// ---------------------------------------------------------------------------
+rr_stft::~rr_stft() { delete fo; }
+
+int rr_stft::process_dev(const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out) {
+    if (n_out) *n_out = 0;
+    if (n_in % M) RR_FAIL(RR_ERR_BAD_ARG, "Stft: %zu samples is not a whole number of %zu-sample chunks", n_in, M);
+    const size_t produce = peek(n_in);
+    if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Stft: out_cap %zu < %zu", cap, produce);
+    if (n_in == 0) return RR_OK;
+    RR_TRY(select());
+    const size_t N = M * P, chunks = n_in / M, H = (P - 1) * M, esz = elem_size(dtype);
+    const size_t frames = produce / N;
+    if (frames) {
+        fo->stream = stream;
+        RR_TRY(fo->prepare(N));
+        // frame 0 ends with the chunk that completes the history (see rr_channelizer::process_dev)
+        const size_t first_complete = (have_chunks >= P - 1) ? 0 : (P - 1 - have_chunks);
+        const long base0 = ((long)first_complete - (long)(P - 1)) * (long)M;  // <= 0 only if the history holds it
+        const size_t n_head = base0 < 0 ? (size_t)(-base0) : 0;
+        const char *head = hist[cur].as<char>() + (H - n_head) * esz;
+        const char *in0 = static_cast<const char *>(d_in) + (base0 > 0 ? (size_t)base0 * esz : 0);
+        RR_TRY(launch_fourier_overlapped(dtype, stream, head, n_head, in0, d_out, N, M, frames, fo->d_window.p,
+                                         fo->d_tw.p, fo->center_dc));
+    }
+    if (H) {
+        RR_TRY(launch_update_hist(dtype, stream, hist[cur].p, hist[cur ^ 1].p, H, d_in, n_in));
+        cur ^= 1;
+    }
+    have_chunks = (have_chunks + chunks > P - 1) ? P - 1 : have_chunks + chunks;
+    if (n_out) *n_out = produce;
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
 // Upsampler (resampling.rs:147-280)
 // ---------------------------------------------------------------------------
 int rr_upsampler::prepare(double input_rate) {
@@ -1347,6 +1382,85 @@ int rr_downsampler_ir_len(const rr_downsampler *h, size_t *ir_len) {
 int rr_downsampler_destroy(rr_downsampler *h) {
     if (!h) return RR_OK;
     RR_CHECK_HANDLE(h, K_DOWNSAMPLER);
+    (void)hipSetDevice(h->device);
+    delete h;
+    return RR_OK;
+}
+
+// ---- Stft (Rechunker -> Overlapper -> Fourier) -----------------------------------------------
+int rr_stft_create(int dtype, size_t chunk_len, size_t chunk_count, const rr_window *window, int center_dc, int device,
+                   rr_stft **out) {
+    RR_GUARD_BEGIN
+    if (!out || !window) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    *out = nullptr;
+    if (chunk_len == 0) RR_FAIL(RR_ERR_CONTRACT, "chunk length must be positive");    // chunks.rs:56
+    if (chunk_count == 0) RR_FAIL(RR_ERR_CONTRACT, "chunk count must be positive");   // chunks.rs:195
+    const size_t N = chunk_len * chunk_count;
+    if (!fourier_pow2_path(dtype, N))
+        RR_FAIL(RR_ERR_BAD_ARG, "Stft: chunk_len * chunk_count must be a power of two the Fourier kernels take (got %zu)", N);
+    if (window->kind != RR_WIN_RECTANGULAR && window->kind != RR_WIN_KAISER)
+        RR_FAIL(RR_ERR_BAD_ARG, "Stft: window must be a built-in window");
+    auto *h = new rr_stft;
+    int st = h->init_base(K_STFT, dtype, device);
+    if (st == RR_OK) {
+        h->fo = new rr_fourier;
+        st = h->fo->init_base(K_FOURIER, dtype, device);
+    }
+    if (st == RR_OK) {
+        h->fo->window = *window;
+        h->fo->center_dc = center_dc != 0;
+        h->M = chunk_len;
+        h->P = chunk_count;
+        const size_t hb = (chunk_count - 1) * chunk_len * elem_size(dtype);
+        st = h->hist[0].reserve(hb ? hb : 16);
+        if (st == RR_OK) st = h->hist[1].reserve(hb ? hb : 16);
+    }
+    if (st != RR_OK) {
+        delete h;
+        return st;
+    }
+    *out = h;
+    return RR_OK;
+    RR_GUARD_END
+}
+int rr_stft_reset(rr_stft *h) {
+    RR_CHECK_HANDLE(h, K_STFT);
+    h->have_chunks = 0;  // chunks.rs:225-233
+    return RR_OK;
+}
+int rr_stft_peek(const rr_stft *h, size_t n_in, size_t *n_out) {
+    RR_CHECK_HANDLE(h, K_STFT);
+    if (!n_out) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    if (n_in % h->M) RR_FAIL(RR_ERR_BAD_ARG, "Stft: input must be whole chunks of %zu samples", h->M);
+    *n_out = h->peek(n_in);
+    return RR_OK;
+}
+int rr_stft_process_dev(rr_stft *h, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_STFT);
+    return h->process_dev(d_in, n_in, d_out, cap, n_out);
+    RR_GUARD_END
+}
+int rr_stft_process(rr_stft *h, const void *in, size_t n_in, void *out, size_t cap, size_t *n_out) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_STFT);
+    if (n_out) *n_out = 0;
+    if (n_in % h->M) RR_FAIL(RR_ERR_BAD_ARG, "Stft: input must be whole chunks of %zu samples", h->M);
+    const size_t produce = h->peek(n_in);
+    if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Stft: out_cap %zu < %zu", cap, produce);
+    size_t got = 0;
+    RR_TRY(host_io(h, in, n_in, out, produce, true, [&](void *di, void *dout, size_t *p) {
+        int s = h->process_dev(di, n_in, dout, produce, p);
+        got = *p;
+        return s;
+    }));
+    if (n_out) *n_out = got;
+    return RR_OK;
+    RR_GUARD_END
+}
+int rr_stft_destroy(rr_stft *h) {
+    if (!h) return RR_OK;
+    RR_CHECK_HANDLE(h, K_STFT);
     (void)hipSetDevice(h->device);
     delete h;
     return RR_OK;

@@ -65,6 +65,23 @@ struct rr_downsampler : rr_block {
 };
 
 // Fourier — analysis.rs:67-73 (previous_chunk_len, fft, window_values)
+// Rechunker(chunk_len) -> Overlapper(chunk_count) -> Fourier (chunks.rs:42-242, analysis.rs:26-133;
+// the wiring of examples/bandwidth_meter/main.rs:66-69): every chunk_len new samples one windowed
+// transform over the last chunk_count * chunk_len samples.
+struct rr_stft : rr_block {
+    size_t M = 0, P = 0;
+    size_t have_chunks = 0;  // chunks in the Overlapper's history, < P
+    rr::DevBuf hist[2];      // the last (P-1)*M samples
+    int cur = 0;
+    rr_fourier *fo = nullptr;  // window + twiddles of the P*M-point transform
+    ~rr_stft() override;
+    size_t peek(size_t n_in) const {
+        const size_t chunks = n_in / M, total = have_chunks + chunks;
+        return total >= P ? (total - (P - 1)) * M * P : 0;
+    }
+    int process_dev(const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
+};
+
 struct rr_upsampler : rr_block {
     double output_rate = 0, bandwidth = 0, quality = 3.0;
     bool have_rate = false;

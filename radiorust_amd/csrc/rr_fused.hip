@@ -614,10 +614,10 @@ __device__ __forceinline__ void apply_twiddle_powers(f2 (&v)[16], f2 w) {
 __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head, long n_head,
                                                  const float2 *__restrict__ in, float2 *__restrict__ out,
                                                  const float *__restrict__ window, const float2 *__restrict__ tw,
-                                                 int center_dc) {
+                                                 int center_dc, long hop) {
     __shared__ f2 lds[4096 + 256];
     const int j = threadIdx.x;
-    const long base = (long)blockIdx.x * 4096 - n_head;  // index into `in` of this frame's first sample
+    const long base = (long)blockIdx.x * hop - n_head;  // index into `in` of this frame's first sample
     float2 *dst = out + (size_t)blockIdx.x * 4096;
     f2 v[16];
 #pragma unroll
@@ -669,12 +669,12 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
 }
 
 int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
-                   const void *window, const void *tw4096, bool center_dc) {
+                   const void *window, const void *tw4096, bool center_dc, size_t hop) {
     if (count == 0) return RR_OK;
     if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fft4096: too many frames");
     hipLaunchKernelGGL(k_fft4096, dim3((unsigned)count), dim3(256), 0, s, (const float2 *)head, (long)n_head,
                        (const float2 *)in, (float2 *)out,
-                       (const float *)window, (const float2 *)tw4096, (int)center_dc);
+                       (const float *)window, (const float2 *)tw4096, (int)center_dc, (long)hop);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }

@@ -341,17 +341,21 @@ int launch_update_hist(int dtype, hipStream_t s, const void *old_hist, void *new
 // (Generic version; the radix-16 register kernel for n = 4096 is in rr_fused.hip.)
 // ---------------------------------------------------------------------------
 template <class T>
-__global__ __launch_bounds__(256) void k_fft_pow2(const v2<T> *__restrict__ in, v2<T> *__restrict__ out, int n,
-                                                  const T *__restrict__ window, const v2<T> *__restrict__ tw,
-                                                  int center_dc) {
+// Frames are cut from the stream [ head (n_head samples) | in ] every `hop` samples (hop = n: the
+// plain chunk-by-chunk Fourier; hop < n: the Overlapper's overlapping chunks, chunks.rs:194-242).
+__global__ __launch_bounds__(256) void k_fft_pow2(const v2<T> *__restrict__ head, long n_head,
+                                                  const v2<T> *__restrict__ in, v2<T> *__restrict__ out, int n,
+                                                  long hop, const T *__restrict__ window,
+                                                  const v2<T> *__restrict__ tw, int center_dc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     v2<T> *a = reinterpret_cast<v2<T> *>(smem);
     v2<T> *b = a + n;
     const size_t chunk = blockIdx.x;
-    const v2<T> *src = in + chunk * (size_t)n;
+    const long base = (long)chunk * hop - n_head;
     v2<T> *dst = out + chunk * (size_t)n;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        v2<T> v = src[i];
+        const long pos = base + i;
+        v2<T> v = pos >= 0 ? in[pos] : head[n_head + pos];
         const T w = window[i];
         v.x *= w;
         v.y *= w;
@@ -445,8 +449,9 @@ int fourier_supported(int dtype, size_t n) {
 }
 
 template <class T>
-static int launch_fourier_t(hipStream_t s, const void *in, void *out, size_t n, size_t count, const void *window,
-                            const void *twiddle, bool center_dc, int dtype) {
+static int launch_fourier_t(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t n,
+                            size_t hop, size_t count, const void *window, const void *twiddle, bool center_dc,
+                            int dtype) {
     if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: too many chunks in one call");
     if (fourier_pow2_path(dtype, n)) {
         const size_t lds = 2 * n * sizeof(v2<T>);
@@ -455,9 +460,11 @@ static int launch_fourier_t(hipStream_t s, const void *in, void *out, size_t n, 
         int threads = (int)(n / 2);
         if (threads > 256) threads = 256;
         if (threads < 64) threads = 64;
-        hipLaunchKernelGGL(fn, dim3((unsigned)count), dim3(threads), lds, s, (const v2<T> *)in, (v2<T> *)out, (int)n,
-                           (const T *)window, (const v2<T> *)twiddle, (int)center_dc);
+        hipLaunchKernelGGL(fn, dim3((unsigned)count), dim3(threads), lds, s, (const v2<T> *)head, (long)n_head,
+                           (const v2<T> *)in, (v2<T> *)out, (int)n, (long)hop, (const T *)window, (const v2<T> *)twiddle,
+                           (int)center_dc);
     } else {
+        if (hop != n || n_head) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: overlapping chunks need a power-of-two length");
         if (count > 65535) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: too many non-power-of-two chunks in one call");
         dim3 grid((unsigned)((n + 255) / 256), (unsigned)count);
         hipLaunchKernelGGL(k_dft_direct<T>, grid, dim3(256), 0, s, (const v2<T> *)in, (v2<T> *)out, (int)n,
@@ -467,13 +474,20 @@ static int launch_fourier_t(hipStream_t s, const void *in, void *out, size_t n, 
     return RR_OK;
 }
 
-int launch_fourier(int dtype, hipStream_t s, const void *in, void *out, size_t n, size_t count, const void *window,
-                   const void *twiddle, bool center_dc) {
+int launch_fourier_overlapped(int dtype, hipStream_t s, const void *head, size_t n_head, const void *in, void *out,
+                              size_t n, size_t hop, size_t count, const void *window, const void *twiddle, bool center_dc) {
     if (count == 0) return RR_OK;
     RR_TRY(fourier_supported(dtype, n));
-    if (dtype == RR_F32 && n == 4096) return launch_fft4096(s, nullptr, 0, in, out, count, window, twiddle, center_dc);
-    if (dtype == RR_F32) return launch_fourier_t<float>(s, in, out, n, count, window, twiddle, center_dc, dtype);
-    return launch_fourier_t<double>(s, in, out, n, count, window, twiddle, center_dc, dtype);
+    if (dtype == RR_F32 && n == 4096)
+        return launch_fft4096(s, head, n_head, in, out, count, window, twiddle, center_dc, hop);
+    if (dtype == RR_F32)
+        return launch_fourier_t<float>(s, head, n_head, in, out, n, hop, count, window, twiddle, center_dc, dtype);
+    return launch_fourier_t<double>(s, head, n_head, in, out, n, hop, count, window, twiddle, center_dc, dtype);
+}
+
+int launch_fourier(int dtype, hipStream_t s, const void *in, void *out, size_t n, size_t count, const void *window,
+                   const void *twiddle, bool center_dc) {
+    return launch_fourier_overlapped(dtype, s, nullptr, 0, in, out, n, n, count, window, twiddle, center_dc);
 }
 
 // ---------------------------------------------------------------------------

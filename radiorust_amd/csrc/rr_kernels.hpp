@@ -61,6 +61,10 @@ int fourier_supported(int dtype, size_t n);
 bool fourier_pow2_path(int dtype, size_t n);
 int launch_fourier(int dtype, hipStream_t s, const void *in, void *out, size_t n, size_t count, const void *window,
                    const void *twiddle, bool center_dc);
+// the same over frames cut every `hop` samples from the stream [ head (n_head samples) | in ]
+// (hop < n: overlapping chunks; power-of-two n only)
+int launch_fourier_overlapped(int dtype, hipStream_t s, const void *head, size_t n_head, const void *in, void *out,
+                              size_t n, size_t hop, size_t count, const void *window, const void *twiddle, bool center_dc);
 
 // ---- fused fast path (rr_fused.hip), Complex<f32> only ------------------------
 // v[m] = sum_i c[i] xs[e0 + D m - i]; xs = NCO-mixed input.  Virtual stream:
@@ -100,7 +104,7 @@ int launch_fused_fir(hipStream_t s, const FusedFirArgs &a);
 // 4096-point windowed forward DFT (radix 16 x 3); tw4096[k] = e^{-j 2 pi k / 4096}, 4096 entries
 // frames are cut from the stream [ head (n_head samples) | in ]
 int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
-                   const void *window, const void *tw4096, bool center_dc);
+                   const void *window, const void *tw4096, bool center_dc, size_t hop = 4096);
 int launch_drop_tail(hipStream_t s, const void *oldh, void *newh, size_t H, size_t drop);
 
 // Polyphase channelizer: frame f = FFT_M( sum_{p<P} w[r + M p] x[M (f0 + f) + r + M p] ), r < M,

@@ -100,3 +100,67 @@ def test_channelizer_device_batch_and_errors(rr, oracle):
         g.process(rr.Samples(1e9, x[: M + 1]))  # not whole chunks
     with pytest.raises(BackendError):
         rr.Channelizer(100, 4)  # bins must be a power of two
+
+
+def overlapped_spectra(oracle, chunks, P, window, center_dc, flt, history=None):
+    """Overlapper(P) + Fourier, chunk by chunk (chunks.rs:194-242, analysis.rs:60-132)."""
+    hist = [] if history is None else history
+    fo = oracle.Fourier(window, center_dc=center_dc, flt=flt)
+    out = []
+    for c in chunks:
+        hist.append(c)
+        if len(hist) >= P:
+            out.append(fo.process(np.concatenate(hist[-P:])))
+            del hist[: len(hist) - (P - 1)]
+    return out, hist
+
+
+@pytest.mark.parametrize("M,P,center,dtype,tol", [(1024, 4, False, np.float32, 1e-5), (256, 4, True, np.float32, 1e-5),
+                                                  (4096, 1, False, np.float32, 1e-5), (2048, 2, True, np.float32, 1e-5),
+                                                  (64, 8, False, np.float64, 1e-12), (512, 16, False, np.float32, 1e-5)])
+def test_stft_parity(rr, oracle, M, P, center, dtype, tol):
+    """rr_stft_*: Rechunker -> Overlapper -> Fourier on the device (4096-point spans run k_fft4096
+    with a hop, the others the generic power-of-two kernel) against the oracle composition."""
+    nchunks = 23
+    x = oracle.synth_iq(22, 0, M * nchunks)
+    if dtype == np.float64:
+        x = x.astype(np.complex128)
+    chunks = [x[i * M : (i + 1) * M] for i in range(nchunks)]
+    win = oracle.Kaiser.with_null_at_bin(2.0)
+    ref, _ = overlapped_spectra(oracle, chunks, P, win, center, np.float64)
+    g = rr.Stft(M, P, rr.Kaiser.with_null_at_bin(2.0), center_dc=center, dtype=dtype)
+    got = []
+    cuts = [0, 1, 2, 10, 11, 20, nchunks]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        got += g.process(rr.Samples(1e6, x[a * M : b * M]))
+    assert len(got) == len(ref) == max(nchunks - (P - 1), 0)
+    for a, b in zip(got, ref):
+        assert len(a.chunk) == M * P and rms_rel(a.chunk, b) <= tol
+
+
+def test_stft_event_resets_history(rr, oracle):
+    M, P = 256, 4
+    x = oracle.synth_iq(23, 0, M * 12)
+    chunks = [x[i * M : (i + 1) * M] for i in range(12)]
+    g = rr.Stft(M, P)
+    a = g.process(rr.Samples(1e6, x[: 5 * M]))
+    ev = rr.EventSignal(rr.Disconnection())
+    mid = g.process(ev)
+    assert len(mid) == 2 and mid[0].is_event() and mid[1] is ev  # SamplesLost first (chunks.rs:225-233)
+    b = g.process(rr.Samples(1e6, x[5 * M :]))
+    r1, _ = overlapped_spectra(oracle, chunks[:5], P, oracle.Rectangular(), False, np.float64)
+    r2, _ = overlapped_spectra(oracle, chunks[5:], P, oracle.Rectangular(), False, np.float64)
+    assert len(a) == len(r1) == 2 and len(b) == len(r2) == 4
+    for s, r in zip(a + b, r1 + r2):
+        assert rms_rel(s.chunk, r) <= 1e-5
+
+
+def test_stft_contract(rr):
+    from radiorust_amd._lib import BackendError, ContractViolation
+
+    with pytest.raises(ContractViolation):
+        rr.Stft(0, 4)
+    with pytest.raises(ContractViolation):
+        rr.Stft(64, 0)
+    with pytest.raises(BackendError):
+        rr.Stft(100, 3)  # 300 points: overlapping chunks need a power-of-two span
