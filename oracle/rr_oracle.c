@@ -9,6 +9,7 @@
 #include "rr_oracle.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 

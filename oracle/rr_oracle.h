@@ -119,6 +119,17 @@ typedef void (*rro_freq_resp_fn)(int64_t bin, double freq, double *out,
                                double quality, size_t fft_len,                \
                                const rro_window *fft_window, int center_dc,   \
                                FLT *out, size_t out_cap_frames);           \
+    /* the same with one thread per block and capacity-1 hand-off (messages  \
+     * of `batch` Filter chunks); spectra bit-equal to rro_chain_run's */     \
+    size_t rro_chain_run_mt_##SUF(const FLT *x, size_t n, double fs,          \
+                                  double precision, double shift,             \
+                                  size_t filter_len, rro_freq_resp_fn fn,     \
+                                  void *ud, const rro_window *filter_window,  \
+                                  double output_rate, double bandwidth,       \
+                                  double quality, size_t fft_len,             \
+                                  const rro_window *fft_window, int center_dc,\
+                                  FLT *out, size_t out_cap_frames,            \
+                                  size_t batch);                              \
     double rro_level_##SUF(const FLT *chunk, size_t n);                       \
     double rro_bandwidth_##SUF(double double_percentile, double sample_rate,  \
                                const FLT *bins, size_t n);                    \

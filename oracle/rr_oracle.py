@@ -136,6 +136,9 @@ def lib() -> C.CDLL:
         g("rro_chain_run").restype = sz
         g("rro_chain_run").argtypes = [vp, sz, d, d, d, sz, _RESPFN, vp, C.POINTER(_CWindow), d, d, d, sz,
                                        C.POINTER(_CWindow), C.c_int, vp, sz]
+        g("rro_chain_run_mt").restype = sz
+        g("rro_chain_run_mt").argtypes = [vp, sz, d, d, d, sz, _RESPFN, vp, C.POINTER(_CWindow), d, d, d, sz,
+                                          C.POINTER(_CWindow), C.c_int, vp, sz, sz]
     _lib = L
     return L
 
@@ -533,10 +536,13 @@ def run_chain(
 
 
 def run_chain_c(x, sample_rate, *, shift, precision=1.0, filter_len, freq_resp, filter_window=None, output_rate,
-                bandwidth, quality=3.0, fft_len, fft_window=None, center_dc=False, flt=np.float32, max_frames=None):
+                bandwidth, quality=3.0, fft_len, fft_window=None, center_dc=False, flt=np.float32, max_frames=None,
+                threads=1, batch=256):
     """Same wiring as run_chain, but the chunk loop runs in C (rro_chain_run):
     returns the spectra as an array [frames, fft_len].  With `max_frames` only
-    the first frames are kept (all the work is still done) — used for timing."""
+    the first frames are kept (all the work is still done) — used for timing.
+    threads=4: one thread per block with capacity-1 hand-off of `batch` Filter
+    chunks per message (rro_chain_run_mt); same spectra, bit for bit."""
     suf, cdt, _ = _dt(flt)
     x = _cin(x, cdt)
     fw = filter_window if filter_window is not None else Kaiser.with_null_at_bin(2.0)
@@ -552,10 +558,15 @@ def run_chain_c(x, sample_rate, *, shift, precision=1.0, filter_len, freq_resp, 
     cap = min(cap, x.size // int(fft_len) + 1)
     out = np.empty((cap, int(fft_len)), dtype=cdt)
     cfw, cffw = fw._c(), ffw._c()
-    frames = getattr(lib(), f"rro_chain_run_{suf}")(
-        x.ctypes.data, x.size, float(sample_rate), float(precision), float(shift), int(filter_len), cfn, None,
-        C.byref(cfw), float(output_rate), float(bandwidth), float(quality), int(fft_len), C.byref(cffw),
-        int(bool(center_dc)), out.ctypes.data, cap)
+    args = (x.ctypes.data, x.size, float(sample_rate), float(precision), float(shift), int(filter_len), cfn, None,
+            C.byref(cfw), float(output_rate), float(bandwidth), float(quality), int(fft_len), C.byref(cffw),
+            int(bool(center_dc)), out.ctypes.data, cap)
+    if int(threads) == 4:
+        frames = getattr(lib(), f"rro_chain_run_mt_{suf}")(*args, int(batch))
+    elif int(threads) == 1:
+        frames = getattr(lib(), f"rro_chain_run_{suf}")(*args)
+    else:
+        raise ValueError("threads must be 1 or 4 (one per block)")
     if frames == C.c_size_t(-1).value:
         raise AssertionError("chain contract violated")
     return out[: min(frames, cap)], frames

@@ -245,3 +245,17 @@ def test_synth_iq_is_counter_based(oracle):
     X = np.abs(np.fft.fft(oracle.synth_iq(1, 0, 4096)))
     top = set(np.argsort(X)[-2:].tolist())
     assert top == {4096 // 16, 4096 - 3 * 4096 // 32}
+
+
+def test_threaded_chain_runner_is_bit_equal(oracle):
+    """rro_chain_run_mt (one thread per block, capacity-1 hand-off, the CPU baseline of bench.py)
+    produces the spectra of the single-threaded runner bit for bit, for several message sizes."""
+    lp = lambda _b, f: 1.0 if abs(f) <= 20e6 else 0.0  # noqa: E731
+    kw = dict(shift=25e6, filter_len=64, freq_resp=lp, output_rate=50e6, bandwidth=40e6, fft_len=4096,
+              fft_window=oracle.Kaiser.with_null_at_bin(2.0), flt=np.float32)
+    x = oracle.synth_iq(1, 0, (1 << 18) + 100)
+    a, fa = oracle.run_chain_c(x, 200e6, **kw)
+    assert fa == 15
+    for batch in (1, 7, 256):
+        b, fb = oracle.run_chain_c(x, 200e6, threads=4, batch=batch, **kw)
+        assert fb == fa and np.array_equal(a, b)
