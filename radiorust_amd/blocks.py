@@ -462,7 +462,7 @@ class Chain(_Block):
         """Name of the mix + FIR + decimate kernel the last call ran ("" = block-by-block)."""
         v = C.c_int()
         _lib.check(_lib.lib().rr_chain_last_path(self._h, C.byref(v)))
-        return ["", "k_mix_fir_decim", "k_ols_decim4", "k_ols_wave"][v.value]
+        return ["", "k_mix_fir_decim", "k_ols_decim4", "k_ols_wave", "k_ols_frame"][v.value]
 
     def process(self, signal):
         if signal.is_event():

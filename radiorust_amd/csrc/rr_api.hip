@@ -657,7 +657,7 @@ bool rr_chain::fused_candidate(double sample_rate) const {
     if (!fl->designed) return false;
     if (!ds->have_rate || ds->prev_rate != sample_rate || !ds->sched.integer_ratio) return false;
     const size_t lc = ds->L + fl->n - 1;
-    return pick_fused_kernel(ds->sched.D, lc, fl->real_taps) != FK_NONE;
+    return pick_fused_kernel(ds->sched.D, lc, fl->real_taps, p.fft_len) != FK_NONE;
 }
 
 int rr_chain::ensure_xh() {
@@ -678,17 +678,22 @@ int rr_chain::ensure_xh() {
 //   direct  k_mix_fir_decim  direct form, real taps, D in {2, 4, 8}; cost ~ Lc           0.222 ms
 //   ols     k_ols_decim4     overlap-save, workgroup per 4096-block, D = 4, any taps       0.21 ms
 //   olsw    k_ols_wave       overlap-save, wave per 1024-block, D = 4, any taps, Lc <= 513 0.144 ms
-// Unforced, olsw runs where it applies unless the filter is so short (Lc < 112) that the direct
-// form is at its load/store floor anyway.  RR_FUSED_KERNEL = direct | ols | olsw forces one of
+//   olsf    k_ols_frame      olsw's blocks + the 4096-point Fourier stage in one kernel (a workgroup
+//                            per frame), D = 4, 129 <= Lc <= 193, fft_len = 4096; 0.233 ms for BOTH
+//                            stages against olsw + k_fft4096 = 0.207: on request only
+// Unforced: olsw unless the filter is so short (Lc < 112) that the direct form is at its load/store
+// floor anyway.  RR_FUSED_KERNEL = direct | ols | olsw | olsf forces one of
 // them where it applies (A/B runs and tests).
-int rr_chain::pick_fused_kernel(uint64_t D, size_t lc, bool real_taps) {
+int rr_chain::pick_fused_kernel(uint64_t D, size_t lc, bool real_taps, size_t fft_len) {
     const bool can_direct = real_taps && fused_fir_supported(D, lc);
     const bool can_ols = ols_decim_supported(D, lc), can_wave = ols_wave_supported(D, lc);
+    const bool can_frame = can_wave && ols_frame_supported(D, lc, fft_len);
     const char *e = std::getenv("RR_FUSED_KERNEL");
     if (e) {
         if (!std::strcmp(e, "direct") && can_direct) return FK_DIRECT;
         if (!std::strcmp(e, "ols") && can_ols) return FK_OLS;
         if (!std::strcmp(e, "olsw") && can_wave) return FK_OLSW;
+        if (!std::strcmp(e, "olsf") && can_frame) return FK_OLSF;
     }
     if (can_wave && (lc >= 112 || !can_direct)) return FK_OLSW;
     if (can_direct) return FK_DIRECT;
@@ -711,8 +716,9 @@ int rr_chain::ensure_ctaps() {
             cc[j + k] += a * (fl->real_taps ? cd(fl->taps_f64[k].real(), 0.0) : fl->taps_f64[k]);
         }
     }
-    const int fk = pick_fused_kernel(ds->sched.D, lc, fl->real_taps);
-    const bool wave = fk == FK_OLSW;
+    const int fk = pick_fused_kernel(ds->sched.D, lc, fl->real_taps, p.fft_len);
+    const bool wave = fk == FK_OLSW || fk == FK_OLSF;
+    use_frame = fk == FK_OLSF;
     use_ols = wave || fk == FK_OLS;
     if (use_ols) {
         // H = DFT_N(c) / N (the inverse transform in the kernel is unnormalised)
@@ -835,6 +841,37 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     a.e0 = (int64_t)ds->sched.first_emit() - (int64_t)carry_len;
     a.D = (uint32_t)ds->sched.D;
     a.xh_out = xh[xh_cur ^ 1].p;  // written by the kernel's last workgroup
+    if (use_frame && n_in >= 1024) {  // (shorter calls: k_ols_wave + k_fft4096 below)
+        // one kernel: FIR stage + Fourier; the decimated samples stay on chip, only the unfinished
+        // frame goes to a small pending buffer
+        if (nfr * LF > cap) RR_FAIL(RR_ERR_CAPACITY, "Chain: out_cap %zu < %zu", cap, nfr * LF);
+        RR_TRY(fo->prepare(LF));
+        RR_TRY(pendbuf[0].reserve(LF * esz));
+        RR_TRY(pendbuf[1].reserve(LF * esz));
+        const void *pin = pend_ptr ? pend_ptr : pending.p;
+        const int po = (pin == pendbuf[pb_cur ^ 1].p) ? pb_cur : (pb_cur ^ 1);
+        a.H = d_olsH.p;
+        a.tw4096 = d_tw4096.p;
+        a.V = ols_V;
+        const int tkf = timers.begin(ST_FUSED_FIR, stream);
+        RR_TRY(launch_ols_frame(stream, a, pin, pending_len, pendbuf[po].p, d_out, fo->d_window.p, fo->d_tw.p,
+                                fo->center_dc));
+        timers.end(tkf, stream);
+        xh_cur ^= 1;
+        if (left) RR_HIP(hipMemcpyAsync(carry.p, xh[xh_cur].as<char>() + (HX - left) * esz, left * esz, hipMemcpyDeviceToDevice, stream));
+        const uint64_t den0 = (uint64_t)fs->denom;
+        fs->phase_idx = (fs->phase_idx + n_in % den0) % den0;
+        carry_len = left;
+        ds->sched.advance(whole, nullptr);
+        zrun += whole;
+        blocks_stale = true;
+        pend_ptr = pendbuf[po].p;
+        pb_cur = po;
+        pending_len = rest;
+        last_fused = FK_OLSF;
+        if (n_out) *n_out = nfr * LF;
+        return RR_OK;
+    }
     char *newv = nullptr;
     char *dbase = nullptr;
     if (split) {

@@ -188,8 +188,11 @@ struct rr_chain : rr_block {
     int ols_N = 4096;  // 4096: k_ols_decim4 (workgroup per block), 1024: k_ols_wave (wave per block)
     rr::DevBuf d_olsH, d_tw4096;
     bool fused_candidate(double sample_rate) const;
-    enum { FK_NONE = 0, FK_DIRECT, FK_OLS, FK_OLSW };
-    static int pick_fused_kernel(uint64_t D, size_t lc, bool real_taps);
+    enum { FK_NONE = 0, FK_DIRECT, FK_OLS, FK_OLSW, FK_OLSF };
+    static int pick_fused_kernel(uint64_t D, size_t lc, bool real_taps, size_t fft_len);
+    bool use_frame = false;      // FK_OLSF: k_ols_frame (FIR stage + Fourier in one kernel)
+    rr::DevBuf pendbuf[2];       // its pending decimated samples, ping-pong
+    int pb_cur = 0;
     int ensure_xh();
     int ensure_ctaps();
     int materialize();  // bring the per-block histories up to date after fused calls

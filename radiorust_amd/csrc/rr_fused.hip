@@ -923,9 +923,9 @@ __device__ __forceinline__ void twiddle16(f2 (&v)[16], f2 w) {
 // Every access pattern below is (lane term) + (compile-time offset), spelled out so that the
 // offsets land in the instructions' immediate fields instead of per-access address arithmetic.
 #ifndef RR_V_WAVELDS
-#define RR_V_WAVELDS 1200
+#define RR_V_WAVELDS 1176
 #endif
-constexpr int kWaveLds = RR_V_WAVELDS;  // A(1023) + 1 = 1198, rounded
+constexpr int kWaveLds = RR_V_WAVELDS;  // A(1023) + 1 = 1174, rounded up to a multiple of 8
 
 __device__ __forceinline__ void wave_sync() {
     // all 64 lanes of the only wave: order LDS writes before the following reads
@@ -1326,6 +1326,414 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
         }
 #endif
     }
+}
+
+// ---------------------------------------------------------------------------
+// Kernel 3f  k_ols_frame: k_ols_wave's blocks + the Fourier stage in one kernel, one workgroup
+// (4 waves) per 4096-sample frame of the decimated stream.  MEASURED SLOWER than the two separate
+// kernels (0.233 ms against 0.143 + 0.052 + gaps = 0.207 ms per 2^26 samples) and therefore only
+// run on request (RR_FUSED_KERNEL=olsf): the 32 KiB frame buffer on top of the wave images leaves
+// room for 8 waves per CU instead of 16, and a block is a 14 k-cycle dependent chain.  Kept as the
+// documented experiment and as a parity case.  The decimated samples never
+// touch HBM: the waves drop their blocks' outputs into a 32 KiB frame buffer in LDS, then four
+// of them run the windowed DFT_4096 of k_fft4096 on it.  Per input sample that removes the
+// 2 B written + 2 B read in between (and one launch); HBM sees 8 B in, 2 B out.
+//
+// Frame f of a call covers the decimated samples [4096 f - pl, 4096 (f + 1) - pl), pl = samples
+// pending from the previous call (the first pl entries of frame 0 come from `pend_in`).  It is
+// covered by 20 blocks of 208 outputs (4160 >= 4096; the 64 surplus outputs are the price, 1.6 %),
+// wave w takes blocks w, w + 4, ..  Workgroup `nfr` (the frame that does not
+// fill) writes its samples to `pend_out` instead of transforming them, and leaves the mixed-sample
+// history for the next call.
+// ---------------------------------------------------------------------------
+int ols_wave_overlap(size_t Lc);
+#ifndef RR_V_FRAMEWAVES
+#define RR_V_FRAMEWAVES 4  // measured: 4 waves 0.233 ms, 5 waves 0.30 (one workgroup per CU), 8 waves 0.26, 10 waves 0.28
+#endif
+constexpr int kFrameWaves = RR_V_FRAMEWAVES, kFrameBlocks = 20;
+
+// the transforms of one 1024-sample block: v = mixed samples in the pair layout of k_ols_wave;
+// y[c] = result[l + 64 c] of the 256-point inverse (see k_ols_wave for the passes)
+__device__ __forceinline__ void wave_block_transform(f2 (&v)[16], f2 (&y)[4], f2 *lds, int l, f2 t_p1,
+                                                     const f2 (&t_p2)[2], const f2 (&t_inv)[3],
+                                                     const float2 (&hv)[16]) {
+    const int g = l >> 4, q = l & 15;
+    f2 *const a_rd = lds + (l + 2 * g);
+    f2 *const b_rd = lds + (l + 4 * g);
+    {
+        f2 e0[8], e1[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            e0[k] = v[2 * k];
+            e1[k] = v[2 * k + 1];
+        }
+        dft8(e0);
+        dft8(e1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = e0[k];
+            v[8 + k] = e1[k];
+        }
+    }
+    wave_sync();  // the previous block's last reads of image B are done
+    {
+        f2 *row = lds + (18 * l + 8 * g);
+#pragma unroll
+        for (int k = 0; k < 16; k += 2)
+            *reinterpret_cast<float4 *>(row + k) = (float4){v[k].x, v[k].y, v[k + 1].x, v[k + 1].y};
+    }
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = a_rd[72 * (k & 3) + 296 * (k >> 2)];
+    twiddle16(v, t_p1);
+    dft16(v);
+    wave_sync();
+    {
+        f2 *col = lds + (144 * (l >> 3) + 8 * (l >> 4) + (l & 7));
+#pragma unroll
+        for (int k = 0; k < 16; ++k) col[8 * k + 2 * (k >> 1)] = v[k];
+    }
+    wave_sync();
+    f2 X[16];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        f2 a[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a[c] = a_rd[72 * m + 144 * c + 8 * (c >> 1)];
+        const f2 w1 = t_p2[m];
+        const f2 w2 = cmul(w1, w1);
+        const f2 w3 = cmul(w2, w1);
+        const f2 w4 = cmul(w2, w2);
+        a[1] = cmul(a[1], w1);
+        a[2] = cmul(a[2], w2);
+        a[3] = cmul(a[3], w3);
+        a[4] = cmul(a[4], w4);
+        a[5] = cmul(a[5], cmul(w4, w1));
+        a[6] = cmul(a[6], cmul(w4, w2));
+        a[7] = cmul(a[7], cmul(w4, w3));
+        dft8(a);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) X[m + 2 * c] = a[c];
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        f2 acc = cmul(X[m], (f2){hv[m].x, hv[m].y});
+        acc = cmac(acc, X[m + 4], (f2){hv[m + 4].x, hv[m + 4].y});
+        acc = cmac(acc, X[m + 8], (f2){hv[m + 8].x, hv[m + 8].y});
+        acc = cmac(acc, X[m + 12], (f2){hv[m + 12].x, hv[m + 12].y});
+        y[m] = acc;
+    }
+    idft4(y[0], y[1], y[2], y[3]);
+    wave_sync();
+    {
+        f2 *row = lds + (4 * l + 4 * (l >> 2));
+        *reinterpret_cast<float4 *>(row) = (float4){y[0].x, y[0].y, y[1].x, y[1].y};
+        *reinterpret_cast<float4 *>(row + 2) = (float4){y[2].x, y[2].y, y[3].x, y[3].y};
+    }
+    wave_sync();
+#pragma unroll
+    for (int pass = 1; pass < 4; ++pass) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) y[c] = b_rd[80 * c];
+        const f2 w1 = t_inv[pass - 1];
+        const f2 w2 = cmul(w1, w1);
+        const f2 w3 = cmul(w2, w1);
+        y[1] = cmul_conj(y[1], w1);
+        y[2] = cmul_conj(y[2], w2);
+        y[3] = cmul_conj(y[3], w3);
+        idft4(y[0], y[1], y[2], y[3]);
+        if (pass == 3) break;
+        wave_sync();
+        if (pass == 1) {
+            f2 *col = lds + (20 * (l >> 2) + (l & 3));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) col[4 * c] = y[c];
+        } else {
+            f2 *col = lds + (80 * g + q);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) col[20 * c] = y[c];
+        }
+        wave_sync();
+    }
+}
+
+struct FrameArgs {
+    const float2 *xh;       // mixed-sample history (hx samples, ends right before in[0])
+    int hx;
+    const float2 *in;
+    long n_in;
+    const float2 *nco;      // denom + 1 entries
+    unsigned denom, idx0;
+    const float2 *H;        // pair-interleaved, as for k_ols_wave
+    const float2 *tw;       // 1024 twiddles + packed lane seeds
+    int V;                  // 192 (per_block = 208 is compiled in through kFrameBlocks)
+    long e0;                // input position of decimated sample 0 of this call
+    long n_dec;             // decimated samples this call produces
+    const float2 *pend_in;  // pl samples pending from the previous call
+    int pl;
+    float2 *pend_out;       // receives the (pl + n_dec) mod 4096 samples left over
+    float2 *spectra;        // (pl + n_dec) / 4096 frames of 4096 bins
+    const float *window;    // Fourier window, 4096
+    const float2 *tw4096;   // e^{-j 2 pi k / 4096}
+    int center_dc;
+    float2 *xh_out;
+    unsigned ph0;           // (idx0 + e0 - V - 4 pl) mod denom
+    unsigned kstep;         // 128 mod denom
+    double inv_denom;
+    unsigned nfr;           // full frames
+};
+
+#ifndef RR_V_FRAMEOCC
+#define RR_V_FRAMEOCC 4
+#endif
+__global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_eu(RR_V_FRAMEOCC, RR_V_FRAMEOCC))) void k_ols_frame(FrameArgs a_) {
+    // The fields used once per workgroup (pending buffers, spectra, window ..) are re-read from the
+    // kernel-argument segment where they are needed: held in SGPRs through the block loop they push
+    // the kernel one VGPR (of spilled SGPRs) over the 128 that two 5-wave workgroups per CU need.
+    const FrameArgs &a = a_;
+    const FrameArgs *ka = (const FrameArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    __shared__ __attribute__((aligned(16))) f2 fr[4096 + 64];               // the frame (+ the surplus of block 19)
+    __shared__ __attribute__((aligned(16))) f2 img[kFrameWaves * kWaveLds];  // wave images; then the DFT_4096 image
+    static_assert(kFrameWaves * kWaveLds >= 4096 + 256, "the DFT_4096 image must fit the wave images");
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    // frames dealt so that an XCD owns a contiguous range (grid: multiple of 8)
+    const unsigned per_xcd = gridDim.x >> 3;
+    const unsigned f = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (f > a.nfr) return;
+    const bool tail = f == a.nfr;  // the frame that does not fill: goes to pend_out
+    const long F0 = 4096l * f - a.pl;  // decimated index (of this call) of the frame's first sample
+    const int hop = 1024 - a.V, per_block = hop >> 2, first = a.V >> 2;
+
+    if (tail && ka->xh_out) {  // mixed-sample history for the next call
+        const int hxe = ka->hx;
+        for (int i = tid; i < hxe; i += 64 * kFrameWaves) {
+            const long pos = a.n_in - hxe + i;
+            float2 v;
+            if (pos >= 0) {
+                const float2 xx = a.in[pos];
+                const float2 pp = a.nco[(unsigned)(((long)ka->idx0 + pos) % (long)a.denom)];
+                v.x = xx.x * pp.x - xx.y * pp.y;
+                v.y = xx.x * pp.y + xx.y * pp.x;
+            } else {
+                v = (pos >= -(long)hxe) ? ka->xh[hxe + pos] : float2{0.f, 0.f};
+            }
+            ka->xh_out[i] = v;
+        }
+    }
+    // the part of frame 0 that was pending
+    if (f == 0)
+        for (int i = tid; i < a.pl; i += 64 * kFrameWaves) {
+            const float2 p = ka->pend_in[i];
+            fr[i] = (f2){p.x, p.y};
+        }
+
+    // lane constants (as in k_ols_wave)
+    f2 t_p1, t_p2[2], t_inv[3];
+    {
+        const float4 *tl = reinterpret_cast<const float4 *>(a.tw + 1024) + l;
+        const float4 s0 = tl[0], s1 = tl[64], s2 = tl[128];
+        t_p1 = (f2){s0.x, s0.y};
+        t_p2[0] = (f2){s0.z, s0.w};
+        t_p2[1] = (f2){s1.x, s1.y};
+        t_inv[0] = (f2){s1.z, s1.w};
+        t_inv[1] = (f2){s2.x, s2.y};
+        t_inv[2] = (f2){s2.z, s2.w};
+    }
+    f2 *const lds = img + w * kWaveLds;
+    size_t zoff = 0;
+
+    // The next block's samples are requested while the current block is transformed (a block alone
+    // is 14 k cycles of which 7 k wait for its samples, and a CU holds only 10 of these waves).  The
+    // request is unconditional - a conditional one would turn every later wait for an H value into a
+    // wait for it (see k_ols_wave) - so the last of a wave's four blocks asks for its own samples
+    // again (an L2 hit), and blocks outside the call's range run on clamped addresses with their
+    // results masked.
+    const long n_clamp = a.n_in - 1024;  // the launcher guarantees n_in >= 1024
+    auto block_b0 = [&](int jb) { return a.e0 - a.V + 4 * (F0 + (long)per_block * jb); };
+    auto clampb = [&](long b) { return b < 0 ? 0 : (b > n_clamp ? n_clamp : b); };
+#ifndef RR_V_FRAMEPF
+#define RR_V_FRAMEPF 0  // 1: request the next block's samples while the current block is transformed
+#endif
+    f4u x[8];
+#if RR_V_FRAMEPF
+    {
+        const f4u *src = reinterpret_cast<const f4u *>(a.in + clampb(block_b0(w))) + l;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = RR_WAVE_LDX(src + 64 * k);
+    }
+#endif
+    for (int jb = w; jb < kFrameBlocks; jb += kFrameWaves) {
+        asm volatile("" : "+v"(t_p1), "+v"(t_p2[0]), "+v"(t_p2[1]), "+v"(t_inv[0]), "+v"(t_inv[1]), "+v"(t_inv[2]));
+        asm volatile("" : "+s"(zoff));
+        const long b0 = block_b0(jb);
+        // phase of the lane's first sample: (idx0 + b0 + 2 l) mod denom, b0 = const + 4 (4096 f + 208 jb)
+        unsigned r;
+        {
+            const double dn = (double)a.denom;
+            const double prod = (double)a.ph0 + 16384.0 * (double)f + (double)(4 * per_block * jb);
+            const double qd = __builtin_floor(prod * a.inv_denom);
+            double rd = __builtin_fma(-qd, dn, prod);
+            if (rd < 0.0) rd += dn;
+            if (rd >= dn) rd -= dn;
+            r = (unsigned)rd + 2u * (unsigned)l;
+            if (a.denom >= 128u) {
+                if (r >= a.denom) r -= a.denom;
+            } else if ((a.denom & (a.denom - 1u)) == 0u) {
+                r &= a.denom - 1u;
+            } else {
+                r %= a.denom;
+            }
+        }
+        f2 v[16];
+        if (b0 >= 0 && b0 <= n_clamp) {
+#if !RR_V_FRAMEPF
+            {
+                const f4u *src = reinterpret_cast<const f4u *>(a.in + b0) + l;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) x[k] = RR_WAVE_LDX(src + 64 * k);
+            }
+#endif
+            if (a.kstep == 0) {
+                const f4u pp = *reinterpret_cast<const f4u *>(a.nco + r);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v[2 * k] = cmul((f2){x[k].x, x[k].y}, (f2){pp.x, pp.y});
+                    v[2 * k + 1] = cmul((f2){x[k].z, x[k].w}, (f2){pp.z, pp.w});
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const f4u pp = *reinterpret_cast<const f4u *>(a.nco + r);
+                    v[2 * k] = cmul((f2){x[k].x, x[k].y}, (f2){pp.x, pp.y});
+                    v[2 * k + 1] = cmul((f2){x[k].z, x[k].w}, (f2){pp.z, pp.w});
+                    r += a.kstep;
+                    if (r >= a.denom) r -= a.denom;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const f4u pp = *reinterpret_cast<const f4u *>(a.nco + r);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const long pos = b0 + 2 * l + j + 128 * k;
+                    const bool inr = pos >= 0 && pos < a.n_in;
+                    const int hxe = ka->hx;
+                    const bool hst = pos < 0 && pos >= -(long)hxe;
+                    const float2 *ptr = inr ? a.in + pos : ka->xh + (hst ? hxe + pos : 0);
+                    const float2 xx = *ptr;
+                    const f2 p = j ? (f2){pp.z, pp.w} : (f2){pp.x, pp.y};
+                    const f2 pk = {inr ? p.x : (hst ? 1.f : 0.f), inr ? p.y : 0.f};
+                    const f2 xv = {(inr || hst) ? xx.x : 0.f, (inr || hst) ? xx.y : 0.f};
+                    v[2 * k + j] = cmul(xv, pk);
+                }
+                r += a.kstep;
+                if (r >= a.denom) r -= a.denom;
+            }
+        }
+        float2 hv[16];
+#pragma unroll
+        for (int kp = 0; kp < 8; ++kp) {
+            const float4 h4 = reinterpret_cast<const float4 *>(a.H + zoff)[l + 64 * kp];
+            hv[2 * kp] = float2{h4.x, h4.y};
+            hv[2 * kp + 1] = float2{h4.z, h4.w};
+        }
+#if RR_V_FRAMEPF
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int jn = jb + kFrameWaves < kFrameBlocks ? jb + kFrameWaves : jb;
+            const f4u *src = reinterpret_cast<const f4u *>(a.in + clampb(block_b0(jn))) + l;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = RR_WAVE_LDX(src + 64 * k);
+        }
+#endif
+        f2 y[4];
+        wave_block_transform(v, y, lds, l, t_p1, t_p2, t_inv, hv);
+        // valid results tau = l + 64 c >= first; frame-relative index i = per_block * jb + tau - first
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int tau = l + 64 * c;
+            const int i = per_block * jb + tau - first;
+            const long m = F0 + i;
+            if (tau >= first && m >= 0 && m < a.n_dec) fr[i] = y[c];
+        }
+    }
+    __syncthreads();
+    asm volatile("" : "+s"(ka));  // not earlier
+    if (tail) {
+        const long have = a.pl + a.n_dec - 4096l * a.nfr;  // samples of the unfinished frame
+        for (int i = tid; i < have; i += 64 * kFrameWaves) {
+            float2 o;
+            o.x = fr[i].x;
+            o.y = fr[i].y;
+            ka->pend_out[i] = o;
+        }
+        return;
+    }
+    if (tid >= 256) return;  // (kFrameWaves >= 4)
+    // ---- Fourier: window, DFT_4096 (radix 16 x 3 as k_fft4096), optional DC centring ---------------
+    f2 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float wv = ka->window[tid + 256 * k];
+        const f2 s = fr[tid + 256 * k];
+        v[k] = (f2){s.x * wv, s.y * wv};
+    }
+    fft4096_regs(v, img, ka->tw4096, tid);
+    float2 *dst = ka->spectra + (size_t)f * 4096;
+    const int rot = ka->center_dc ? 2048 : 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        float2 o;
+        o.x = v[k].x;
+        o.y = v[k].y;
+        dst[(tid + 256 * k + rot) & 4095] = o;
+    }
+}
+
+bool ols_frame_supported(uint64_t D, size_t Lc, size_t fft_len) {
+    return D == 4 && fft_len == 4096 && Lc >= 1 && ols_wave_overlap(Lc) == 192;  // 208 outputs per block compiled in
+}
+
+int launch_ols_frame(hipStream_t s, const FusedFirArgs &a, const void *pend_in, size_t pl, void *pend_out, void *spectra,
+                     const void *window, const void *tw4096, bool center_dc) {
+    if (a.V != 192) RR_FAIL(RR_ERR_BAD_ARG, "fused frame kernel: overlap %d not instantiated", a.V);
+    const size_t total = pl + a.n_out, nfr = total / 4096;
+    if (total == 0) return RR_OK;
+    if (a.n_in < 1024) RR_FAIL(RR_ERR_BAD_ARG, "fused frame kernel: needs at least 1024 input samples per call");
+    if (nfr > 0x7ffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "fused frame kernel: too many frames");
+    FrameArgs f;
+    f.xh = (const float2 *)a.xh;
+    f.hx = (int)a.hx;
+    f.in = (const float2 *)a.in;
+    f.n_in = (long)a.n_in;
+    f.nco = (const float2 *)a.nco;
+    f.denom = a.denom;
+    f.idx0 = a.idx0;
+    f.H = (const float2 *)a.H;
+    f.tw = (const float2 *)a.tw4096;  // the 1024-entry table + lane seeds (FusedFirArgs field name)
+    f.V = a.V;
+    f.e0 = (long)a.e0;
+    f.n_dec = (long)a.n_out;
+    f.pend_in = (const float2 *)pend_in;
+    f.pl = (int)pl;
+    f.pend_out = (float2 *)pend_out;
+    f.spectra = (float2 *)spectra;
+    f.window = (const float *)window;
+    f.tw4096 = (const float2 *)tw4096;
+    f.center_dc = center_dc ? 1 : 0;
+    f.xh_out = (float2 *)a.xh_out;
+    const int64_t den = (int64_t)a.denom;
+    int64_t ph = ((int64_t)a.idx0 + a.e0 - a.V - 4 * (int64_t)pl) % den;
+    if (ph < 0) ph += den;
+    f.ph0 = (unsigned)ph;
+    f.kstep = (unsigned)(128 % den);
+    f.inv_denom = 1.0 / (double)den;
+    f.nfr = (unsigned)nfr;
+    const unsigned grid = (unsigned)((nfr + 1 + 7) / 8 * 8);
+    hipLaunchKernelGGL(k_ols_frame, dim3(grid), dim3(64 * kFrameWaves), 0, s, f);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
 }
 
 int ols_wave_overlap(size_t Lc) {  // V: multiple of 64 covering the Lc - 1 wrapped samples

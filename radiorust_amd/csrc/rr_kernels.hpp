@@ -98,6 +98,12 @@ int launch_ols_decim(hipStream_t s, const FusedFirArgs &a);
 bool ols_wave_supported(uint64_t D, size_t Lc);
 int ols_wave_overlap(size_t Lc);
 int launch_ols_wave(hipStream_t s, const FusedFirArgs &a);
+// k_ols_frame: the same stage + the 4096-point Fourier stage in one kernel (a workgroup per frame of the
+// decimated stream; H / tw4096 fields as for launch_ols_wave).  pend_in: pl decimated samples pending from
+// the previous call; pend_out receives the (pl + n_out) mod 4096 left over; spectra: (pl + n_out) / 4096 frames.
+bool ols_frame_supported(uint64_t D, size_t Lc, size_t fft_len);
+int launch_ols_frame(hipStream_t s, const FusedFirArgs &a, const void *pend_in, size_t pl, void *pend_out, void *spectra,
+                     const void *window, const void *tw4096, bool center_dc);
 bool fused_fir_supported(uint64_t D, size_t Lc);
 int fused_fir_R(uint64_t D);  // outputs per lane of the instantiation for D
 int launch_fused_fir(hipStream_t s, const FusedFirArgs &a);

@@ -30,7 +30,7 @@ for r in range(rounds):
         d = json.loads(line[0])
         k = d["kernels"]
         res[l]["fir"].append(k.get("fused_mix_fir_decim", {}).get("avg_ms", float("nan")))
-        res[l]["fft"].append(k.get("fourier", {}).get("avg_ms", float("nan")))
+        res[l]["fft"].append(k.get("fourier", {}).get("avg_ms", 0.0))
         res[l]["step"].append(d["ms_per_step"])
 for l in libs:
     f = res[l]

@@ -204,7 +204,7 @@ def test_chain_complex_response(rr, oracle, allow_fused):
         assert g.last_path_fused()
 
 
-@pytest.mark.parametrize("kernel", ["ols", "olsw", "direct"])
+@pytest.mark.parametrize("kernel", ["ols", "olsw", "olsf", "direct"])
 def test_chain_overlap_save_kernel_forced(rr, oracle, monkeypatch, kernel):
     """RR_FUSED_KERNEL selects the fused FIR implementation: overlap-save with a workgroup per
     4096-block (ols), with a wave per 1024-block (olsw), or the direct form (direct)."""
@@ -217,7 +217,7 @@ def test_chain_overlap_save_kernel_forced(rr, oracle, monkeypatch, kernel):
     for a, b in ((0, 70001), (70001, 200000), (200000, n)):
         out += g.process(rr.Samples(fs, x[a:b]))
     assert g.last_path_fused() and len(out) == 15
-    assert g.last_path_kernel() == {"ols": "k_ols_decim4", "olsw": "k_ols_wave", "direct": "k_mix_fir_decim"}[kernel]
+    assert g.last_path_kernel() == {"ols": "k_ols_decim4", "olsw": "k_ols_wave", "olsf": "k_ols_frame", "direct": "k_mix_fir_decim"}[kernel]
     for a, b in zip(out, t64):
         assert rms_rel(a.chunk, b) <= 1e-5
 
@@ -245,7 +245,7 @@ def test_chain_wave_kernel_randomised(rr, oracle, seed):
     fused_calls = 0
     for a, b in zip(cuts[:-1], cuts[1:]):
         out += g.process(rr.Samples(fs, x[a:b]))
-        fused_calls += g.last_path_kernel() == "k_ols_wave"
+        fused_calls += g.last_path_kernel() in ("k_ols_wave", "k_ols_frame")
     assert len(out) == len(t64) and len(out) >= 7
     assert fused_calls >= 2, (cuts, fused_calls)
     for a, b in zip(out, t64):
