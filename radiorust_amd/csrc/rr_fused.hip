@@ -937,6 +937,9 @@ __device__ __forceinline__ void wave_sync() {
 #ifndef RR_V_WAVEWG
 #define RR_V_WAVEWG 1  // independent waves (blocks) per workgroup (LOOP = false only)
 #endif
+#ifndef RR_V_WAVERUN
+#define RR_V_WAVERUN 0  // persistent form: 0 = round-robin blocks with prefetch; R > 0 = runs of R neighbouring blocks, tables loaded once
+#endif
 #ifndef RR_V_WAVEOCCL
 #define RR_V_WAVEOCCL 3  // waves per SIMD of the persistent form (register budget 512 / n)
 #endif
@@ -984,12 +987,21 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
         // neighbours in memory, as with one block per wave.  Contiguous runs per wave were measured
         // slower (0.146 vs 0.128 ms for the bare load/store loop): 3072 separate streams.
         const unsigned wpx = gridDim.x >> 3, xcd = blockIdx.x & 7, i = blockIdx.x >> 3;  // grid: multiple of 8
+#if RR_V_WAVERUN > 0
+        // run mode: RR_V_WAVERUN neighbouring blocks per wave, H and the seeds loaded once per run
+        // (fewer vector-memory instructions per block), no prefetch
+        blk = (xcd * wpx + i) * RR_V_WAVERUN;
+        bstride = 1;
+        if (blk >= nblocks) return;
+        cnt = nblocks - blk < RR_V_WAVERUN ? nblocks - blk : RR_V_WAVERUN;
+#else
         const unsigned per_xcd = (nblocks + 7) >> 3;
         const unsigned lo = xcd * per_xcd, hi = lo + per_xcd < nblocks ? lo + per_xcd : nblocks;
         blk = lo + i;
         bstride = wpx;
         if (blk >= hi) return;
         cnt = (hi - blk + wpx - 1) / wpx;
+#endif
     } else {
         const unsigned per_xcd = (nblocks + 7) >> 3;
         const unsigned within = (blockIdx.x >> 3) * RR_V_WAVEWG + (threadIdx.x >> 6);
@@ -1039,7 +1051,8 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
     // (measured), so everything comes in 16-byte pieces: lane l takes the sample pairs
     // x[2 l + 128 k' .. + 1], k' < 8, and its 6 twiddle seeds as 3 packed entries.
     f4u x[8];
-    if (LOOP || (b0 >= 0 && b0 + 1024 <= n_in)) {
+    constexpr bool PF = LOOP && RR_V_WAVERUN == 0;  // prefetching form
+    if (PF || (!LOOP && b0 >= 0 && b0 + 1024 <= n_in)) {
         const long bs = !LOOP ? b0 : (b0 < 0 ? 0 : (b0 > n_in - 1024 ? n_in - 1024 : b0));
         const f4u *src = reinterpret_cast<const f4u *>(in + bs) + l;
 #pragma unroll
@@ -1061,9 +1074,27 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
     f2 *const a_rd = lds + (l + 2 * g);  // A(l + 64 m + 256 c) = a_rd + 72 m + 296 c
     f2 *const b_rd = lds + (l + 4 * g);  // B(l + 64 c) = b_rd + 80 c
     size_t zoff = 0;
+    float2 hv[16];
+#if RR_V_WAVERUN > 0
+    if constexpr (LOOP) {
+#pragma unroll
+        for (int kp = 0; kp < 8; ++kp) {
+            const float4 h4 = reinterpret_cast<const float4 *>(H)[l + 64 * kp];
+            hv[2 * kp] = float2{h4.x, h4.y};
+            hv[2 * kp + 1] = float2{h4.z, h4.w};
+        }
+    }
+#endif
 
     for (unsigned it = 0; it < cnt; ++it, blk += bstride, b0 += bhop) {
         RR_STAMP_T(wt0);
+        if constexpr (LOOP && RR_V_WAVERUN > 0) {
+            if (b0 >= 0 && b0 + 1024 <= n_in) {
+                const f4u *src = reinterpret_cast<const f4u *>(in + b0) + l;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) x[k] = RR_WAVE_LDX(src + 64 * k);
+            }
+        }
         if constexpr (LOOP) {
             // What stays in registers across blocks is decided here, not by invariant-code motion
             // (which would hoist the 60 derived twiddles and the 16 H values, and then spill): the
@@ -1128,21 +1159,22 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
         // the 16 H values of the lane, used in pass 2.  Requested BEFORE the next block's samples:
         // loads complete in order (vmcnt), so waiting for a load issued after the prefetch would
         // wait for the prefetch as well.
-        float2 hv[16];
         // (H arrives pair-interleaved from the host, Hp[kp][l] = {H[l + 128 kp], H[l + 128 kp + 64]}:
         //  8 loads of 16 bytes per lane; measured cost of vector-memory traffic here is per
         //  instruction, not per byte)
+        if constexpr (!(LOOP && RR_V_WAVERUN > 0)) {
 #pragma unroll
-        for (int kp = 0; kp < 8; ++kp) {
-            const float4 h4 = reinterpret_cast<const float4 *>(H + zoff)[l + 64 * kp];
-            hv[2 * kp] = float2{h4.x, h4.y};
-            hv[2 * kp + 1] = float2{h4.z, h4.w};
+            for (int kp = 0; kp < 8; ++kp) {
+                const float4 h4 = reinterpret_cast<const float4 *>(H + zoff)[l + 64 * kp];
+                hv[2 * kp] = float2{h4.x, h4.y};
+                hv[2 * kp + 1] = float2{h4.z, h4.w};
+            }
         }
         // ---- request the next block ---------------------------------------------------------------
         // Unconditional (the position is clamped into the input, n_in >= 1024 is the launcher's
         // duty): with the loads under a condition, the compiler must assume at every later wait
         // that they were NOT issued, and then each wait for an H value also waits for them.
-        if constexpr (LOOP) {
+        if constexpr (PF) {
             __builtin_amdgcn_sched_barrier(0);
             long nb = b0 + bhop;
             nb = nb < 0 ? 0 : (nb > n_in - 1024 ? n_in - 1024 : nb);
@@ -1757,8 +1789,12 @@ int launch_ols_wave(hipStream_t s, const FusedFirArgs &a) {
 #endif
 #if RR_V_WAVELOOP > 0
     // one resident set = 256 CUs x 4 SIMDs x RR_V_WAVEOCCL waves; the grid must be a multiple of 8
+#if RR_V_WAVERUN > 0
+    unsigned grid = (unsigned)(((nblocks + RR_V_WAVERUN - 1) / RR_V_WAVERUN + 7) / 8 * 8), threads = 64;
+#else
     const size_t cap = (size_t)1024 * RR_V_WAVEOCCL * RR_V_WAVELOOP;
     unsigned grid = (unsigned)(nblocks < cap ? (nblocks + 7) / 8 * 8 : cap), threads = 64;
+#endif
     auto kern = k_ols_wave<true>;
     if (a.n_in < 1024) {  // the persistent form prefetches whole blocks from inside the input
         kern = k_ols_wave<false>;
@@ -1770,7 +1806,7 @@ int launch_ols_wave(hipStream_t s, const FusedFirArgs &a) {
     auto kern = k_ols_wave<false>;
 #endif
     const bool looped = kern == k_ols_wave<true>;
-    const unsigned hopm_run = looped ? (unsigned)((int64_t)(grid / 8) * (1024 - a.V) % den) : hopm;
+    const unsigned hopm_run = (looped && RR_V_WAVERUN == 0) ? (unsigned)((int64_t)(grid / 8) * (1024 - a.V) % den) : hopm;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, s, (const float2 *)a.xh, (int)a.hx,
                        (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0,
                        (const float2 *)a.H, (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out, (long)a.e0,
