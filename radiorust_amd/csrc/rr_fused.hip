@@ -1518,7 +1518,7 @@ struct FrameArgs {
 #ifndef RR_V_FRAMEOCC
 #define RR_V_FRAMEOCC 4
 #endif
-__global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_eu(RR_V_FRAMEOCC, RR_V_FRAMEOCC))) void k_ols_frame(FrameArgs a_) {
+__global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_eu(2, RR_V_FRAMEOCC))) void k_ols_frame(FrameArgs a_) {
     // The fields used once per workgroup (pending buffers, spectra, window ..) are re-read from the
     // kernel-argument segment where they are needed: held in SGPRs through the block loop they push
     // the kernel one VGPR (of spilled SGPRs) over the 128 that two 5-wave workgroups per CU need.
@@ -1582,7 +1582,7 @@ __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_e
     // results masked.
     const long n_clamp = a.n_in - 1024;  // the launcher guarantees n_in >= 1024
     auto block_b0 = [&](int jb) { return a.e0 - a.V + 4 * (F0 + (long)per_block * jb); };
-    auto clampb = [&](long b) { return b < 0 ? 0 : (b > n_clamp ? n_clamp : b); };
+    [[maybe_unused]] auto clampb = [&](long b) { return b < 0 ? 0 : (b > n_clamp ? n_clamp : b); };
 #ifndef RR_V_FRAMEPF
 #define RR_V_FRAMEPF 0  // 1: request the next block's samples while the current block is transformed
 #endif
@@ -1811,6 +1811,143 @@ int launch_ols_wave(hipStream_t s, const FusedFirArgs &a) {
                        (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0,
                        (const float2 *)a.H, (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out, (long)a.e0,
                        (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, hopm_run, kstep, 1.0 / (double)den);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Kernel 5  k_channelizer256<P>: the 256-bin polyphase channelizer (BASELINE configs[2]) with one
+// wave per run of frames.  Frame f folds the P chunks 256 (f + p) .. + 255 of the windowed span into
+// 256 values (4 per lane), then a forward DFT_256 as radix 4 x 4 x 4 x 4 with wave-local exchanges
+// (no workgroup barrier).  Consecutive frames share P - 1 chunks, so a wave keeps a sliding window of
+// chunks in registers and loads one new chunk (4 loads) per frame; the window values of the lane
+// (4 P) and the three twiddle seeds stay in registers for the whole run.
+// ---------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(64) void k_channelizer256(const float2 *__restrict__ hist, long hist_len,
+                                                       const float2 *__restrict__ in, long base0,
+                                                       const float *__restrict__ window,
+                                                       const float2 *__restrict__ tw, float2 *__restrict__ out,
+                                                       unsigned nframes, unsigned run) {
+    __shared__ __attribute__((aligned(16))) f2 lds[320];  // B(i) = i + 4 (i >> 4), i < 256
+    const int l = threadIdx.x, g = l >> 4, q = l & 15;
+    // workgroups b, b + 8, .. share an XCD: neighbouring runs on one XCD (grid: multiple of 8)
+    const unsigned wpx = gridDim.x >> 3;
+    const unsigned f0 = ((blockIdx.x & 7) * wpx + (blockIdx.x >> 3)) * run;
+    if (f0 >= nframes) return;
+    const unsigned cnt = nframes - f0 < run ? nframes - f0 : run;
+
+    float wv[P][4];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wv[p][c] = window[l + 64 * c + 256 * p];
+    // twiddle seeds of passes 1..3: e^{-j 2 pi (l mod ns) / (4 ns)}, ns = 4, 16, 64 (tw[k] = e^{-j 2 pi k / 256})
+    const float2 s1 = tw[(l & 3) * 16], s2 = tw[q * 4], s3 = tw[l];
+    const f2 seed[3] = {(f2){s1.x, s1.y}, (f2){s2.x, s2.y}, (f2){s3.x, s3.y}};
+
+    // chunk ci of the stream starts at base0 + 256 ci; base0 and hist_len are multiples of 256, so a
+    // chunk lies entirely in the history or entirely in the input
+    auto load_chunk = [&](long ci, f2(&dst)[4]) {
+        const long pos = base0 + 256 * ci;
+        const float2 *src = pos >= 0 ? in + pos : hist + (hist_len + pos);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float2 v = src[l + 64 * c];
+            dst[c] = (f2){v.x, v.y};
+        }
+    };
+    f2 xs[P][4];
+#pragma unroll
+    for (int p = 0; p + 1 < P; ++p) load_chunk((long)f0 + p, xs[p]);
+
+    f2 *const b_rd = lds + (l + 4 * g);  // B(l + 64 c) = b_rd + 80 c
+    for (unsigned it = 0; it < cnt; ++it) {
+        load_chunk((long)f0 + it + (P - 1), xs[P - 1]);
+        // fold: y[c] = sum_p w[l + 64 c + 256 p] x[256 (f + p) + l + 64 c]
+        f2 y[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f2 acc = xs[0][c] * wv[0][c];
+#pragma unroll
+            for (int p = 1; p < P; ++p) acc = __builtin_elementwise_fma(xs[p][c], (f2){wv[p][c], wv[p][c]}, acc);
+            y[c] = acc;
+        }
+#pragma unroll
+        for (int p = 0; p + 1 < P; ++p)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xs[p][c] = xs[p + 1][c];
+        // forward DFT_256, Stockham radix 4 x 4: butterfly l reads in[l + 64 c]
+        dft4(y[0], y[1], y[2], y[3]);  // pass 0 (Ns = 1): out 4 l + c
+        wave_sync();                   // the previous frame's reads are done
+        {
+            f2 *row = lds + (4 * l + 4 * (l >> 2));
+            *reinterpret_cast<float4 *>(row) = (float4){y[0].x, y[0].y, y[1].x, y[1].y};
+            *reinterpret_cast<float4 *>(row + 2) = (float4){y[2].x, y[2].y, y[3].x, y[3].y};
+        }
+        wave_sync();
+#pragma unroll
+        for (int pass = 1; pass < 4; ++pass) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) y[c] = b_rd[80 * c];
+            const f2 w1 = seed[pass - 1];
+            const f2 w2 = cmul(w1, w1);
+            const f2 w3 = cmul(w2, w1);
+            y[1] = cmul(y[1], w1);
+            y[2] = cmul(y[2], w2);
+            y[3] = cmul(y[3], w3);
+            dft4(y[0], y[1], y[2], y[3]);
+            if (pass == 3) break;  // natural order: y[c] = X[l + 64 c]
+            wave_sync();
+            if (pass == 1) {
+                f2 *col = lds + (20 * (l >> 2) + (l & 3));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) col[4 * c] = y[c];
+            } else {
+                f2 *col = lds + (80 * g + q);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) col[20 * c] = y[c];
+            }
+            wave_sync();
+        }
+        float2 *dst = out + (size_t)(f0 + it) * 256 + l;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float2 o;
+            o.x = y[c].x;
+            o.y = y[c].y;
+            dst[64 * c] = o;
+        }
+    }
+}
+
+bool channelizer256_supported(int dtype, size_t M, size_t P) {
+    return dtype == RR_F32 && M == 256 && (P == 1 || P == 2 || P == 3 || P == 4 || P == 6 || P == 8);
+}
+
+int launch_channelizer256(hipStream_t s, const void *hist, size_t hist_len, const void *in, long base0, size_t P,
+                          size_t nframes, const void *window, const void *tw, void *out) {
+    if (nframes == 0) return RR_OK;
+    if (nframes > 0x7ffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: too many frames in one call");
+#ifndef RR_V_CHANRUN
+#define RR_V_CHANRUN 16
+#endif
+    const unsigned run = RR_V_CHANRUN;
+    const unsigned grid = (unsigned)(((nframes + run - 1) / run + 7) / 8 * 8);
+#define RR_CHAN_LAUNCH(PP)                                                                                        \
+    hipLaunchKernelGGL(k_channelizer256<PP>, dim3(grid), dim3(64), 0, s, (const float2 *)hist, (long)hist_len,    \
+                       (const float2 *)in, base0, (const float *)window, (const float2 *)tw, (float2 *)out,      \
+                       (unsigned)nframes, run)
+    switch (P) {
+        case 1: RR_CHAN_LAUNCH(1); break;
+        case 2: RR_CHAN_LAUNCH(2); break;
+        case 3: RR_CHAN_LAUNCH(3); break;
+        case 4: RR_CHAN_LAUNCH(4); break;
+        case 6: RR_CHAN_LAUNCH(6); break;
+        case 8: RR_CHAN_LAUNCH(8); break;
+        default: RR_FAIL(RR_ERR_BAD_ARG, "channelizer256: %zu taps per branch not instantiated", P);
+    }
+#undef RR_CHAN_LAUNCH
     RR_HIP(hipGetLastError());
     return RR_OK;
 }

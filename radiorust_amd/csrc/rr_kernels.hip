@@ -9,6 +9,8 @@
 // over Complex<f32>/<f64>; no MFMA (not a dense contraction).
 #include "rr_kernels.hpp"
 
+#include <cstdlib>
+
 namespace rr {
 
 template <class T> struct V2;
@@ -546,6 +548,8 @@ int launch_channelizer(int dtype, hipStream_t s, const void *hist, size_t hist_l
                        size_t M, size_t P, size_t nframes, const void *window, const void *tw, void *out) {
     if (nframes == 0) return RR_OK;
     if (nframes > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: too many frames in one call");
+    if (channelizer256_supported(dtype, M, P) && !std::getenv("RR_CHANNELIZER_GENERIC"))
+        return launch_channelizer256(s, hist, hist_len, in, base0, P, nframes, window, tw, out);
     const size_t lds = 2 * M * elem_size(dtype);
     int threads = (int)(M / 2);
     threads = threads > 256 ? 256 : (threads < 64 ? 64 : threads);

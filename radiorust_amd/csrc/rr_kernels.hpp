@@ -118,6 +118,11 @@ int launch_drop_tail(hipStream_t s, const void *oldh, void *newh, size_t H, size
 // base0 = index (relative to in[0], may be negative) of the first sample of frame 0.
 int launch_channelizer(int dtype, hipStream_t s, const void *hist, size_t hist_len, const void *in, long base0,
                        size_t M, size_t P, size_t nframes, const void *window, const void *tw, void *out);
+// f32, M = 256, P in {1, 2, 3, 4, 6, 8}: one wave per run of frames, sliding window of chunks in
+// registers, radix-4 DFT_256 with wave-local exchanges (rr_fused.hip)
+bool channelizer256_supported(int dtype, size_t M, size_t P);
+int launch_channelizer256(hipStream_t s, const void *hist, size_t hist_len, const void *in, long base0, size_t P,
+                          size_t nframes, const void *window, const void *tw, void *out);
 
 // Upsampler (resampling.rs:237-267) as a gather: out[m] = sum over the inputs t with
 // 0 <= m - before[t] < L, ascending t, of x[t] * ir[m - before[t]], rounded like the reference's

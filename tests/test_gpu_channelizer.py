@@ -39,7 +39,9 @@ def reference_frames(oracle, chunks, M, P, flt, history=None):
 
 
 @pytest.mark.parametrize("M,P,dtype,tol", [(256, 4, np.float32, 1e-5), (64, 3, np.float32, 1e-5), (256, 1, np.float32, 1e-5),
-                                           (128, 4, np.float64, 1e-12)])
+                                           (128, 4, np.float64, 1e-12), (256, 2, np.float32, 1e-5), (256, 3, np.float32, 1e-5),
+                                           (256, 6, np.float32, 1e-5), (256, 8, np.float32, 1e-5), (256, 5, np.float32, 1e-5),
+                                           (256, 4, np.float64, 1e-12)])
 def test_channelizer_parity(rr, oracle, M, P, dtype, tol):
     nchunks = 37
     x = oracle.synth_iq(21, 0, M * nchunks)
