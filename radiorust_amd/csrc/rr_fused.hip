@@ -26,6 +26,24 @@
 //   registers (Stockham autosort through a padded 32 KiB LDS image), one
 //   workgroup per spectrum (analysis.rs:105-115); center_dc is an index
 //   rotation on the store.
+//
+// Kernel 3   k_ols_decim4     the stage of kernel 1 by overlap-save, a workgroup per 4096-block
+// Kernel 3w  k_ols_wave       ... a WAVE per 1024-block: the default for 4x decimation
+// Kernel 3f  k_ols_frame      k_ols_wave's blocks + kernel 2 in one kernel (measured slower; on request)
+// Kernel 4   k_filter_ols4096 the Filter block alone by overlap-save (n = 256 .. 2048)
+// Kernel 5   k_channelizer256 256-bin polyphase channelizer, a wave per run of frames
+//
+// Build-time switches (all default to the measured-best setting; scripts/build_variant.sh builds
+// a second library with other values for A/B runs in one GPU session, scripts/ab_bench.py):
+//   RR_V_STAGGER, RR_V_CUSTAG, RR_V_WGPCU, RR_V_R4, RR_V_T256   variants of kernel 1 (all slower)
+//   RR_V_WAVEWG   independent waves per workgroup of kernel 3w (1)
+//   RR_V_WAVELOOP, RR_V_WAVEOCCL, RR_V_WAVERUN   persistent forms of kernel 3w (0: one block per wave)
+//   RR_V_WAVENT   streaming hint on the sample loads/stores of kernel 3w (1; no measurable effect)
+//   RR_V_WAVELDS  LDS elements per wave image (1176)
+//   RR_V_FRAMEWAVES, RR_V_FRAMEPF, RR_V_FRAMEOCC   kernel 3f: waves per frame (4), prefetch (0)
+//   RR_V_CHANRUN  frames per wave of kernel 5 (16)
+//   RR_STAMP      s_memtime stamps per phase (scripts/stamp_run.py, stamp_wave.py)
+//   RR_ABLATE, RR_OLS_ABLATE, RR_WAVE_ABLATE   measurement builds that skip a phase (results are WRONG)
 #include "rr_blocks.hpp"
 
 #include <hip/hip_fp16.h>
