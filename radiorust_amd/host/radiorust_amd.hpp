@@ -794,6 +794,88 @@ template <class Flt> class Downsampler : public BlockBase<Downsampler<Flt>, Flt>
     }
 };
 
+// ---- Upsampler (resampling.rs:147-280) ----------------------------------------------------
+template <class Flt> class Upsampler : public BlockBase<Upsampler<Flt>, Flt> {
+    using Base = BlockBase<Upsampler<Flt>, Flt>;
+    using Sig = typename Base::Sig;
+    rr_upsampler *h_ = nullptr;
+
+  public:
+    Upsampler(size_t output_chunk_len, double output_rate, double bandwidth, double quality = 3.0, int device = 0) {
+        check(rr_upsampler_create(dtype_of<Flt>(), output_rate, bandwidth, quality, device, &h_));  // asserts of :185-186
+        auto pool = std::make_shared<ChunkBufPool<Complex<Flt>>>();
+        auto scratch = std::make_shared<ChunkBufPool<Complex<Flt>>>();
+        auto output_chunk = std::make_shared<std::optional<ChunkBuf<Complex<Flt>>>>();
+        output_chunk->emplace(pool->get_with_capacity(output_chunk_len));
+        this->spawn([this, pool, scratch, output_chunk, output_chunk_len, output_rate](Sig signal, auto &send) {
+            if (signal.is_event()) return send(std::move(signal));  // resampling.rs:269-271
+            const size_t n = signal.chunk.len();
+            size_t produce = 0;
+            check(rr_upsampler_peek(h_, signal.sample_rate, n, &produce));
+            auto raw = scratch->get_with_capacity(produce ? produce : 1);
+            raw.resize(produce);
+            size_t n_out = 0;
+            check(rr_upsampler_process(h_, signal.sample_rate, signal.chunk.data(), n, raw.data(), produce, &n_out));
+            for (size_t i = 0; i < n_out; ++i) {  // regroup into chunks of output_chunk_len (resampling.rs:251-261)
+                (*output_chunk)->push(raw.data()[i]);
+                if ((*output_chunk)->len() >= output_chunk_len) {
+                    Chunk<Complex<Flt>> done = (*output_chunk)->finalize();
+                    output_chunk->emplace(pool->get_with_capacity(output_chunk_len));
+                    if (!send(Sig::Samples(output_rate, std::move(done)))) return false;
+                }
+            }
+            return true;
+        });
+    }
+    ~Upsampler() {
+        this->shutdown();
+        rr_upsampler_destroy(h_);
+    }
+    static std::unique_ptr<Upsampler> new_(size_t output_chunk_len, double output_rate, double bandwidth) {
+        return std::make_unique<Upsampler>(output_chunk_len, output_rate, bandwidth, 3.0);
+    }
+    static std::unique_ptr<Upsampler> with_quality(size_t l, double r, double b, double q) {
+        return std::make_unique<Upsampler>(l, r, b, q);
+    }
+};
+
+// ---- FmDemod (modulation.rs:83-158) -------------------------------------------------------
+template <class Flt> class FmDemod : public BlockBase<FmDemod<Flt>, Flt> {
+    using Base = BlockBase<FmDemod<Flt>, Flt>;
+    using Sig = typename Base::Sig;
+    rr_fmdemod *h_ = nullptr;
+    std::atomic<double> deviation_;  // the watch channel of modulation.rs:104
+
+  public:
+    explicit FmDemod(double deviation, int device = 0) : deviation_(deviation) {
+        check(rr_fmdemod_create(dtype_of<Flt>(), deviation, device, &h_));
+        auto pool = std::make_shared<ChunkBufPool<Complex<Flt>>>();
+        this->spawn([this, pool](Sig signal, auto &send) {
+            if (signal.is_event()) {
+                if (signal.event->is_interrupt()) check(rr_fmdemod_reset(h_));  // modulation.rs:145-149
+                return send(std::move(signal));
+            }
+            check(rr_fmdemod_set_deviation(h_, deviation_.load()));  // has_changed() / borrow_and_update()
+            const size_t n = signal.chunk.len();
+            auto out = pool->get_with_capacity(n ? n : 1);
+            out.resize(n);
+            size_t n_out = 0;
+            check(rr_fmdemod_process(h_, signal.sample_rate, signal.chunk.data(), n, out.data(), n, &n_out));
+            out.truncate(n_out);
+            return send(Sig::Samples(signal.sample_rate, out.finalize()));
+        });
+    }
+    ~FmDemod() {
+        this->shutdown();
+        rr_fmdemod_destroy(h_);
+    }
+    double deviation() const { return deviation_.load(); }                 // modulation.rs:163-165
+    FmDemod &set_deviation(double d) {                                      // modulation.rs:167-170
+        deviation_.store(d);
+        return *this;
+    }
+};
+
 // ---- Fourier (analysis.rs:26-133) ---------------------------------------------------------
 template <class Flt> class Fourier : public BlockBase<Fourier<Flt>, Flt> {
     using Base = BlockBase<Fourier<Flt>, Flt>;

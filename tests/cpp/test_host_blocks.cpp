@@ -218,6 +218,62 @@ static void test_filter_swallow_and_interrupt() {  // filters.rs:240,260,262-265
     feeder.join();
 }
 
+// Upsampler -> FmDemod as blocks (resampling.rs:147-280, modulation.rs:83-158): an FM-modulated tone at
+// 48 kS/s goes up to 384 kS/s and is demodulated there; the Upsampler's output is compared bit for bit
+// with the oracle, the demodulated samples within 4 ulp of pi * factor.
+static void test_upsampler_fmdemod_blocks() {
+    using S = Sig<float>;
+    const double fi = 48000.0, fo = 384000.0, dev = 5000.0;
+    const size_t n = 4096, chunk = 512, out_chunk = 1024;
+    std::vector<Complex<float>> x(n);
+    double ph = 0.0;
+    for (size_t t = 0; t < n; ++t) {
+        ph += 0.5 * std::sin(2.0 * M_PI * 300.0 * (double)t / fi) * dev / fi * 2.0 * M_PI;
+        x[t] = Complex<float>((float)std::cos(ph), (float)std::sin(ph));
+    }
+    auto [sender, sender_connector] = flow::new_sender<S>();
+    auto up = blocks::Upsampler<float>::new_(out_chunk, fo, 40000.0);
+    auto dem = std::make_unique<blocks::FmDemod<float>>(dev);
+    auto [receiver, receiver_connector] = flow::new_receiver<S>();
+    up->feed_from(sender_connector);
+    dem->feed_from(*up);
+    receiver_connector->feed_from(*dem);
+    std::thread feeder([&, s = &sender] {
+        for (size_t off = 0; off < n; off += chunk) {
+            std::vector<Complex<float>> c(x.begin() + off, x.begin() + off + chunk);
+            s->send(S::Samples(fi, Chunk<Complex<float>>::from(c)));
+        }
+    });
+    // oracle: the same two blocks
+    rro_upsampler_f32 *ou = rro_upsampler_new_f32(fo, 40000.0, 3.0);
+    rro_fmdemod_f32 *od = rro_fmdemod_new_f32(dev);
+    std::vector<float> uref(2 * 8 * n + 64), dref(2 * 8 * n + 64);
+    size_t nu = 0;
+    for (size_t off = 0; off < n; off += chunk)
+        nu += rro_upsampler_process_f32(ou, fi, reinterpret_cast<const float *>(x.data() + off), chunk, uref.data() + 2 * nu, 8 * n + 32 - nu);
+    CHECK(nu == 8 * n);
+    rro_fmdemod_process_f32(od, fo, uref.data(), nu, dref.data());
+    const size_t want_chunks = nu / out_chunk;
+    const double atol = 4.0 * 1.1920929e-7 * M_PI * (fo / dev / (2.0 * M_PI));
+    size_t got = 0;
+    double worst = 0.0;
+    while (got < want_chunks) {
+        auto m = receiver.recv();
+        if (!m) break;
+        CHECK(!m->is_event() && m->chunk.len() == out_chunk && m->sample_rate == fo);
+        for (size_t i = 0; i < out_chunk; ++i) {
+            const double d = std::fabs((double)m->chunk[i].real() - (double)dref[2 * (got * out_chunk + i)]);
+            if (d > worst) worst = d;
+            CHECK(m->chunk[i].imag() == 0.f);
+        }
+        ++got;
+    }
+    feeder.join();
+    CHECK(got == want_chunks && worst <= atol);
+    rro_upsampler_free_f32(ou);
+    rro_fmdemod_free_f32(od);
+}
+
 static void test_contract_violation_is_loud() {  // resampling.rs:51-56
     bool threw = false;
     try {
@@ -240,6 +296,7 @@ int main(int argc, char **argv) {
         {"fourier (analysis.rs:139-209)", test_fourier, true},
         {"filter_swallow_and_interrupt", test_filter_swallow_and_interrupt, true},
         {"pipeline_vs_oracle", test_pipeline_vs_oracle, true},
+        {"upsampler_fmdemod_blocks", test_upsampler_fmdemod_blocks, true},
         {"contract_violation_is_loud", test_contract_violation_is_loud, true},
     };
     int ran = 0;
