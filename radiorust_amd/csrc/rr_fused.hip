@@ -1381,10 +1381,11 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
 // ---------------------------------------------------------------------------
 // Kernel 3f  k_ols_frame: k_ols_wave's blocks + the Fourier stage in one kernel, one workgroup
 // (4 waves) per 4096-sample frame of the decimated stream.  MEASURED SLOWER than the two separate
-// kernels (0.233 ms against 0.143 + 0.052 + gaps = 0.207 ms per 2^26 samples) and therefore only
-// run on request (RR_FUSED_KERNEL=olsf): the 32 KiB frame buffer on top of the wave images leaves
-// room for 8 waves per CU instead of 16, and a block is a 14 k-cycle dependent chain.  Kept as the
-// documented experiment and as a parity case.  The decimated samples never
+// kernels (0.217 ms against 0.143 + 0.052 + gaps = 0.207 ms per 2^26 samples) and therefore only
+// run on request (RR_FUSED_KERNEL=olsf): the 34 KiB frame buffer next to the wave images leaves room
+// for 12 waves per CU with half-size images (0.217 ms; 8 waves with full-size ones: 0.233 ms) instead
+// of 16, and a block is a 14 k-cycle dependent chain.  Kept as the documented experiment and as a
+// parity case.  The decimated samples never
 // touch HBM: the waves drop their blocks' outputs into a 32 KiB frame buffer in LDS, then four
 // of them run the windowed DFT_4096 of k_fft4096 on it.  Per input sample that removes the
 // 2 B written + 2 B read in between (and one launch); HBM sees 8 B in, 2 B out.
@@ -1398,12 +1399,17 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
 // ---------------------------------------------------------------------------
 int ols_wave_overlap(size_t Lc);
 #ifndef RR_V_FRAMEWAVES
-#define RR_V_FRAMEWAVES 4  // measured: 4 waves 0.233 ms, 5 waves 0.30 (one workgroup per CU), 8 waves 0.26, 10 waves 0.28
+#define RR_V_FRAMEWAVES 4  // measured (full-size images): 4 waves 0.233 ms, 5 waves 0.30 (one workgroup per CU), 8 waves 0.26, 10 waves 0.28
 #endif
 constexpr int kFrameWaves = RR_V_FRAMEWAVES, kFrameBlocks = 20;
 
 // the transforms of one 1024-sample block: v = mixed samples in the pair layout of k_ols_wave;
 // y[c] = result[l + 64 c] of the 256-point inverse (see k_ols_wave for the passes)
+// HALF: the forward exchanges go through an image of 512 elements in two rounds (lanes 0-31 write,
+// everyone reads the lower half of what it needs, then lanes 32-63 and the upper half): 4.6 KiB of LDS
+// per wave instead of 9.2, two more wave-local round trips per block.
+constexpr int kWaveLdsHalf = 584;  // A(511) + 1 = 582, rounded up to a multiple of 8
+template <bool HALF>
 __device__ __forceinline__ void wave_block_transform(f2 (&v)[16], f2 (&y)[4], f2 *lds, int l, f2 t_p1,
                                                      const f2 (&t_p2)[2], const f2 (&t_inv)[3],
                                                      const float2 (&hv)[16]) {
@@ -1426,30 +1432,73 @@ __device__ __forceinline__ void wave_block_transform(f2 (&v)[16], f2 (&y)[4], f2
         }
     }
     wave_sync();  // the previous block's last reads of image B are done
-    {
+    if constexpr (!HALF) {
         f2 *row = lds + (18 * l + 8 * g);
 #pragma unroll
         for (int k = 0; k < 16; k += 2)
             *reinterpret_cast<float4 *>(row + k) = (float4){v[k].x, v[k].y, v[k + 1].x, v[k + 1].y};
-    }
-    wave_sync();
+        wave_sync();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = a_rd[72 * (k & 3) + 296 * (k >> 2)];
+        for (int k = 0; k < 16; ++k) v[k] = a_rd[72 * (k & 3) + 296 * (k >> 2)];
+    } else {
+        // rows 0..31 (elements < 512) belong to lanes 0..31; a reader's k < 8 are its elements < 512
+        f2 w[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) w[k] = v[k];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if ((l >> 5) == h) {
+                f2 *row = lds + (18 * (l & 31) + 8 * ((l & 31) >> 4));
+#pragma unroll
+                for (int k = 0; k < 16; k += 2)
+                    *reinterpret_cast<float4 *>(row + k) = (float4){w[k].x, w[k].y, w[k + 1].x, w[k + 1].y};
+            }
+            wave_sync();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[8 * h + k] = a_rd[72 * (k & 3) + 296 * (k >> 2)];  // in[l + 64 (8 h + k)] - 512 h
+            wave_sync();
+        }
+    }
     twiddle16(v, t_p1);
     dft16(v);
-    wave_sync();
-    {
-        f2 *col = lds + (144 * (l >> 3) + 8 * (l >> 4) + (l & 7));
+    f2 ain[2][8];
+    if constexpr (!HALF) {
+        wave_sync();
+        {
+            f2 *col = lds + (144 * (l >> 3) + 8 * (l >> 4) + (l & 7));
 #pragma unroll
-        for (int k = 0; k < 16; ++k) col[8 * k + 2 * (k >> 1)] = v[k];
+            for (int k = 0; k < 16; ++k) col[8 * k + 2 * (k >> 1)] = v[k];
+        }
+        wave_sync();
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) ain[m][c] = a_rd[72 * m + 144 * c + 8 * (c >> 1)];
+    } else {
+        // elements 128 h' + p + 8 k with h' = l / 8 < 4 (lanes 0..31) are the lower 512; a reader's c < 4 too
+        if constexpr (true) wave_sync();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if ((l >> 5) == h) {
+                const int ll = l & 31;
+                f2 *col = lds + (144 * (ll >> 3) + 8 * (ll >> 4) + (ll & 7));
+#pragma unroll
+                for (int k = 0; k < 16; ++k) col[8 * k + 2 * (k >> 1)] = v[k];
+            }
+            wave_sync();
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ain[m][4 * h + c] = a_rd[72 * m + 144 * c + 8 * (c >> 1)];
+            wave_sync();
+        }
     }
-    wave_sync();
     f2 X[16];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         f2 a[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) a[c] = a_rd[72 * m + 144 * c + 8 * (c >> 1)];
+        for (int c = 0; c < 8; ++c) a[c] = ain[m][c];
         const f2 w1 = t_p2[m];
         const f2 w2 = cmul(w1, w1);
         const f2 w3 = cmul(w2, w1);
@@ -1536,15 +1585,23 @@ struct FrameArgs {
 #ifndef RR_V_FRAMEOCC
 #define RR_V_FRAMEOCC 4
 #endif
-__global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_eu(2, RR_V_FRAMEOCC))) void k_ols_frame(FrameArgs a_) {
+#ifndef RR_V_FRAMEOCCMIN
+#define RR_V_FRAMEOCCMIN 3  // 12 waves per CU need <= 168 VGPRs
+#endif
+__global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_eu(RR_V_FRAMEOCCMIN, RR_V_FRAMEOCC))) void k_ols_frame(FrameArgs a_) {
     // The fields used once per workgroup (pending buffers, spectra, window ..) are re-read from the
     // kernel-argument segment where they are needed: held in SGPRs through the block loop they push
     // the kernel one VGPR (of spilled SGPRs) over the 128 that two 5-wave workgroups per CU need.
     const FrameArgs &a = a_;
     const FrameArgs *ka = (const FrameArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-    __shared__ __attribute__((aligned(16))) f2 fr[4096 + 64];               // the frame (+ the surplus of block 19)
-    __shared__ __attribute__((aligned(16))) f2 img[kFrameWaves * kWaveLds];  // wave images; then the DFT_4096 image
-    static_assert(kFrameWaves * kWaveLds >= 4096 + 256, "the DFT_4096 image must fit the wave images");
+#ifndef RR_V_FRAMEHALF
+#define RR_V_FRAMEHALF 1  // half-size wave images: 3 workgroups per CU instead of 2
+#endif
+    constexpr int kImg = RR_V_FRAMEHALF ? kWaveLdsHalf : kWaveLds;
+    // the frame (+ the surplus of block 19); once every lane holds its 16 frame samples it becomes the
+    // padded exchange image of the DFT_4096
+    __shared__ __attribute__((aligned(16))) f2 fr[4096 + 256];
+    __shared__ __attribute__((aligned(16))) f2 img[kFrameWaves * kImg];  // wave images
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     // frames dealt so that an XCD owns a contiguous range (grid: multiple of 8)
     const unsigned per_xcd = gridDim.x >> 3;
@@ -1589,7 +1646,7 @@ __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_e
         t_inv[1] = (f2){s2.x, s2.y};
         t_inv[2] = (f2){s2.z, s2.w};
     }
-    f2 *const lds = img + w * kWaveLds;
+    f2 *const lds = img + w * kImg;
     size_t zoff = 0;
 
     // The next block's samples are requested while the current block is transformed (a block alone
@@ -1698,7 +1755,7 @@ __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_e
         }
 #endif
         f2 y[4];
-        wave_block_transform(v, y, lds, l, t_p1, t_p2, t_inv, hv);
+        wave_block_transform<RR_V_FRAMEHALF != 0>(v, y, lds, l, t_p1, t_p2, t_inv, hv);
         // valid results tau = l + 64 c >= first; frame-relative index i = per_block * jb + tau - first
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -1729,7 +1786,11 @@ __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_e
         const f2 s = fr[tid + 256 * k];
         v[k] = (f2){s.x * wv, s.y * wv};
     }
-    fft4096_regs(v, img, ka->tw4096, tid);
+    // all four waves must have read the frame before it is overwritten (named barrier of the 256 lanes
+    // left: the fifth.. waves of larger workgroups have returned, so a workgroup barrier would hang)
+    static_assert(kFrameWaves == 4 || !RR_V_FRAMEHALF, "the in-place DFT image needs a barrier of exactly the four transforming waves");
+    __syncthreads();
+    fft4096_regs(v, fr, ka->tw4096, tid);
     float2 *dst = ka->spectra + (size_t)f * 4096;
     const int rot = ka->center_dc ? 2048 : 0;
 #pragma unroll
