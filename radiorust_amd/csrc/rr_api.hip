@@ -589,7 +589,7 @@ int StageTimers::begin(int stage, hipStream_t s) {
         if (hipEventCreate(&e) != hipSuccess) return nullptr;
         return e;
     };
-    Pair p{get(), get(), stage};
+    Pair p{get(), get(), stage, false};
     if (!p.a || !p.b) return -1;
     (void)hipEventRecord(p.a, s);
     pending.push_back(p);
@@ -598,6 +598,37 @@ int StageTimers::begin(int stage, hipStream_t s) {
 void StageTimers::end(int idx, hipStream_t s) {
     if (idx >= 0) (void)hipEventRecord(pending[idx].b, s);
 }
+bool StageTimers::begin_ext(int stage, hipEvent_t *a, hipEvent_t *b) {
+    *a = *b = nullptr;
+    if (!on) return false;
+    if (pending.size() >= 8192 && drain() != RR_OK) return false;
+    hipEvent_t e[2] = {nullptr, nullptr};
+    for (hipEvent_t &x : e) {
+        if (!pool.empty()) {
+            x = pool.back();
+            pool.pop_back();
+        } else if (hipEventCreate(&x) != hipSuccess) {
+            return false;
+        }
+    }
+    pending.push_back(Pair{e[0], e[1], stage, false});
+    *a = e[0];
+    *b = e[1];
+    return true;
+}
+int StageTimers::next(int idx, int stage, hipStream_t s) {
+    if (idx < 0) return begin(stage, s);
+    end(idx, s);
+    hipEvent_t e = nullptr;
+    if (!pool.empty()) {
+        e = pool.back();
+        pool.pop_back();
+    } else if (hipEventCreate(&e) != hipSuccess) {
+        return -1;
+    }
+    pending.push_back(Pair{pending[idx].b, e, stage, true});
+    return (int)pending.size() - 1;
+}
 int StageTimers::drain() {
     for (Pair &p : pending) {
         RR_HIP(hipEventSynchronize(p.b));
@@ -605,7 +636,7 @@ int StageTimers::drain() {
         RR_HIP(hipEventElapsedTime(&ms, p.a, p.b));
         total_ms[p.stage] += ms;
         launches[p.stage] += 1;
-        pool.push_back(p.a);
+        if (!p.a_shared) pool.push_back(p.a);
         pool.push_back(p.b);
     }
     pending.clear();
@@ -620,7 +651,7 @@ void StageTimers::reset() {
 }
 StageTimers::~StageTimers() {
     for (Pair &p : pending) {
-        (void)hipEventDestroy(p.a);
+        if (!p.a_shared) (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
     }
     for (hipEvent_t e : pool) (void)hipEventDestroy(e);
@@ -891,14 +922,20 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     a.H = d_olsH.p;
     a.tw4096 = d_tw4096.p;
     a.V = ols_V;
-    int tk = timers.begin(ST_FUSED_FIR, stream);
+    // k_ols_wave + k_fft4096: the launches record their own start / end (no marker packets, which
+    // cost ~4 us of stream time each); the other kernels are bracketed by recorded events
+    const bool ext = timers.on && use_ols && ols_N == 1024 && split && dec > 0;
+    int tk = -1;
+    if (ext)
+        timers.begin_ext(ST_FUSED_FIR, &a.ev_start, &a.ev_stop);
+    else
+        tk = timers.begin(ST_FUSED_FIR, stream);
     if (use_ols && ols_N == 1024)
         RR_TRY(launch_ols_wave(stream, a));
     else if (use_ols)
         RR_TRY(launch_ols_decim(stream, a));
     else
         RR_TRY(launch_fused_fir(stream, a));
-    timers.end(tk, stream);
     xh_cur ^= 1;
     if (left) RR_HIP(hipMemcpyAsync(carry.p, xh[xh_cur].as<char>() + (HX - left) * esz, left * esz, hipMemcpyDeviceToDevice, stream));
     const uint64_t den = (uint64_t)fs->denom;
@@ -909,12 +946,18 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     blocks_stale = true;
     // Fourier on whole frames, the rest stays pending (resampling.rs:121-131)
     size_t wrote = 0;
-    tk = timers.begin(ST_FOURIER, stream);
+    hipEvent_t fa = nullptr, fb = nullptr;
+    if (ext) {
+        if (nfr) timers.begin_ext(ST_FOURIER, &fa, &fb);
+    } else {
+        tk = timers.next(tk, ST_FOURIER, stream);  // (the carry copy above, if any, counts for the FIR stage)
+    }
     if (split) {
         if (nfr * LF > cap) RR_FAIL(RR_ERR_CAPACITY, "Chain: out_cap %zu < %zu", cap, nfr * LF);
         RR_TRY(fo->prepare(LF));
         const void *head = pend_ptr ? pend_ptr : pending.p;
-        RR_TRY(launch_fft4096(stream, head, pending_len, newv, d_out, nfr, fo->d_window.p, fo->d_tw.p, fo->center_dc));
+        RR_TRY(launch_fft4096(stream, head, pending_len, newv, d_out, nfr, fo->d_window.p, fo->d_tw.p, fo->center_dc, 4096,
+                              fa, fb));
         wrote = nfr * LF;
         if (nfr) {  // the leftover is the tail of the new outputs
             pend_ptr = newv + (nfr * LF - pending_len) * esz;
@@ -927,7 +970,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
         RR_TRY(fo->process_dev(LF, dbase, nfr * LF, d_out, cap, &wrote));
         if (rest) RR_HIP(hipMemcpyAsync(pending.p, dbase + nfr * LF * esz, rest * esz, hipMemcpyDeviceToDevice, stream));
     }
-    timers.end(tk, stream);
+    if (!ext) timers.end(tk, stream);
     pending_len = rest;
     last_fused = use_ols ? (ols_N == 1024 ? FK_OLSW : FK_OLS) : FK_DIRECT;
     if (n_out) *n_out = wrote;

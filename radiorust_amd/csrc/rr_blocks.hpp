@@ -138,13 +138,17 @@ struct rr_channelizer : rr_block {
 enum Stage { ST_FREQSHIFT = 0, ST_FILTER, ST_DECIM, ST_FOURIER, ST_FUSED_FIR, ST_FUSED_FFT, ST_COUNT };
 struct StageTimers {
     bool on = false;
-    struct Pair { hipEvent_t a, b; int stage; };
+    struct Pair { hipEvent_t a, b; int stage; bool a_shared; };  // a_shared: `a` is the previous pair's `b`
     std::vector<Pair> pending;
     std::vector<hipEvent_t> pool;
     double total_ms[ST_COUNT] = {};
     uint64_t launches[ST_COUNT] = {};
     int begin(int stage, hipStream_t s);  // returns index into pending or -1
     void end(int idx, hipStream_t s);
+    // ends stage `idx` and begins `stage` with ONE event (a record costs ~4 us of stream time)
+    int next(int idx, int stage, hipStream_t s);
+    // a pair whose events the launch itself fills in (hipExtLaunchKernel): no marker packets
+    bool begin_ext(int stage, hipEvent_t *a, hipEvent_t *b);
     int drain();
     void reset();
     ~StageTimers();

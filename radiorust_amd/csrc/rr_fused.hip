@@ -46,6 +46,7 @@
 //   RR_ABLATE, RR_OLS_ABLATE, RR_WAVE_ABLATE   measurement builds that skip a phase (results are WRONG)
 #include "rr_blocks.hpp"
 
+#include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
 
 #include <cmath>
@@ -687,12 +688,18 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
 }
 
 int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
-                   const void *window, const void *tw4096, bool center_dc, size_t hop) {
+                   const void *window, const void *tw4096, bool center_dc, size_t hop, hipEvent_t ev_start,
+                   hipEvent_t ev_stop) {
     if (count == 0) return RR_OK;
     if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fft4096: too many frames");
-    hipLaunchKernelGGL(k_fft4096, dim3((unsigned)count), dim3(256), 0, s, (const float2 *)head, (long)n_head,
-                       (const float2 *)in, (float2 *)out,
-                       (const float *)window, (const float2 *)tw4096, (int)center_dc, (long)hop);
+    if (ev_start && ev_stop)
+        hipExtLaunchKernelGGL(k_fft4096, dim3((unsigned)count), dim3(256), 0, s, ev_start, ev_stop, 0, (const float2 *)head,
+                              (long)n_head, (const float2 *)in, (float2 *)out, (const float *)window,
+                              (const float2 *)tw4096, (int)center_dc, (long)hop);
+    else
+        hipLaunchKernelGGL(k_fft4096, dim3((unsigned)count), dim3(256), 0, s, (const float2 *)head, (long)n_head,
+                           (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw4096,
+                           (int)center_dc, (long)hop);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
@@ -1886,10 +1893,18 @@ int launch_ols_wave(hipStream_t s, const FusedFirArgs &a) {
 #endif
     const bool looped = kern == k_ols_wave<true>;
     const unsigned hopm_run = (looped && RR_V_WAVERUN == 0) ? (unsigned)((int64_t)(grid / 8) * (1024 - a.V) % den) : hopm;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, s, (const float2 *)a.xh, (int)a.hx,
-                       (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0,
-                       (const float2 *)a.H, (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out, (long)a.e0,
-                       (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, hopm_run, kstep, 1.0 / (double)den);
+    if (a.ev_start && a.ev_stop)
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, s, a.ev_start, a.ev_stop, 0, (const float2 *)a.xh, (int)a.hx,
+                              (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0,
+                              (const float2 *)a.H, (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out,
+                              (long)a.e0, (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, hopm_run,
+                              kstep, 1.0 / (double)den);
+    else
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, s, (const float2 *)a.xh, (int)a.hx,
+                           (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0,
+                           (const float2 *)a.H, (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out, (long)a.e0,
+                           (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, hopm_run, kstep,
+                           1.0 / (double)den);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }

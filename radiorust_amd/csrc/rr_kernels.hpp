@@ -89,6 +89,9 @@ struct FusedFirArgs {
     const void *H = nullptr;       // DFT_4096(c) / 4096, complex f32
     const void *tw4096 = nullptr;  // e^{-j 2 pi k / 4096}
     int V = 0;                     // overlap (samples), multiple of 256
+    // optional: the launch itself records its start / end in these events (hipExtLaunchKernel):
+    // kernel-only timing without marker packets on the stream
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 bool ols_decim_supported(uint64_t D, size_t Lc);
 int ols_decim_overlap(size_t Lc);
@@ -110,7 +113,8 @@ int launch_fused_fir(hipStream_t s, const FusedFirArgs &a);
 // 4096-point windowed forward DFT (radix 16 x 3); tw4096[k] = e^{-j 2 pi k / 4096}, 4096 entries
 // frames are cut from the stream [ head (n_head samples) | in ]
 int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
-                   const void *window, const void *tw4096, bool center_dc, size_t hop = 4096);
+                   const void *window, const void *tw4096, bool center_dc, size_t hop = 4096,
+                   hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 int launch_drop_tail(hipStream_t s, const void *oldh, void *newh, size_t H, size_t drop);
 
 // Polyphase channelizer: frame f = FFT_M( sum_{p<P} w[r + M p] x[M (f0 + f) + r + M p] ), r < M,
