@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=100.0, help="GPU load before the warm-up steps, for steady clocks")
     ap.add_argument("--no-fused", action="store_true", help="force the block-by-block kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-all", action="store_true", help="time every kernel inside the timed region, not only the dominant one")
     ap.add_argument("--traffic-json", default=None, help="file holding measured HBM bytes per launch (PMC pass)")
     args = ap.parse_args()
 
@@ -164,7 +165,9 @@ def main():
     lib = rr._lib.lib()
     import ctypes as C
 
-    lib.rr_chain_timing_enable(chain._h, 1)
+    # inside the timed region only the dominant kernel is timed (a timed launch costs ~5 us of stream
+    # time); the other kernels' averages come from a few extra steps after the timed region
+    lib.rr_chain_timing_enable(chain._h, 2 if not (args.no_fused or args.time_all) else 1)
     lib.rr_chain_timing_reset(chain._h)
 
     barrier = ranks.barrier
@@ -218,17 +221,29 @@ def main():
         del a, b
 
     # per-kernel device time from the library's hipEvents
+    def read_stages():
+        out, i = {}, 0
+        while True:
+            name = lib.rr_chain_timing_stage_name(i)
+            if not name:
+                return out
+            ms, cnt = C.c_double(), C.c_uint64()
+            rr._lib.check(lib.rr_chain_timing_read(chain._h, i, C.byref(ms), C.byref(cnt)))
+            if cnt.value:
+                out[name.decode()] = {"launches": cnt.value, "avg_ms": ms.value / cnt.value}
+            i += 1
+
+    timed_stages = read_stages()
+    other = {}
+    if not args.no_fused:  # the remaining kernels, outside the timed region
+        lib.rr_chain_timing_enable(chain._h, 1)
+        lib.rr_chain_timing_reset(chain._h)
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        other = {k: v for k, v in read_stages().items() if k not in timed_stages}
     stages = {}
-    i = 0
-    while True:
-        name = lib.rr_chain_timing_stage_name(i)
-        if not name:
-            break
-        ms, cnt = C.c_double(), C.c_uint64()
-        rr._lib.check(lib.rr_chain_timing_read(chain._h, i, C.byref(ms), C.byref(cnt)))
-        if cnt.value:
-            stages[name.decode()] = {"launches": cnt.value, "avg_ms": ms.value / cnt.value}
-        i += 1
+    stages.update(timed_stages)
 
     if rank == 0:
         value = whole_job_rate(n, args.steps, world, elapsed)
@@ -281,6 +296,8 @@ def main():
                 "frac_of_measured_copy": round(achieved / copy_gbs, 5) if copy_gbs else None,
             },
             "kernels": {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 5)} for k, v in stages.items()},
+            "kernels_outside_timed_region": {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 5)}
+                                             for k, v in other.items()},
             "parity_first_spectrum_rms": parity,
             "parity_fused_vs_block_by_block_last_step_rms": fused_vs_blocks,
         }

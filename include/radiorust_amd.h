@@ -287,7 +287,9 @@ int rr_chain_destroy(rr_chain *h);
  * chain launches is bracketed by hipEvents on the chain's stream.  Stages:
  * see rr_chain_timing_stage_name(); read returns the accumulated device time
  * and launch count of one stage since the last reset and waits for the events
- * it needs. */
+ * it needs.  on = 1: every stage; on = 2: only the fused mix + FIR + decimate
+ * stage (a timed launch costs about 5 us of stream time; the benchmark times only
+ * its dominant kernel inside the timed region); on = 0: off. */
 int rr_chain_timing_enable(rr_chain *h, int on);
 int rr_chain_timing_reset(rr_chain *h);
 int rr_chain_timing_read(rr_chain *h, int stage, double *total_ms, uint64_t *launches);

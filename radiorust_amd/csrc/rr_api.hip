@@ -577,7 +577,7 @@ int rr_channelizer::process_dev(const void *d_in, size_t n_in, void *d_out, size
 // stage timers
 // ---------------------------------------------------------------------------
 int StageTimers::begin(int stage, hipStream_t s) {
-    if (!on) return -1;
+    if (!on || (only_stage >= 0 && stage != only_stage)) return -1;
     if (pending.size() >= 8192 && drain() != RR_OK) return -1;
     auto get = [&]() -> hipEvent_t {
         if (!pool.empty()) {
@@ -600,7 +600,7 @@ void StageTimers::end(int idx, hipStream_t s) {
 }
 bool StageTimers::begin_ext(int stage, hipEvent_t *a, hipEvent_t *b) {
     *a = *b = nullptr;
-    if (!on) return false;
+    if (!on || (only_stage >= 0 && stage != only_stage)) return false;
     if (pending.size() >= 8192 && drain() != RR_OK) return false;
     hipEvent_t e[2] = {nullptr, nullptr};
     for (hipEvent_t &x : e) {
@@ -619,6 +619,7 @@ bool StageTimers::begin_ext(int stage, hipEvent_t *a, hipEvent_t *b) {
 int StageTimers::next(int idx, int stage, hipStream_t s) {
     if (idx < 0) return begin(stage, s);
     end(idx, s);
+    if (only_stage >= 0 && stage != only_stage) return -1;
     hipEvent_t e = nullptr;
     if (!pool.empty()) {
         e = pool.back();
@@ -1900,6 +1901,7 @@ int rr_chain_last_path(const rr_chain *h, int *fused) {
 int rr_chain_timing_enable(rr_chain *h, int on) {
     RR_CHECK_HANDLE(h, K_CHAIN);
     h->timers.on = on != 0;
+    h->timers.only_stage = on == 2 ? ST_FUSED_FIR : -1;
     return RR_OK;
 }
 int rr_chain_timing_reset(rr_chain *h) {

@@ -138,6 +138,7 @@ struct rr_channelizer : rr_block {
 enum Stage { ST_FREQSHIFT = 0, ST_FILTER, ST_DECIM, ST_FOURIER, ST_FUSED_FIR, ST_FUSED_FFT, ST_COUNT };
 struct StageTimers {
     bool on = false;
+    int only_stage = -1;  // >= 0: only this stage is timed (each timed launch costs ~5 us of stream time)
     struct Pair { hipEvent_t a, b; int stage; bool a_shared; };  // a_shared: `a` is the previous pair's `b`
     std::vector<Pair> pending;
     std::vector<hipEvent_t> pool;
