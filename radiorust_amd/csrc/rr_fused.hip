@@ -35,7 +35,7 @@
 //
 // Build-time switches (all default to the measured-best setting; scripts/build_variant.sh builds
 // a second library with other values for A/B runs in one GPU session, scripts/ab_bench.py):
-//   RR_V_STAGGER, RR_V_CUSTAG, RR_V_WGPCU, RR_V_R4, RR_V_T256   variants of kernel 1 (all slower)
+//   RR_V_STAGGER, RR_V_CUSTAG, RR_V_WGPCU, RR_V_R4, RR_V_T256, RR_V_CONTIG   variants of kernel 1 (all slower)
 //   RR_V_WAVEWG   independent waves per workgroup of kernel 3w (1)
 //   RR_V_WAVELOOP, RR_V_WAVEOCCL, RR_V_WAVERUN   persistent forms of kernel 3w (0: one block per wave)
 //   RR_V_WAVENT   streaming hint on the sample loads/stores of kernel 3w (1; no measurable effect)
@@ -133,9 +133,22 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
         const unsigned b = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, rmd = nwg & 7, xcd = b & 7;
         chunk = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (b >> 3);
     }
+#ifndef RR_V_CONTIG
+    // an XCD owns a contiguous range of tiles and its workgroups take them round robin, so that the
+    // tiles in flight at any moment are neighbours in memory (grid: multiple of 8); contiguous runs
+    // per workgroup (RR_V_CONTIG) measured 3 % slower
+    const unsigned tstride = gridDim.x >> 3;
+    const unsigned per_xcd_t = (ntiles + 7) >> 3;
+    const unsigned tile_begin = (blockIdx.x & 7) * per_xcd_t + (blockIdx.x >> 3);
+    unsigned tile_end = ((blockIdx.x & 7) + 1) * per_xcd_t;
+    if (tile_end > ntiles) tile_end = ntiles;
+    (void)tiles_per_wg;
+#else
+    const unsigned tstride = 1;
     const unsigned tile_begin = chunk * tiles_per_wg;
     unsigned tile_end = tile_begin + tiles_per_wg;
     if (tile_end > ntiles) tile_end = ntiles;
+#endif
     // The workgroup that owns the last run of tiles also leaves the mixed-sample
     // history for the next call: xh_out = the last hx_out mixed samples of this call.
     if (xh_out && chunk == gridDim.x - 1) {
@@ -164,7 +177,7 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
     auto lds_addr = [&](int s) -> int { return (s >> LOG2_RD) * STRIDE + (s & (RD - 1)) * 8; };
     const int a0 = lds_addr(sfirst), a1 = lds_addr(sfirst + 1);
     const unsigned step = (unsigned)((2 * T) % denom);
-    const unsigned tstep = (unsigned)(((long)D * OUTS) % denom);
+    const unsigned tstep = (unsigned)(((long)D * OUTS * tstride) % denom);
     const bool nco_const = (step == 0 && tstep == 0);  // phasor of a lane never changes (e.g. denom = 8)
 
     auto tile_lo_of = [&](unsigned tile) -> long { return lo0 + (long)D * OUTS * tile; };
@@ -224,12 +237,12 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
 #ifdef RR_STAMP
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    for (unsigned tile = tile_begin; tile < tile_end; ++tile) {
+    for (unsigned tile = tile_begin; tile < tile_end; tile += tstride) {
         RR_STAMP_T(ts0);
         // ---- stage: (prefetched) raw samples -> mix -> LDS; each prefetch slot is
         //      re-issued for the next tile as soon as it has been consumed ----------
-        const long next_lo = tile_lo + (long)D * OUTS;
-        const bool next_interior = (tile + 1 < tile_end) && interior_of(next_lo);
+        const long next_lo = tile_lo + (long)D * OUTS * tstride;
+        const bool next_interior = (tile + tstride < tile_end) && interior_of(next_lo);
         // x * p = x.re * (p.re, p.im) + x.im * (-p.im, p.re): one packed mul + one packed fma
         auto mix = [](f2 xv, f2 p, f2 pj) -> f2 { return __builtin_elementwise_fma(xv.yy, pj, xv.xx * p); };
         if (cur_interior) {
@@ -443,9 +456,15 @@ static int launch_mfd(hipStream_t s, const FusedFirArgs &a) {
 #else
     size_t nwg = 256 * (512 / T) * (32 / G::RD);  // LDS-limited: 8 waves/CU at 32 samples per lane, 12-16 at 16
 #endif
+#ifndef RR_V_CONTIG
+    if (nwg > ntiles) nwg = ntiles;
+    nwg = (nwg + 7) / 8 * 8;
+    const size_t tpw = 0;
+#else
     if (nwg > ntiles) nwg = ntiles;
     const size_t tpw = (ntiles + nwg - 1) / nwg;
     nwg = (ntiles + tpw - 1) / tpw;
+#endif
     const int in_al = (reinterpret_cast<uintptr_t>(a.in) % 16 == 0) ? 1 : 0;
     const int out_al = (reinterpret_cast<uintptr_t>(a.out) % 16 == 0) ? 1 : 0;
     hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(T), lds, s, (const float2 *)a.xh, (int)a.hx, (const float2 *)a.in,
