@@ -303,6 +303,7 @@ def main():
             line["parity_first_spectrum_rms"] = float(np.sqrt(np.sum(np.abs(first_spectrum - ref0) ** 2) / np.sum(np.abs(ref0) ** 2)))
         assert first_frames >= 0
         print(json.dumps(line))
+    barrier()  # rank 0's un-timed checks are done before anybody tears the group down
     ranks.close()
 
 
