@@ -321,14 +321,16 @@ int rr_channelizer_destroy(rr_channelizer *h);
 /* (src/blocks/chunks.rs:42-242, analysis.rs:26-133; the wiring of               */
 /* examples/bandwidth_meter/main.rs:66-69) on the device without materialising   */
 /* the overlapping chunks: every chunk_len new samples one windowed transform    */
-/* over the last chunk_count * chunk_len samples, all bins.  Input: whole chunks  */
-/* of chunk_len samples; output: n_out = frames * chunk_len * chunk_count bins.  */
+/* over the last chunk_count * chunk_len samples, all bins.  Input: any number of */
+/* samples (the Rechunker's patchwork is kept in the handle, chunks.rs:62-64);    */
+/* output: n_out = frames * chunk_len * chunk_count bins.                        */
 /* chunk_len * chunk_count must be a power of two (<= 8192 f32, <= 4096 f64).    */
 /* ------------------------------------------------------------------------ */
 typedef struct rr_stft rr_stft;
 int rr_stft_create(int dtype, size_t chunk_len, size_t chunk_count, const rr_window *window,
                    int center_dc, int device, rr_stft **out);
-/* Any event makes the Overlapper drop its history (chunks.rs:225-233). */
+/* Any event (and a change of sample rate) makes the Rechunker drop its patchwork
+ * and the Overlapper its history (chunks.rs:72-88, 225-233). */
 int rr_stft_reset(rr_stft *h);
 int rr_stft_peek(const rr_stft *h, size_t n_in, size_t *n_out);
 int rr_stft_process(rr_stft *h, const void *in, size_t n_in, void *out, size_t out_cap,

@@ -522,7 +522,7 @@ class Channelizer(_Block):
 class Stft(_Block):
     """Overlapped Fourier analysis: Rechunker(chunk_len) -> Overlapper(chunk_count) ->
     Fourier.with_window(window) (chunks.rs:42-242, analysis.rs:26-133; the wiring of
-    examples/bandwidth_meter/main.rs:66-69).  Input chunks must be multiples of chunk_len."""
+    examples/bandwidth_meter/main.rs:66-69).  Input chunks may have any length."""
 
     _destroy = "rr_stft_destroy"
 
@@ -531,6 +531,7 @@ class Stft(_Block):
         super().__init__()
         self._code, self._cdt = _dtype_code(dtype)
         self.chunk_len, self.chunk_count = int(chunk_len), int(chunk_count)
+        self._rate = None
         w = window if window is not None else Rectangular()
         spec = w._spec()
         if spec is None:
@@ -546,11 +547,16 @@ class Stft(_Block):
         if signal.is_event():
             _lib.check(_lib.lib().rr_stft_reset(self._h))
             return [EventSignal(SamplesLost()), signal]
+        pre = []
+        if self._rate is not None and signal.sample_rate != self._rate:  # chunks.rs:72-79
+            _lib.check(_lib.lib().rr_stft_reset(self._h))
+            pre = [EventSignal(SamplesLost())]
+        self._rate = signal.sample_rate
         n_out = C.c_size_t()
         _lib.check(_lib.lib().rr_stft_peek(self._h, len(signal.chunk), C.byref(n_out)))
         y = self._host_call(_lib.lib().rr_stft_process, (), signal.chunk, n_out.value)
         N = self.chunk_len * self.chunk_count
-        return [Samples(signal.sample_rate, y[i * N : (i + 1) * N]) for i in range(len(y) // N)]
+        return pre + [Samples(signal.sample_rate, y[i * N : (i + 1) * N]) for i in range(len(y) // N)]
 
     def process_dev(self, d_in: int, n_in: int, d_out: int, cap: int) -> int:
         n_out = C.c_size_t()

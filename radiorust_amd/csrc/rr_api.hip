@@ -358,14 +358,33 @@ int rr_downsampler::process_dev(double input_rate, const void *d_in, size_t n_in
 // ---------------------------------------------------------------------------
 rr_stft::~rr_stft() { delete fo; }
 
-int rr_stft::process_dev(const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out) {
+int rr_stft::process_dev(const void *d_in_, size_t n_in_, void *d_out, size_t cap, size_t *n_out) {
     if (n_out) *n_out = 0;
-    if (n_in % M) RR_FAIL(RR_ERR_BAD_ARG, "Stft: %zu samples is not a whole number of %zu-sample chunks", n_in, M);
-    const size_t produce = peek(n_in);
+    const size_t produce = peek(n_in_);
     if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Stft: out_cap %zu < %zu", cap, produce);
-    if (n_in == 0) return RR_OK;
+    if (n_in_ == 0) return RR_OK;
     RR_TRY(select());
-    const size_t N = M * P, chunks = n_in / M, H = (P - 1) * M, esz = elem_size(dtype);
+    const size_t N = M * P, H = (P - 1) * M, esz = elem_size(dtype);
+    // Rechunker (chunks.rs:42-177): whole chunks of M out of [patchwork | input]; the rest waits
+    const size_t total = carry_len + n_in_, n_in = total / M * M, left = total - n_in;
+    RR_TRY(carry.reserve(M * esz));
+    const char *d_in = static_cast<const char *>(d_in_);
+    if (n_in == 0) {  // not even one chunk yet
+        RR_HIP(hipMemcpyAsync(carry.as<char>() + carry_len * esz, d_in, n_in_ * esz, hipMemcpyDeviceToDevice, stream));
+        carry_len = total;
+        return RR_OK;
+    }
+    if (carry_len) {  // ragged input: the chunks are assembled once (aligned input takes the zero-copy path)
+        RR_TRY(work.reserve(n_in * esz));
+        RR_HIP(hipMemcpyAsync(work.p, carry.p, carry_len * esz, hipMemcpyDeviceToDevice, stream));
+        RR_HIP(hipMemcpyAsync(work.as<char>() + carry_len * esz, d_in, (n_in - carry_len) * esz, hipMemcpyDeviceToDevice, stream));
+        if (left) RR_HIP(hipMemcpyAsync(carry.p, d_in + (n_in_ - left) * esz, left * esz, hipMemcpyDeviceToDevice, stream));
+        d_in = work.as<char>();
+    } else if (left) {
+        RR_HIP(hipMemcpyAsync(carry.p, d_in + n_in * esz, left * esz, hipMemcpyDeviceToDevice, stream));
+    }
+    carry_len = left;
+    const size_t chunks = n_in / M;
     const size_t frames = produce / N;
     if (frames) {
         fo->stream = stream;
@@ -375,7 +394,7 @@ int rr_stft::process_dev(const void *d_in, size_t n_in, void *d_out, size_t cap,
         const long base0 = ((long)first_complete - (long)(P - 1)) * (long)M;  // <= 0 only if the history holds it
         const size_t n_head = base0 < 0 ? (size_t)(-base0) : 0;
         const char *head = hist[cur].as<char>() + (H - n_head) * esz;
-        const char *in0 = static_cast<const char *>(d_in) + (base0 > 0 ? (size_t)base0 * esz : 0);
+        const char *in0 = d_in + (base0 > 0 ? (size_t)base0 * esz : 0);
         RR_TRY(launch_fourier_overlapped(dtype, stream, head, n_head, in0, d_out, N, M, frames, fo->d_window.p,
                                          fo->d_tw.p, fo->center_dc));
     }
@@ -1507,12 +1526,12 @@ int rr_stft_create(int dtype, size_t chunk_len, size_t chunk_count, const rr_win
 int rr_stft_reset(rr_stft *h) {
     RR_CHECK_HANDLE(h, K_STFT);
     h->have_chunks = 0;  // chunks.rs:225-233
+    h->carry_len = 0;    // chunks.rs:80-88
     return RR_OK;
 }
 int rr_stft_peek(const rr_stft *h, size_t n_in, size_t *n_out) {
     RR_CHECK_HANDLE(h, K_STFT);
     if (!n_out) RR_FAIL(RR_ERR_BAD_ARG, "null");
-    if (n_in % h->M) RR_FAIL(RR_ERR_BAD_ARG, "Stft: input must be whole chunks of %zu samples", h->M);
     *n_out = h->peek(n_in);
     return RR_OK;
 }
@@ -1526,7 +1545,6 @@ int rr_stft_process(rr_stft *h, const void *in, size_t n_in, void *out, size_t c
     RR_GUARD_BEGIN
     RR_CHECK_HANDLE(h, K_STFT);
     if (n_out) *n_out = 0;
-    if (n_in % h->M) RR_FAIL(RR_ERR_BAD_ARG, "Stft: input must be whole chunks of %zu samples", h->M);
     const size_t produce = h->peek(n_in);
     if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Stft: out_cap %zu < %zu", cap, produce);
     size_t got = 0;

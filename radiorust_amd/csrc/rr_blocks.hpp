@@ -74,9 +74,12 @@ struct rr_stft : rr_block {
     rr::DevBuf hist[2];      // the last (P-1)*M samples
     int cur = 0;
     rr_fourier *fo = nullptr;  // window + twiddles of the P*M-point transform
+    // the Rechunker's patchwork (chunks.rs:62-64): < M samples waiting for the rest of their chunk
+    rr::DevBuf carry, work;
+    size_t carry_len = 0;
     ~rr_stft() override;
     size_t peek(size_t n_in) const {
-        const size_t chunks = n_in / M, total = have_chunks + chunks;
+        const size_t chunks = (carry_len + n_in) / M, total = have_chunks + chunks;
         return total >= P ? (total - (P - 1)) * M * P : 0;
     }
     int process_dev(const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);

@@ -166,3 +166,25 @@ def test_stft_contract(rr):
         rr.Stft(64, 0)
     with pytest.raises(BackendError):
         rr.Stft(100, 3)  # 300 points: overlapping chunks need a power-of-two span
+
+
+def test_stft_rechunks_arbitrary_input(rr, oracle):
+    """The Rechunker in front (chunks.rs:42-177; the reference's own test feeds 4096-sample chunks into
+    Rechunker(1024), chunks.rs:247-271): input messages of any length give the same spectra as whole
+    chunks, and a change of sample rate drops the patchwork and the history behind a SamplesLost."""
+    M, P = 1024, 2
+    x = oracle.synth_iq(24, 0, M * 9 + 300)
+    chunks = [x[i * M : (i + 1) * M] for i in range(9)]
+    ref, _ = overlapped_spectra(oracle, chunks, P, oracle.Rectangular(), False, np.float64)
+    g = rr.Stft(M, P)
+    got = []
+    for a, b in ((0, 4096), (4096, 4097), (4097, 4100), (4100, 9000), (9000, len(x))):
+        got += g.process(rr.Samples(1.0, x[a:b]))
+    assert len(got) == len(ref) == 8 and all(len(s.chunk) == M * P for s in got)
+    for s, r in zip(got, ref):
+        assert rms_rel(s.chunk, r) <= 1e-5
+    out = g.process(rr.Samples(2.0, x[: 3 * M]))  # new rate: 300 pending samples and the history are dropped
+    assert out[0].is_event() and len(out) == 1 + 2
+    ref2, _ = overlapped_spectra(oracle, chunks[:3], P, oracle.Rectangular(), False, np.float64)
+    for s, r in zip(out[1:], ref2):
+        assert s.sample_rate == 2.0 and rms_rel(s.chunk, r) <= 1e-5
