@@ -729,6 +729,7 @@ int rr_chain::ensure_xh() {
 //   direct  k_mix_fir_decim  direct form, real taps, D in {2, 4, 8}; cost ~ Lc           0.222 ms
 //   ols     k_ols_decim4     overlap-save, workgroup per 4096-block, D = 4, any taps       0.21 ms
 //   olsw    k_ols_wave       overlap-save, wave per 1024-block, D = 4, any taps, Lc <= 513 0.144 ms
+//                            (chosen up to Lc = 385)
 //   olsf    k_ols_frame      olsw's blocks + the 4096-point Fourier stage in one kernel (a workgroup
 //                            per frame), D = 4, 129 <= Lc <= 193, fft_len = 4096; 0.233 ms for BOTH
 //                            stages against olsw + k_fft4096 = 0.207: on request only
@@ -746,7 +747,9 @@ int rr_chain::pick_fused_kernel(uint64_t D, size_t lc, bool real_taps, size_t ff
         if (!std::strcmp(e, "olsw") && can_wave) return FK_OLSW;
         if (!std::strcmp(e, "olsf") && can_frame) return FK_OLSF;
     }
-    if (can_wave && (lc >= 112 || !can_direct)) return FK_OLSW;
+    // beyond an overlap of 384 of the 1024 samples (Lc > 385) the 4096-blocks are ahead (measured:
+    // Lc = 455: 0.252 against 0.259 ms per step; Lc = 375: 0.250 against 0.222)
+    if (can_wave && (lc >= 112 || !can_direct) && (ols_wave_overlap(lc) <= 384 || !can_ols)) return FK_OLSW;
     if (can_direct) return FK_DIRECT;
     if (can_ols) return FK_OLS;
     return FK_NONE;
