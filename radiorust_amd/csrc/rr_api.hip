@@ -747,10 +747,14 @@ int rr_chain::pick_fused_kernel(uint64_t D, size_t lc, bool real_taps, size_t ff
         if (!std::strcmp(e, "olsw") && can_wave) return FK_OLSW;
         if (!std::strcmp(e, "olsf") && can_frame) return FK_OLSF;
     }
-    // beyond an overlap of 384 of the 1024 samples (Lc > 385) the 4096-blocks are ahead (measured:
-    // Lc = 455: 0.252 against 0.259 ms per step; Lc = 375: 0.250 against 0.222)
-    if (can_wave && (lc >= 112 || !can_direct) && (ols_wave_overlap(lc) <= 384 || !can_ols)) return FK_OLSW;
+    // 4x decimation: overlap-save unless the filter is short; beyond an overlap of 384 of the 1024 samples
+    // (Lc > 385) the 4096-blocks are ahead (measured: Lc = 455: 0.252 against 0.259 ms per step, the direct
+    // form 0.54; Lc = 375: 0.250 against 0.222)
+    const bool long_enough = lc >= 112 || !can_direct;
+    if (can_wave && long_enough && (ols_wave_overlap(lc) <= 384 || !can_ols)) return FK_OLSW;
+    if (can_ols && long_enough) return FK_OLS;
     if (can_direct) return FK_DIRECT;
+    if (can_wave) return FK_OLSW;
     if (can_ols) return FK_OLS;
     return FK_NONE;
 }
