@@ -1158,7 +1158,7 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
         base += hopm_run;  // (bstride * hop) mod denom
         if (base >= denom) base -= denom;
         // ---- mix: v[2 k' + j] = xs[b0 + 2 l + j + 128 k'] ------------------------------------------
-        // (the NCO table holds 2 * denom entries, so the pair r, r + 1 is one 16-byte read)
+        // (the NCO table carries entry 0 once more behind entry denom - 1, so the pair r, r + 1 is one 16-byte read)
         f2 v[16];
         if (b0 >= 0 && b0 + 1024 <= n_in) {
             if (kstep == 0) {  // the period divides 128: one pair of phasors per lane
@@ -1169,13 +1169,19 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
                     v[2 * k + 1] = cmul((f2){x[k].z, x[k].w}, (f2){pp.z, pp.w});
                 }
             } else {
+                // general period: the lane's pair at the block start from the table, the seven
+                // 128-sample steps by the rotations kept behind the table (one product each; a
+                // last-bit difference from the table's own entries, far inside the chain's 1e-5)
+                const f4u pp = *reinterpret_cast<const f4u *>(nco + r);
+                const f2 p0 = {pp.x, pp.y}, p1 = {pp.z, pp.w};
+                v[0] = cmul((f2){x[0].x, x[0].y}, p0);
+                v[1] = cmul((f2){x[0].z, x[0].w}, p1);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const f4u pp = *reinterpret_cast<const f4u *>(nco + r);
-                    v[2 * k] = cmul((f2){x[k].x, x[k].y}, (f2){pp.x, pp.y});
-                    v[2 * k + 1] = cmul((f2){x[k].z, x[k].w}, (f2){pp.z, pp.w});
-                    r += kstep;
-                    if (r >= denom) r -= denom;
+                for (int k = 1; k < 8; ++k) {
+                    const float2 rt = nco[denom + 1 + k];  // uniform address: a scalar read
+                    const f2 rot = {rt.x, rt.y};
+                    v[2 * k] = cmul((f2){x[k].x, x[k].y}, cmul(p0, rot));
+                    v[2 * k + 1] = cmul((f2){x[k].z, x[k].w}, cmul(p1, rot));
                 }
             }
         } else {
