@@ -275,6 +275,11 @@ int rr_chain_peek(rr_chain *h, double sample_rate, size_t n_in, size_t *n_frames
 /* Consumes n_in samples; writes n_frames*fft_len spectrum bins (n_out). */
 int rr_chain_process(rr_chain *h, double sample_rate, const void *in, size_t n_in,
                      void *out, size_t out_cap, size_t *n_out);
+/* The same without waiting: copies and kernels are queued on the handle's stream
+ * (true overlap needs pinned / registered host buffers, rr_host_*); n_out is known at
+ * once, `out` is valid after rr_wait(h) or once rr_query(h) returns RR_OK. */
+int rr_chain_enqueue(rr_chain *h, double sample_rate, const void *in, size_t n_in,
+                     void *out, size_t out_cap, size_t *n_out);
 int rr_chain_process_dev(rr_chain *h, double sample_rate, const void *d_in,
                          size_t n_in, void *d_out, size_t out_cap, size_t *n_out);
 /* Which kernels the last process call ran: 0 = block-by-block; non-zero = fused

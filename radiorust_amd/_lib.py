@@ -129,6 +129,7 @@ SIGNATURES = {
     "rr_chain_interrupt": (_i, [_vp]),
     "rr_chain_peek": (_i, [_vp, _d, _sz, _psz]),
     "rr_chain_process": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
+    "rr_chain_enqueue": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
     "rr_chain_process_dev": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
     "rr_chain_last_path": (_i, [_vp, C.POINTER(_i)]),
     "rr_chain_destroy": (_i, [_vp]),

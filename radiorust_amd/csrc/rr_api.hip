@@ -1912,7 +1912,8 @@ int rr_chain_process_dev(rr_chain *h, double rate, const void *d_in, size_t n_in
     return h->process_dev(rate, d_in, n_in, d_out, cap, n_out);
     RR_GUARD_END
 }
-int rr_chain_process(rr_chain *h, double rate, const void *in, size_t n_in, void *out, size_t cap, size_t *n_out) {
+static int chain_host(rr_chain *h, double rate, const void *in, size_t n_in, void *out, size_t cap, size_t *n_out,
+                      bool blocking) {
     RR_GUARD_BEGIN
     RR_CHECK_HANDLE(h, K_CHAIN);
     if (n_out) *n_out = 0;
@@ -1923,7 +1924,7 @@ int rr_chain_process(rr_chain *h, double rate, const void *in, size_t n_in, void
     const size_t need = frames * h->p.fft_len;
     if (need > cap) RR_FAIL(RR_ERR_CAPACITY, "Chain: out_cap %zu < %zu", cap, need);
     size_t got = 0;
-    RR_TRY(host_io(h, in, n_in, out, need, true, [&](void *di, void *dout, size_t *p) {
+    RR_TRY(host_io(h, in, n_in, out, need, blocking, [&](void *di, void *dout, size_t *p) {
         int s = h->process_dev(rate, di, n_in, dout, need, p);
         got = *p;
         return s;
@@ -1931,6 +1932,12 @@ int rr_chain_process(rr_chain *h, double rate, const void *in, size_t n_in, void
     if (n_out) *n_out = got;
     return RR_OK;
     RR_GUARD_END
+}
+int rr_chain_process(rr_chain *h, double rate, const void *in, size_t n_in, void *out, size_t cap, size_t *n_out) {
+    return chain_host(h, rate, in, n_in, out, cap, n_out, true);
+}
+int rr_chain_enqueue(rr_chain *h, double rate, const void *in, size_t n_in, void *out, size_t cap, size_t *n_out) {
+    return chain_host(h, rate, in, n_in, out, cap, n_out, false);
 }
 int rr_chain_last_path(const rr_chain *h, int *fused) {
     RR_CHECK_HANDLE(h, K_CHAIN);

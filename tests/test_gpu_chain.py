@@ -250,3 +250,29 @@ def test_chain_wave_kernel_randomised(rr, oracle, seed):
     assert fused_calls >= 2, (cuts, fused_calls)
     for a, b in zip(out, t64):
         assert rms_rel(a.chunk, b) <= 1e-5
+
+
+def test_chain_enqueue_with_pinned_buffers(rr, oracle):
+    """rr_chain_enqueue: the asynchronous host-pointer entry; n_out is final at enqueue time,
+    the spectra are there after rr_wait."""
+    import ctypes as C
+
+    L = rr._lib.lib()
+    fs, n = 200e6, 1 << 17
+    x = oracle.synth_iq(1, 0, n)
+    t64 = oracle_spectra(oracle, x, fs, CFG2, np.float64)
+    g = make(rr, oracle, CFG2, True)
+    g._ensure_design(fs)
+    p_in, p_out = C.c_void_p(), C.c_void_p()
+    cap = 8 * 4096
+    assert L.rr_host_alloc(n * 8, C.byref(p_in)) == 0 and L.rr_host_alloc(cap * 8, C.byref(p_out)) == 0
+    C.memmove(p_in, x.ctypes.data, n * 8)
+    cnt = C.c_size_t()
+    assert L.rr_chain_enqueue(g._h, fs, p_in, n, p_out, cap, C.byref(cnt)) == 0
+    assert cnt.value == len(t64) * 4096 == 7 * 4096
+    g.wait()
+    assert g.query()
+    y = np.frombuffer((C.c_char * (cnt.value * 8)).from_address(p_out.value), dtype=np.complex64).reshape(-1, 4096)
+    for a, b in zip(y, t64):
+        assert rms_rel(a, b) <= 1e-5
+    assert L.rr_host_free(p_in) == 0 and L.rr_host_free(p_out) == 0
