@@ -276,3 +276,41 @@ def test_chain_enqueue_with_pinned_buffers(rr, oracle):
     for a, b in zip(y, t64):
         assert rms_rel(a, b) <= 1e-5
     assert L.rr_host_free(p_in) == 0 and L.rr_host_free(p_out) == 0
+
+
+def test_chain_enqueue_back_to_back_matches_blocking_calls(rr, oracle):
+    """Several rr_chain_enqueue calls in flight (their copies and kernels overlap on three streams, two sets
+    of staging buffers, growing call sizes): after one rr_wait every call's spectra equal those of the same
+    stream pushed through the blocking entry, bit for bit."""
+    import ctypes as C
+
+    L = rr._lib.lib()
+    fs = 200e6
+    sizes = [1 << 15, 3000, 1 << 16, 0, 70001, 1 << 17, 1 << 15, 123457]
+    x = oracle.synth_iq(5, 0, sum(sizes))
+    ref = make(rr, oracle, CFG2, True)
+    want, off = [], 0
+    for n in sizes:
+        got = ref.process(rr.Samples(fs, x[off : off + n]))
+        want.append(np.concatenate([np.asarray(s.chunk) for s in got]) if got else np.empty(0, np.complex64))
+        off += n
+    g = make(rr, oracle, CFG2, True)
+    g._ensure_design(fs)
+    bufs, off = [], 0
+    for n in sizes:
+        p_in, p_out = C.c_void_p(), C.c_void_p()
+        cap = (n // 4 // 4096 + 2) * 4096
+        assert L.rr_host_alloc(max(n, 1) * 8, C.byref(p_in)) == 0 and L.rr_host_alloc(cap * 8, C.byref(p_out)) == 0
+        C.memmove(p_in, x[off : off + n].ctypes.data, n * 8)
+        off += n
+        bufs.append((p_in, p_out, cap, C.c_size_t()))
+    for n, (p_in, p_out, cap, cnt) in zip(sizes, bufs):
+        assert L.rr_chain_enqueue(g._h, fs, p_in, n, p_out, cap, C.byref(cnt)) == 0
+    g.wait()
+    assert g.query()
+    for w, (p_in, p_out, cap, cnt) in zip(want, bufs):
+        assert cnt.value == w.size
+        if cnt.value:
+            y = np.frombuffer((C.c_char * (cnt.value * 8)).from_address(p_out.value), dtype=np.complex64)
+            assert np.array_equal(y.view(np.uint32), np.ascontiguousarray(w).view(np.uint32))
+        assert L.rr_host_free(p_in) == 0 and L.rr_host_free(p_out) == 0
