@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--no-fused", action="store_true", help="force the block-by-block kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--time-all", action="store_true", help="time every kernel inside the timed region, not only the dominant one")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="rank logic rehearsal only: all ranks share cuda:0 and line up over gloo (RCCL refuses two ranks on one GPU)")
     ap.add_argument("--traffic-json", default=None, help="file holding measured HBM bytes per launch (PMC pass)")
     args = ap.parse_args()
 
@@ -116,10 +118,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the backend has no CPU path")
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     from radiorust_amd.dist import Ranks, whole_job_rate
 
-    ranks = Ranks("nccl")
+    if args.rehearse_on_one_gpu:
+        torch.cuda.set_device(0)
+        ranks = Ranks("gloo")
+        ranks.local_rank = 0
+    else:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        ranks = Ranks("nccl")
     world, rank, local_rank = ranks.world, ranks.rank, ranks.local_rank
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world} rank(s)", file=sys.stderr)
@@ -302,6 +309,8 @@ def main():
             line["cpu_baseline"], ref0 = cpu_baseline()
             line["parity_first_spectrum_rms"] = float(np.sqrt(np.sum(np.abs(first_spectrum - ref0) ** 2) / np.sum(np.abs(ref0) ** 2)))
         assert first_frames >= 0
+        if args.rehearse_on_one_gpu:
+            line["rehearsal"] = "all ranks shared cuda:0 over gloo: not a measurement"
         print(json.dumps(line))
     barrier()  # rank 0's un-timed checks are done before anybody tears the group down
     ranks.close()
