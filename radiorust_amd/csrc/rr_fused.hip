@@ -1012,16 +1012,36 @@ __device__ __forceinline__ void st_stream(float2 *p, float2 v) {
 #define RR_WAVE_LDX(p) (*(p))
 #define RR_WAVE_STY(p, v) (*(p) = (v))
 #endif
-template <bool LOOP>
-__global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
-    __attribute__((amdgpu_waves_per_eu(LOOP ? RR_V_WAVEOCCL : 4, LOOP ? RR_V_WAVEOCCL : 4))) void k_ols_wave(
+// MODE 0: one block per wave.  MODE 1 (LOOP): persistent one-wave workgroups.  MODE 2 (CUR): persistent
+// workgroups of kCuWaves waves, one per CU, with H staged in LDS once per workgroup: per block and lane
+// the vector-memory instructions shrink from 24 (8 samples, 8 H, 3 seeds, 1 NCO, 4 stores) to 12-13.
+#ifndef RR_V_WAVECU
+#define RR_V_WAVECU 16  // waves of a CU-resident workgroup (MODE 2): 16 x 9408 B images + 8 KiB of H = 155 KiB of LDS
+#endif
+#ifndef RR_V_WAVEBUFST
+#define RR_V_WAVEBUFST 1  // the block's outputs leave as buffer stores with out-of-range lanes dropped (no branch)
+#endif
+#ifndef RR_V_WAVECUPF
+#define RR_V_WAVECUPF 1  // MODE 2: request the next block's samples while the current block is transformed
+#endif
+constexpr int kCuWaves = RR_V_WAVECU;
+template <int MODE>
+__global__ __launch_bounds__(MODE == 2 ? 64 * kCuWaves : (MODE == 1 ? 64 : 64 * RR_V_WAVEWG))
+    __attribute__((amdgpu_waves_per_eu(MODE == 2 ? kCuWaves / 4 : (MODE == 1 ? RR_V_WAVEOCCL : 4),
+                                       MODE == 2 ? kCuWaves / 4 : (MODE == 1 ? RR_V_WAVEOCCL : 4)))) void k_ols_wave(
         const float2 *__restrict__ xh, int hx, const float2 *__restrict__ in, long n_in, const float2 *__restrict__ nco,
         unsigned denom, unsigned idx0, const float2 *__restrict__ H, const float2 *__restrict__ tw, int V,
         float2 *__restrict__ out, long n_out, long e0, float2 *__restrict__ xh_out, int hx_out, unsigned nblocks,
         unsigned ph0, unsigned hopm, unsigned hopm_run, unsigned kstep, double inv_denom) {
-    __shared__ __attribute__((aligned(16))) f2 lds_all[LOOP ? 1 : RR_V_WAVEWG][kWaveLds];
-    f2 *const lds = lds_all[LOOP ? 0 : (threadIdx.x >> 6)];
+    constexpr bool LOOP = MODE != 0, CUR = MODE == 2;
+    __shared__ __attribute__((aligned(16))) f2 lds_all[CUR ? kCuWaves : (LOOP ? 1 : RR_V_WAVEWG)][kWaveLds];
+    __shared__ __attribute__((aligned(16))) float4 Hs[CUR ? 512 : 1];
+    f2 *const lds = lds_all[MODE == 1 ? 0 : (threadIdx.x >> 6)];
     const int l = threadIdx.x & 63;
+    if constexpr (CUR) {  // the pair-interleaved response, once per workgroup (before any wave leaves)
+        for (int i = threadIdx.x; i < 512; i += 64 * kCuWaves) Hs[i] = reinterpret_cast<const float4 *>(H)[i];
+        __syncthreads();
+    }
     // Workgroups b, b+8, .. share an XCD.  Blocks are dealt so that neighbouring blocks run on one
     // XCD (and, with LOOP, in one wave): the V samples two neighbours share come from HBM once.
     unsigned blk, cnt, bstride;
@@ -1030,7 +1050,9 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
         // them round robin (wave i: i, i + wpx, ..), so that the blocks in flight at any moment are
         // neighbours in memory, as with one block per wave.  Contiguous runs per wave were measured
         // slower (0.146 vs 0.128 ms for the bare load/store loop): 3072 separate streams.
-        const unsigned wpx = gridDim.x >> 3, xcd = blockIdx.x & 7, i = blockIdx.x >> 3;  // grid: multiple of 8
+        const unsigned wpw = CUR ? kCuWaves : 1;  // waves per workgroup
+        const unsigned wpx = (gridDim.x >> 3) * wpw, xcd = blockIdx.x & 7;  // grid: multiple of 8
+        const unsigned i = (blockIdx.x >> 3) * wpw + (CUR ? (threadIdx.x >> 6) : 0);
 #if RR_V_WAVERUN > 0
         // run mode: RR_V_WAVERUN neighbouring blocks per wave, H and the seeds loaded once per run
         // (fewer vector-memory instructions per block), no prefetch
@@ -1095,10 +1117,9 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
     // (measured), so everything comes in 16-byte pieces: lane l takes the sample pairs
     // x[2 l + 128 k' .. + 1], k' < 8, and its 6 twiddle seeds as 3 packed entries.
     f4u x[8];
-    constexpr bool PF = LOOP && RR_V_WAVERUN == 0;  // prefetching form
-    if (PF || (!LOOP && b0 >= 0 && b0 + 1024 <= n_in)) {
-        const long bs = !LOOP ? b0 : (b0 < 0 ? 0 : (b0 > n_in - 1024 ? n_in - 1024 : b0));
-        const f4u *src = reinterpret_cast<const f4u *>(in + bs) + l;
+    constexpr bool PF = LOOP && RR_V_WAVERUN == 0 && (!CUR || RR_V_WAVECUPF);  // prefetching form
+    if (!LOOP && b0 >= 0 && b0 + 1024 <= n_in) {
+        const f4u *src = reinterpret_cast<const f4u *>(in + b0) + l;
 #pragma unroll
         for (int k = 0; k < 8; ++k) x[k] = RR_WAVE_LDX(src + 64 * k);
     }
@@ -1119,6 +1140,34 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
     f2 *const b_rd = lds + (l + 4 * g);  // B(l + 64 c) = b_rd + 80 c
     size_t zoff = 0;
     float2 hv[16];
+    auto lane_phase = [&](unsigned bs) {  // (bs + 2 l) mod denom, bs < denom
+        unsigned r = bs + 2u * (unsigned)l;
+        if (denom >= 128u) {
+            if (r >= denom) r -= denom;
+        } else if ((denom & (denom - 1u)) == 0u) {
+            r &= denom - 1u;
+        } else {
+            r %= denom;
+        }
+        return r;
+    };
+    // the lane's phasor pair at the block start.  The prefetching form requests the next block's pair
+    // together with its samples: asked for at the block start it would sit behind the previous block's
+    // stores in the in-order vmcnt queue, a full round trip in front of every block's first product.
+    f4u pp_next;
+    if constexpr (PF) {
+        // The first block's pair and samples are waited for HERE, in front of the loop.  Entering the loop
+        // with them in flight, the wait at the top of the loop would have to serve both ways in - the newest
+        // operations of the queue on this way, four stores behind them on the way round - and the
+        // compiler then takes vmcnt(0): every block would wait for the previous block's stores.
+        pp_next = *reinterpret_cast<const f4u *>(nco + lane_phase(base));
+        const long bs = b0 < 0 ? 0 : (b0 > n_in - 1024 ? n_in - 1024 : b0);
+        const f4u *src = reinterpret_cast<const f4u *>(in + bs) + l;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = RR_WAVE_LDX(src + 64 * k);
+        asm volatile("" : "+v"(t_p1), "+v"(t_p2[0]), "+v"(t_p2[1]), "+v"(t_inv[0]), "+v"(t_inv[1]), "+v"(t_inv[2]));
+        asm volatile("" : "+v"(pp_next), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+    }
 #if RR_V_WAVERUN > 0
     if constexpr (LOOP) {
 #pragma unroll
@@ -1132,7 +1181,7 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
 
     for (unsigned it = 0; it < cnt; ++it, blk += bstride, b0 += bhop) {
         RR_STAMP_T(wt0);
-        if constexpr (LOOP && RR_V_WAVERUN > 0) {
+        if constexpr (LOOP && !PF) {
             if (b0 >= 0 && b0 + 1024 <= n_in) {
                 const f4u *src = reinterpret_cast<const f4u *>(in + b0) + l;
 #pragma unroll
@@ -1147,22 +1196,17 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
             asm volatile("" : "+s"(zoff));  // an opaque 0 added to H below
         }
         // ---- phase of the lane's first sample (2 l into the block) -------------------------------
-        unsigned r = base + 2u * (unsigned)l;
-        if (denom >= 128u) {
-            if (r >= denom) r -= denom;
-        } else if ((denom & (denom - 1u)) == 0u) {
-            r &= denom - 1u;
-        } else {
-            r %= denom;
-        }
+        unsigned r = lane_phase(base);
         base += hopm_run;  // (bstride * hop) mod denom
         if (base >= denom) base -= denom;
         // ---- mix: v[2 k' + j] = xs[b0 + 2 l + j + 128 k'] ------------------------------------------
         // (the NCO table carries entry 0 once more behind entry denom - 1, so the pair r, r + 1 is one 16-byte read)
         f2 v[16];
         if (b0 >= 0 && b0 + 1024 <= n_in) {
+            f4u pp;
+            if constexpr (PF) pp = pp_next;
+            else pp = *reinterpret_cast<const f4u *>(nco + r);
             if (kstep == 0) {  // the period divides 128: one pair of phasors per lane
-                const f4u pp = *reinterpret_cast<const f4u *>(nco + r);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     v[2 * k] = cmul((f2){x[k].x, x[k].y}, (f2){pp.x, pp.y});
@@ -1172,7 +1216,6 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
                 // general period: the lane's pair at the block start from the table, the seven
                 // 128-sample steps by the rotations kept behind the table (one product each; a
                 // last-bit difference from the table's own entries, far inside the chain's 1e-5)
-                const f4u pp = *reinterpret_cast<const f4u *>(nco + r);
                 const f2 p0 = {pp.x, pp.y}, p1 = {pp.z, pp.w};
                 v[0] = cmul((f2){x[0].x, x[0].y}, p0);
                 v[1] = cmul((f2){x[0].z, x[0].w}, p1);
@@ -1212,7 +1255,7 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
         // (H arrives pair-interleaved from the host, Hp[kp][l] = {H[l + 128 kp], H[l + 128 kp + 64]}:
         //  8 loads of 16 bytes per lane; measured cost of vector-memory traffic here is per
         //  instruction, not per byte)
-        if constexpr (!(LOOP && RR_V_WAVERUN > 0)) {
+        if constexpr (!(LOOP && RR_V_WAVERUN > 0) && !CUR) {
 #pragma unroll
             for (int kp = 0; kp < 8; ++kp) {
                 const float4 h4 = reinterpret_cast<const float4 *>(H + zoff)[l + 64 * kp];
@@ -1226,6 +1269,7 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
         // that they were NOT issued, and then each wait for an H value also waits for them.
         if constexpr (PF) {
             __builtin_amdgcn_sched_barrier(0);
+            pp_next = *reinterpret_cast<const f4u *>(nco + lane_phase(base));  // base: already the next block's
             long nb = b0 + bhop;
             nb = nb < 0 ? 0 : (nb > n_in - 1024 ? n_in - 1024 : nb);
             const f4u *src = reinterpret_cast<const f4u *>(in + nb) + l;
@@ -1326,6 +1370,16 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
             for (int c = 0; c < 8; ++c) X[m + 2 * c] = a[c];
         }
         // * H and fold the four 256-bin quarters: Y[l + 64 m] = sum_q X[l + 64 (m + 4 q)] H[l + 64 (m + 4 q)]
+        if constexpr (CUR) {
+            int hl = l;
+            asm volatile("" : "+v"(hl));  // read here, in every block: hoisted out of the loop the 16 values cost 32 registers
+#pragma unroll
+            for (int kp = 0; kp < 8; ++kp) {
+                const float4 h4 = Hs[hl + 64 * kp];
+                hv[2 * kp] = float2{h4.x, h4.y};
+                hv[2 * kp + 1] = float2{h4.z, h4.w};
+            }
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             f2 acc = cmul(X[m], (f2){hv[m].x, hv[m].y});
@@ -1375,8 +1429,26 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
 #endif
         RR_STAMP_T(ws5);
         // ---- store the valid part -----------------------------------------------------------------
-        const long mbase = (long)blk * per_block;
         const int first = V >> 2;
+#if RR_V_WAVEBUFST
+        {
+            // Buffer stores: the lanes outside the block's valid part (and behind the end of the output)
+            // carry an out-of-range offset and are dropped by the address check - four stores in
+            // straight-line code.  Under a condition the compiler has to assume at the next wait for a
+            // load that they were not issued, and waits for everything instead (vmcnt counts in order).
+            const long mb = (long)__builtin_amdgcn_readfirstlane((int)blk) * per_block;
+            const long left = n_out - mb;
+            const unsigned recs = (unsigned)(left < per_block ? left : per_block) * 8u;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + mb, 0, recs, 0x00020000);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int tau = l + 64 * c;
+                const unsigned off = tau >= first ? (unsigned)(tau - first) * 8u : 0xffffffffu;
+                __builtin_amdgcn_raw_buffer_store_b64(y[c], rs, off, 0, RR_V_WAVENT ? 2 : 0);
+            }
+        }
+#else
+        const long mbase = (long)blk * per_block;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int tau = l + 64 * c;
@@ -1388,6 +1460,7 @@ __global__ __launch_bounds__(LOOP ? 64 : 64 * RR_V_WAVEWG)
                 RR_WAVE_STY(out + m, w);
             }
         }
+#endif
 #if defined(RR_STAMP) && RR_WAVE_ABLATE == 0
         {
             RR_STAMP_T(ws6);
@@ -1895,6 +1968,9 @@ int launch_ols_wave(hipStream_t s, const FusedFirArgs &a) {
     int64_t ph = ((int64_t)a.idx0 + a.e0 - a.V) % den;
     if (ph < 0) ph += den;
     const unsigned hopm = (unsigned)((int64_t)(1024 - a.V) % den), kstep = (unsigned)(128 % den);
+#ifndef RR_V_WAVECUR
+#define RR_V_WAVECUR 0  // > 0: CU-resident persistent workgroups (k_ols_wave<2>), that many per CU
+#endif
 #ifndef RR_V_WAVELOOP
 #define RR_V_WAVELOOP 0  // 0: one block per wave (measured faster: 0.144 vs 0.168 ms); G > 0: persistent waves, G resident sets
 #endif
@@ -1906,18 +1982,30 @@ int launch_ols_wave(hipStream_t s, const FusedFirArgs &a) {
     const size_t cap = (size_t)1024 * RR_V_WAVEOCCL * RR_V_WAVELOOP;
     unsigned grid = (unsigned)(nblocks < cap ? (nblocks + 7) / 8 * 8 : cap), threads = 64;
 #endif
-    auto kern = k_ols_wave<true>;
+    auto kern = k_ols_wave<1>;
+    unsigned wpw = 1;
     if (a.n_in < 1024) {  // the persistent form prefetches whole blocks from inside the input
-        kern = k_ols_wave<false>;
+        kern = k_ols_wave<0>;
         grid = (unsigned)((nblocks + 7) / 8 * 8);
+    }
+#elif RR_V_WAVECUR > 0
+    // CU-resident workgroups: RR_V_WAVECUR per CU's worth of LDS (1), 256 CUs
+    unsigned grid = 256 * RR_V_WAVECUR, threads = 64 * kCuWaves, wpw = kCuWaves;
+    auto kern = k_ols_wave<2>;
+    if (a.n_in < 1024 || nblocks < 4096) {
+        const size_t per_xcd = (nblocks + 7) / 8;
+        kern = k_ols_wave<0>;
+        grid = (unsigned)((per_xcd + RR_V_WAVEWG - 1) / RR_V_WAVEWG * 8);
+        threads = 64 * RR_V_WAVEWG;
+        wpw = 1;
     }
 #else
     const size_t per_xcd = (nblocks + 7) / 8;
-    const unsigned grid = (unsigned)((per_xcd + RR_V_WAVEWG - 1) / RR_V_WAVEWG * 8), threads = 64 * RR_V_WAVEWG;
-    auto kern = k_ols_wave<false>;
+    const unsigned grid = (unsigned)((per_xcd + RR_V_WAVEWG - 1) / RR_V_WAVEWG * 8), threads = 64 * RR_V_WAVEWG, wpw = 1;
+    auto kern = k_ols_wave<0>;
 #endif
-    const bool looped = kern == k_ols_wave<true>;
-    const unsigned hopm_run = (looped && RR_V_WAVERUN == 0) ? (unsigned)((int64_t)(grid / 8) * (1024 - a.V) % den) : hopm;
+    const bool looped = kern != k_ols_wave<0>;
+    const unsigned hopm_run = (looped && RR_V_WAVERUN == 0) ? (unsigned)((int64_t)(grid / 8) * wpw * (1024 - a.V) % den) : hopm;
     if (a.ev_start && a.ev_stop)
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, s, a.ev_start, a.ev_stop, 0, (const float2 *)a.xh, (int)a.hx,
                               (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0,

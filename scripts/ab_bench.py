@@ -10,7 +10,7 @@ import sys
 
 rounds = int(sys.argv[1])
 libs = sys.argv[2:]
-res = {l: {"fir": [], "fft": [], "step": []} for l in libs}
+res = {l: {"fir": [], "fft": [], "step": [], "rms": []} for l in libs}
 for r in range(rounds):
     for l in libs:
         env = dict(os.environ)
@@ -32,6 +32,7 @@ for r in range(rounds):
         res[l]["fir"].append(k.get("fused_mix_fir_decim", {}).get("avg_ms", float("nan")))
         res[l]["fft"].append(k.get("fourier", {}).get("avg_ms", 0.0))
         res[l]["step"].append(d["ms_per_step"])
+        res[l]["rms"].append(d.get("parity_fused_vs_block_by_block_last_step_rms") or 0.0)
 for l in libs:
     f = res[l]
-    print(f"{l:40s} fir med={statistics.median(f['fir']):.4f} min={min(f['fir']):.4f}  fft med={statistics.median(f['fft']):.4f}  step med={statistics.median(f['step']):.4f} min={min(f['step']):.4f}")
+    print(f"{l:40s} fir med={statistics.median(f['fir']):.4f} min={min(f['fir']):.4f}  fft med={statistics.median(f['fft']):.4f}  step med={statistics.median(f['step']):.4f} min={min(f['step']):.4f}  rms vs block-by-block {max(f['rms']):.2e}")
