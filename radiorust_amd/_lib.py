@@ -114,6 +114,7 @@ SIGNATURES = {
     "rr_downsampler_enqueue": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
     "rr_downsampler_process_dev": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
     "rr_downsampler_ir_len": (_i, [_vp, _psz]),
+    "rr_downsampler_last_kernel": (_i, [_vp, C.POINTER(_i)]),
     "rr_downsampler_destroy": (_i, [_vp]),
     "rr_fourier_create": (_i, [_i, C.POINTER(Window), _i, _i, C.POINTER(_vp)]),
     "rr_fourier_set_sampled_window": (_i, [_vp, _sz, _vp]),

@@ -238,6 +238,12 @@ class Downsampler(_Block):
         _lib.check(_lib.lib().rr_downsampler_ir_len(self._h, C.byref(v)))
         return v.value
 
+    def last_kernel(self) -> int:
+        """0 = k_fir; 1 / 2 / 3 = the chain's fused kernels (k_mix_fir_decim / k_ols_decim4 / k_ols_wave)."""
+        v = C.c_int()
+        _lib.check(_lib.lib().rr_downsampler_last_kernel(self._h, C.byref(v)))
+        return v.value
+
     def process_raw(self, sample_rate, chunk) -> np.ndarray:
         """Outputs produced by this input chunk, not yet regrouped."""
         n_out = C.c_size_t()

@@ -182,7 +182,10 @@ int rr_filter::design(double sample_rate, size_t len, const rr_c64 *resp, const 
         cast_to<double>(w.data(), w.size(), bytes);
     RR_TRY(upload(d_taps, bytes.data(), bytes.size(), stream));
     use_ols4096 = filter_ols4096_supported(dtype, len);
-    if (use_ols4096) {
+    // shorter power-of-two filters: the same kernel for long calls (a 4096-block per 4096 - n outputs),
+    // k_fir for short ones
+    big_ols4096 = dtype == RR_F32 && (len == 64 || len == 128);
+    if (use_ols4096 || big_ols4096) {
         std::vector<cd> gg(4096, cd(0, 0));
         for (size_t i = 0; i < len; ++i) gg[i] = g[i];
         fft_f64(gg, false);
@@ -202,7 +205,7 @@ int rr_filter::design(double sample_rate, size_t len, const rr_c64 *resp, const 
         for (size_t i = 0; i < gb.size(); ++i) gh[i] = f32_to_f16_bits(gb[i]);
         RR_TRY(upload(d_G4096h, gh.data(), gh.size() * sizeof(uint16_t), stream));
     }
-    use_ols = !use_ols4096 && ols_supported(dtype, len);
+    use_ols = !use_ols4096 && !big_ols4096 && ols_supported(dtype, len);
     if (use_ols) {
         // the reference's extended response (filters.rs:220-238), transformed in f64 here
         std::vector<cd> ext(2 * len, cd(0, 0));
@@ -243,6 +246,9 @@ int rr_filter::design(double sample_rate, size_t len, const rr_c64 *resp, const 
     return RR_OK;
 }
 
+// n = 64, 128: calls that produce fewer samples than this stay on k_fir
+static constexpr size_t kFilterBigCall = 16384;
+
 int rr_filter::process_dev(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap,
                            size_t *n_out, bool out_f16, bool g_f16) {
     if (n_out) *n_out = 0;
@@ -256,7 +262,7 @@ int rr_filter::process_dev(double sample_rate, const void *d_in, size_t n_in, vo
     const size_t produce = peek(n_in);
     if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Filter: out_cap %zu < %zu", cap, produce);
     RR_TRY(select());
-    if (produce && use_ols4096) {
+    if (produce && (use_ols4096 || (big_ols4096 && produce >= kFilterBigCall))) {
         RR_TRY(launch_filter_ols4096(stream, hist[cur].p, hist_valid ? n : 0, d_in, n_in, g_f16 ? d_G4096h.p : d_G4096.p,
                                      d_tw4096.p, n, d_out, produce, hist_valid ? 0 : (long)n, out_f16, g_f16));
     } else if (produce && use_ols) {
@@ -287,6 +293,9 @@ int rr_filter::process_dev(double sample_rate, const void *d_in, size_t n_in, vo
 // ---------------------------------------------------------------------------
 // Downsampler
 // ---------------------------------------------------------------------------
+// Calls shorter than this stay on k_fir (a fused kernel's launch needs whole blocks to pay off)
+static constexpr size_t kFastMinSamples = 4096;
+
 int rr_downsampler::prepare(double input_rate) {
     if (have_rate && input_rate == prev_rate) return RR_OK;
     std::vector<double> ir;
@@ -360,10 +369,83 @@ int rr_downsampler::process_dev(double input_rate, const void *d_in, size_t n_in
         a.emit = d_emit.as<uint32_t>();
         a.max_step = (uint32_t)std::ceil(input_rate / output_rate) + 1;
     }
+    last_kernel = 0;
+    if (produce && sched.integer_ratio && n_in >= kFastMinSamples) {
+        RR_TRY(ensure_fast());
+        if (fast_kind != rr_chain::FK_NONE) {
+            // the chain's kernels with every phasor = 1: out[m] = sum_i c[i] x[e0 + D m - i], c = reverse(ir);
+            // the kernel's last workgroup leaves the last L samples as the next call's history
+            FusedFirArgs f;
+            f.xh = hist[cur].p;
+            f.hx = L;
+            f.in = d_in;
+            f.n_in = n_in;
+            f.nco = f_one.p;
+            f.denom = 1;
+            f.idx0 = 0;
+            f.taps = f_ctaps.p;
+            f.Gp = f_Gp;
+            f.out = d_out;
+            f.n_out = produce;
+            f.e0 = (int64_t)a.e0;
+            f.D = a.D;
+            f.xh_out = hist[cur ^ 1].p;
+            f.H = f_H.p;
+            f.tw4096 = f_tw.p;
+            f.V = f_V;
+            if (fast_kind == rr_chain::FK_OLSW)
+                RR_TRY(launch_ols_wave(stream, f));
+            else if (fast_kind == rr_chain::FK_OLS)
+                RR_TRY(launch_ols_decim(stream, f));
+            else
+                RR_TRY(launch_fused_fir(stream, f));
+            cur ^= 1;
+            last_kernel = fast_kind;
+            if (n_out) *n_out = produce;
+            return RR_OK;
+        }
+    }
     if (produce) RR_TRY(launch_fir(dtype, stream, a));
     RR_TRY(launch_update_hist(dtype, stream, hist[cur].p, hist[cur ^ 1].p, L, d_in, n_in));
     cur ^= 1;
     if (n_out) *n_out = produce;
+    return RR_OK;
+}
+
+// Tables for the fast path (integer ratio, f32).  RR_DOWNSAMPLER_GENERIC=1 keeps k_fir (A/B runs, tests).
+int rr_downsampler::ensure_fast() {
+    if (fast_version == design_version) return RR_OK;
+    fast_version = design_version;
+    fast_kind = rr_chain::FK_NONE;
+    const char *e = std::getenv("RR_DOWNSAMPLER_GENERIC");
+    if (dtype != RR_F32 || !sched.integer_ratio || (e && std::atoi(e) != 0)) return RR_OK;
+    int kind = rr_chain::pick_fused_kernel(sched.D, L, true, 0);
+    if (kind == rr_chain::FK_OLSF) kind = rr_chain::FK_OLSW;
+    if (kind == rr_chain::FK_NONE) return RR_OK;
+    std::vector<double> c(L);
+    std::vector<cd> cc(L);
+    for (size_t i = 0; i < L; ++i) {
+        c[i] = ir_f64[L - 1 - i];
+        cc[i] = cd(c[i], 0.0);
+    }
+    FusedFirTables t;
+    build_fused_fir_tables(kind, sched.D, c, cc, t);
+    if (kind == rr_chain::FK_DIRECT) {
+        RR_TRY(upload(f_ctaps, t.ctaps.data(), t.ctaps.size() * sizeof(float), stream));
+        f_Gp = t.Gp;
+    } else {
+        RR_TRY(upload(f_H, t.H.data(), t.H.size() * sizeof(float), stream));
+        RR_TRY(upload(f_tw, t.tw.data(), t.tw.size() * sizeof(float), stream));
+        f_V = t.V;
+    }
+    // NCO table of period 1: entry, wrap entry and the 8 rotations behind them (rr_freqshifter::prepare)
+    float ones[2 * 10];
+    for (int i = 0; i < 10; ++i) {
+        ones[2 * i] = 1.f;
+        ones[2 * i + 1] = 0.f;
+    }
+    RR_TRY(upload(f_one, ones, sizeof(ones), stream));
+    fast_kind = kind;
     return RR_OK;
 }
 
@@ -773,26 +855,16 @@ int rr_chain::pick_fused_kernel(uint64_t D, size_t lc, bool real_taps, size_t ff
     return FK_NONE;
 }
 
-// c = reverse(ir) (*) g in f64, cast to f32 and laid out in the step order of
-// k_mix_fir_decim: tb[t*D + p] = c[D*(Gp-1-t) + (D-1-p)], zero beyond Lc
-int rr_chain::ensure_ctaps() {
-    if (ctaps_fl == fl->design_version && ctaps_ds == ds->design_version) return RR_OK;
-    const size_t n = fl->n, L = ds->L;
-    const size_t lc = L + n - 1;
-    std::vector<double> c(lc, 0.0);
-    std::vector<cd> cc(lc, cd(0, 0));
-    for (size_t j = 0; j < L; ++j) {
-        const double a = ds->ir_f64[L - 1 - j];
-        for (size_t k = 0; k < n; ++k) {
-            c[j + k] += a * fl->taps_f64[k].real();
-            cc[j + k] += a * (fl->real_taps ? cd(fl->taps_f64[k].real(), 0.0) : fl->taps_f64[k]);
-        }
-    }
-    const int fk = pick_fused_kernel(ds->sched.D, lc, fl->real_taps, p.fft_len);
-    const bool wave = fk == FK_OLSW || fk == FK_OLSF;
-    use_frame = fk == FK_OLSF;
-    use_ols = wave || fk == FK_OLS;
-    if (use_ols) {
+// Host side of the fused decimating-FIR kernels' tables, for combined taps c (c[i] multiplies x[t - i];
+// `c` real parts, `cc` complex).  kind = rr_chain::FK_*:
+//   FK_DIRECT           ctaps in the step order of k_mix_fir_decim: tb[t*D + p] = c[D*(Gp-1-t) + (D-1-p)], zero beyond Lc
+//   FK_OLS              H = DFT_4096(c) / 4096 and e^{-j 2 pi k / 4096}
+//   FK_OLSW / FK_OLSF   H = DFT_1024(c) / 1024 pair-interleaved, e^{-j 2 pi k / 1024} + the lane seeds
+void build_fused_fir_tables(int kind, uint64_t D_, const std::vector<double> &c, const std::vector<cd> &cc, FusedFirTables &t) {
+    const size_t lc = c.size();
+    t.kind = kind;
+    const bool wave = kind == rr_chain::FK_OLSW || kind == rr_chain::FK_OLSF;
+    if (wave || kind == rr_chain::FK_OLS) {
         // H = DFT_N(c) / N (the inverse transform in the kernel is unnormalised)
         const size_t N = wave ? 1024 : 4096;
         std::vector<cd> h(N, cd(0, 0));
@@ -832,26 +904,51 @@ int rr_chain::ensure_ctaps() {
                 twv(4 * l, e2 + 2);           // inverse pass 3
             }
         }
-        RR_TRY(upload(d_olsH, hb.data(), hb.size() * sizeof(float), stream));
-        RR_TRY(upload(d_tw4096, twb.data(), twb.size() * sizeof(float), stream));
-        ols_V = wave ? ols_wave_overlap(lc) : ols_decim_overlap(lc);
-        ols_N = (int)N;
-        Lc = lc;
-        ctaps_fl = fl->design_version;
-        ctaps_ds = ds->design_version;
-        return RR_OK;
+        t.H.swap(hb);
+        t.tw.swap(twb);
+        t.V = wave ? ols_wave_overlap(lc) : ols_decim_overlap(lc);
+        t.N = (int)N;
+        return;
     }
-    const int D = (int)ds->sched.D, R = fused_fir_R(ds->sched.D);
+    const int D = (int)D_;
     const int gp = (int)((lc + D - 1) / D);  // tap groups of D; the kernel runs gp/R full rounds + a partial one
-    (void)R;
-    std::vector<float> tb((size_t)gp * D, 0.f);
-    for (int t = 0; t < gp; ++t)
+    t.ctaps.assign((size_t)gp * D, 0.f);
+    for (int g = 0; g < gp; ++g)
         for (int q = 0; q < D; ++q) {
-            const size_t i = (size_t)D * (gp - 1 - t) + (D - 1 - q);
-            if (i < lc) tb[(size_t)t * D + q] = (float)c[i];
+            const size_t i = (size_t)D * (gp - 1 - g) + (D - 1 - q);
+            if (i < lc) t.ctaps[(size_t)g * D + q] = (float)c[i];
         }
-    RR_TRY(upload(d_ctaps, tb.data(), tb.size() * sizeof(float), stream));
-    Gp = gp;
+    t.Gp = gp;
+}
+
+// c = reverse(ir) (*) g in f64, cast to f32; tables by build_fused_fir_tables
+int rr_chain::ensure_ctaps() {
+    if (ctaps_fl == fl->design_version && ctaps_ds == ds->design_version) return RR_OK;
+    const size_t n = fl->n, L = ds->L;
+    const size_t lc = L + n - 1;
+    std::vector<double> c(lc, 0.0);
+    std::vector<cd> cc(lc, cd(0, 0));
+    for (size_t j = 0; j < L; ++j) {
+        const double a = ds->ir_f64[L - 1 - j];
+        for (size_t k = 0; k < n; ++k) {
+            c[j + k] += a * fl->taps_f64[k].real();
+            cc[j + k] += a * (fl->real_taps ? cd(fl->taps_f64[k].real(), 0.0) : fl->taps_f64[k]);
+        }
+    }
+    const int fk = pick_fused_kernel(ds->sched.D, lc, fl->real_taps, p.fft_len);
+    FusedFirTables t;
+    build_fused_fir_tables(fk, ds->sched.D, c, cc, t);
+    use_frame = fk == FK_OLSF;
+    use_ols = fk != FK_DIRECT;
+    if (use_ols) {
+        RR_TRY(upload(d_olsH, t.H.data(), t.H.size() * sizeof(float), stream));
+        RR_TRY(upload(d_tw4096, t.tw.data(), t.tw.size() * sizeof(float), stream));
+        ols_V = t.V;
+        ols_N = t.N;
+    } else {
+        RR_TRY(upload(d_ctaps, t.ctaps.data(), t.ctaps.size() * sizeof(float), stream));
+        Gp = t.Gp;
+    }
     Lc = lc;
     ctaps_fl = fl->design_version;
     ctaps_ds = ds->design_version;
@@ -1498,6 +1595,12 @@ int rr_downsampler_process_dev(rr_downsampler *h, double rate, const void *d_in,
 int rr_downsampler_ir_len(const rr_downsampler *h, size_t *ir_len) {
     RR_CHECK_HANDLE(h, K_DOWNSAMPLER);
     *ir_len = h->L;
+    return RR_OK;
+}
+int rr_downsampler_last_kernel(const rr_downsampler *h, int *kernel) {
+    RR_CHECK_HANDLE(h, K_DOWNSAMPLER);
+    if (!kernel) RR_FAIL(RR_ERR_BAD_ARG, "null output");
+    *kernel = h->last_kernel;
     return RR_OK;
 }
 int rr_downsampler_destroy(rr_downsampler *h) {

@@ -30,6 +30,7 @@ struct rr_filter : rr_block {
     bool use_ols = false;          // long power-of-two filters: overlap-save fast convolution
     rr::DevBuf d_H, d_olstw;       // H = FFT_2n([0 | g / 2n]) and e^{-j 2 pi k / 2n}, k < n
     bool use_ols4096 = false;      // f32, n in {256..2048}: 4096-point blocks, radix-16 kernel
+    bool big_ols4096 = false;      // f32, n in {64, 128}: the same for calls of >= 16384 outputs
     rr::DevBuf d_G4096, d_tw4096;
     rr::DevBuf d_G4096h;           // the same table rounded to IEEE half (rr_filter_process_dev_f16's option)
     rr::DevBuf hist[2];            // previous_chunk (n samples), ping-pong
@@ -46,6 +47,14 @@ struct rr_filter : rr_block {
 };
 
 // Downsampler — resampling.rs:62-67 (ir, ringbuf, ringbuf_pos, pos)
+// tables of the fused decimating-FIR kernels (rr_api.hip: build_fused_fir_tables)
+struct FusedFirTables {
+    int kind = 0;
+    std::vector<float> ctaps, H, tw;
+    int Gp = 0, V = 0, N = 0;
+};
+void build_fused_fir_tables(int kind, uint64_t D, const std::vector<double> &c, const std::vector<rr::cd> &cc, FusedFirTables &t);
+
 struct rr_downsampler : rr_block {
     double output_rate = 0, bandwidth = 0, quality = 3.0;
     bool have_rate = false;
@@ -59,6 +68,13 @@ struct rr_downsampler : rr_block {
     std::vector<uint32_t> emit;
     rr::DevBuf d_emit;
     uint64_t design_version = 0;
+    // integer ratios 2, 4, 8 (f32): the chain's fused kernels with an all-ones NCO table instead of k_fir
+    int fast_kind = 0;  // rr_chain::FK_*; FK_NONE: k_fir
+    uint64_t fast_version = ~0ull;
+    rr::DevBuf f_ctaps, f_H, f_tw, f_one;
+    int f_Gp = 0, f_V = 0;
+    int last_kernel = 0;  // what the last call ran (rr_chain::FK_*, 0 = k_fir)
+    int ensure_fast();
     int prepare(double input_rate);
     int peek(double input_rate, size_t n_in, size_t *n_out);
     int process_dev(double input_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);

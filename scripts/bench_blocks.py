@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""The four blocks of the path one at a time (device-resident stream of 2^26 samples, cfg2's parameters):
+ms per call, GSamples/s and the fraction of the block's own HBM roofline (FreqShifter 16 B,
+Filter 16 B, Downsampler 8 + 8/D B, Fourier 16 B per input sample)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import radiorust_amd as rr
+
+N, fs = 1 << 26, 200e6
+st = torch.cuda.current_stream().cuda_stream
+d_in = torch.empty(N, dtype=torch.complex64, device="cuda")
+rr.synth_iq_dev(0, st, 1, 0, N, d_in.data_ptr())
+d_out = torch.empty(N, dtype=torch.complex64, device="cuda")
+
+
+def run(name, bytes_per_sample, call, K=10):
+    for _ in range(3):
+        call()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(K):
+        call()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / K
+    print(f"{name:44s} {dt*1e3:7.3f} ms  {N/dt/1e9:6.1f} GSamples/s  {bytes_per_sample*N/dt/1e9:5.0f} GB/s algorithmic "
+          f"({bytes_per_sample} B/sample) = {100*bytes_per_sample*N/dt/8e12:4.1f} % of the HBM roofline")
+
+
+sh = rr.FreqShifter.with_shift(25e6)
+sh.set_stream(st)
+run("FreqShifter 25 MHz", 16, lambda: sh.process_dev(fs, d_in.data_ptr(), N, d_out.data_ptr(), N))
+lp = lambda b, f: 1.0 if abs(f) <= 20e6 else 0.0
+for n in (64, 256, 1024):
+    fl = rr.Filter.new(lp)
+    fl.set_stream(st)
+    run(f"Filter n={n} lowpass 20 MHz", 16, lambda: fl.process_dev(fs, n, d_in.data_ptr(), N, d_out.data_ptr(), N))
+for generic in (False, True):
+    if generic:
+        os.environ["RR_DOWNSAMPLER_GENERIC"] = "1"
+    ds = rr.Downsampler.new(4096, 50e6, 40e6)
+    ds.set_stream(st)
+    run(f"Downsampler 200->50 MS/s L=120{' (k_fir)' if generic else ''}", 10, lambda: ds.process_dev(fs, d_in.data_ptr(), N, d_out.data_ptr(), N))
+    if not generic:
+        print("   kernel:", ds.last_kernel())
+os.environ.pop("RR_DOWNSAMPLER_GENERIC", None)
+ds8 = rr.Downsampler.new(4096, 48000.0, 40000.0)
+ds8.set_stream(st)
+run("Downsampler 384->48 kS/s L=288 (D=8)", 9, lambda: ds8.process_dev(384000.0, d_in.data_ptr(), N, d_out.data_ptr(), N))
+fo = rr.Fourier.with_window(rr.Kaiser.with_null_at_bin(2.0))
+fo.set_stream(st)
+run("Fourier 4096 Kaiser(null@2)", 16, lambda: fo.process_dev(4096, d_in.data_ptr(), N, d_out.data_ptr(), N))

@@ -274,6 +274,37 @@ def test_filter_overlap_save_f64_and_batched(rr, oracle):
     check(d_out.cpu().numpy()[:wrote], np.concatenate(r64), np.concatenate(r32))
 
 
+@pytest.mark.parametrize("n", [64, 128])
+def test_filter_short_power_of_two_long_calls(rr, oracle, n):
+    """n = 64 / 128 in f32: calls that produce >= 16384 samples run k_filter_ols4096 (4096-point blocks),
+    shorter ones k_fir; one stream through a mix of both, against the chunk-by-chunk oracle."""
+    import torch
+
+    fs = 200e6
+    ks = [3, 400, 1, 300, 2, 2]  # chunks per call
+    x = oracle.synth_iq(21, 0, n * sum(ks))
+    g = rr.Filter.new(lowpass(20e6))
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.empty_like(d_in)
+    off = wrote = 0
+    for k in ks:
+        wrote += g.process_dev(fs, n, d_in.data_ptr() + 8 * off, n * k, d_out.data_ptr() + 8 * wrote, n * k)
+        off += n * k
+    torch.cuda.synchronize()
+    assert wrote == n * (sum(ks) - 1)
+    o64 = oracle.Filter(lowpass(20e6), flt=np.float64)
+    o32 = oracle.Filter(lowpass(20e6), flt=np.float32)
+    r64 = [o64.process(fs, x[i * n : (i + 1) * n]) for i in range(sum(ks))][1:]
+    r32 = [o32.process(fs, x[i * n : (i + 1) * n]) for i in range(sum(ks))][1:]
+    got = d_out.cpu().numpy()[:wrote]
+    check(got, np.concatenate(r64), np.concatenate(r32))
+    # the seams between the kernels
+    r = np.concatenate(r64)
+    for edge in (n * 2, n * 402, n * 403, n * 703):
+        check(got[edge - n : edge + n], r[edge - n : edge + n])
+
+
 def test_filter_needs_design_status(rr):
     from radiorust_amd._lib import RR_ERR_NEED_DESIGN
 
@@ -311,6 +342,52 @@ def test_downsampler_parity(rr, oracle, fin, fout, bw, q):
         t32.append(r32)
     assert g.ir_len() == len(o64.ir())
     check(np.concatenate(got), np.concatenate(t64), np.concatenate(t32))
+
+
+# integer ratios 2, 4, 8 in f32: calls of >= 4096 samples run the chain's fused kernels with an all-ones
+# NCO table (rr_downsampler_last_kernel: 1 k_mix_fir_decim, 2 k_ols_decim4, 3 k_ols_wave), shorter
+# ones k_fir; the stream of outputs must not notice the switches
+FAST_CASES = [
+    (200e6, 50e6, 40e6, 3.0, 3),      # cfg2's Downsampler: L = 120, D = 4 -> k_ols_wave
+    (200e6, 50e6, 47e6, 3.0, 2),      # L = 400: beyond k_ols_wave's overlap -> k_ols_decim4
+    (200e6, 50e6, 30e6, 3.0, 1),      # L = 60: short -> k_mix_fir_decim
+    (384000.0, 48000.0, 40000.0, 3.0, 1),   # the reference's simple_receiver second stage: D = 8, L = 288
+    (96000.0, 48000.0, 30000.0, 3.0, 1),    # D = 2
+]
+
+
+@pytest.mark.parametrize("fin,fout,bw,q,kernel", FAST_CASES)
+def test_downsampler_fast_paths(rr, oracle, fin, fout, bw, q, kernel):
+    n = 150000
+    x = oracle.synth_iq(11, 0, n)
+    cuts = [0, 5000, 5003, 9099, 9100, 60000, 60001, 140001, n]
+    g = rr.Downsampler.with_quality(1000, fout, bw, q)
+    o64 = oracle.Downsampler(1000, fout, bw, q, flt=np.float64)
+    o32 = oracle.Downsampler(1000, fout, bw, q, flt=np.float32)
+    got, t64, t32, kernels = [], [], [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        y = g.process_raw(fin, x[a:b])
+        kernels.append(g.last_kernel())
+        r64, r32 = o64.process(fin, x[a:b]), o32.process(fin, x[a:b])
+        assert len(y) == len(r64)
+        got.append(y)
+        t64.append(r64)
+        t32.append(r32)
+    assert kernels == [kernel, 0, kernel, 0, kernel, 0, kernel, kernel], (kernels, g.ir_len())
+    check(np.concatenate(got), np.concatenate(t64), np.concatenate(t32))
+    # every piece on its own too (a wrong history hand-over would hide in the overall RMS)
+    for y, r in zip(got, t64):
+        if len(y) > 50:
+            check(y, r)
+
+
+def test_downsampler_fast_path_can_be_switched_off(rr, oracle, monkeypatch):
+    monkeypatch.setenv("RR_DOWNSAMPLER_GENERIC", "1")
+    g = rr.Downsampler.new(1000, 50e6, 40e6)
+    x = oracle.synth_iq(12, 0, 20000)
+    y = g.process_raw(200e6, x)
+    assert g.last_kernel() == 0
+    check(y, oracle.Downsampler(1000, 50e6, 40e6, flt=np.float64).process(200e6, x))
 
 
 def test_downsampler_output_chunks_and_events(rr, oracle):
