@@ -107,6 +107,7 @@ SIGNATURES = {
     "rr_filter_enqueue": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
     "rr_filter_process_dev": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
     "rr_filter_process_dev_f16": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz, _i]),
+    "rr_filter_last_kernel": (_i, [_vp, C.POINTER(_i)]),
     "rr_filter_destroy": (_i, [_vp]),
     "rr_downsampler_create": (_i, [_i, _d, _d, _d, _i, C.POINTER(_vp)]),
     "rr_downsampler_peek": (_i, [_vp, _d, _sz, _psz]),

@@ -201,6 +201,12 @@ class Filter(_Block):
         return n_out.value
 
 
+    def last_kernel(self) -> int:
+        """0 k_fir, 1 k_filter_ols, 2 k_filter_ols4096, 3 k_filter_wave."""
+        v = C.c_int()
+        _lib.check(_lib.lib().rr_filter_last_kernel(self._h, C.byref(v)))
+        return v.value
+
     def process_dev_f16(self, sample_rate, chunk_len: int, d_in: int, n_in: int, d_out_f16: int, cap: int,
                         response_f16: bool = False) -> int:
         """As process_dev with half-precision output pairs (and optionally a half-precision response table)."""

@@ -205,6 +205,20 @@ int rr_filter::design(double sample_rate, size_t len, const rr_c64 *resp, const 
         for (size_t i = 0; i < gb.size(); ++i) gh[i] = f32_to_f16_bits(gb[i]);
         RR_TRY(upload(d_G4096h, gh.data(), gh.size() * sizeof(uint16_t), stream));
     }
+    {
+        const char *e = std::getenv("RR_FILTER_KERNEL");  // "ols4096" / "fir" keep the older kernels (A/B runs, tests)
+        use_wave = filter_wave_supported(dtype, len) && !(e && (!std::strcmp(e, "ols4096") || !std::strcmp(e, "fir")));
+        if (e && !std::strcmp(e, "fir")) big_ols4096 = false;
+    }
+    if (use_wave) {
+        std::vector<double> c(len);
+        for (size_t i = 0; i < len; ++i) c[i] = g[i].real();
+        FusedFirTables t;
+        build_fused_fir_tables(rr_chain::FK_OLSW, 1, c, g, t);
+        RR_TRY(upload(d_Hw, t.H.data(), t.H.size() * sizeof(float), stream));
+        RR_TRY(upload(d_tww, t.tw.data(), t.tw.size() * sizeof(float), stream));
+        wave_V = t.V;
+    }
     use_ols = !use_ols4096 && !big_ols4096 && ols_supported(dtype, len);
     if (use_ols) {
         // the reference's extended response (filters.rs:220-238), transformed in f64 here
@@ -262,10 +276,17 @@ int rr_filter::process_dev(double sample_rate, const void *d_in, size_t n_in, vo
     const size_t produce = peek(n_in);
     if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Filter: out_cap %zu < %zu", cap, produce);
     RR_TRY(select());
-    if (produce && (use_ols4096 || (big_ols4096 && produce >= kFilterBigCall))) {
+    last_kernel = 0;
+    if (produce && use_wave && produce >= kFilterBigCall && !out_f16 && !g_f16) {
+        RR_TRY(launch_filter_wave(stream, hist[cur].p, hist_valid ? n : 0, d_in, n_in, d_Hw.p, d_tww.p, wave_V, d_out, produce,
+                                  hist_valid ? 0 : (long)n));
+        last_kernel = 3;
+    } else if (produce && (use_ols4096 || (big_ols4096 && produce >= kFilterBigCall))) {
+        last_kernel = 2;
         RR_TRY(launch_filter_ols4096(stream, hist[cur].p, hist_valid ? n : 0, d_in, n_in, g_f16 ? d_G4096h.p : d_G4096.p,
                                      d_tw4096.p, n, d_out, produce, hist_valid ? 0 : (long)n, out_f16, g_f16));
     } else if (produce && use_ols) {
+        last_kernel = 1;
         RR_TRY(launch_filter_ols(dtype, stream, hist[cur].p, d_in, n, produce / n, hist_valid ? 0 : 1, d_H.p, d_olstw.p, d_out));
     } else if (produce) {
         FirArgs a;
@@ -1522,6 +1543,12 @@ int rr_filter_process_dev_f16(rr_filter *h, double sample_rate, const void *d_in
     RR_CHECK_HANDLE(h, K_FILTER);
     return h->process_dev(sample_rate, d_in, n_in, d_out_f16, cap, n_out, true, response_f16 != 0);
     RR_GUARD_END
+}
+int rr_filter_last_kernel(const rr_filter *h, int *kernel) {
+    RR_CHECK_HANDLE(h, K_FILTER);
+    if (!kernel) RR_FAIL(RR_ERR_BAD_ARG, "null output");
+    *kernel = h->last_kernel;
+    return RR_OK;
 }
 int rr_filter_destroy(rr_filter *h) {
     if (!h) return RR_OK;

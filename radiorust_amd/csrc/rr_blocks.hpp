@@ -31,6 +31,10 @@ struct rr_filter : rr_block {
     rr::DevBuf d_H, d_olstw;       // H = FFT_2n([0 | g / 2n]) and e^{-j 2 pi k / 2n}, k < n
     bool use_ols4096 = false;      // f32, n in {256..2048}: 4096-point blocks, radix-16 kernel
     bool big_ols4096 = false;      // f32, n in {64, 128}: the same for calls of >= 16384 outputs
+    bool use_wave = false;         // f32, n <= 385: k_filter_wave (a wave per 1024-block) for calls of >= 16384 outputs
+    rr::DevBuf d_Hw, d_tww;        // its tables (DFT_1024(g) / 1024 pair-interleaved; twiddles + lane seeds)
+    int wave_V = 0;
+    int last_kernel = 0;           // 0 k_fir, 1 k_filter_ols (2n-point), 2 k_filter_ols4096, 3 k_filter_wave
     rr::DevBuf d_G4096, d_tw4096;
     rr::DevBuf d_G4096h;           // the same table rounded to IEEE half (rr_filter_process_dev_f16's option)
     rr::DevBuf hist[2];            // previous_chunk (n samples), ping-pong

@@ -31,6 +31,7 @@
 // Kernel 3w  k_ols_wave       ... a WAVE per 1024-block: the default for 4x decimation
 // Kernel 3f  k_ols_frame      k_ols_wave's blocks + kernel 2 in one kernel (measured slower; on request)
 // Kernel 4   k_filter_ols4096 the Filter block alone by overlap-save (n = 256 .. 2048)
+// Kernel 4w  k_filter_wave    the Filter block alone, a wave per 1024-sample block (n <= 385)
 // Kernel 5   k_channelizer256 256-bin polyphase channelizer, a wave per run of frames
 //
 // Build-time switches (all default to the measured-best setting; scripts/build_variant.sh builds
@@ -2018,6 +2019,237 @@ int launch_ols_wave(hipStream_t s, const FusedFirArgs &a) {
                            (const float2 *)a.H, (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out, (long)a.e0,
                            (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, hopm_run, kstep,
                            1.0 / (double)den);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Kernel 4w  k_filter_wave: the Filter block alone (filters.rs:240-259) for short responses (n <= 385
+// taps), Complex<f32>, with ONE WAVE per 1024-sample block - k_ols_wave's structure without the
+// mixer and the decimation:
+//   y = IDFT_1024(DFT_1024(x_block) * H),  H = DFT_1024(g) / 1024,  V = ceil((n - 1) / 64) * 64,
+// the last 1024 - V results of a block are valid (n = 64: 94 %).  The forward transform is k_ols_wave's
+// (radix 8 x 16 x 8 on sample pairs); the inverse is the same routine on conj(Y) - Y leaves the forward
+// transform as Y[l + 64 k] and goes through LDS once more to come back in the pair layout.  All
+// exchanges are wave-local (no workgroup barrier); 16 waves per CU.
+// ---------------------------------------------------------------------------
+// forward DFT_1024 of v (pair layout: v[2 k' + j] = x[2 l + j + 128 k']) -> X[k] = DFT[l + 64 k]
+// (`mid` runs between the second exchange's writes and reads, where the fewest registers are live)
+template <class Mid>
+__device__ __forceinline__ void wave_dft1024(f2 (&v)[16], f2 (&X)[16], f2 *lds, int l, f2 t_p1, const f2 (&t_p2)[2], Mid &&mid) {
+    const int g = l >> 4;
+    f2 *const a_rd = lds + (l + 2 * g);  // A(l + 64 m + 256 c) = a_rd + 72 m + 296 c
+    {
+        f2 e0[8], e1[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            e0[k] = v[2 * k];
+            e1[k] = v[2 * k + 1];
+        }
+        dft8(e0);
+        dft8(e1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = e0[k];
+            v[8 + k] = e1[k];
+        }
+    }
+    {
+        f2 *row = lds + (18 * l + 8 * g);  // A(16 l + e) = 18 l + 8 g + e
+#pragma unroll
+        for (int k = 0; k < 16; k += 2)
+            *reinterpret_cast<float4 *>(row + k) = (float4){v[k].x, v[k].y, v[k + 1].x, v[k + 1].y};
+    }
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = a_rd[72 * (k & 3) + 296 * (k >> 2)];  // in[l + 64 k]
+    twiddle16(v, t_p1);
+    dft16(v);
+    wave_sync();
+    {
+        f2 *col = lds + (144 * (l >> 3) + 8 * (l >> 4) + (l & 7));
+#pragma unroll
+        for (int k = 0; k < 16; ++k) col[8 * k + 2 * (k >> 1)] = v[k];
+    }
+    mid();
+    wave_sync();
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        f2 a[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a[c] = a_rd[72 * m + 144 * c + 8 * (c >> 1)];
+        const f2 w1 = t_p2[m];
+        const f2 w2 = cmul(w1, w1);
+        const f2 w3 = cmul(w2, w1);
+        const f2 w4 = cmul(w2, w2);
+        a[1] = cmul(a[1], w1);
+        a[2] = cmul(a[2], w2);
+        a[3] = cmul(a[3], w3);
+        a[4] = cmul(a[4], w4);
+        a[5] = cmul(a[5], cmul(w4, w1));
+        a[6] = cmul(a[6], cmul(w4, w2));
+        a[7] = cmul(a[7], cmul(w4, w3));
+        dft8(a);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) X[m + 2 * c] = a[c];
+    }
+}
+
+// The same transform run backwards (every stage transposed, in reverse order; the DFT matrix is symmetric,
+// so this is again the forward DFT_1024): input Z[k] = z[l + 64 k] - the layout wave_dft1024 leaves its
+// result in -, output in the pair layout v[2 k' + j] = DFT[2 l + j + 128 k'].  The LDS image is the same,
+// reads and writes change places.
+__device__ __forceinline__ void wave_dft1024_t(f2 (&Z)[16], f2 (&v)[16], f2 *lds, int l, f2 t_p1, const f2 (&t_p2)[2]) {
+    const int g = l >> 4;
+    f2 *const a_rd = lds + (l + 2 * g);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        f2 a[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a[c] = Z[m + 2 * c];
+        dft8(a);
+        const f2 w1 = t_p2[m];
+        const f2 w2 = cmul(w1, w1);
+        const f2 w3 = cmul(w2, w1);
+        const f2 w4 = cmul(w2, w2);
+        a[1] = cmul(a[1], w1);
+        a[2] = cmul(a[2], w2);
+        a[3] = cmul(a[3], w3);
+        a[4] = cmul(a[4], w4);
+        a[5] = cmul(a[5], cmul(w4, w1));
+        a[6] = cmul(a[6], cmul(w4, w2));
+        a[7] = cmul(a[7], cmul(w4, w3));
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a_rd[72 * m + 144 * c + 8 * (c >> 1)] = a[c];
+    }
+    wave_sync();
+    {
+        const f2 *col = lds + (144 * (l >> 3) + 8 * (l >> 4) + (l & 7));
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = col[8 * k + 2 * (k >> 1)];
+    }
+    dft16(v);
+    twiddle16(v, t_p1);
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a_rd[72 * (k & 3) + 296 * (k >> 2)] = v[k];
+    wave_sync();
+    {
+        const f2 *row = lds + (18 * l + 8 * g);
+        f2 e0[8], e1[8];
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+            const float4 p = *reinterpret_cast<const float4 *>(row + k), q = *reinterpret_cast<const float4 *>(row + 8 + k);
+            e0[k] = (f2){p.x, p.y};
+            e0[k + 1] = (f2){p.z, p.w};
+            e1[k] = (f2){q.x, q.y};
+            e1[k + 1] = (f2){q.z, q.w};
+        }
+        dft8(e0);
+        dft8(e1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[2 * k] = e0[k];
+            v[2 * k + 1] = e1[k];
+        }
+    }
+}
+
+#ifndef RR_V_FLTWOCC
+#define RR_V_FLTWOCC 3  // waves per SIMD the register budget is cut for (140 registers; at 4 the kernel spills 12)
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_FLTWOCC, RR_V_FLTWOCC))) void k_filter_wave(
+    const float2 *__restrict__ hist, int hist_len, const float2 *__restrict__ in, long n_in,
+    const float2 *__restrict__ H, const float2 *__restrict__ tw, int V, float2 *__restrict__ out, long n_out, long e0,
+    unsigned nblocks) {
+    __shared__ __attribute__((aligned(16))) f2 lds[kWaveLds];
+    const int l = threadIdx.x;
+    // workgroups b, b + 8, .. share an XCD: neighbouring blocks (which share V samples) on one XCD
+    const unsigned per_xcd = (nblocks + 7) >> 3, within = blockIdx.x >> 3;
+    const unsigned blk = (blockIdx.x & 7) * per_xcd + within;
+    if (blk >= nblocks || within >= per_xcd) return;
+    const int hop = 1024 - V;
+    const long b0 = e0 - V + (long)blk * hop;
+    f2 v[16];
+    if (b0 >= 0 && b0 + 1024 <= n_in) {
+        const f4u *src = reinterpret_cast<const f4u *>(in + b0) + l;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f4u x = *(src + 64 * k);
+            v[2 * k] = (f2){x.x, x.y};
+            v[2 * k + 1] = (f2){x.z, x.w};
+        }
+    } else {
+        // edges: the previous chunk in front (none after a reset), nothing behind the input
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const long pos = b0 + 2 * l + j + 128 * k;
+                const bool inr = pos >= 0 && pos < n_in;
+                const bool hst = pos < 0 && pos >= -(long)hist_len;
+                const float2 *ptr = inr ? in + pos : hist + (hst ? hist_len + pos : 0);
+                f2 xv = {0.f, 0.f};
+                if (inr || hst) {
+                    const float2 xx = *ptr;
+                    xv = (f2){xx.x, xx.y};
+                }
+                v[2 * k + j] = xv;
+            }
+    }
+    f2 t_p1, t_p2[2];
+    {
+        const float4 *tl = reinterpret_cast<const float4 *>(tw + 1024) + l;
+        const float4 s0 = tl[0], s1 = tl[64];
+        t_p1 = (f2){s0.x, s0.y};
+        t_p2[0] = (f2){s0.z, s0.w};
+        t_p2[1] = (f2){s1.x, s1.y};
+    }
+    float4 h4[8];
+    f2 X[16];
+    wave_dft1024(v, X, lds, l, t_p1, t_p2, [&] {
+#pragma unroll
+        for (int kp = 0; kp < 8; ++kp) h4[kp] = reinterpret_cast<const float4 *>(H)[l + 64 * kp];
+    });
+    // Z = conj(X H), then the transform run backwards: conj(y) in the pair layout
+#pragma unroll
+    for (int kp = 0; kp < 8; ++kp) {
+        const f2 p0 = cmul(X[2 * kp], (f2){h4[kp].x, h4[kp].y}), p1 = cmul(X[2 * kp + 1], (f2){h4[kp].z, h4[kp].w});
+        X[2 * kp] = (f2){p0.x, -p0.y};
+        X[2 * kp + 1] = (f2){p1.x, -p1.y};
+    }
+    wave_sync();  // the forward image has been read
+    wave_dft1024_t(X, v, lds, l, t_p1, t_p2);
+    const long mb = (long)blk * hop;
+    const long left = n_out - mb;
+    const unsigned recs = (unsigned)(left < hop ? left : hop) * 8u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + mb, 0, recs, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int t = 2 * l + 128 * k;  // V is even: a pair is valid or not as a whole
+        const unsigned off = t >= V ? (unsigned)(t - V) * 8u : 0xffffffffu;
+        const f2 y0 = {v[2 * k].x, -v[2 * k].y}, y1 = {v[2 * k + 1].x, -v[2 * k + 1].y};
+        // (a pair that straddles the end of the output: only its first half is stored)
+        if (off != 0xffffffffu && off + 16u > recs) {
+            if (off + 8u <= recs) __builtin_amdgcn_raw_buffer_store_b64(y0, rs, off, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b128((f4){y0.x, y0.y, y1.x, y1.y}, rs, off, 0, 0);
+        }
+    }
+}
+
+bool filter_wave_supported(int dtype, size_t n) { return dtype == RR_F32 && n >= 2 && n - 1 <= 384; }
+
+int launch_filter_wave(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *H,
+                       const void *tw, int V, void *out, size_t n_out, long e0) {
+    if (n_out == 0) return RR_OK;
+    const size_t hop = 1024 - V;
+    const size_t nblocks = (n_out + hop - 1) / hop;
+    if (nblocks > 0x7ffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "Filter: too many blocks");
+    const size_t per_xcd = (nblocks + 7) / 8;
+    hipLaunchKernelGGL(k_filter_wave, dim3((unsigned)(per_xcd * 8)), dim3(64), 0, s, (const float2 *)hist, (int)hist_len,
+                       (const float2 *)in, (long)n_in, (const float2 *)H, (const float2 *)tw, V, (float2 *)out, (long)n_out,
+                       e0, (unsigned)nblocks);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }

@@ -98,6 +98,10 @@ int ols_decim_overlap(size_t Lc);
 int launch_ols_decim(hipStream_t s, const FusedFirArgs &a);
 // one-wave-per-block variant (k_ols_wave): H = DFT_1024(c) / 1024 and tw = e^{-j 2 pi k / 1024}
 // go in the H / tw4096 fields, V = ols_wave_overlap(Lc)
+// k_filter_wave: the Filter alone, one wave per 1024-sample block (n - 1 <= 384, f32); H / tw as for k_ols_wave
+bool filter_wave_supported(int dtype, size_t n);
+int launch_filter_wave(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *H,
+                       const void *tw, int V, void *out, size_t n_out, long e0);
 bool ols_wave_supported(uint64_t D, size_t Lc);
 int ols_wave_overlap(size_t Lc);
 int launch_ols_wave(hipStream_t s, const FusedFirArgs &a);

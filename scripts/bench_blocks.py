@@ -31,7 +31,7 @@ sh = rr.FreqShifter.with_shift(25e6)
 sh.set_stream(st)
 run("FreqShifter 25 MHz", 16, lambda: sh.process_dev(fs, d_in.data_ptr(), N, d_out.data_ptr(), N))
 lp = lambda b, f: 1.0 if abs(f) <= 20e6 else 0.0
-for n in (64, 256, 1024):
+for n in (64, 128, 256, 1024):
     fl = rr.Filter.new(lp)
     fl.set_stream(st)
     run(f"Filter n={n} lowpass 20 MHz", 16, lambda: fl.process_dev(fs, n, d_in.data_ptr(), N, d_out.data_ptr(), N))

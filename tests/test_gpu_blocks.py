@@ -274,24 +274,32 @@ def test_filter_overlap_save_f64_and_batched(rr, oracle):
     check(d_out.cpu().numpy()[:wrote], np.concatenate(r64), np.concatenate(r32))
 
 
-@pytest.mark.parametrize("n", [64, 128])
-def test_filter_short_power_of_two_long_calls(rr, oracle, n):
-    """n = 64 / 128 in f32: calls that produce >= 16384 samples run k_filter_ols4096 (4096-point blocks),
-    shorter ones k_fir; one stream through a mix of both, against the chunk-by-chunk oracle."""
+@pytest.mark.parametrize("n,forced", [(64, None), (128, None), (48, None), (256, None), (385, None), (64, "ols4096"), (128, "ols4096")])
+def test_filter_short_power_of_two_long_calls(rr, oracle, n, forced, monkeypatch):
+    """Short filters in f32: calls that produce >= 16384 samples run k_filter_wave (a wave per 1024-sample
+    block; RR_FILTER_KERNEL=ols4096: k_filter_ols4096 for n = 64 / 128), shorter ones the small-call kernels;
+    one stream through a mix of both, against the chunk-by-chunk oracle."""
     import torch
 
+    if forced:
+        monkeypatch.setenv("RR_FILTER_KERNEL", forced)
     fs = 200e6
-    ks = [3, 400, 1, 300, 2, 2]  # chunks per call
+    kb = -(-20000 // n)  # chunks of a call that is long enough for the big-call kernel
+    ks = [3, kb + 7, 1, kb, 2, 2]  # chunks per call
     x = oracle.synth_iq(21, 0, n * sum(ks))
     g = rr.Filter.new(lowpass(20e6))
     g.set_stream(torch.cuda.current_stream().cuda_stream)
     d_in = torch.from_numpy(x).cuda()
     d_out = torch.empty_like(d_in)
     off = wrote = 0
+    kernels = []
     for k in ks:
         wrote += g.process_dev(fs, n, d_in.data_ptr() + 8 * off, n * k, d_out.data_ptr() + 8 * wrote, n * k)
+        kernels.append(g.last_kernel())
         off += n * k
     torch.cuda.synchronize()
+    big = 2 if forced else 3
+    assert kernels[1] == big and kernels[3] == big and 3 not in (kernels[0], kernels[2], kernels[4]), kernels
     assert wrote == n * (sum(ks) - 1)
     o64 = oracle.Filter(lowpass(20e6), flt=np.float64)
     o32 = oracle.Filter(lowpass(20e6), flt=np.float32)
@@ -301,7 +309,7 @@ def test_filter_short_power_of_two_long_calls(rr, oracle, n):
     check(got, np.concatenate(r64), np.concatenate(r32))
     # the seams between the kernels
     r = np.concatenate(r64)
-    for edge in (n * 2, n * 402, n * 403, n * 703):
+    for edge in (n * 2, n * (kb + 9), n * (kb + 10), n * (2 * kb + 10)):
         check(got[edge - n : edge + n], r[edge - n : edge + n])
 
 
