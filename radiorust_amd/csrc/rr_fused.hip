@@ -650,6 +650,9 @@ __device__ __forceinline__ void apply_twiddle_powers(f2 (&v)[16], f2 w) {
 
 // The input stream of frames is [ head (n_head samples) | in ]: the head is the
 // Downsampler's partly filled output chunk left over by the previous call.
+#ifndef RR_V_FFTPK
+#define RR_V_FFTPK 1
+#endif
 __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head, long n_head,
                                                  const float2 *__restrict__ in, float2 *__restrict__ out,
                                                  const float *__restrict__ window, const float2 *__restrict__ tw,
@@ -659,6 +662,37 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
     const long base = (long)blockIdx.x * hop - n_head;  // index into `in` of this frame's first sample
     float2 *dst = out + (size_t)blockIdx.x * 4096;
     f2 v[16];
+#if RR_V_FFTPK
+    // the lane's 16 window values as 4 loads of 16 bytes (packed copy behind the table), its two twiddle
+    // seeds up front, the frame's samples with the streaming hint when frames do not overlap
+    float wv[16];
+    {
+        const float4 *wp = reinterpret_cast<const float4 *>(window + 4096) + 4 * j;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 w4 = wp[q];
+            wv[4 * q] = w4.x;
+            wv[4 * q + 1] = w4.y;
+            wv[4 * q + 2] = w4.z;
+            wv[4 * q + 3] = w4.w;
+        }
+    }
+    const float2 s1 = tw[16 * (j & 15)], s2 = tw[j];
+    if (base >= 0 && hop >= 4096) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const f2 x = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(in + base + j) + 256 * k);
+            v[k] = x * wv[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const long i = base + j + 256 * k;
+            const float2 x = (i >= 0) ? in[i] : head[n_head + i];
+            v[k] = (f2){x.x * wv[k], x.y * wv[k]};
+        }
+    }
+#else
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const long i = base + j + 256 * k;
@@ -666,6 +700,7 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
         const float w = window[j + 256 * k];
         v[k] = (f2){x.x * w, x.y * w};
     }
+#endif
     // pass 0 (Ns = 1): no twiddles; out index 16 j + k
     dft16(v);
 #pragma unroll
@@ -677,7 +712,11 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
     {
         // e^{-j 2 pi k (j mod 16) / 256} = w^k with w = tw[16 (j mod 16)]: one
         // table read, powers by a depth-4 product tree (error ~4 ulp, not 15)
+#if RR_V_FFTPK
+        const float2 t = s1;
+#else
         const float2 t = tw[16 * (j & 15)];
+#endif
         apply_twiddle_powers(v, (f2){t.x, t.y});
     }
     dft16(v);
@@ -692,7 +731,11 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = lds[pad16(j + 256 * k)];
     {
+#if RR_V_FFTPK
+        const float2 t = s2;
+#else
         const float2 t = tw[j];  // e^{-j 2 pi j / 4096}, coalesced
+#endif
         apply_twiddle_powers(v, (f2){t.x, t.y});
     }
     dft16(v);
@@ -700,10 +743,14 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int o = (j + 256 * k + rot) & 4095;
+#if RR_V_FFTPK
+        __builtin_nontemporal_store(v[k], reinterpret_cast<f2 *>(dst) + o);
+#else
         float2 w;
         w.x = v[k].x;
         w.y = v[k].y;
         dst[o] = w;
+#endif
     }
 }
 
