@@ -653,14 +653,27 @@ __device__ __forceinline__ void apply_twiddle_powers(f2 (&v)[16], f2 w) {
 #ifndef RR_V_FFTPK
 #define RR_V_FFTPK 1
 #endif
+#ifndef RR_V_FFTXCD
+#define RR_V_FFTXCD 0  // a contiguous eighth of the frames per XCD: measured slower here (0.181 against 0.176 ms per 2^26 samples)
+#endif
 __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head, long n_head,
                                                  const float2 *__restrict__ in, float2 *__restrict__ out,
                                                  const float *__restrict__ window, const float2 *__restrict__ tw,
-                                                 int center_dc, long hop) {
+                                                 int center_dc, long hop, unsigned count) {
     __shared__ f2 lds[4096 + 256];
     const int j = threadIdx.x;
-    const long base = (long)blockIdx.x * hop - n_head;  // index into `in` of this frame's first sample
-    float2 *dst = out + (size_t)blockIdx.x * 4096;
+#if RR_V_FFTXCD
+    // workgroups b, b + 8, .. share an XCD: every XCD takes a contiguous eighth of the frames (grid: a multiple
+    // of 8).  That mapping took k_freqshift (4 KiB per workgroup and trip) from 4.7 to 5.4 TB/s; with a whole
+    // 32 KiB frame per workgroup it does not pay.
+    const unsigned per_xcd = gridDim.x >> 3;
+    const unsigned fr = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (fr >= count) return;
+#else
+    const unsigned fr = blockIdx.x;
+#endif
+    const long base = (long)fr * hop - n_head;  // index into `in` of this frame's first sample
+    float2 *dst = out + (size_t)fr * 4096;
     f2 v[16];
 #if RR_V_FFTPK
     // the lane's 16 window values as 4 loads of 16 bytes (packed copy behind the table), its two twiddle
@@ -759,14 +772,15 @@ int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *i
                    hipEvent_t ev_stop) {
     if (count == 0) return RR_OK;
     if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fft4096: too many frames");
+    const unsigned grid = RR_V_FFTXCD ? (unsigned)((count + 7) / 8 * 8) : (unsigned)count;
     if (ev_start && ev_stop)
-        hipExtLaunchKernelGGL(k_fft4096, dim3((unsigned)count), dim3(256), 0, s, ev_start, ev_stop, 0, (const float2 *)head,
+        hipExtLaunchKernelGGL(k_fft4096, dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, (const float2 *)head,
                               (long)n_head, (const float2 *)in, (float2 *)out, (const float *)window,
-                              (const float2 *)tw4096, (int)center_dc, (long)hop);
+                              (const float2 *)tw4096, (int)center_dc, (long)hop, (unsigned)count);
     else
-        hipLaunchKernelGGL(k_fft4096, dim3((unsigned)count), dim3(256), 0, s, (const float2 *)head, (long)n_head,
+        hipLaunchKernelGGL(k_fft4096, dim3(grid), dim3(256), 0, s, (const float2 *)head, (long)n_head,
                            (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw4096,
-                           (int)center_dc, (long)hop);
+                           (int)center_dc, (long)hop, (unsigned)count);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
@@ -2471,6 +2485,9 @@ int launch_ols_decim(hipStream_t s, const FusedFirArgs &a) {
 // ---------------------------------------------------------------------------
 // OUT16: outputs rounded to IEEE half (re, im) - 12 instead of 16 algorithmic bytes per sample;
 // G16: the response table held as halves (SURVEY 8(d) cfg5's second and third points).
+#ifndef RR_V_FLTXCD
+#define RR_V_FLTXCD 0  // a contiguous eighth of the blocks per XCD: no difference (0.327 / 0.326 ms)
+#endif
 template <bool OUT16, bool G16>
 __global__ __launch_bounds__(256) void k_filter_ols4096(const float2 *__restrict__ hist, int hist_len,
                                                         const float2 *__restrict__ in, long n_in,
@@ -2479,7 +2496,14 @@ __global__ __launch_bounds__(256) void k_filter_ols4096(const float2 *__restrict
     __shared__ f2 lds[4096 + 256];
     const int j = threadIdx.x;
     const int hop = 4096 - V;
-    const long b0 = e0 - V + (long)blockIdx.x * hop;
+#if RR_V_FLTXCD
+    // a contiguous eighth of the blocks per XCD (grid: a multiple of 8), see k_fft4096
+    const unsigned blk = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if ((long)blk * hop >= n_out) return;
+#else
+    const unsigned blk = blockIdx.x;
+#endif
+    const long b0 = e0 - V + (long)blk * hop;
     f2 v[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -2513,7 +2537,7 @@ __global__ __launch_bounds__(256) void k_filter_ols4096(const float2 *__restrict
     }
     __syncthreads();  // the forward transform's last LDS reads are done
     fft4096_regs(v, lds, tw, j);
-    const long mbase = (long)blockIdx.x * hop;
+    const long mbase = (long)blk * hop;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int t = j + 256 * k;
@@ -2544,7 +2568,7 @@ int launch_filter_ols4096(hipStream_t s, const void *hist, size_t hist_len, cons
     if (nblocks > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "Filter: too many blocks");
     auto kern = out_f16 ? (g_f16 ? k_filter_ols4096<true, true> : k_filter_ols4096<true, false>)
                         : (g_f16 ? k_filter_ols4096<false, true> : k_filter_ols4096<false, false>);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), 0, s, (const float2 *)hist, (int)hist_len,
+    hipLaunchKernelGGL(kern, dim3(RR_V_FLTXCD ? (unsigned)((nblocks + 7) / 8 * 8) : (unsigned)nblocks), dim3(256), 0, s, (const float2 *)hist, (int)hist_len,
                        (const float2 *)in, (long)n_in, G, (const float2 *)tw4096, V, out, (long)n_out, e0);
     RR_HIP(hipGetLastError());
     return RR_OK;

@@ -37,14 +37,46 @@ static int set_dyn_lds(const void *fn, size_t bytes) {
 // Pure streaming: 8 B in + 8 B out per sample (16 B/lane vector accesses for f32),
 // the phase table stays in L2/MALL (it is at most a few MB for sane precisions).
 // ---------------------------------------------------------------------------
+#ifndef RR_V_FSXCD
+#define RR_V_FSXCD 1  // 0.232 -> 0.199 ms per 2^26 samples
+#endif
+#ifndef RR_V_FSUNROLL
+#define RR_V_FSUNROLL 1  // with the XCD mapping: 0.199 -> 0.177 ms
+#endif
 template <class T, int VEC>
 __global__ __launch_bounds__(256) void k_freqshift(const v2<T> *__restrict__ in, v2<T> *__restrict__ out, size_t n,
                                                    const v2<T> *__restrict__ table, uint32_t denom, uint32_t idx0) {
     const size_t nthreads = (size_t)gridDim.x * blockDim.x;
-    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+#if RR_V_FSXCD
+    // workgroups b, b + 8, .. share an XCD: give each XCD a contiguous eighth of every grid stride (grid: multiple of 8)
+    const size_t lb = (size_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+#else
+    const size_t lb = blockIdx.x;
+#endif
+    size_t i = (lb * blockDim.x + threadIdx.x) * VEC;
     // phase index of this thread's first sample and its advance per grid stride
     uint32_t r = (uint32_t)(((uint64_t)idx0 + i % denom) % denom);
     const uint32_t step = (uint32_t)((nthreads * VEC) % denom);
+#if RR_V_FSUNROLL
+    if constexpr (VEC == 2 && sizeof(T) == 4) {
+        typedef float f4s __attribute__((ext_vector_type(4)));
+        if (step == 0) {
+            const v2<T> p0 = table[r], p1 = table[r + 1 == denom ? 0 : r + 1];
+            const size_t stride = nthreads * VEC;
+            for (; i + 3 * stride + VEC <= n; i += 4 * stride) {
+                f4s v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f4s *>(in + i + u * stride));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const v2<T> y0 = cmul<T>(make_float2(v[u].x, v[u].y), p0);
+                    const v2<T> y1 = cmul<T>(make_float2(v[u].z, v[u].w), p1);
+                    __builtin_nontemporal_store((f4s){y0.x, y0.y, y1.x, y1.y}, reinterpret_cast<f4s *>(out + i + u * stride));
+                }
+            }
+        }
+    }
+#endif
     for (; i + VEC <= n; i += nthreads * VEC) {
         v2<T> x[VEC], y[VEC];
         if constexpr (VEC == 2 && sizeof(T) == 4) {
@@ -88,7 +120,24 @@ int launch_freqshift(int dtype, hipStream_t s, const void *in, void *out, size_t
     const bool vec = f32 && (reinterpret_cast<uintptr_t>(in) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0);
     const size_t per = vec ? 2 : 1;
     size_t blocks = (n + block * per - 1) / (block * per);
-    if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 blocks per CU
+    if (blocks > 256 * 16) {
+        blocks = 256 * 16;  // grid-stride beyond 16 blocks per CU
+        // ... and a whole number of table periods per grid stride where some grid of 8 .. 16 blocks per CU
+        // gives that: the kernel then keeps the lane's two phasors in registers (blocks must be a multiple of
+        // denom / gcd(denom, samples per block), and of 8 for the XCD mapping)
+        uint64_t g = denom, t = (uint64_t)block * per;
+        while (t) {
+            const uint64_t q = g % t;
+            g = t;
+            t = q;
+        }
+        uint64_t unit = denom / g;
+        while (unit % 8) unit *= 2;
+        if (unit <= blocks && blocks / unit * unit >= 256 * 8) blocks = blocks / unit * unit;
+    }
+#if RR_V_FSXCD
+    blocks = (blocks + 7) / 8 * 8;  // (the kernel's block -> XCD mapping)
+#endif
     if (f32) {
         if (vec)
             hipLaunchKernelGGL((k_freqshift<float, 2>), dim3(blocks), dim3(block), 0, s, (const float2 *)in,

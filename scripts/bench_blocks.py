@@ -50,3 +50,6 @@ run("Downsampler 384->48 kS/s L=288 (D=8)", 9, lambda: ds8.process_dev(384000.0,
 fo = rr.Fourier.with_window(rr.Kaiser.with_null_at_bin(2.0))
 fo.set_stream(st)
 run("Fourier 4096 Kaiser(null@2)", 16, lambda: fo.process_dev(4096, d_in.data_ptr(), N, d_out.data_ptr(), N))
+fm = rr.FmDemod(75000.0)
+fm.set_stream(st)
+run("FmDemod", 16, lambda: fm.process_dev(fs, d_in.data_ptr(), N, d_out.data_ptr(), N))
