@@ -653,6 +653,9 @@ __device__ __forceinline__ void apply_twiddle_powers(f2 (&v)[16], f2 w) {
 #ifndef RR_V_FFTPK
 #define RR_V_FFTPK 1
 #endif
+#ifndef RR_V_FFTWIN
+#define RR_V_FFTWIN 0  // > 0: frames dealt to the XCDs in a moving window, that many neighbouring frames per XCD
+#endif
 #ifndef RR_V_FFTXCD
 #define RR_V_FFTXCD 0  // a contiguous eighth of the frames per XCD: measured slower here (0.181 against 0.176 ms per 2^26 samples)
 #endif
@@ -662,7 +665,10 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
                                                  int center_dc, long hop, unsigned count) {
     __shared__ f2 lds[4096 + 256];
     const int j = threadIdx.x;
-#if RR_V_FFTXCD
+#if RR_V_FFTWIN > 0
+    const unsigned fr = blockIdx.x / (8 * RR_V_FFTWIN) * (8 * RR_V_FFTWIN) + (blockIdx.x % (8 * RR_V_FFTWIN) & 7) * RR_V_FFTWIN + (blockIdx.x % (8 * RR_V_FFTWIN) >> 3);
+    if (fr >= count) return;
+#elif RR_V_FFTXCD
     // workgroups b, b + 8, .. share an XCD: every XCD takes a contiguous eighth of the frames (grid: a multiple
     // of 8).  That mapping took k_freqshift (4 KiB per workgroup and trip) from 4.7 to 5.4 TB/s; with a whole
     // 32 KiB frame per workgroup it does not pay.
@@ -772,7 +778,8 @@ int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *i
                    hipEvent_t ev_stop) {
     if (count == 0) return RR_OK;
     if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fft4096: too many frames");
-    const unsigned grid = RR_V_FFTXCD ? (unsigned)((count + 7) / 8 * 8) : (unsigned)count;
+    const unsigned grid = RR_V_FFTWIN > 0 ? (unsigned)((count + 8 * RR_V_FFTWIN - 1) / (8 * RR_V_FFTWIN) * (8 * RR_V_FFTWIN))
+                                         : (RR_V_FFTXCD ? (unsigned)((count + 7) / 8 * 8) : (unsigned)count);
     if (ev_start && ev_stop)
         hipExtLaunchKernelGGL(k_fft4096, dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, (const float2 *)head,
                               (long)n_head, (const float2 *)in, (float2 *)out, (const float *)window,
@@ -2235,6 +2242,9 @@ __device__ __forceinline__ void wave_dft1024_t(f2 (&Z)[16], f2 (&v)[16], f2 *lds
     }
 }
 
+#ifndef RR_V_FLTWWIN
+#define RR_V_FLTWWIN 64
+#endif
 #ifndef RR_V_FLTWNT
 #define RR_V_FLTWNT 3  // bit 0: streaming stores, bit 1: streaming loads (measured n = 64: 0.203 / 0.196 / 0.202 / 0.193 ms for 0 / 1 / 2 / 3)
 #endif
@@ -2248,9 +2258,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_FLTWOCC
     __shared__ __attribute__((aligned(16))) f2 lds[kWaveLds];
     const int l = threadIdx.x;
     // workgroups b, b + 8, .. share an XCD: neighbouring blocks (which share V samples) on one XCD
+#if RR_V_FLTWWIN > 0
+    // (in a moving window of 8 G blocks, G neighbouring blocks per XCD, as k_ols_wave)
+    constexpr unsigned G = RR_V_FLTWWIN;
+    const unsigned blk = blockIdx.x / (8 * G) * (8 * G) + (blockIdx.x % (8 * G) & 7) * G + (blockIdx.x % (8 * G) >> 3);
+    if (blk >= nblocks) return;
+#else
     const unsigned per_xcd = (nblocks + 7) >> 3, within = blockIdx.x >> 3;
     const unsigned blk = (blockIdx.x & 7) * per_xcd + within;
     if (blk >= nblocks || within >= per_xcd) return;
+#endif
     const int hop = 1024 - V;
     const long b0 = e0 - V + (long)blk * hop;
     f2 v[16];
@@ -2329,8 +2346,12 @@ int launch_filter_wave(hipStream_t s, const void *hist, size_t hist_len, const v
     const size_t hop = 1024 - V;
     const size_t nblocks = (n_out + hop - 1) / hop;
     if (nblocks > 0x7ffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "Filter: too many blocks");
-    const size_t per_xcd = (nblocks + 7) / 8;
-    hipLaunchKernelGGL(k_filter_wave, dim3((unsigned)(per_xcd * 8)), dim3(64), 0, s, (const float2 *)hist, (int)hist_len,
+#if RR_V_FLTWWIN > 0
+    const size_t grid = (nblocks + 8 * RR_V_FLTWWIN - 1) / (8 * RR_V_FLTWWIN) * (8 * RR_V_FLTWWIN);
+#else
+    const size_t grid = (nblocks + 7) / 8 * 8;
+#endif
+    hipLaunchKernelGGL(k_filter_wave, dim3((unsigned)grid), dim3(64), 0, s, (const float2 *)hist, (int)hist_len,
                        (const float2 *)in, (long)n_in, (const float2 *)H, (const float2 *)tw, V, (float2 *)out, (long)n_out,
                        e0, (unsigned)nblocks);
     RR_HIP(hipGetLastError());
