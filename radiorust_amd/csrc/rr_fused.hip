@@ -2366,6 +2366,9 @@ int launch_filter_wave(hipStream_t s, const void *hist, size_t hist_len, const v
 // chunks in registers and loads one new chunk (4 loads) per frame; the window values of the lane
 // (4 P) and the three twiddle seeds stay in registers for the whole run.
 // ---------------------------------------------------------------------------
+#ifndef RR_V_CHANWIN
+#define RR_V_CHANWIN 4  // cfg3: one contiguous eighth of the runs per XCD 0.250 ms; windows of 1 .. 6 and 64 runs per XCD 0.222-0.226; 8: 0.232, 16: 0.265, 32: 0.233
+#endif
 template <int P>
 __global__ __launch_bounds__(64) void k_channelizer256(const float2 *__restrict__ hist, long hist_len,
                                                        const float2 *__restrict__ in, long base0,
@@ -2375,8 +2378,15 @@ __global__ __launch_bounds__(64) void k_channelizer256(const float2 *__restrict_
     __shared__ __attribute__((aligned(16))) f2 lds[320];  // B(i) = i + 4 (i >> 4), i < 256
     const int l = threadIdx.x, g = l >> 4, q = l & 15;
     // workgroups b, b + 8, .. share an XCD: neighbouring runs on one XCD (grid: multiple of 8)
+#if RR_V_CHANWIN > 0
+    // runs dealt to the XCDs in a moving window: RR_V_CHANWIN neighbouring runs per XCD (as k_ols_wave's blocks)
+    const unsigned rb = blockIdx.x / (8 * RR_V_CHANWIN) * (8 * RR_V_CHANWIN) + (blockIdx.x % (8 * RR_V_CHANWIN) & 7) * RR_V_CHANWIN +
+                        (blockIdx.x % (8 * RR_V_CHANWIN) >> 3);
+    const unsigned f0 = rb * run;
+#else
     const unsigned wpx = gridDim.x >> 3;
     const unsigned f0 = ((blockIdx.x & 7) * wpx + (blockIdx.x >> 3)) * run;
+#endif
     if (f0 >= nframes) return;
     const unsigned cnt = nframes - f0 < run ? nframes - f0 : run;
 
@@ -2476,7 +2486,11 @@ int launch_channelizer256(hipStream_t s, const void *hist, size_t hist_len, cons
 #define RR_V_CHANRUN 16
 #endif
     const unsigned run = RR_V_CHANRUN;
+#if RR_V_CHANWIN > 0
+    const unsigned grid = (unsigned)(((nframes + run - 1) / run + 8 * RR_V_CHANWIN - 1) / (8 * RR_V_CHANWIN) * (8 * RR_V_CHANWIN));
+#else
     const unsigned grid = (unsigned)(((nframes + run - 1) / run + 7) / 8 * 8);
+#endif
 #define RR_CHAN_LAUNCH(PP)                                                                                        \
     hipLaunchKernelGGL(k_channelizer256<PP>, dim3(grid), dim3(64), 0, s, (const float2 *)hist, (long)hist_len,    \
                        (const float2 *)in, base0, (const float *)window, (const float2 *)tw, (float2 *)out,      \
