@@ -1586,6 +1586,9 @@ __global__ __launch_bounds__(MODE == 2 ? 64 * kCuWaves : (MODE == 1 ? 64 : 64 * 
 // history for the next call.
 // ---------------------------------------------------------------------------
 int ols_wave_overlap(size_t Lc);
+#ifndef RR_V_FRAMEWIN
+#define RR_V_FRAMEWIN 1  // frames round robin over the XCDs: 0.1915 ms; a contiguous eighth per XCD (0): 0.1965
+#endif
 #ifndef RR_V_FRAMEWAVES
 #define RR_V_FRAMEWAVES 4  // measured (full-size images): 4 waves 0.233 ms, 5 waves 0.30 (one workgroup per CU), 8 waves 0.26, 10 waves 0.28
 #endif
@@ -1792,8 +1795,14 @@ __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_e
     __shared__ __attribute__((aligned(16))) f2 img[kFrameWaves * kImg];  // wave images
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     // frames dealt so that an XCD owns a contiguous range (grid: multiple of 8)
+#if RR_V_FRAMEWIN > 0
+    // frames dealt to the XCDs in a moving window, RR_V_FRAMEWIN neighbouring frames per XCD
+    const unsigned f = blockIdx.x / (8 * RR_V_FRAMEWIN) * (8 * RR_V_FRAMEWIN) + (blockIdx.x % (8 * RR_V_FRAMEWIN) & 7) * RR_V_FRAMEWIN +
+                       (blockIdx.x % (8 * RR_V_FRAMEWIN) >> 3);
+#else
     const unsigned per_xcd = gridDim.x >> 3;
     const unsigned f = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+#endif
     if (f > a.nfr) return;
     const bool tail = f == a.nfr;  // the frame that does not fill: goes to pend_out
     const long F0 = 4096l * f - a.pl;  // decimated index (of this call) of the frame's first sample
@@ -2029,7 +2038,11 @@ int launch_ols_frame(hipStream_t s, const FusedFirArgs &a, const void *pend_in, 
     f.kstep = (unsigned)(128 % den);
     f.inv_denom = 1.0 / (double)den;
     f.nfr = (unsigned)nfr;
+#if RR_V_FRAMEWIN > 0
+    const unsigned grid = (unsigned)((nfr + 1 + 8 * RR_V_FRAMEWIN - 1) / (8 * RR_V_FRAMEWIN) * (8 * RR_V_FRAMEWIN));
+#else
     const unsigned grid = (unsigned)((nfr + 1 + 7) / 8 * 8);
+#endif
     hipLaunchKernelGGL(k_ols_frame, dim3(grid), dim3(64 * kFrameWaves), 0, s, f);
     RR_HIP(hipGetLastError());
     return RR_OK;
