@@ -1144,6 +1144,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 * kCuWaves : (MODE == 1 ? 64 : 64 * 
 #if RR_V_WAVEWIN > 0
         // windowed: the XCDs work side by side in a moving window of 8 G blocks, G neighbouring blocks each
         // (instead of one far-apart eighth of the stream per XCD)
+        static_assert(RR_V_WAVEWG == 1, "the windowed mapping deals one-wave workgroups");
         constexpr unsigned G = RR_V_WAVEWIN;
         const unsigned grp = blockIdx.x / (8 * G), rem = blockIdx.x % (8 * G);
         blk = grp * 8 * G + (rem & 7) * G + (rem >> 3);
