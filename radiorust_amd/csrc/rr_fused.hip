@@ -100,6 +100,9 @@ __device__ __forceinline__ void lds_barrier() {
     __syncthreads();
 }
 
+#ifndef RR_V_MFDWIN
+#define RR_V_MFDWIN 0
+#endif
 template <int D, int R, int T>
 __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict__ xh, int hx,
                                                         const float2 *__restrict__ in, long n_in, int in_aligned16,
@@ -134,7 +137,15 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
         const unsigned b = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, rmd = nwg & 7, xcd = b & 7;
         chunk = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (b >> 3);
     }
-#ifndef RR_V_CONTIG
+#if RR_V_MFDWIN
+    // every round of the grid covers one contiguous window of tiles, an eighth of the window per XCD
+    // (the mapping of k_freqshift; grid: multiple of 8)
+    const unsigned tstride = gridDim.x;
+    const unsigned tile_begin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const unsigned tile_end = ntiles;
+    (void)tiles_per_wg;
+    (void)chunk;
+#elif !defined(RR_V_CONTIG)
     // an XCD owns a contiguous range of tiles and its workgroups take them round robin, so that the
     // tiles in flight at any moment are neighbours in memory (grid: multiple of 8); contiguous runs
     // per workgroup (RR_V_CONTIG) measured 3 % slower
