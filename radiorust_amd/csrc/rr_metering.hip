@@ -6,6 +6,7 @@
 // The reference accumulates in f64 in index order (and `bandwidth` scans with an early
 // exit), so one lane per frame does the sequential part over energies staged in LDS by
 // the whole workgroup; no a*b+c contraction anywhere (the reference is Rust).
+#include <cstdlib>
 #include "rr_kernels.hpp"
 
 namespace rr {
@@ -189,11 +190,97 @@ __global__ __launch_bounds__(256) void k_upsample(const CT *__restrict__ hist, l
     out[m] = o;
 }
 
+// Integer ratios U = 2 .. 8, f32: a lane produces the U outputs that one input releases (m = U t + p, p < U).
+// They all sum over the same inputs t - jmax .. t, so a workgroup stages its 256 + J inputs
+// in LDS once (the taps come as scalar loads) and every input read serves U outputs (the one-output-per-lane form above reads 30 inputs
+// and 30 taps from L1/L2 per output: 1.38 ms for 2^24 inputs at U = 4).  Per output the same products in
+// the same order, each product rounded and then added (-ffp-contract=off: packed multiply, packed add):
+// still bit-equal to the reference's scatter-add.
+constexpr int kUpJmax = 512;  // inputs in front of a tile that can reach into it: (L - 1) / U
+template <int U>
+__global__ __launch_bounds__(256) void k_upsample_int(const float2 *__restrict__ hist, long hn,
+                                                      const float2 *__restrict__ in, long n_in,
+                                                      const float *__restrict__ ir, int L, float2 *__restrict__ out,
+                                                      long n_out) {
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) char up_smem[];
+    const int J = (L - 1) / U;  // the oldest input of output U t is t - J
+    f2v *xs = reinterpret_cast<f2v *>(up_smem);  // inputs tile0 - J .. tile0 + 255
+    const long tile0 = (long)blockIdx.x * 256;
+    for (int i = threadIdx.x; i < 256 + J; i += 256) {
+        const long t = tile0 - J + i;
+        float2 x;
+        x.x = 0.f;
+        x.y = 0.f;
+        if (t >= 0) {
+            if (t < n_in) x = in[t];
+        } else if (t >= -hn) {
+            x = hist[hn + t];
+        }
+        xs[i] = (f2v){x.x, x.y};
+    }
+    __syncthreads();
+    f2v acc[U];
+#pragma unroll
+    for (int p = 0; p < U; ++p) acc[p] = (f2v){0.f, 0.f};
+    // The taps are read straight from the table: the index is the same in every lane, so they arrive as scalar
+    // loads (as 120 broadcast reads from LDS per lane they were the bottleneck: 0.447 ms).
+    // j = J: only the phases with p + U J < L have a tap there
+    {
+        const f2v x = xs[threadIdx.x];
+#pragma unroll
+        for (int p = 0; p < U; ++p)
+            if (p + U * J < L) acc[p] = acc[p] + x * ir[p + U * J];
+    }
+#pragma unroll 8
+    for (int j = J - 1; j >= 0; --j) {
+        const f2v x = xs[threadIdx.x + (J - j)];
+#pragma unroll
+        for (int p = 0; p < U; ++p) acc[p] = acc[p] + x * ir[p + U * j];
+    }
+    // the tile's 256 U outputs leave in order: through LDS, so that every store instruction writes 512
+    // contiguous bytes (a lane's own U outputs are 8 U bytes apart from its neighbour's)
+    __syncthreads();  // the inputs have been read
+    f2v *ys = xs;     // (256 U <= 256 + J is not guaranteed: the launcher sizes the buffer for both uses)
+#pragma unroll
+    for (int p = 0; p < U; ++p) ys[U * threadIdx.x + p] = acc[p];
+    __syncthreads();
+    const long mt = tile0 * U;
+#pragma unroll
+    for (int p = 0; p < U; ++p) {
+        const long m = mt + 256 * p + threadIdx.x;
+        if (m < n_out) __builtin_nontemporal_store(ys[256 * p + threadIdx.x], reinterpret_cast<f2v *>(out) + m);
+    }
+}
+
+template <int U>
+static void launch_upsample_int(hipStream_t s, const void *hist, size_t hn, const void *in, size_t n_in, const void *ir,
+                                size_t L, void *out, size_t n_out) {
+    const size_t J = (L - 1) / U;
+    const size_t lds = ((256 + J) > 256 * (size_t)U ? (256 + J) : 256 * (size_t)U) * 8;
+    const unsigned blocks = (unsigned)((n_out + 256 * U - 1) / (256 * U));
+    hipLaunchKernelGGL(k_upsample_int<U>, dim3(blocks), dim3(256), lds, s, (const float2 *)hist, (long)hn,
+                       (const float2 *)in, (long)n_in, (const float *)ir, (int)L, (float2 *)out, (long)n_out);
+}
+
 int launch_upsample(int dtype, hipStream_t s, const void *hist, size_t hn, const void *in, size_t n_in,
                     const void *ir, size_t L, uint64_t U, const int32_t *before, void *out, size_t n_out) {
     if (n_out == 0) return RR_OK;
     if (L > 0x7fffffffull || n_out > 0x7fffffffull * 256) RR_FAIL(RR_ERR_BAD_ARG, "Upsampler: size out of range");
     if (U == 0 && !before) RR_FAIL(RR_ERR_BAD_ARG, "Upsampler: schedule missing");
+    if (dtype == RR_F32 && U >= 2 && U <= 8 && (L - 1) / U <= (size_t)kUpJmax && n_out >= 4096 && !std::getenv("RR_UPSAMPLER_GENERIC")) {
+        switch (U) {
+            case 2: launch_upsample_int<2>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
+            case 3: launch_upsample_int<3>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
+            case 4: launch_upsample_int<4>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
+            case 5: launch_upsample_int<5>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
+            case 6: launch_upsample_int<6>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
+            case 7: launch_upsample_int<7>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
+            default: launch_upsample_int<8>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
+        }
+        RR_HIP(hipGetLastError());
+        return RR_OK;
+    }
     const unsigned blocks = (unsigned)((n_out + 255) / 256);
     if (dtype == RR_F32)
         hipLaunchKernelGGL((k_upsample<float, float2>), dim3(blocks), dim3(256), 0, s, (const float2 *)hist, (long)hn,

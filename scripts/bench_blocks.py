@@ -53,3 +53,11 @@ run("Fourier 4096 Kaiser(null@2)", 16, lambda: fo.process_dev(4096, d_in.data_pt
 fm = rr.FmDemod(75000.0)
 fm.set_stream(st)
 run("FmDemod", 16, lambda: fm.process_dev(fs, d_in.data_ptr(), N, d_out.data_ptr(), N))
+up = rr.Upsampler.new(4096, 200e6, 40e6)
+up.set_stream(st)
+NU, NO = N // 4, N
+def up_call():
+    up.process_dev(50e6, d_in.data_ptr(), NU, d_out.data_ptr(), NO)
+N = NU  # (the rates of this line are per input sample: 8 B in + 32 B out)
+run("Upsampler 50->200 MS/s", 40, up_call)
+N = NO

@@ -42,6 +42,21 @@ def test_upsampler_bit_exact(rr, oracle, fi, fo, bw, q, flt):
     assert g.ir_len() == len(o.ir())
 
 
+@pytest.mark.parametrize("U", [2, 3, 5, 6, 7])
+def test_upsampler_integer_ratio_kernel_bit_exact(rr, oracle, U):
+    """Integer ratios 2 .. 8 in f32 run k_upsample_int for calls of >= 4096 outputs (a lane produces the U
+    outputs one input releases, inputs staged in LDS, outputs leave through LDS in order): still bit-equal
+    to the reference's scatter-add order, also at ragged call sizes and across the switch between kernels."""
+    fi, fo = 1000.0, 1000.0 * U
+    x = oracle.synth_iq(30 + U, 0, 12000)
+    g = rr.Upsampler.with_quality(1000, fo, 420.0, 3.0)
+    o = oracle.Upsampler(1000, fo, 420.0, 3.0, flt=np.float32)
+    for a, b in zip([0, 5, 3000, 3001, 3300, 9001], [5, 3000, 3001, 3300, 9001, 12000]):
+        y, r = g.process_raw(fi, x[a:b]), o.process(fi, x[a:b])
+        assert len(y) == len(r) == U * (b - a)
+        assert np.array_equal(y.view(np.float32), r.view(np.float32)), (a, b)
+
+
 def test_upsampler_rate_change_chunks_and_events(rr, oracle):
     g = rr.Upsampler.new(500, 384000.0, 20000.0)
     o = oracle.Upsampler(500, 384000.0, 20000.0, flt=np.float32)
