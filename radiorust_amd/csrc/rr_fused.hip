@@ -1058,6 +1058,9 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifndef RR_V_WAVELOOPWIN
+#define RR_V_WAVELOOPWIN 1  // persistent forms: 1 = the grid's rounds cover contiguous windows, 0 = a contiguous eighth of the blocks per XCD
+#endif
 #ifndef RR_V_WAVEWIN
 #define RR_V_WAVEWIN 64  // > 0: blocks dealt to the XCDs in a moving window, that many neighbouring blocks per XCD (0: one contiguous eighth of the stream per XCD; measured 0.1375 -> 0.135 ms, G = 16 .. 1024 alike, 2 .. 8 no gain)
 #endif
@@ -1144,12 +1147,20 @@ __global__ __launch_bounds__(MODE == 2 ? 64 * kCuWaves : (MODE == 1 ? 64 : 64 * 
         if (blk >= nblocks) return;
         cnt = nblocks - blk < RR_V_WAVERUN ? nblocks - blk : RR_V_WAVERUN;
 #else
+#if RR_V_WAVELOOPWIN
+        // every round of the grid covers one contiguous window of blocks, an eighth of the window per XCD
+        blk = xcd * wpx + i;
+        bstride = 8 * wpx;
+        if (blk >= nblocks) return;
+        cnt = (nblocks - blk + bstride - 1) / bstride;
+#else
         const unsigned per_xcd = (nblocks + 7) >> 3;
         const unsigned lo = xcd * per_xcd, hi = lo + per_xcd < nblocks ? lo + per_xcd : nblocks;
         blk = lo + i;
         bstride = wpx;
         if (blk >= hi) return;
         cnt = (hi - blk + wpx - 1) / wpx;
+#endif
 #endif
     } else {
 #if RR_V_WAVEWIN > 0
@@ -2118,7 +2129,7 @@ int launch_ols_wave(hipStream_t s, const FusedFirArgs &a) {
     auto kern = k_ols_wave<0>;
 #endif
     const bool looped = kern != k_ols_wave<0>;
-    const unsigned hopm_run = (looped && RR_V_WAVERUN == 0) ? (unsigned)((int64_t)(grid / 8) * wpw * (1024 - a.V) % den) : hopm;
+    const unsigned hopm_run = (looped && RR_V_WAVERUN == 0) ? (unsigned)((int64_t)(grid / 8) * wpw * (RR_V_WAVELOOPWIN ? 8 : 1) * (1024 - a.V) % den) : hopm;
     if (a.ev_start && a.ev_stop)
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, s, a.ev_start, a.ev_stop, 0, (const float2 *)a.xh, (int)a.hx,
                               (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0,
