@@ -38,11 +38,18 @@
 // a second library with other values for A/B runs in one GPU session, scripts/ab_bench.py):
 //   RR_V_STAGGER, RR_V_CUSTAG, RR_V_WGPCU, RR_V_R4, RR_V_T256, RR_V_CONTIG   variants of kernel 1 (all slower)
 //   RR_V_WAVEWG   independent waves per workgroup of kernel 3w (1)
-//   RR_V_WAVELOOP, RR_V_WAVEOCCL, RR_V_WAVERUN   persistent forms of kernel 3w (0: one block per wave)
+//   RR_V_WAVEWIN  kernel 3w: blocks dealt to the XCDs in a moving window, that many per XCD (64; 0: an eighth of the stream per XCD)
+//   RR_V_WAVEBUFST  kernel 3w: outputs as buffer stores with out-of-range lanes dropped (1)
+//   RR_V_WAVELOOP, RR_V_WAVEOCCL, RR_V_WAVERUN, RR_V_WAVELOOPWIN   persistent one-wave forms of kernel 3w (0: one block per wave)
+//   RR_V_WAVECUR, RR_V_WAVECU, RR_V_WAVECUPF   persistent CU-resident workgroups with H in LDS (0)
 //   RR_V_WAVENT   streaming hint on the sample loads/stores of kernel 3w (1; no measurable effect)
 //   RR_V_WAVELDS  LDS elements per wave image (1176)
-//   RR_V_FRAMEWAVES, RR_V_FRAMEPF, RR_V_FRAMEOCC   kernel 3f: waves per frame (4), prefetch (0)
-//   RR_V_CHANRUN  frames per wave of kernel 5 (16)
+//   RR_V_FRAMEWAVES, RR_V_FRAMEPF, RR_V_FRAMEOCC, RR_V_FRAMEWIN   kernel 3f: waves per frame (4), prefetch (0), frames per XCD in a window (1)
+//   RR_V_FFTPK, RR_V_FFTXCD, RR_V_FFTWIN   kernel 2: packed window copy + seeds up front + streaming hints (1), XCD mappings (0, 0)
+//   RR_V_FLTXCD   kernel 4: a contiguous eighth of the blocks per XCD (0)
+//   RR_V_FLTWOCC, RR_V_FLTWNT, RR_V_FLTWWIN   kernel 4w: register budget in waves per SIMD (3), streaming hints (3), window (64)
+//   RR_V_CHANRUN, RR_V_CHANWIN  kernel 5: frames per wave (16), runs per XCD in a window (4)
+//   RR_V_MFDWIN   kernel 1: tiles dealt in windows (0)
 //   RR_STAMP      s_memtime stamps per phase (scripts/stamp_run.py, stamp_wave.py)
 //   RR_ABLATE, RR_OLS_ABLATE, RR_WAVE_ABLATE   measurement builds that skip a phase (results are WRONG)
 #include "rr_blocks.hpp"
