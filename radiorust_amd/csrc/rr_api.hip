@@ -672,7 +672,14 @@ int rr_fourier::prepare(size_t len) {
     } else {
         RR_TRY(upload(d_window, wb.data(), wb.size(), stream));
     }
-    RR_TRY(upload(d_tw, tb.data(), tb.size(), stream));
+    if (dtype == RR_F32 && len == 1024) {  // k_fft1024 finds its lane seeds behind the table
+        std::vector<float> twb(2 * 1024);
+        std::memcpy(twb.data(), tb.data(), twb.size() * sizeof(float));
+        append_wave1024_seeds(twb);
+        RR_TRY(upload(d_tw, twb.data(), twb.size() * sizeof(float), stream));
+    } else {
+        RR_TRY(upload(d_tw, tb.data(), tb.size(), stream));
+    }
     window_f64.swap(vals);
     n = len;
     return RR_OK;
@@ -919,21 +926,7 @@ void build_fused_fir_tables(int kind, uint64_t D_, const std::vector<double> &c,
                         hp[2 * dst + 1] = hb[2 * src + 1];
                     }
             hb.swap(hp);
-            // lane seeds of the transforms behind the table: 3 entries of two twiddles per lane
-            auto twv = [&](size_t i, float *dst) {
-                dst[0] = twb[2 * i];
-                dst[1] = twb[2 * i + 1];
-            };
-            twb.resize(2 * (N + 2 * 3 * 64));
-            for (size_t l = 0; l < 64; ++l) {
-                float *e0 = &twb[2 * N + 4 * l], *e1 = e0 + 4 * 64, *e2 = e1 + 4 * 64;
-                twv(8 * (l & 7), e0);         // pass 1
-                twv(l, e0 + 2);               // pass 2, m = 0
-                twv(l + 64, e1);              // pass 2, m = 1
-                twv(64 * (l & 3), e1 + 2);    // inverse pass 1
-                twv(16 * (l & 15), e2);       // inverse pass 2
-                twv(4 * l, e2 + 2);           // inverse pass 3
-            }
+            append_wave1024_seeds(twb);
         }
         t.H.swap(hb);
         t.tw.swap(twb);

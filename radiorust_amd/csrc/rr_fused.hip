@@ -58,6 +58,7 @@
 #include <hip/hip_fp16.h>
 
 #include <cmath>
+#include <vector>
 #include <utility>
 
 namespace rr {
@@ -2378,6 +2379,90 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_FLTWOCC
         } else {
             __builtin_amdgcn_raw_buffer_store_b128((f4){y0.x, y0.y, y1.x, y1.y}, rs, off, 0, RR_V_FLTWNT & 1 ? 2 : 0);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Kernel 2w  k_fft1024: window * v -> 1024-point forward DFT with one wave per frame (analysis.rs:105-115
+// for chunks of 1024): the forward network of k_filter_wave on the windowed samples.  Frames come from
+// [ head | in ] at distance `hop` (the overlapped analysis of rr_stft), the twiddle table carries the lane
+// seeds behind its 1024 entries (rr_fourier::prepare).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fft1024(
+    const float2 *__restrict__ head, long n_head, const float2 *__restrict__ in, float2 *__restrict__ out,
+    const float *__restrict__ window, const float2 *__restrict__ tw, int center_dc, long hop, unsigned count) {
+    __shared__ __attribute__((aligned(16))) f2 lds[kWaveLds];
+    const int l = threadIdx.x;
+    // frames dealt to the XCDs in a moving window, 16 neighbouring frames per XCD
+    const unsigned fr = blockIdx.x / 128 * 128 + (blockIdx.x % 128 & 7) * 16 + (blockIdx.x % 128 >> 3);
+    if (fr >= count) return;
+    const long base = (long)fr * hop - n_head;
+    f2 v[16];
+    if (base >= 0) {
+        const f4u *src = reinterpret_cast<const f4u *>(in + base) + l;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f4u x = hop >= 1024 ? __builtin_nontemporal_load(src + 64 * k) : *(src + 64 * k);
+            const float2 w = *reinterpret_cast<const float2 *>(window + 2 * l + 128 * k);
+            v[2 * k] = (f2){x.x * w.x, x.y * w.x};
+            v[2 * k + 1] = (f2){x.z * w.y, x.w * w.y};
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const long i = base + 2 * l + j + 128 * k;
+                const float2 x = (i >= 0) ? in[i] : head[n_head + i];
+                const float w = window[2 * l + j + 128 * k];
+                v[2 * k + j] = (f2){x.x * w, x.y * w};
+            }
+    }
+    f2 t_p1, t_p2[2];
+    {
+        const float4 *tl = reinterpret_cast<const float4 *>(tw + 1024) + l;
+        const float4 s0 = tl[0], s1 = tl[64];
+        t_p1 = (f2){s0.x, s0.y};
+        t_p2[0] = (f2){s0.z, s0.w};
+        t_p2[1] = (f2){s1.x, s1.y};
+    }
+    f2 X[16];
+    wave_dft1024(v, X, lds, l, t_p1, t_p2, [] {});
+    f2 *dst = reinterpret_cast<f2 *>(out) + (size_t)fr * 1024;
+    const int rot = center_dc ? 512 : 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) __builtin_nontemporal_store(X[k], dst + ((l + 64 * k + rot) & 1023));
+}
+
+int launch_fft1024(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
+                   const void *window, const void *tw1024, bool center_dc, size_t hop) {
+    if (count == 0) return RR_OK;
+    if (count > 0x7fffff00ull) RR_FAIL(RR_ERR_BAD_ARG, "fft1024: too many frames");
+    const unsigned grid = (unsigned)((count + 127) / 128 * 128);
+    hipLaunchKernelGGL(k_fft1024, dim3(grid), dim3(64), 0, s, (const float2 *)head, (long)n_head, (const float2 *)in,
+                       (float2 *)out, (const float *)window, (const float2 *)tw1024, (int)center_dc, (long)hop,
+                       (unsigned)count);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// the six twiddle seeds per lane of the wave-level 1024-point transforms, appended behind e^{-j 2 pi k / 1024}
+// (3 entries of two twiddles per lane; k_ols_wave, k_filter_wave, k_fft1024)
+void append_wave1024_seeds(std::vector<float> &twb) {
+    const size_t N = 1024;
+    auto twv = [&](size_t i, float *dst) {
+        dst[0] = twb[2 * i];
+        dst[1] = twb[2 * i + 1];
+    };
+    twb.resize(2 * (N + 2 * 3 * 64));
+    for (size_t l = 0; l < 64; ++l) {
+        float *e0 = &twb[2 * N + 4 * l], *e1 = e0 + 4 * 64, *e2 = e1 + 4 * 64;
+        twv(8 * (l & 7), e0);         // pass 1
+        twv(l, e0 + 2);               // pass 2, m = 0
+        twv(l + 64, e1);              // pass 2, m = 1
+        twv(64 * (l & 3), e1 + 2);    // inverse pass 1
+        twv(16 * (l & 15), e2);       // inverse pass 2
+        twv(4 * l, e2 + 2);           // inverse pass 3
     }
 }
 

@@ -531,6 +531,12 @@ int launch_fourier_overlapped(int dtype, hipStream_t s, const void *head, size_t
     RR_TRY(fourier_supported(dtype, n));
     if (dtype == RR_F32 && n == 4096)
         return launch_fft4096(s, head, n_head, in, out, count, window, twiddle, center_dc, hop);
+    static const bool generic = [] { const char *e = std::getenv("RR_FOURIER_GENERIC"); return e && std::atoi(e) != 0; }();
+    if (dtype == RR_F32 && n == 1024 && !generic)
+        return launch_fft1024(s, head, n_head, in, out, count, window, twiddle, center_dc, hop);
+    // 256-point chunks side by side: the channelizer's one-branch case (fold of one chunk = window * x, every bin kept)
+    if (dtype == RR_F32 && n == 256 && hop == 256 && !center_dc && !generic)
+        return launch_channelizer256(s, head, n_head, in, -(long)n_head, 1, count, window, twiddle, out);
     if (dtype == RR_F32)
         return launch_fourier_t<float>(s, head, n_head, in, out, n, hop, count, window, twiddle, center_dc, dtype);
     return launch_fourier_t<double>(s, head, n_head, in, out, n, hop, count, window, twiddle, center_dc, dtype);

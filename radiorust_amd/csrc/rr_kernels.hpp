@@ -1,6 +1,7 @@
 // rr_kernels.hpp — launchers of the gfx950 kernels (rr_kernels.hip).
 // All launchers are asynchronous on `stream` and return an rr_status.
 #pragma once
+#include <vector>
 #include "rr_internal.hpp"
 
 namespace rr {
@@ -116,6 +117,10 @@ int fused_fir_R(uint64_t D);  // outputs per lane of the instantiation for D
 int launch_fused_fir(hipStream_t s, const FusedFirArgs &a);
 // 4096-point windowed forward DFT (radix 16 x 3); tw4096[k] = e^{-j 2 pi k / 4096}, 4096 entries
 // frames are cut from the stream [ head (n_head samples) | in ]
+// k_fft1024: a wave per 1024-sample frame; tw1024 = e^{-j 2 pi k / 1024} followed by the lane seeds (append_wave1024_seeds)
+int launch_fft1024(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
+                   const void *window, const void *tw1024, bool center_dc, size_t hop);
+void append_wave1024_seeds(std::vector<float> &twb);
 int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
                    const void *window, const void *tw4096, bool center_dc, size_t hop = 4096,
                    hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
