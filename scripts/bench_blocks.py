@@ -61,3 +61,12 @@ def up_call():
 N = NU  # (the rates of this line are per input sample: 8 B in + 32 B out)
 run("Upsampler 50->200 MS/s", 40, up_call)
 N = NO
+# the reference example's analysis stage (bandwidth_meter/main.rs:66-69): chunks of 1024, Overlapper(4), Fourier with
+# Kaiser(null at bin 4): one 4096-point spectrum per 1024 new samples: 8 B in + 32 B out per input sample
+NS = N // 4
+d_big = torch.empty(N + 8192, dtype=torch.complex64, device="cuda")
+sf = rr.Stft(1024, 4, rr.Kaiser.with_null_at_bin(4.0))
+sf.set_stream(st)
+N = NS
+run("Stft 1024 x 4 (example's analysis)", 40, lambda: sf.process_dev(d_in.data_ptr(), NS, d_big.data_ptr(), NO + 8192))
+N = NO
