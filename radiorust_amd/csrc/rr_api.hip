@@ -661,13 +661,14 @@ int rr_fourier::prepare(size_t len) {
         cast_to<double>(vals.data(), len, wb);
         cast_to<double>(tw.data(), tw.size(), tb);
     }
-    if (dtype == RR_F32 && len == 4096) {
-        // k_fft4096 reads the 16 window values of a lane (w[j + 256 k], k < 16) as four 16-byte pieces from a
-        // second copy behind the table: wp[16 j + k] = w[j + 256 k]
-        std::vector<float> both(2 * 4096);
-        std::memcpy(both.data(), wb.data(), 4096 * sizeof(float));
-        for (size_t j = 0; j < 256; ++j)
-            for (size_t k = 0; k < 16; ++k) both[4096 + 16 * j + k] = both[j + 256 * k];
+    if (dtype == RR_F32 && (len == 4096 || len == 2048)) {
+        // k_fft4096 / k_fft2048 read the 16 window values of a lane (w[j + T k], k < 16, T = len / 16 lanes) as four
+        // 16-byte pieces from a second copy behind the table: wp[16 j + k] = w[j + T k]
+        const size_t T = len / 16;
+        std::vector<float> both(2 * len);
+        std::memcpy(both.data(), wb.data(), len * sizeof(float));
+        for (size_t j = 0; j < T; ++j)
+            for (size_t k = 0; k < 16; ++k) both[len + 16 * j + k] = both[j + T * k];
         RR_TRY(upload(d_window, both.data(), both.size() * sizeof(float), stream));
     } else {
         RR_TRY(upload(d_window, wb.data(), wb.size(), stream));

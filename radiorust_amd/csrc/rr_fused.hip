@@ -811,6 +811,170 @@ int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *i
     return RR_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Kernel 2s  k_fft512: window * v -> 512-point forward DFT, radix 8 x 8 x 8, one wave per frame (8 values per
+// lane, wave-local exchanges through a padded 4.5 KiB image).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int pad8(int i) { return i + (i >> 3); }
+__device__ __forceinline__ void twiddle8(f2 (&a)[8], f2 w1) {  // a[k] *= w1^k
+    const f2 w2 = cmulf(w1, w1), w3 = cmulf(w2, w1), w4 = cmulf(w2, w2);
+    a[1] = cmulf(a[1], w1);
+    a[2] = cmulf(a[2], w2);
+    a[3] = cmulf(a[3], w3);
+    a[4] = cmulf(a[4], w4);
+    a[5] = cmulf(a[5], cmulf(w4, w1));
+    a[6] = cmulf(a[6], cmulf(w4, w2));
+    a[7] = cmulf(a[7], cmulf(w4, w3));
+}
+__device__ __forceinline__ void wave_sync();
+__global__ __launch_bounds__(64) void k_fft512(const float2 *__restrict__ head, long n_head,
+                                               const float2 *__restrict__ in, float2 *__restrict__ out,
+                                               const float *__restrict__ window, const float2 *__restrict__ tw,
+                                               int center_dc, long hop, unsigned count) {
+    __shared__ f2 lds[512 + 64];
+    const int l = threadIdx.x;
+    // frames dealt to the XCDs in a moving window, 16 neighbouring frames per XCD
+    const unsigned fr = blockIdx.x / 128 * 128 + (blockIdx.x % 128 & 7) * 16 + (blockIdx.x % 128 >> 3);
+    if (fr >= count) return;
+    const long base = (long)fr * hop - n_head;
+    f2 a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const long i = base + l + 64 * k;
+        const float2 x = (i >= 0) ? in[i] : head[n_head + i];
+        const float w = window[l + 64 * k];
+        a[k] = (f2){x.x * w, x.y * w};
+    }
+    const float2 s1 = tw[8 * (l & 7)], s2 = tw[l];  // tw[k] = e^{-j 2 pi k / 512}
+    dft8(a);  // pass 0 (Ns = 1): out 8 l + k
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lds[pad8(8 * l + k)] = a[k];
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = lds[pad8(l + 64 * k)];
+    twiddle8(a, (f2){s1.x, s1.y});  // pass 1 (Ns = 8): e^{-j 2 pi (l mod 8) k / 64}; out (l / 8) 64 + l % 8 + 8 k
+    dft8(a);
+    wave_sync();
+    {
+        const int b = (l >> 3) * 64 + (l & 7);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lds[pad8(b + 8 * k)] = a[k];
+    }
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = lds[pad8(l + 64 * k)];
+    twiddle8(a, (f2){s2.x, s2.y});  // pass 2 (Ns = 64): e^{-j 2 pi l k / 512}; out l + 64 k
+    dft8(a);
+    f2 *dst = reinterpret_cast<f2 *>(out) + (size_t)fr * 512;
+    const int rot = center_dc ? 256 : 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(a[k], dst + ((l + 64 * k + rot) & 511));
+}
+
+int launch_fft512(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
+                  const void *window, const void *tw512, bool center_dc, size_t hop) {
+    if (count == 0) return RR_OK;
+    if (count > 0x7fffff00ull) RR_FAIL(RR_ERR_BAD_ARG, "fft512: too many frames");
+    const unsigned grid = (unsigned)((count + 127) / 128 * 128);
+    hipLaunchKernelGGL(k_fft512, dim3(grid), dim3(64), 0, s, (const float2 *)head, (long)n_head, (const float2 *)in,
+                       (float2 *)out, (const float *)window, (const float2 *)tw512, (int)center_dc, (long)hop,
+                       (unsigned)count);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Kernel 2h  k_fft2048: window * v -> 2048-point forward DFT, radix 16 x 16 x 8 (Stockham autosort through one
+// padded 17 KiB LDS image), a workgroup of 128 lanes per frame, 16 values per lane: the 2048-point sibling of
+// k_fft4096 (analysis.rs:105-115; rr_stft with 2048-sample spans).  The window table carries a packed copy
+// behind its 2048 entries (wp[16 t + k] = w[t + 128 k], rr_fourier::prepare).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_fft2048(const float2 *__restrict__ head, long n_head,
+                                                 const float2 *__restrict__ in, float2 *__restrict__ out,
+                                                 const float *__restrict__ window, const float2 *__restrict__ tw,
+                                                 int center_dc, long hop) {
+    __shared__ f2 lds[2048 + 128];
+    const int t = threadIdx.x;
+    const long base = (long)blockIdx.x * hop - n_head;
+    f2 v[16];
+    {
+        float wv[16];
+        const float4 *wp = reinterpret_cast<const float4 *>(window + 2048) + 4 * t;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 w4 = wp[q];
+            wv[4 * q] = w4.x;
+            wv[4 * q + 1] = w4.y;
+            wv[4 * q + 2] = w4.z;
+            wv[4 * q + 3] = w4.w;
+        }
+        if (base >= 0) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = reinterpret_cast<const f2 *>(in + base + t)[128 * k] * wv[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const long i = base + t + 128 * k;
+                const float2 x = (i >= 0) ? in[i] : head[n_head + i];
+                v[k] = (f2){x.x * wv[k], x.y * wv[k]};
+            }
+        }
+    }
+    // twiddle seeds: pass 1 e^{-j 2 pi (t mod 16) / 256} = tw[8 (t mod 16)]; pass 2 tw[t], tw[t + 128]  (tw[k] = e^{-j 2 pi k / 2048})
+    const float2 s1 = tw[8 * (t & 15)], s2a = tw[t], s2b = tw[t + 128];
+    // pass 0 (Ns = 1, radix 16): butterflies t over x[t + 128 k]; out 16 t + k
+    dft16(v);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[pad16(16 * t + k)] = v[k];
+    __syncthreads();
+    // pass 1 (Ns = 16, radix 16): in y[t + 128 k]; out (t / 16) 256 + t % 16 + 16 k
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = lds[pad16(t + 128 * k)];
+    apply_twiddle_powers(v, (f2){s1.x, s1.y});
+    dft16(v);
+    __syncthreads();
+    {
+        const int b = (t >> 4) * 256 + (t & 15);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lds[pad16(b + 16 * k)] = v[k];
+    }
+    __syncthreads();
+    // pass 2 (Ns = 256, radix 8): butterflies j = t and t + 128 over z[j + 256 k]; out X[j + 256 k]
+    f2 *dst = reinterpret_cast<f2 *>(out) + (size_t)blockIdx.x * 2048;
+    const int rot = center_dc ? 1024 : 0;
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+        const int j = t + 128 * sidx;
+        f2 a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = lds[pad16(j + 256 * k)];
+        const float2 sw = sidx ? s2b : s2a;
+        const f2 w1 = {sw.x, sw.y};
+        const f2 w2 = cmulf(w1, w1), w3 = cmulf(w2, w1), w4 = cmulf(w2, w2);
+        a[1] = cmulf(a[1], w1);
+        a[2] = cmulf(a[2], w2);
+        a[3] = cmulf(a[3], w3);
+        a[4] = cmulf(a[4], w4);
+        a[5] = cmulf(a[5], cmulf(w4, w1));
+        a[6] = cmulf(a[6], cmulf(w4, w2));
+        a[7] = cmulf(a[7], cmulf(w4, w3));
+        dft8(a);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(a[k], dst + ((j + 256 * k + rot) & 2047));
+    }
+}
+
+int launch_fft2048(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
+                   const void *window, const void *tw2048, bool center_dc, size_t hop) {
+    if (count == 0) return RR_OK;
+    if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fft2048: too many frames");
+    hipLaunchKernelGGL(k_fft2048, dim3((unsigned)count), dim3(128), 0, s, (const float2 *)head, (long)n_head,
+                       (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw2048, (int)center_dc,
+                       (long)hop);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
 // forward 4096-point DFT in registers + one padded LDS image (radix 16 x 3, Stockham)
 __device__ __forceinline__ void fft4096_regs(f2 (&v)[16], f2 *lds, const float2 *__restrict__ tw, int j) {
     // in: v[k] = x[j + 256 k]; out: v[k] = X[j + 256 k]

@@ -117,6 +117,12 @@ int fused_fir_R(uint64_t D);  // outputs per lane of the instantiation for D
 int launch_fused_fir(hipStream_t s, const FusedFirArgs &a);
 // 4096-point windowed forward DFT (radix 16 x 3); tw4096[k] = e^{-j 2 pi k / 4096}, 4096 entries
 // frames are cut from the stream [ head (n_head samples) | in ]
+// k_fft512: a wave per 512-sample frame (plain window and twiddle tables)
+int launch_fft512(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
+                  const void *window, const void *tw512, bool center_dc, size_t hop);
+// k_fft2048: 128 lanes per 2048-sample frame; the window table carries the packed copy wp[16 t + k] = w[t + 128 k] behind its 2048 entries
+int launch_fft2048(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
+                   const void *window, const void *tw2048, bool center_dc, size_t hop);
 // k_fft1024: a wave per 1024-sample frame; tw1024 = e^{-j 2 pi k / 1024} followed by the lane seeds (append_wave1024_seeds)
 int launch_fft1024(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
                    const void *window, const void *tw1024, bool center_dc, size_t hop);

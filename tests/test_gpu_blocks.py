@@ -459,7 +459,7 @@ def test_fourier_reference_kat_on_gpu(rr):
 
 
 @pytest.mark.parametrize("n,center", [(4096, False), (4096, True), (8192, False), (256, True), (256, False), (1024, False),
-                                      (1024, True), (2, False), (1, True), (1000, True), (7, True), (4095, False), (12000, False)])
+                                      (1024, True), (2048, False), (2048, True), (2, False), (1, True), (1000, True), (7, True), (4095, False), (12000, False)])
 def test_fourier_parity(rr, oracle, n, center):
     x = oracle.synth_iq(12, 0, n)
     gw, ow = rr.Kaiser.with_null_at_bin(2.0), oracle.Kaiser.with_null_at_bin(2.0)
@@ -497,10 +497,10 @@ def test_fourier_batched_device_api(rr, oracle):
     check(d_out.cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("n,center", [(1024, False), (1024, True), (256, False)])
+@pytest.mark.parametrize("n,center", [(1024, False), (1024, True), (256, False), (2048, False), (2048, True), (512, False), (512, True)])
 def test_fourier_wave_kernels_batched(rr, oracle, n, center, monkeypatch):
-    """Chunks of 1024 (k_fft1024: a wave per chunk) and of 256 (the channelizer's one-branch case) in f32: many
-    chunks per call on the device, every chunk against the f64 oracle."""
+    """Chunks of 512 / 1024 (k_fft512 / k_fft1024: a wave per chunk), 2048 (k_fft2048: 128 lanes per chunk) and 256
+    (the channelizer's one-branch case) in f32: many chunks per call on the device, every chunk against the f64 oracle."""
     import torch
 
     k = 300
