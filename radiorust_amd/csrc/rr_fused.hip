@@ -27,6 +27,7 @@
 //   workgroup per spectrum (analysis.rs:105-115); center_dc is an index
 //   rotation on the store.
 //
+// Kernel 2s/2w/2h/2x  k_fft512 / k_fft1024 / k_fft2048 / k_fft8192: the same for the other power-of-two chunk lengths
 // Kernel 3   k_ols_decim4     the stage of kernel 1 by overlap-save, a workgroup per 4096-block
 // Kernel 3w  k_ols_wave       ... a WAVE per 1024-block: the default for 4x decimation
 // Kernel 3f  k_ols_frame      k_ols_wave's blocks + kernel 2 in one kernel (measured slower; on request)
@@ -970,6 +971,103 @@ int launch_fft2048(hipStream_t s, const void *head, size_t n_head, const void *i
     if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fft2048: too many frames");
     hipLaunchKernelGGL(k_fft2048, dim3((unsigned)count), dim3(128), 0, s, (const float2 *)head, (long)n_head,
                        (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw2048, (int)center_dc,
+                       (long)hop);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Kernel 2x  k_fft8192: window * v -> 8192-point forward DFT, radix 16 x 16 x 32 (Stockham autosort through one
+// padded 68 KiB LDS image), a workgroup of 256 lanes per frame, 32 values per lane.  The radix-32 butterfly
+// of the last pass is two 16-point DFTs (even / odd inputs) and 16 radix-2 butterflies with W_32^m.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fft8192(const float2 *__restrict__ head, long n_head,
+                                                 const float2 *__restrict__ in, float2 *__restrict__ out,
+                                                 const float *__restrict__ window, const float2 *__restrict__ tw,
+                                                 int center_dc, long hop) {
+    extern __shared__ __attribute__((aligned(16))) char fft8192_smem[];
+    f2 *lds = reinterpret_cast<f2 *>(fft8192_smem);  // 8192 + 512 elements
+    const int t = threadIdx.x;
+    const long base = (long)blockIdx.x * hop - n_head;
+    f2 v[2][16];
+    // pass 0 (Ns = 1, radix 16): butterflies j = t, t + 256 over x[j + 512 k]; out 16 j + k
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = t + 256 * h;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const long i = base + j + 512 * k;
+            const float2 x = (i >= 0) ? in[i] : head[n_head + i];
+            const float w = window[j + 512 * k];
+            v[h][k] = (f2){x.x * w, x.y * w};
+        }
+        dft16(v[h]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lds[pad16(16 * j + k)] = v[h][k];
+    }
+    __syncthreads();
+    // pass 1 (Ns = 16, radix 16): in y[j + 512 k]; twiddle e^{-j 2 pi (j mod 16) k / 256} = tw[32 (j mod 16)]^k;
+    // out (j / 16) 256 + j % 16 + 16 k
+    {
+        const float2 s1 = tw[32 * (t & 15)];  // (t + 256) mod 16 = t mod 16: one seed for both butterflies
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = t + 256 * h;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[h][k] = lds[pad16(j + 512 * k)];
+            apply_twiddle_powers(v[h], (f2){s1.x, s1.y});
+            dft16(v[h]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = t + 256 * h;
+        const int b = (j >> 4) * 256 + (j & 15);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lds[pad16(b + 16 * k)] = v[h][k];
+    }
+    __syncthreads();
+    // pass 2 (Ns = 256, radix 32): butterfly t over z[t + 256 k], k < 32; twiddle tw[t]^k; out X[t + 256 k]
+    // even inputs k = 2 a -> v[0][a] * (w^2)^a; odd inputs k = 2 a + 1 -> v[1][a] * w * (w^2)^a
+    {
+        const float2 s2 = tw[t];
+        const f2 w = {s2.x, s2.y};
+        const f2 w2 = cmulf(w, w);
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            v[0][a] = lds[pad16(t + 256 * (2 * a))];
+            v[1][a] = cmulf(lds[pad16(t + 256 * (2 * a + 1))], w);
+        }
+        apply_twiddle_powers(v[0], w2);
+        apply_twiddle_powers(v[1], w2);
+        dft16(v[0]);  // E[m]
+        dft16(v[1]);  // O[m]
+        f2 *dst = reinterpret_cast<f2 *>(out) + (size_t)blockIdx.x * 8192;
+        const int rot = center_dc ? 4096 : 0;
+        // X[m] = E[m] + W_32^m O[m], X[m + 16] = E[m] - W_32^m O[m];  W_32^m = e^{-j 2 pi m / 32} = tw[256 m] (a scalar read)
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const float2 c = tw[256 * m];
+            const f2 o = cmulf(v[1][m], (f2){c.x, c.y});
+            __builtin_nontemporal_store(v[0][m] + o, dst + ((t + 256 * m + rot) & 8191));
+            __builtin_nontemporal_store(v[0][m] - o, dst + ((t + 256 * (m + 16) + rot) & 8191));
+        }
+    }
+}
+
+int launch_fft8192(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
+                   const void *window, const void *tw8192, bool center_dc, size_t hop) {
+    if (count == 0) return RR_OK;
+    if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fft8192: too many frames");
+    const size_t lds = (8192 + 512) * sizeof(float2);
+    static bool attr_set = false;  // (more than 64 KiB of dynamic LDS needs the opt-in once per process and device; harmless to repeat)
+    if (!attr_set) {
+        RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft8192), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_fft8192, dim3((unsigned)count), dim3(256), lds, s, (const float2 *)head, (long)n_head,
+                       (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw8192, (int)center_dc,
                        (long)hop);
     RR_HIP(hipGetLastError());
     return RR_OK;

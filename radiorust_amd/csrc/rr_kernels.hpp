@@ -117,6 +117,9 @@ int fused_fir_R(uint64_t D);  // outputs per lane of the instantiation for D
 int launch_fused_fir(hipStream_t s, const FusedFirArgs &a);
 // 4096-point windowed forward DFT (radix 16 x 3); tw4096[k] = e^{-j 2 pi k / 4096}, 4096 entries
 // frames are cut from the stream [ head (n_head samples) | in ]
+// k_fft8192: 256 lanes per 8192-sample frame, 32 values per lane (plain window and twiddle tables)
+int launch_fft8192(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
+                   const void *window, const void *tw8192, bool center_dc, size_t hop);
 // k_fft512: a wave per 512-sample frame (plain window and twiddle tables)
 int launch_fft512(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
                   const void *window, const void *tw512, bool center_dc, size_t hop);
