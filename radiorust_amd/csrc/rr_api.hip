@@ -512,8 +512,7 @@ int rr_stft::process_dev(const void *d_in_, size_t n_in_, void *d_out, size_t ca
         const size_t n_head = base0 < 0 ? (size_t)(-base0) : 0;
         const char *head = hist[cur].as<char>() + (H - n_head) * esz;
         const char *in0 = d_in + (base0 > 0 ? (size_t)base0 * esz : 0);
-        RR_TRY(launch_fourier_overlapped(dtype, stream, head, n_head, in0, d_out, N, M, frames, fo->d_window.p,
-                                         fo->d_tw.p, fo->center_dc));
+        RR_TRY(fo->transform_dev(head, n_head, in0, d_out, M, frames));
     }
     if (H) {
         RR_TRY(launch_update_hist(dtype, stream, hist[cur].p, hist[cur ^ 1].p, H, d_in, n_in));
@@ -683,6 +682,82 @@ int rr_fourier::prepare(size_t len) {
     }
     window_f64.swap(vals);
     n = len;
+    bs_M = 0;
+    {
+        const char *e = std::getenv("RR_FOURIER_GENERIC");
+        const bool pow2 = (len & (len - 1)) == 0;
+        if (dtype == RR_F32 && !pow2 && len >= 32 && len <= 4096 && !(e && std::atoi(e) != 0)) {
+            size_t M = 512;
+            while (M < 2 * len - 1) M *= 2;
+            // chirp w_m = e^{+j pi m^2 / n}, the phase reduced exactly (m^2 mod 2n) before it is evaluated
+            std::vector<cd> w(len);
+            for (size_t m = 0; m < len; ++m) {
+                const uint64_t r = (uint64_t)m * m % (2 * len);
+                const double ang = M_PI * (double)r / (double)len;
+                w[m] = cd(std::cos(ang), std::sin(ang));
+            }
+            std::vector<cd> bb(M, cd(0, 0));
+            bb[0] = w[0];
+            for (size_t m = 1; m < len; ++m) bb[m] = bb[M - m] = w[m];
+            fft_f64(bb, false);
+            std::vector<float> cf(2 * len), wf(2 * len), Bf(2 * M);
+            for (size_t m = 0; m < len; ++m) {
+                const cd c = std::conj(w[m]) * window_f64[m];
+                cf[2 * m] = (float)c.real();
+                cf[2 * m + 1] = (float)c.imag();
+                wf[2 * m] = (float)w[m].real();
+                wf[2 * m + 1] = (float)w[m].imag();
+            }
+            for (size_t m = 0; m < M; ++m) {
+                Bf[2 * m] = (float)(bb[m].real() / (double)M);
+                Bf[2 * m + 1] = (float)(bb[m].imag() / (double)M);
+            }
+            RR_TRY(upload(d_bs_c, cf.data(), cf.size() * sizeof(float), stream));
+            RR_TRY(upload(d_bs_w, wf.data(), wf.size() * sizeof(float), stream));
+            RR_TRY(upload(d_bs_B, Bf.data(), Bf.size() * sizeof(float), stream));
+            if (!bs_fft) {
+                bs_fft = new rr_fourier;
+                RR_TRY(bs_fft->init_base(K_FOURIER, RR_F32, device));
+            }
+            bs_fft->stream = stream;
+            RR_TRY(bs_fft->prepare(M));  // rectangular window: all ones
+            bs_M = M;
+        }
+    }
+    return RR_OK;
+}
+
+rr_fourier::~rr_fourier() { delete bs_fft; }
+
+int rr_fourier::transform_dev(const void *head, size_t n_head, const void *in, void *out, size_t hop, size_t count) {
+    if (!bs_M) return launch_fourier_overlapped(dtype, stream, head, n_head, in, out, n, hop, count, d_window.p, d_tw.p, center_dc);
+    const size_t M = bs_M, esz = elem_size(dtype);
+    // passes of at most 2^22 workspace elements per buffer (32 MiB each)
+    size_t per_pass = ((size_t)1 << 22) / M;
+    if (per_pass > 65535) per_pass = 65535;
+    RR_TRY(bs_ws[0].reserve(per_pass * M * esz));
+    RR_TRY(bs_ws[1].reserve(per_pass * M * esz));
+    bs_fft->stream = stream;
+    for (size_t f0 = 0; f0 < count; f0 += per_pass) {
+        const size_t F = count - f0 < per_pass ? count - f0 : per_pass;
+        // frame f0's first sample sits f0 * hop behind the start of [head | in]
+        const size_t skip = f0 * hop;
+        const char *hd = static_cast<const char *>(head);
+        const char *src = static_cast<const char *>(in);
+        size_t nh = n_head;
+        if (skip >= n_head) {
+            src += (skip - n_head) * esz;
+            nh = 0;
+        } else {
+            hd += skip * esz;
+            nh = n_head - skip;
+        }
+        RR_TRY(launch_bs_pre(stream, hd, nh, src, hop, n, M, d_bs_c.p, bs_ws[0].p, F));
+        RR_TRY(launch_fourier(RR_F32, stream, bs_ws[0].p, bs_ws[1].p, M, F, bs_fft->d_window.p, bs_fft->d_tw.p, false));
+        RR_TRY(launch_bs_mul(stream, bs_ws[1].p, d_bs_B.p, M, F));
+        RR_TRY(launch_fourier(RR_F32, stream, bs_ws[1].p, bs_ws[0].p, M, F, bs_fft->d_window.p, bs_fft->d_tw.p, false));
+        RR_TRY(launch_bs_post(stream, bs_ws[0].p, d_bs_w.p, n, M, static_cast<char *>(out) + f0 * n * esz, center_dc, F));
+    }
     return RR_OK;
 }
 
@@ -694,7 +769,7 @@ int rr_fourier::process_dev(size_t chunk_len, const void *d_in, size_t n_in, voi
     if (n_in == 0) return RR_OK;
     RR_TRY(select());
     RR_TRY(prepare(chunk_len));
-    RR_TRY(launch_fourier(dtype, stream, d_in, d_out, chunk_len, n_in / chunk_len, d_window.p, d_tw.p, center_dc));
+    RR_TRY(transform_dev(nullptr, 0, d_in, d_out, chunk_len, n_in / chunk_len));
     if (n_out) *n_out = n_in;
     return RR_OK;
 }
@@ -1651,8 +1726,9 @@ int rr_stft_create(int dtype, size_t chunk_len, size_t chunk_count, const rr_win
     if (chunk_len == 0) RR_FAIL(RR_ERR_CONTRACT, "chunk length must be positive");    // chunks.rs:56
     if (chunk_count == 0) RR_FAIL(RR_ERR_CONTRACT, "chunk count must be positive");   // chunks.rs:195
     const size_t N = chunk_len * chunk_count;
-    if (!fourier_pow2_path(dtype, N))
-        RR_FAIL(RR_ERR_BAD_ARG, "Stft: chunk_len * chunk_count must be a power of two the Fourier kernels take (got %zu)", N);
+    // overlapped frames: the power-of-two kernels, or Bluestein over them (f32, 32 .. 4096 points)
+    if (!fourier_pow2_path(dtype, N) && !(dtype == RR_F32 && N >= 32 && N <= 4096))
+        RR_FAIL(RR_ERR_BAD_ARG, "Stft: chunk_len * chunk_count = %zu: powers of two, or 32 .. 4096 for Complex<f32>", N);
     if (window->kind != RR_WIN_RECTANGULAR && window->kind != RR_WIN_KAISER)
         RR_FAIL(RR_ERR_BAD_ARG, "Stft: window must be a built-in window");
     auto *h = new rr_stft;

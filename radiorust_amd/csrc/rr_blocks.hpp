@@ -139,7 +139,15 @@ struct rr_fourier : rr_block {
     size_t sampled_n = 0;
     std::vector<double> window_f64;  // scaled window of the current design
     rr::DevBuf d_window, d_tw;
+    // Bluestein for lengths that are not powers of two (f32, 32 <= n <= 4096): two transforms of bs_M points
+    // by a nested rectangular-window Fourier, tables c = window * conj(chirp), B = F(chirp) / M, w = chirp
+    size_t bs_M = 0;
+    rr_fourier *bs_fft = nullptr;
+    rr::DevBuf d_bs_c, d_bs_B, d_bs_w, bs_ws[2];
+    ~rr_fourier() override;
     int prepare(size_t len);
+    // `count` windowed transforms of n points over [head | in] at distance hop
+    int transform_dev(const void *head, size_t n_head, const void *in, void *out, size_t hop, size_t count);
     int process_dev(size_t chunk_len, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
 };
 

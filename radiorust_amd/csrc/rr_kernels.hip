@@ -525,6 +525,74 @@ static int launch_fourier_t(hipStream_t s, const void *head, size_t n_head, cons
     return RR_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Bluestein's algorithm for chunk lengths that are not powers of two (Complex<f32>): with w_m = e^{+j pi m^2 / n},
+//   X[k] = conj(w_k) * sum_i (x[i] win[i] conj(w_i)) w_{k-i}
+// a linear convolution, done as two M-point transforms (M = power of two >= 2 n - 1) by the kernels above:
+//   a = x * c (c = win * conj(w), zero-padded to M)  ->  A = F(a)  ->  conj(A * B), B = F(w arranged circularly) / M
+//   ->  F again (= conj of the inverse transform)  ->  X[k] = conj(result[k] * w_k).
+// Three elementwise kernels around the two transforms; rr_fourier::transform_dev drives them.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bs_pre(const float2 *__restrict__ head, long n_head, const float2 *__restrict__ in,
+                                                long hop, int n, int M, const float2 *__restrict__ c, float2 *__restrict__ ws) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float2 v;
+    v.x = 0.f;
+    v.y = 0.f;
+    if (m < n) {
+        const long i = (long)blockIdx.y * hop - n_head + m;
+        const float2 x = (i >= 0) ? in[i] : head[n_head + i];
+        v = cmul<float>(x, c[m]);
+    }
+    ws[(size_t)blockIdx.y * M + m] = v;
+}
+__global__ __launch_bounds__(256) void k_bs_mul(float2 *__restrict__ ws, const float2 *__restrict__ B, int M) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float2 *p = ws + (size_t)blockIdx.y * M + m;
+    const float2 v = cmul<float>(*p, B[m]);
+    float2 o;
+    o.x = v.x;
+    o.y = -v.y;
+    *p = o;
+}
+__global__ __launch_bounds__(256) void k_bs_post(const float2 *__restrict__ ws, const float2 *__restrict__ w, int n, int M,
+                                                 float2 *__restrict__ out, int center_dc) {
+    const int kk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (kk >= n) return;
+    const float2 v = cmul<float>(ws[(size_t)blockIdx.y * M + kk], w[kk]);
+    int o = kk + (center_dc ? n / 2 : 0);  // rotate_right(n / 2)
+    if (o >= n) o -= n;
+    float2 r;
+    r.x = v.x;
+    r.y = -v.y;
+    out[(size_t)blockIdx.y * n + o] = r;
+}
+int launch_bs_pre(hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n, size_t M,
+                  const void *c, void *ws, size_t frames) {
+    if (frames == 0) return RR_OK;
+    if (frames > 65535) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: too many frames in one Bluestein pass");
+    hipLaunchKernelGGL(k_bs_pre, dim3((unsigned)((M + 255) / 256), (unsigned)frames), dim3(256), 0, s, (const float2 *)head,
+                       (long)n_head, (const float2 *)in, (long)hop, (int)n, (int)M, (const float2 *)c, (float2 *)ws);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+int launch_bs_mul(hipStream_t s, void *ws, const void *B, size_t M, size_t frames) {
+    if (frames == 0) return RR_OK;
+    hipLaunchKernelGGL(k_bs_mul, dim3((unsigned)((M + 255) / 256), (unsigned)frames), dim3(256), 0, s, (float2 *)ws,
+                       (const float2 *)B, (int)M);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+int launch_bs_post(hipStream_t s, const void *ws, const void *w, size_t n, size_t M, void *out, bool center_dc, size_t frames) {
+    if (frames == 0) return RR_OK;
+    hipLaunchKernelGGL(k_bs_post, dim3((unsigned)((n + 255) / 256), (unsigned)frames), dim3(256), 0, s, (const float2 *)ws,
+                       (const float2 *)w, (int)n, (int)M, (float2 *)out, (int)center_dc);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
 int launch_fourier_overlapped(int dtype, hipStream_t s, const void *head, size_t n_head, const void *in, void *out,
                               size_t n, size_t hop, size_t count, const void *window, const void *twiddle, bool center_dc) {
     if (count == 0) return RR_OK;

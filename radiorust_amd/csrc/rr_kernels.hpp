@@ -117,6 +117,11 @@ int fused_fir_R(uint64_t D);  // outputs per lane of the instantiation for D
 int launch_fused_fir(hipStream_t s, const FusedFirArgs &a);
 // 4096-point windowed forward DFT (radix 16 x 3); tw4096[k] = e^{-j 2 pi k / 4096}, 4096 entries
 // frames are cut from the stream [ head (n_head samples) | in ]
+// Bluestein's elementwise stages (rr_kernels.hip), f32: frames <= 65535 per launch
+int launch_bs_pre(hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n, size_t M,
+                  const void *c, void *ws, size_t frames);
+int launch_bs_mul(hipStream_t s, void *ws, const void *B, size_t M, size_t frames);
+int launch_bs_post(hipStream_t s, const void *ws, const void *w, size_t n, size_t M, void *out, bool center_dc, size_t frames);
 // k_fft8192: 256 lanes per 8192-sample frame, 32 values per lane (plain window and twiddle tables)
 int launch_fft8192(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
                    const void *window, const void *tw8192, bool center_dc, size_t hop);

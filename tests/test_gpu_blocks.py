@@ -521,6 +521,27 @@ def test_fourier_wave_kernels_batched(rr, oracle, n, center, monkeypatch):
     check(got.reshape(-1), ref)
 
 
+@pytest.mark.parametrize("n,center,k", [(1000, True, 2100), (33, False, 500), (1500, False, 64), (4095, True, 9), (100, True, 300)])
+def test_fourier_bluestein_batched(rr, oracle, n, center, k):
+    """Chunk lengths that are not powers of two (f32, 32 .. 4096) run Bluestein's algorithm over the power-of-two
+    kernels, in passes of at most 2^22 workspace elements (n = 1000: 2048 chunks per pass, so 2100 chunks take
+    two): chunks from the start, the pass boundary and the end against the f64 oracle."""
+    import torch
+
+    x = oracle.synth_iq(16, 0, n * k)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.empty_like(d_in)
+    win, owin = rr.Kaiser.with_null_at_bin(2.0), oracle.Kaiser.with_null_at_bin(2.0)
+    g = rr.Fourier(win, center)
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    assert g.process_dev(n, d_in.data_ptr(), n * k, d_out.data_ptr(), n * k) == n * k
+    torch.cuda.synchronize()
+    o64 = oracle.Fourier(owin, center, flt=np.float64)
+    got = d_out.cpu().numpy().reshape(k, n)
+    for i in sorted({0, 1, k // 2, min(2047, k - 1), min(2048, k - 1), k - 1}):
+        check(got[i], o64.process(x[i * n : (i + 1) * n]))
+
+
 def test_fourier_errors(rr):
     from radiorust_amd._lib import BackendError
 
