@@ -339,7 +339,8 @@ int rr_channelizer_destroy(rr_channelizer *h);
 /* over the last chunk_count * chunk_len samples, all bins.  Input: any number of */
 /* samples (the Rechunker's patchwork is kept in the handle, chunks.rs:62-64);    */
 /* output: n_out = frames * chunk_len * chunk_count bins.                        */
-/* chunk_len * chunk_count must be a power of two (<= 8192 f32, <= 4096 f64).    */
+/* chunk_len * chunk_count: a power of two (<= 8192 f32, <= 4096 f64) or, for
+ * Complex<f32>, any length 32 .. 4096 (Bluestein over the power-of-two kernels). */
 /* ------------------------------------------------------------------------ */
 typedef struct rr_stft rr_stft;
 int rr_stft_create(int dtype, size_t chunk_len, size_t chunk_count, const rr_window *window,
