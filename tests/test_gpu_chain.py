@@ -314,3 +314,43 @@ def test_chain_enqueue_back_to_back_matches_blocking_calls(rr, oracle):
             y = np.frombuffer((C.c_char * (cnt.value * 8)).from_address(p_out.value), dtype=np.complex64)
             assert np.array_equal(y.view(np.uint32), np.ascontiguousarray(w).view(np.uint32))
         assert L.rr_host_free(p_in) == 0 and L.rr_host_free(p_out) == 0
+
+
+def test_handles_run_concurrently_from_different_threads(rr, oracle):
+    """SURVEY 8(b) threading: a handle belongs to one task at a time, different handles run concurrently from
+    different OS threads (tokio work stealing).  Four chains with their own streams and seeds, each driven by
+    its own thread through ragged calls; every result equals the same chain run alone."""
+    import threading
+
+    fs, n = 200e6, 1 << 17
+    cuts = [0, 1000, 70001, 70064, n]
+    xs = [oracle.synth_iq(40 + i, 0, n) for i in range(4)]
+
+    def run(x):
+        g = make(rr, oracle, CFG2, True)
+        out = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            out += [np.array(s.chunk) for s in g.process(rr.Samples(fs, x[a:b]))]
+        return out
+
+    alone = [run(x) for x in xs]
+    got = [None] * 4
+    errs = []
+
+    def worker(i):
+        try:
+            for _ in range(3):
+                got[i] = run(xs[i])
+        except Exception as e:  # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for a, g_ in zip(alone, got):
+        assert len(a) == len(g_) == 7
+        for u, v in zip(a, g_):
+            assert np.array_equal(u.view(np.uint32), v.view(np.uint32))
