@@ -27,7 +27,7 @@
 //   workgroup per spectrum (analysis.rs:105-115); center_dc is an index
 //   rotation on the store.
 //
-// Kernel 2s/2w/2h/2x  k_fft512 / k_fft1024 / k_fft2048 / k_fft8192: the same for the other power-of-two chunk lengths
+// Kernel 2t/2s/2w/2h/2x  k_fft64, k_fft128 / k_fft512 / k_fft1024 / k_fft2048 / k_fft8192: the same for the other power-of-two chunk lengths
 // Kernel 3   k_ols_decim4     the stage of kernel 1 by overlap-save, a workgroup per 4096-block
 // Kernel 3w  k_ols_wave       ... a WAVE per 1024-block: the default for 4x decimation
 // Kernel 3f  k_ols_frame      k_ols_wave's blocks + kernel 2 in one kernel (measured slower; on request)
@@ -880,6 +880,83 @@ int launch_fft512(hipStream_t s, const void *head, size_t n_head, const void *in
     hipLaunchKernelGGL(k_fft512, dim3(grid), dim3(64), 0, s, (const float2 *)head, (long)n_head, (const float2 *)in,
                        (float2 *)out, (const float *)window, (const float2 *)tw512, (int)center_dc, (long)hop,
                        (unsigned)count);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Kernel 2t  k_fft64 / k_fft128: the small chunk lengths, several frames per wave (8 x 64 or 4 x 128 points):
+// 64 = radix 8 x 8 with 8 lanes per frame, 128 = radix 8 x 16 with 16 lanes per frame (the radix-16 pass on the
+// lower 8 lanes of each frame).  Frames side by side only (hop = n).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_fft64(const float2 *__restrict__ in, float2 *__restrict__ out,
+                                              const float *__restrict__ window, const float2 *__restrict__ tw,
+                                              int center_dc, unsigned count) {
+    __shared__ f2 lds[8 * 72];
+    const int l = threadIdx.x, f = l >> 3, q = l & 7;
+    const unsigned fr = blockIdx.x * 8 + f;
+    const bool live = fr < count;
+    const f2 *src = reinterpret_cast<const f2 *>(in) + (size_t)(live ? fr : 0) * 64 + q;
+    f2 a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = src[8 * k] * window[q + 8 * k];
+    const float2 s1 = tw[q];  // tw[k] = e^{-j 2 pi k / 64}
+    dft8(a);                  // pass 0 (Ns = 1): out 8 q + k
+    f2 *img = lds + 72 * f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) img[pad8(8 * q + k)] = a[k];
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = img[pad8(q + 8 * k)];
+    twiddle8(a, (f2){s1.x, s1.y});  // pass 1 (Ns = 8): e^{-j 2 pi q k / 64}; out q + 8 k
+    dft8(a);
+    if (!live) return;
+    f2 *dst = reinterpret_cast<f2 *>(out) + (size_t)fr * 64;
+    const int rot = center_dc ? 32 : 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dst[(q + 8 * k + rot) & 63] = a[k];
+}
+
+__global__ __launch_bounds__(64) void k_fft128(const float2 *__restrict__ in, float2 *__restrict__ out,
+                                               const float *__restrict__ window, const float2 *__restrict__ tw,
+                                               int center_dc, unsigned count) {
+    __shared__ f2 lds[4 * 144];
+    const int l = threadIdx.x, f = l >> 4, q = l & 15;
+    const unsigned fr = blockIdx.x * 4 + f;
+    const bool live = fr < count;
+    const f2 *src = reinterpret_cast<const f2 *>(in) + (size_t)(live ? fr : 0) * 128 + q;
+    f2 a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = src[16 * k] * window[q + 16 * k];
+    const float2 s1 = tw[q & 7];  // tw[k] = e^{-j 2 pi k / 128}
+    dft8(a);                      // pass 0 (Ns = 1): butterflies q over x[q + 16 k]; out 8 q + k
+    f2 *img = lds + 144 * f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) img[pad8(8 * q + k)] = a[k];
+    wave_sync();
+    // pass 1 (Ns = 8, radix 16): butterflies j < 8 over y[j + 8 k], k < 16; twiddle tw[j]^k; out j + 8 k
+    f2 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = img[pad8((q & 7) + 8 * k)];
+    apply_twiddle_powers(v, (f2){s1.x, s1.y});
+    dft16(v);
+    if (!live || q >= 8) return;
+    f2 *dst = reinterpret_cast<f2 *>(out) + (size_t)fr * 128;
+    const int rot = center_dc ? 64 : 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dst[(q + 8 * k + rot) & 127] = v[k];
+}
+
+int launch_fft_small(hipStream_t s, const void *in, void *out, size_t n, size_t count, const void *window, const void *tw,
+                     bool center_dc) {
+    if (count == 0) return RR_OK;
+    if (count > 0x7fffff00ull) RR_FAIL(RR_ERR_BAD_ARG, "fft: too many frames");
+    if (n == 64)
+        hipLaunchKernelGGL(k_fft64, dim3((unsigned)((count + 7) / 8)), dim3(64), 0, s, (const float2 *)in, (float2 *)out,
+                           (const float *)window, (const float2 *)tw, (int)center_dc, (unsigned)count);
+    else
+        hipLaunchKernelGGL(k_fft128, dim3((unsigned)((count + 3) / 4)), dim3(64), 0, s, (const float2 *)in, (float2 *)out,
+                           (const float *)window, (const float2 *)tw, (int)center_dc, (unsigned)count);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }

@@ -600,6 +600,8 @@ int launch_fourier_overlapped(int dtype, hipStream_t s, const void *head, size_t
     if (dtype == RR_F32 && n == 4096)
         return launch_fft4096(s, head, n_head, in, out, count, window, twiddle, center_dc, hop);
     static const bool generic = [] { const char *e = std::getenv("RR_FOURIER_GENERIC"); return e && std::atoi(e) != 0; }();
+    if (dtype == RR_F32 && (n == 64 || n == 128) && hop == n && n_head == 0 && !generic)
+        return launch_fft_small(s, in, out, n, count, window, twiddle, center_dc);
     if (dtype == RR_F32 && n == 8192 && !generic)
         return launch_fft8192(s, head, n_head, in, out, count, window, twiddle, center_dc, hop);
     if (dtype == RR_F32 && n == 512 && !generic)

@@ -125,6 +125,9 @@ int launch_bs_post(hipStream_t s, const void *ws, const void *w, size_t n, size_
 // k_fft8192: 256 lanes per 8192-sample frame, 32 values per lane (plain window and twiddle tables)
 int launch_fft8192(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
                    const void *window, const void *tw8192, bool center_dc, size_t hop);
+// k_fft64 / k_fft128: 8 / 4 frames per wave, frames side by side (n = 64 or 128)
+int launch_fft_small(hipStream_t s, const void *in, void *out, size_t n, size_t count, const void *window, const void *tw,
+                     bool center_dc);
 // k_fft512: a wave per 512-sample frame (plain window and twiddle tables)
 int launch_fft512(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
                   const void *window, const void *tw512, bool center_dc, size_t hop);

@@ -497,13 +497,13 @@ def test_fourier_batched_device_api(rr, oracle):
     check(d_out.cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("n,center", [(1024, False), (1024, True), (256, False), (2048, False), (2048, True), (512, False), (512, True), (8192, True)])
+@pytest.mark.parametrize("n,center", [(1024, False), (1024, True), (256, False), (2048, False), (2048, True), (512, False), (512, True), (8192, True), (64, False), (64, True), (128, False), (128, True)])
 def test_fourier_wave_kernels_batched(rr, oracle, n, center, monkeypatch):
     """Chunks of 512 / 1024 (k_fft512 / k_fft1024: a wave per chunk), 2048 (k_fft2048: 128 lanes per chunk) and 256
     (the channelizer's one-branch case) in f32: many chunks per call on the device, every chunk against the f64 oracle."""
     import torch
 
-    k = 300 if n < 8192 else 40
+    k = 301 if n < 8192 else 40  # (301: the last wave of the 64- / 128-point kernels is partly empty)
     x = oracle.synth_iq(15, 0, n * k)
     d_in = torch.from_numpy(x).cuda()
     d_out = torch.empty_like(d_in)
@@ -515,7 +515,7 @@ def test_fourier_wave_kernels_batched(rr, oracle, n, center, monkeypatch):
     o64 = oracle.Fourier(owin, center, flt=np.float64)
     o32 = oracle.Fourier(owin, center, flt=np.float32)
     got = d_out.cpu().numpy().reshape(k, n)
-    for i in (0, 1, 127, 128, 129, 255, 299) if k == 300 else (0, 1, 17, 39):
+    for i in (0, 1, 127, 128, 129, 255, 299, 300) if k == 301 else (0, 1, 17, 39):
         check(got[i], o64.process(x[i * n : (i + 1) * n]), o32.process(x[i * n : (i + 1) * n]))
     ref = np.concatenate([o64.process(x[i * n : (i + 1) * n]) for i in range(k)])
     check(got.reshape(-1), ref)
