@@ -17,8 +17,10 @@ has reached its steady state: measured on MI355X, the first ~10 steps after an i
 ms, steps 10-40 at 0.22-0.23 ms, and from ~100 steps on 0.193-0.205 ms; a streaming workload lives in
 the last regime.
 
-N > 1: launched by torch.distributed.run, one rank per GPU, one independent IQ
-channel per rank (seed = rank + 1).  The path shards by channel: there is NO
+N > 1: one rank per GPU, one independent IQ channel per rank (seed = rank + 1).  Launched either by
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or bare -- `python bench.py
+--gpus N` without WORLD_SIZE starts the N ranks itself as child processes, BEFORE anything in this
+process touches the GPU, relays rank 0's JSON line and exits non-zero if any rank fails.  The path shards by channel: there is NO
 data-path collective; torch.distributed (RCCL) is used only for the barriers and
 the max-over-ranks of the elapsed time.  scaling = weak.
 
@@ -113,6 +115,13 @@ def main():
     ap.add_argument("--traffic-json", default=None, help="file holding measured HBM bytes per launch (PMC pass)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the driver's form `python bench.py --gpus N`: this process only starts the ranks (fresh child
+        # processes, nothing here has touched torch.cuda or HIP) and passes rank 0's line on
+        from radiorust_amd.dist import spawn_ranks
+
+        raise SystemExit(spawn_ranks([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], args.gpus))
+
     import numpy as np
     import torch
 
@@ -184,6 +193,7 @@ def main():
     elapsed = time.perf_counter() - t0
     fused = chain.last_path_fused()
     fused_kernel = chain.last_path_kernel()
+    per_rank_elapsed = ranks.gather_over_ranks(elapsed)
     elapsed = ranks.max_over_ranks(elapsed)
 
     # Full-size consistency check (not timed): replay the same calls through the block-by-block
@@ -282,6 +292,7 @@ def main():
                 "path": "fused" if fused else "block-by-block",
                 "sharding": "one independent channel per GPU, no collective",
             },
+            "per_rank_MSamples_s": [round(n * args.steps / e / 1e6, 1) for e in per_rank_elapsed],
             "pct_hbm_roofline_whole_chain": round(100.0 * ALG_BYTES_PER_SAMPLE * value * 1e6 / world / (HBM_PEAK_GBS * 1e9), 3),
             "roofline": {
                 "bound": "hbm",

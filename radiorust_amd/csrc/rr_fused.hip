@@ -54,18 +54,18 @@
 //   RR_STAMP      s_memtime stamps per phase (scripts/stamp_run.py, stamp_wave.py)
 //   RR_ABLATE, RR_OLS_ABLATE, RR_WAVE_ABLATE   measurement builds that skip a phase (results are WRONG)
 #include "rr_blocks.hpp"
+#include "rr_wave_math.hpp"
 
 #include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 #include <utility>
 
 namespace rr {
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------
 // geometry shared by host and device
@@ -537,137 +537,6 @@ int launch_fused_fir(hipStream_t s, const FusedFirArgs &a) {
 // ---------------------------------------------------------------------------
 // 4096-point windowed FFT, radix 16 x 3
 // ---------------------------------------------------------------------------
-// ---- packed complex arithmetic -------------------------------------------------
-// A complex f32 lives in one 64-bit VGPR pair (re = low, im = high).  Multiplying by
-// +-j is a swap with one sign flip; VOP3P packed adds take that for free through
-// their op_sel / neg modifiers, so butterflies need no moves.  hipcc does not find
-// these forms on its own (it emitted ~340 v_mov per 4096-point transform), hence the
-// four one-instruction helpers below.
-__device__ __forceinline__ f2 add_mj(f2 a, f2 t) {  // a + (-j) t = (a.x + t.y, a.y - t.x)
-    f2 r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(t));
-    return r;
-}
-__device__ __forceinline__ f2 add_pj(f2 a, f2 t) {  // a + (+j) t = (a.x - t.y, a.y + t.x)
-    f2 r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(t));
-    return r;
-}
-__device__ __forceinline__ f2 mul_mj(f2 a) {  // (-j) a = (a.y, -a.x)
-    f2 r;
-    asm("v_pk_add_f32 %0, %1, 0 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "v"(a));
-    return r;
-}
-__device__ __forceinline__ f2 mul_pj(f2 a) {  // (+j) a = (-a.y, a.x)
-    f2 r;
-    asm("v_pk_add_f32 %0, %1, 0 op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[1,0]" : "=v"(r) : "v"(a));
-    return r;
-}
-// a * w with the pre-rotated partner wj = (+j) w = (-w.y, w.x): two packed ops
-__device__ __forceinline__ f2 cmul2(f2 a, f2 w, f2 wj) { return __builtin_elementwise_fma(a.yy, wj, a.xx * w); }
-__device__ __forceinline__ f2 cmulf(f2 a, f2 b) { return cmul2(a, b, mul_pj(b)); }
-
-// forward 4-point DFT (kernel e^{-j 2 pi n k / 4}): 8 packed adds
-__device__ __forceinline__ void dft4(f2 &a, f2 &b, f2 &c, f2 &d) {
-    const f2 s0 = a + c, s1 = a - c, s2 = b + d, t = b - d;
-    a = s0 + s2;
-    c = s0 - s2;
-    b = add_mj(s1, t);
-    d = add_pj(s1, t);
-}
-// inverse 4-point DFT (kernel e^{+j 2 pi n k / 4})
-__device__ __forceinline__ void idft4(f2 &a, f2 &b, f2 &c, f2 &d) {
-    const f2 s0 = a + c, s1 = a - c, s2 = b + d, t = b - d;
-    a = s0 + s2;
-    c = s0 - s2;
-    b = add_pj(s1, t);
-    d = add_mj(s1, t);
-}
-
-// multiply by a compile-time constant (wr, wi): two packed ops on constant pairs
-__device__ __forceinline__ f2 cmulc(f2 v, float wr, float wi) {
-    return __builtin_elementwise_fma(v.yy, (f2){-wi, wr}, v.xx * (f2){wr, wi});
-}
-
-// in-register forward 16-point DFT, natural order in and out
-__device__ __forceinline__ void dft16(f2 (&v)[16]) {
-    constexpr float C1 = 0.92387953251128673848f, S1 = 0.38268343236508978178f, H = 0.70710678118654752440f;
-    // t[a][b] = DFT4 over m of v[a + 4m]
-#pragma unroll
-    for (int a = 0; a < 4; ++a) dft4(v[a], v[a + 4], v[a + 8], v[a + 12]);  // v[a + 4b] now holds t[a][b]
-    // twiddle W16^(a b)
-    v[1 + 4] = cmulc(v[1 + 4], C1, -S1);   // a=1,b=1: W^1
-    v[1 + 8] = cmulc(v[1 + 8], H, -H);     // a=1,b=2: W^2
-    v[1 + 12] = cmulc(v[1 + 12], S1, -C1); // a=1,b=3: W^3
-    v[2 + 4] = cmulc(v[2 + 4], H, -H);     // a=2,b=1: W^2
-    v[2 + 8] = mul_mj(v[2 + 8]);           // a=2,b=2: W^4 = -j
-    v[2 + 12] = cmulc(v[2 + 12], -H, -H);  // a=2,b=3: W^6
-    v[3 + 4] = cmulc(v[3 + 4], S1, -C1);   // a=3,b=1: W^3
-    v[3 + 8] = cmulc(v[3 + 8], -H, -H);    // a=3,b=2: W^6
-    v[3 + 12] = cmulc(v[3 + 12], -C1, S1); // a=3,b=3: W^9
-    // X[b + 4c] = DFT4 over a of t[a][b]; t[a][b] sits in v[a + 4b]
-#pragma unroll
-    for (int b = 0; b < 4; ++b) dft4(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]);  // v[4b + c] = X[b + 4c]
-    // natural order: X[k], k = b + 4c  <-  v[4b + c]  (register renaming, no instructions)
-    f2 t[16];
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) t[b + 4 * c] = v[4 * b + c];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = t[k];
-}
-
-// in-register forward 8-point DFT, natural order in and out (29 packed ops)
-__device__ __forceinline__ void dft8(f2 (&v)[8]) {
-    constexpr float H = 0.70710678118654752440f;
-    f2 a0 = v[0] + v[4], a1 = v[1] + v[5], a2 = v[2] + v[6], a3 = v[3] + v[7];
-    f2 b0 = v[0] - v[4], b1 = v[1] - v[5], b2 = v[2] - v[6], b3 = v[3] - v[7];
-    b1 = cmulc(b1, H, -H);   // W8^1
-    b2 = mul_mj(b2);         // W8^2 = -j
-    b3 = cmulc(b3, -H, -H);  // W8^3
-    dft4(a0, a1, a2, a3);    // X[0], X[2], X[4], X[6]
-    dft4(b0, b1, b2, b3);    // X[1], X[3], X[5], X[7]
-    v[0] = a0;
-    v[2] = a1;
-    v[4] = a2;
-    v[6] = a3;
-    v[1] = b0;
-    v[3] = b1;
-    v[5] = b2;
-    v[7] = b3;
-}
-
-__device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
-
-// v[k] *= w^k, k = 1..15.  Powers by a product tree at most 4 deep (error ~4 ulp, not 15);
-// every power is kept with its rotated partner (+j) w^k so that each product is two packed ops.
-__device__ __forceinline__ void apply_twiddle_powers(f2 (&v)[16], f2 w) {
-    f2 p[16], q[16];  // p[k] = w^k, q[k] = (+j) w^k
-    p[1] = w;
-    q[1] = mul_pj(w);
-#define RR_TWP(k, a, b)          \
-    p[k] = cmul2(p[a], p[b], q[b]); \
-    q[k] = mul_pj(p[k]);
-    RR_TWP(2, 1, 1)
-    RR_TWP(3, 2, 1)
-    RR_TWP(4, 2, 2)
-    RR_TWP(5, 4, 1)
-    RR_TWP(6, 4, 2)
-    RR_TWP(7, 4, 3)
-    RR_TWP(8, 4, 4)
-    RR_TWP(9, 8, 1)
-    RR_TWP(10, 8, 2)
-    RR_TWP(11, 8, 3)
-    RR_TWP(12, 8, 4)
-    RR_TWP(13, 8, 5)
-    RR_TWP(14, 8, 6)
-    RR_TWP(15, 8, 7)
-#undef RR_TWP
-#pragma unroll
-    for (int k = 1; k < 16; ++k) v[k] = cmul2(v[k], p[k], q[k]);
-}
-
 // The input stream of frames is [ head (n_head samples) | in ]: the head is the
 // Downsampler's partly filled output chunk left over by the previous call.
 #ifndef RR_V_FFTPK
@@ -743,11 +612,11 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
     // pass 0 (Ns = 1): no twiddles; out index 16 j + k
     dft16(v);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) lds[pad16(16 * j + k)] = v[k];
+    for (int k = 0; k < 16; ++k) lds_st(lds + pad16(16 * j + k), v[k]);
     __syncthreads();
     // pass 1 (Ns = 16): twiddle e^{-j 2 pi k (j mod 16) / 256}; out (j/16)*256 + j%16 + 16 k
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = lds[pad16(j + 256 * k)];
+    for (int k = 0; k < 16; ++k) v[k] = lds_ld(lds + pad16(j + 256 * k));
     {
         // e^{-j 2 pi k (j mod 16) / 256} = w^k with w = tw[16 (j mod 16)]: one
         // table read, powers by a depth-4 product tree (error ~4 ulp, not 15)
@@ -763,12 +632,12 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
     {
         const int base = (j >> 4) * 256 + (j & 15);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) lds[pad16(base + 16 * k)] = v[k];
+        for (int k = 0; k < 16; ++k) lds_st(lds + pad16(base + 16 * k), v[k]);
     }
     __syncthreads();
     // pass 2 (Ns = 256): twiddle e^{-j 2 pi k j / 4096}; out j + 256 k
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = lds[pad16(j + 256 * k)];
+    for (int k = 0; k < 16; ++k) v[k] = lds_ld(lds + pad16(j + 256 * k));
     {
 #if RR_V_FFTPK
         const float2 t = s2;
@@ -816,18 +685,6 @@ int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *i
 // Kernel 2s  k_fft512: window * v -> 512-point forward DFT, radix 8 x 8 x 8, one wave per frame (8 values per
 // lane, wave-local exchanges through a padded 4.5 KiB image).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int pad8(int i) { return i + (i >> 3); }
-__device__ __forceinline__ void twiddle8(f2 (&a)[8], f2 w1) {  // a[k] *= w1^k
-    const f2 w2 = cmulf(w1, w1), w3 = cmulf(w2, w1), w4 = cmulf(w2, w2);
-    a[1] = cmulf(a[1], w1);
-    a[2] = cmulf(a[2], w2);
-    a[3] = cmulf(a[3], w3);
-    a[4] = cmulf(a[4], w4);
-    a[5] = cmulf(a[5], cmulf(w4, w1));
-    a[6] = cmulf(a[6], cmulf(w4, w2));
-    a[7] = cmulf(a[7], cmulf(w4, w3));
-}
-__device__ __forceinline__ void wave_sync();
 __global__ __launch_bounds__(64) void k_fft512(const float2 *__restrict__ head, long n_head,
                                                const float2 *__restrict__ in, float2 *__restrict__ out,
                                                const float *__restrict__ window, const float2 *__restrict__ tw,
@@ -1344,47 +1201,6 @@ __global__ __launch_bounds__(256) void k_ols_decim4(const float2 *__restrict__ x
 // lane and pass).  V = overlap (multiple of 64, >= Lc - 1), hop = 1024 - V; the overlap
 // re-reads come from L2 because neighbouring blocks run on the same XCD.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ f2 cmul(f2 a, f2 w) {  // a * w, two packed ops, no rotated copy of w
-    f2 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
-        : "=v"(r)
-        : "v"(a), "v"(w), "v"(t));
-    return r;
-}
-__device__ __forceinline__ f2 cmul_conj(f2 a, f2 w) {  // a * conj(w)
-    f2 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
-    return r;
-}
-// acc + a * w
-__device__ __forceinline__ f2 cmac(f2 acc, f2 a, f2 w) {
-    f2 t, r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(t) : "v"(a), "v"(w), "v"(acc));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
-        : "=v"(r)
-        : "v"(a), "v"(w), "v"(t));
-    return r;
-}
-
-// v[k] *= w^k, k = 1..15, product tree at most 4 deep
-__device__ __forceinline__ void twiddle16(f2 (&v)[16], f2 w) {
-    f2 p[16];
-    p[1] = w;
-    p[2] = cmul(p[1], p[1]);
-    p[3] = cmul(p[2], p[1]);
-    p[4] = cmul(p[2], p[2]);
-    p[5] = cmul(p[4], p[1]);
-    p[6] = cmul(p[4], p[2]);
-    p[7] = cmul(p[4], p[3]);
-    p[8] = cmul(p[4], p[4]);
-#pragma unroll
-    for (int k = 9; k < 16; ++k) p[k] = cmul(p[8], p[k - 8]);
-#pragma unroll
-    for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], p[k]);
-}
-
 // LDS images of one wave (element = 8 bytes).  Image A holds the 1024-point intermediate of
 // the forward transform at  A(i) = i + 2 (i >> 4) + 8 (i >> 8):  rows of 16 elements at a
 // stride of 18 (16-byte aligned for ds_write_b128, and an odd multiple of 16 bytes so that the
@@ -1398,12 +1214,6 @@ __device__ __forceinline__ void twiddle16(f2 (&v)[16], f2 w) {
 #endif
 constexpr int kWaveLds = RR_V_WAVELDS;  // A(1023) + 1 = 1174, rounded up to a multiple of 8
 
-__device__ __forceinline__ void wave_sync() {
-    // all 64 lanes of the only wave: order LDS writes before the following reads
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 #ifndef RR_V_WAVELOOPWIN
 #define RR_V_WAVELOOPWIN 1  // persistent forms: 1 = the grid's rounds cover contiguous windows, 0 = a contiguous eighth of the blocks per XCD
@@ -1772,7 +1582,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 * kCuWaves : (MODE == 1 ? 64 : 64 * 
         }
         wave_sync();
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = a_rd[72 * (k & 3) + 296 * (k >> 2)];  // in[l + 64 k]
+        for (int k = 0; k < 16; ++k) v[k] = lds_ld(a_rd + (72 * (k & 3) + 296 * (k >> 2)));  // in[l + 64 k]
 #endif
         RR_STAMP_T(ws2);
         // pass 1 (Ns = 8, radix 16): twiddle e^{-j 2 pi k (l mod 8) / 128}; out 128 (l / 8) + l % 8 + 8 k
@@ -1787,7 +1597,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 * kCuWaves : (MODE == 1 ? 64 : 64 * 
             // A(128 h + p + 8 k), h = l / 8, p = l % 8: 144 h + 8 (h / 2) + p + 8 k + 2 (k / 2)
             f2 *col = lds + (144 * (l >> 3) + 8 * (l >> 4) + (l & 7));
 #pragma unroll
-            for (int k = 0; k < 16; ++k) col[8 * k + 2 * (k >> 1)] = v[k];
+            for (int k = 0; k < 16; ++k) lds_st(col + (8 * k + 2 * (k >> 1)), v[k]);
         }
         wave_sync();
 #endif
@@ -1803,7 +1613,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 * kCuWaves : (MODE == 1 ? 64 : 64 * 
 #else
             // A(l + 64 m + 128 c) = a_rd + 72 m + 144 c + 8 (c / 2)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) a[c] = a_rd[72 * m + 144 * c + 8 * (c >> 1)];
+            for (int c = 0; c < 8; ++c) a[c] = lds_ld(a_rd + (72 * m + 144 * c + 8 * (c >> 1)));
 #endif
 #if RR_WAVE_ABLATE != 5
             const f2 w1 = t_p2[m];
@@ -1857,7 +1667,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 * kCuWaves : (MODE == 1 ? 64 : 64 * 
 #pragma unroll
         for (int pass = 1; pass < 4; ++pass) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) y[c] = b_rd[80 * c];
+            for (int c = 0; c < 4; ++c) y[c] = lds_ld(b_rd + (80 * c));
             // twiddles e^{+j 2 pi c (l mod ns) / (4 ns)} = conj(tw[(l mod ns) 256 / ns])^c, ns = 4^pass
             const f2 w1 = t_inv[pass - 1];
             const f2 w2 = cmul(w1, w1);
@@ -1871,11 +1681,11 @@ __global__ __launch_bounds__(MODE == 2 ? 64 * kCuWaves : (MODE == 1 ? 64 : 64 * 
             if (pass == 1) {  // out 16 (l >> 2) + (l & 3) + 4 c: B = 20 (l >> 2) + (l & 3) + 4 c
                 f2 *col = lds + (20 * (l >> 2) + (l & 3));
 #pragma unroll
-                for (int c = 0; c < 4; ++c) col[4 * c] = y[c];
+                for (int c = 0; c < 4; ++c) lds_st(col + (4 * c), y[c]);
             } else {  // out 64 g + q + 16 c: B = 80 g + q + 20 c
                 f2 *col = lds + (80 * g + q);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) col[20 * c] = y[c];
+                for (int c = 0; c < 4; ++c) lds_st(col + (20 * c), y[c]);
             }
             wave_sync();
         }
@@ -3081,8 +2891,12 @@ bool filter_ols4096_supported(int dtype, size_t n) {
 }
 
 int launch_filter_ols4096(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *G,
-                          const void *tw4096, size_t n, void *out, size_t n_out, long e0, bool out_f16, bool g_f16) {
+                          const void *tw4096, size_t n, void *out, size_t n_out, long e0, bool out_f16, bool g_f16, int variant,
+                          size_t persist_min_blocks) {
     if (n_out == 0) return RR_OK;
+    // the rebuilt kernel (rr_filter_ols.hip) serves every call; variant -1 keeps this first version (A/B runs)
+    if (variant >= 0)
+        return launch_filter_blk4096(s, hist, hist_len, in, n_in, G, tw4096, n, out, n_out, e0, out_f16, g_f16, variant, persist_min_blocks);
     const int V = (int)n;  // n is a multiple of 256 here, V >= n - 1
     const size_t hop = 4096 - V;
     const size_t nblocks = (n_out + hop - 1) / hop;

@@ -48,7 +48,15 @@ int launch_filter_ols(int dtype, hipStream_t s, const void *hist, const void *in
 bool filter_ols4096_supported(int dtype, size_t n);
 int launch_filter_ols4096(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *G,
                           const void *tw4096, size_t n, void *out, size_t n_out, long e0, bool out_f16 = false,
-                          bool g_f16 = false);
+                          bool g_f16 = false, int variant = 1, size_t persist_min_blocks = 2048);
+
+// the rebuilt 4096-point block kernel (rr_filter_ols.hip): same contract; V = n (any n <= 2048 works, the tables are
+// those of launch_filter_ols4096).  variant: 0 one block per workgroup, 1 persistent + prefetch (default), 2 persistent
+// with two LDS images and the twiddle powers kept in registers; calls of fewer than persist_min_blocks blocks
+// (or n_in < 4096) run variant 0.  (RR_FILTER4K_VARIANT / RR_FILTER4K_MIN_BLOCKS, read at design time.)
+int launch_filter_blk4096(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *G,
+                          const void *tw4096, size_t n, void *out, size_t n_out, long e0, bool out_f16, bool g_f16,
+                          int variant, size_t persist_min_blocks);
 
 // new_hist (H samples) = last H samples of [ zeros | old_hist (H) | in (n_in) ]
 int launch_update_hist(int dtype, hipStream_t s, const void *old_hist, void *new_hist, size_t H, const void *in,

@@ -63,3 +63,68 @@ def test_single_rank_needs_no_process_group():
     assert r.world == 1 and r.rank == 0 and r.dist is None
     r.barrier()
     assert r.max_over_ranks(1.25) == 1.25 and r.channel_seed() == 1
+
+
+SPAWNED = textwrap.dedent(
+    """
+    import json, os, sys
+    sys.path.insert(0, %r)
+    from radiorust_amd.dist import Ranks
+    r = Ranks("gloo")
+    r.barrier()
+    rates = r.gather_over_ranks(100.0 * (r.rank + 1))
+    if os.environ.get("FAIL_RANK") == str(r.rank):
+        sys.exit(7)
+    r.barrier()
+    if r.rank == 0:
+        print(json.dumps({"n_gpus": r.world, "per_rank": rates}), flush=True)
+    else:
+        print("not the line", flush=True)
+    r.close()
+    """
+) % ROOT
+
+LAUNCHER = textwrap.dedent(
+    """
+    import sys
+    sys.path.insert(0, %r)
+    from radiorust_amd.dist import spawn_ranks
+    sys.exit(spawn_ranks([sys.executable, sys.argv[1]], int(sys.argv[2]), timeout_s=100))
+    """
+) % ROOT
+
+
+def _launch(tmp_path, world, env=None):
+    worker, launcher = tmp_path / "w.py", tmp_path / "l.py"
+    worker.write_text(SPAWNED)
+    launcher.write_text(LAUNCHER)
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, str(launcher), str(worker), str(world)], env=e, capture_output=True, text=True,
+                          timeout=150)
+
+
+def test_spawn_ranks_relays_rank0_line(tmp_path):
+    """What `python bench.py --gpus N` does without a launcher: N child ranks, rank 0's standard output is
+    the job's standard output (one JSON line), the other ranks' output goes to standard error."""
+    p = _launch(tmp_path, 3)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d == {"n_gpus": 3, "per_rank": [100.0, 200.0, 300.0]}
+    assert "not the line" in p.stderr
+
+
+def test_spawn_ranks_fails_if_any_rank_fails(tmp_path):
+    p = _launch(tmp_path, 2, {"FAIL_RANK": "1"})
+    assert p.returncode == 7, (p.returncode, p.stderr[-2000:])
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_spawns_before_touching_the_gpu():
+    """bench.py decides to spawn right after parsing its arguments: nothing above that point imports torch
+    or the backend (a process that has initialised the GPU must not start or become another one)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[: src.index("spawn_ranks([sys.executable")]
+    assert "import torch" not in head and "import radiorust_amd" not in head

@@ -604,6 +604,45 @@ def test_filter_f16_output(rr, oracle, resp16):
     assert 5e-5 < err < (8e-4 if resp16 else 4e-4), err
 
 
+@pytest.mark.parametrize("n", [1024, 256, 2048])
+def test_filter_block4096_variants(rr, oracle, n, monkeypatch):
+    """The 4096-point block kernel of the long Filters (rr_filter_ols.hip; BASELINE configs[4]: n = 1024 at
+    2 GS/s) in its three forms - one block per workgroup, persistent workgroups with the next block's samples
+    prefetched, and persistent with two LDS images - on one stream cut into calls of different sizes (first
+    chunk swallowed, calls shorter than a block, blocks reaching into the history and past the input), each
+    against the chunk-by-chunk oracle; the three forms do the same arithmetic in the same order, so their
+    outputs are bit-equal.  RR_FILTER4K_MIN_BLOCKS=1 lets the persistent forms run on calls this small."""
+    import torch
+
+    fs = 2e9
+    ks = [1, 2, 37, 1, 5, 64, 3]  # chunks per call
+    x = oracle.synth_iq(33, 0, n * sum(ks))
+    o64 = oracle.Filter(lowpass(200e6), flt=np.float64)
+    o32 = oracle.Filter(lowpass(200e6), flt=np.float32)
+    r64 = np.concatenate([o64.process(fs, x[i * n : (i + 1) * n]) for i in range(sum(ks))][1:])
+    r32 = np.concatenate([o32.process(fs, x[i * n : (i + 1) * n]) for i in range(sum(ks))][1:])
+    d_in = torch.from_numpy(x).cuda()
+    outs = {}
+    monkeypatch.setenv("RR_FILTER4K_MIN_BLOCKS", "1")
+    for variant in (0, 1, 2, -1):
+        monkeypatch.setenv("RR_FILTER4K_VARIANT", str(variant))
+        g = rr.Filter.new(lowpass(200e6))
+        g.set_stream(torch.cuda.current_stream().cuda_stream)
+        d_out = torch.zeros_like(d_in)
+        off = wrote = 0
+        for k in ks:
+            wrote += g.process_dev(fs, n, d_in.data_ptr() + 8 * off, n * k, d_out.data_ptr() + 8 * wrote, n * k)
+            assert g.last_kernel() == 2
+            off += n * k
+        torch.cuda.synchronize()
+        assert wrote == n * (sum(ks) - 1)
+        got = d_out.cpu().numpy()
+        assert not np.any(got[wrote:]), "wrote past the produced samples"
+        check(got[:wrote], r64, r32)
+        outs[variant] = got[:wrote]
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
 def test_filter_f16_unsupported(rr):
     import torch
     from radiorust_amd._lib import BackendError
