@@ -53,50 +53,87 @@ def lowpass20(_bin, f):
     return 1.0 if abs(f) <= 20e6 else 0.0
 
 
-def cpu_baseline(budget_s: float = 8.0):
-    """Oracle chain (oracle/rr_oracle.c, -O3, scalar) on a bounded sample of the same workload,
-    sized from a short probe to ~budget_s per variant: (i) one thread per block with capacity-1
-    hand-off — the parallelism tokio gives the reference — reported as `value`,
-    and (ii) everything on one thread."""
+def cpu_baseline(budget_s: float = 6.0):
+    """The CPU oracle (C restatement of the reference blocks, chunk by chunk) timed on this host's cores on
+    bounded samples of BASELINE's CPU-runnable workloads: cfg2 (the benchmark's chain; `value`:
+    one thread per block with capacity-1 hand-off — the parallelism tokio gives the reference, SURVEY 8(d) — and
+    single-threaded), cfg1 (FreqShifter + 4096-tap Filter at 48 kS/s) and cfg5 (1024-tap Filter at 2 GS/s).
+    Timing build: the oracle's sources compiled on this host with the fastest of a few gcc flag sets
+    (`-O3 -march=native ..`, contraction allowed); the parity build (-ffp-contract=off) is only used for the
+    spot check of the GPU's first spectrum."""
     import numpy as np
 
     from oracle import rr_oracle as o
 
     kw = dict(shift=25e6, filter_len=64, freq_resp=lowpass20, output_rate=50e6, bandwidth=40e6, fft_len=4096,
               fft_window=o.Kaiser.with_null_at_bin(2.0), flt=np.float32, max_frames=1)
+    _path, flags, flag_rates = o.pick_native()
     probe = 1 << 20
     x = o.synth_iq(1, 0, probe)
-    res = {}
-    for threads in (4, 1):
-        t = time.perf_counter()
-        o.run_chain_c(x, 200e6, threads=threads, **kw)
-        rate = probe / (time.perf_counter() - t)
-        n = int(min(max(rate * budget_s, probe), 1 << 28))
-        res[threads] = max(probe, n // probe * probe)
-    n = max(res.values())
-    x = o.synth_iq(1, 0, n)
-    out = {}
-    for threads in (4, 1):
-        xs = x[: res[threads]]
-        t = time.perf_counter()
-        _, frames = o.run_chain_c(xs, 200e6, threads=threads, **kw)
-        dt = time.perf_counter() - t
-        out[threads] = (len(xs) / dt / 1e6, len(xs), frames, dt)
+    out, configs = {}, {}
+    with o.native():
+        res = {}
+        for threads in (4, 1):
+            t = time.perf_counter()
+            o.run_chain_c(x, 200e6, threads=threads, **kw)
+            rate = probe / (time.perf_counter() - t)
+            n = int(min(max(rate * budget_s, probe), 1 << 28))
+            res[threads] = max(probe, n // probe * probe)
+        x = o.synth_iq(1, 0, max(res.values()))
+        for threads in (4, 1):
+            xs = x[: res[threads]]
+            t = time.perf_counter()
+            _, frames = o.run_chain_c(xs, 200e6, threads=threads, **kw)
+            dt = time.perf_counter() - t
+            out[threads] = (len(xs) / dt / 1e6, len(xs), frames, dt)
+
+        def time_blocks(blocks, fs, chunk, budget):
+            """chunks of `chunk` samples through the blocks in turn on one thread, for about `budget` seconds"""
+            n_done, t0 = 0, time.perf_counter()
+            pos = 0
+            while True:
+                c = x[pos : pos + chunk]
+                pos = (pos + chunk) % (len(x) - chunk)
+                for b in blocks:
+                    c = b(fs, c)
+                    if c is None:
+                        break
+                n_done += chunk
+                dt = time.perf_counter() - t0
+                if dt >= budget:
+                    return n_done / dt / 1e6, n_done, dt
+
+        # cfg1: FreqShifter 700 Hz -> Filter |f| <= 16 kHz in chunks of 4096 at 48 kS/s (SURVEY 8(d))
+        fs1 = o.FreqShifter(1.0, 700.0, flt=np.float32)
+        fl1 = o.Filter(lambda _b, f: 1.0 if abs(f) <= 16e3 else 0.0, flt=np.float32)
+        v, nn, dt = time_blocks([fs1.process, fl1.process], 48000.0, 4096, budget_s / 2)
+        configs["cfg1"] = {"value": round(v, 3), "unit": "MSamples/s", "cores": 1,
+                           "sample": f"{nn} samples in chunks of 4096 (FreqShifter + 4096-tap Filter, 48 kS/s), {dt:.1f} s"}
+        # cfg5: Filter n = 1024, |f| <= 200 MHz at 2 GS/s
+        fl5 = o.Filter(lambda _b, f: 1.0 if abs(f) <= 200e6 else 0.0, flt=np.float32)
+        v, nn, dt = time_blocks([fl5.process], 2e9, 1024, budget_s / 2)
+        configs["cfg5"] = {"value": round(v, 3), "unit": "MSamples/s", "cores": 1,
+                           "sample": f"{nn} samples in chunks of 1024 (1024-tap Filter, 2 GS/s), {dt:.1f} s"}
     v4, n4, f4, d4 = out[4]
     v1, n1, f1, d1 = out[1]
+    configs["cfg2"] = {"value": round(v4, 3), "unit": "MSamples/s", "cores": 4, "single_thread": round(v1, 3)}
     head = 4096 * 4 + 64 + 4  # inputs the first spectrum depends on
     kw64 = dict(kw, flt=np.float64)
     kw64.pop("max_frames")
-    ref0 = o.run_chain_c(o.synth_iq(1, 0, head + 64), 200e6, **kw64)[0][0]
+    ref0 = o.run_chain_c(o.synth_iq(1, 0, head + 64), 200e6, **kw64)[0][0]  # parity build
     return {
         "value": round(v4, 3),
         "unit": "MSamples/s",
         "cores": 4,
         "kind": "port",
         "sample": f"{n4} complex samples of the same cfg2 stream ({f4} spectra), {d4:.1f} s, C restatement of the "
-                  f"reference blocks chunk by chunk (gcc -O3, scalar), one thread per block, capacity-1 hand-off",
+                  f"reference blocks chunk by chunk (gcc {flags}, built on this host), one thread per block, capacity-1 hand-off",
         "single_thread": {"value": round(v1, 3), "cores": 1, "sample": f"{n1} samples ({f1} spectra), {d1:.1f} s"},
+        "configs": configs,
+        "cpu_model": o.cpu_model(),
+        "nproc": os.cpu_count(),
         "host_cores_available": os.cpu_count(),
+        "build": {"chosen": flags, "probe_MSamples_s_single_thread": flag_rates},
     }, ref0
 
 

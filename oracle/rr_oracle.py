@@ -47,11 +47,102 @@ class _CWindow(C.Structure):
     _fields_ = [("kind", C.c_int), ("beta", C.c_double), ("fn", _WINFN), ("ud", C.c_void_p)]
 
 
+NATIVE_FLAG_SETS = ("-O3", "-O3 -march=native", "-O3 -march=native -mprefer-vector-width=256")
+
+
+def _host_tag() -> str:
+    import hashlib
+    import platform
+
+    return hashlib.sha1((cpu_model() + platform.machine()).encode()).hexdigest()[:10]
+
+
+def build_native(flags: str | None = None) -> str:
+    """The same sources compiled for THIS host's cores (`-march=native`, a*b+c contraction allowed): the timing
+    build of bench.py's cpu_baseline.  It is built where it runs (the GPU box's host CPU is not this
+    container's), into a file named after the host's CPU model so that a copy made elsewhere is never loaded.
+    Never used for parity: results may differ from the parity build in the last bits.
+    flags = None: the fastest of NATIVE_FLAG_SETS on a short probe of the cfg2 chain (the auto-vectoriser's
+    choices differ a lot between hosts: 15 / 21 / 28 MSamples/s for the three sets on one Xeon)."""
+    if flags is None:
+        return pick_native()[0]
+    import hashlib
+
+    out = os.path.join(_HERE, "_build", f"librr_oracle_native_{_host_tag()}_{hashlib.sha1(flags.encode()).hexdigest()[:6]}.so")
+    srcs = [os.path.join(_HERE, f) for f in ("rr_oracle.c", "rr_oracle_impl.inc", "rr_oracle.h")]
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.run([os.environ.get("CC", "gcc"), *flags.split(), "-fPIC", "-std=gnu11", "-shared", "-o", out, srcs[0], "-lm",
+                    "-lpthread"], check=True)
+    return out
+
+
+_native_choice = None
+
+
+def pick_native():
+    """(path, flags, {flags: MSamples/s}) of the fastest timing build on this host (single-threaded cfg2 probe)."""
+    global _native_choice, _lib
+    if _native_choice is not None:
+        return _native_choice
+    import time
+
+    x = synth_iq(1, 0, 1 << 19)
+    rates = {}
+    saved = _lib
+    try:
+        for fl in NATIVE_FLAG_SETS:
+            _lib = _bind(C.CDLL(build_native(fl)))
+            best = 0.0
+            for _ in range(2):
+                t = time.perf_counter()
+                run_chain_c(x, 200e6, shift=25e6, filter_len=64, freq_resp=lambda _b, f: 1.0 if abs(f) <= 20e6 else 0.0,
+                            output_rate=50e6, bandwidth=40e6, fft_len=4096, fft_window=Kaiser.with_null_at_bin(2.0),
+                            flt=np.float32, max_frames=1)
+                best = max(best, x.size / (time.perf_counter() - t) / 1e6)
+            rates[fl] = round(best, 2)
+    finally:
+        _lib = saved
+    fl = max(rates, key=rates.get)
+    _native_choice = (build_native(fl), fl, rates)
+    return _native_choice
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+class native:
+    """Context manager: inside it every oracle call goes to the `-march=native` timing build."""
+
+    def __enter__(self):
+        global _lib
+        self._saved = _lib
+        _lib = _bind(C.CDLL(build_native()))
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
+        return False
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    L = C.CDLL(build())
+    _lib = _bind(C.CDLL(build()))
+    return _lib
+
+
+def _bind(L):
     d = C.c_double
     for name in ("rro_bessel_i0", "rro_kaiser_alpha_to_beta", "rro_kaiser_null_at_bin_to_beta", "rro_sinc"):
         getattr(L, name).restype = d
@@ -139,7 +230,6 @@ def lib() -> C.CDLL:
         g("rro_chain_run_mt").restype = sz
         g("rro_chain_run_mt").argtypes = [vp, sz, d, d, d, sz, _RESPFN, vp, C.POINTER(_CWindow), d, d, d, sz,
                                           C.POINTER(_CWindow), C.c_int, vp, sz, sz]
-    _lib = L
     return L
 
 

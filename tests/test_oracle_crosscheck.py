@@ -8,6 +8,7 @@ parameters of the reference's examples (simple_receiver.rs:25-62,
 bandwidth_meter/main.rs:51-72).
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -259,3 +260,24 @@ def test_threaded_chain_runner_is_bit_equal(oracle):
     for batch in (1, 7, 256):
         b, fb = oracle.run_chain_c(x, 200e6, threads=4, batch=batch, **kw)
         assert fb == fa and np.array_equal(a, b)
+
+
+def test_native_timing_build_agrees_with_parity_build():
+    """bench.py's cpu_baseline times the oracle's sources compiled for the host (`-march=native`, contraction
+    allowed; the fastest of a few flag sets).  That build is never the checker, but it must be the same
+    computation: its spectra agree with the parity build's to f32 rounding."""
+    from oracle import rr_oracle as o
+
+    path, flags, rates = o.pick_native()
+    assert flags in o.NATIVE_FLAG_SETS and set(rates) == set(o.NATIVE_FLAG_SETS) and os.path.exists(path)
+    x = o.synth_iq(3, 0, 1 << 17)
+    kw = dict(shift=25e6, filter_len=64, freq_resp=lambda _b, f: 1.0 if abs(f) <= 20e6 else 0.0, output_rate=50e6,
+              bandwidth=40e6, fft_len=4096, fft_window=o.Kaiser.with_null_at_bin(2.0), flt=np.float32)
+    a, fa = o.run_chain_c(x, 200e6, **kw)
+    with o.native():
+        b, fb = o.run_chain_c(x, 200e6, **kw)
+    c, _ = o.run_chain_c(x, 200e6, **kw)  # back on the parity build
+    assert fa == fb and np.array_equal(a, c)
+    err = np.sqrt(np.sum(np.abs(a - b) ** 2) / np.sum(np.abs(a) ** 2))
+    assert err < 1e-5, err
+    assert o.cpu_model()
