@@ -16,7 +16,7 @@
 //   * LDS reads and writes stay single 8-byte operations (the two-address forms run at half rate);
 //   * MODE 1: persistent workgroups that request the next block's samples before transforming the
 //     current one; MODE 2: the same with two LDS images (4 instead of 8 barriers per block) and the
-//     twiddle powers kept in registers across blocks.
+//     twiddle powers and the lane's G values kept in registers across blocks.
 #include "rr_blocks.hpp"
 #include "rr_wave_math.hpp"
 
@@ -24,12 +24,22 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace rr {
 
 namespace {
 
 constexpr int kImg = 4096 + 256;  // padded image: pad16(4095) = 4350
+
+#ifndef RR_V_F4KVOL
+#define RR_V_F4KVOL 1  // 0: plain LDS accesses, which the compiler pairs into ds_read2_b64 / ds_write2_b64 (A/B runs)
+#endif
+__device__ __forceinline__ f2 img_ld(const f2 *p) { return RR_V_F4KVOL ? lds_ldv(p) : *p; }
+__device__ __forceinline__ void img_st(f2 *p, f2 v) {
+    if (RR_V_F4KVOL) lds_stv(p, v);
+    else *p = v;
+}
 
 // LDS-only workgroup barrier: the plain __syncthreads() also drains vmcnt, i.e. it would wait for the
 // next block's prefetch and for the previous block's stores at every exchange.
@@ -79,14 +89,17 @@ struct Blk4096Args {
     long n_out;
     long e0;
     unsigned nblocks;
+    unsigned blk_lo, blk_hi;  // the blocks that lie entirely inside the input
+    unsigned npersist;        // persistent forms: workgroups of the block loop (the rest: one edge block each)
 };
 
 // MODE 0: one block per workgroup.  MODE 1: persistent, next block's samples prefetched, one image.
 // MODE 2: persistent + prefetch, two images, twiddle powers kept.
 template <bool OUT16, bool G16, int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 0 ? 4 : (MODE == 1 ? 3 : 2), MODE == 0 ? 4 : (MODE == 1 ? 3 : 2))))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 0 ? 4 : (MODE == 2 ? 2 : 3), MODE == 0 ? 4 : (MODE == 2 ? 2 : 3))))
 void k_filter_blk4096(Blk4096Args a) {
     constexpr bool DB = MODE == 2, KEEP = MODE == 2, PF = MODE != 0;
+    constexpr bool KEEPG = MODE >= 2;  // MODE 3: MODE 1 with the lane's G values kept in registers
     // where the next block's samples are requested: in the middle of the forward transform (MODE 2: 256 registers)
     // or behind the G product (MODE 1: 32 registers fewer through the forward transform)
     constexpr bool PFEARLY = MODE == 2;
@@ -123,13 +136,13 @@ void k_filter_blk4096(Blk4096Args a) {
         {
             f2 *w = imgA + w0_off;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) lds_stv(w + k, v[k]);
+            for (int k = 0; k < 16; ++k) img_st(w + k, v[k]);
         }
         lds_bar();
         {
             const f2 *r = imgA + rd_off;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = lds_ldv(r + 272 * k);
+            for (int k = 0; k < 16; ++k) v[k] = img_ld(r + 272 * k);
         }
         if constexpr (KEEP) {
 #pragma unroll
@@ -142,14 +155,14 @@ void k_filter_blk4096(Blk4096Args a) {
         {
             f2 *w = imgB + w1_off;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) lds_stv(w + 17 * k, v[k]);
+            for (int k = 0; k < 16; ++k) img_st(w + 17 * k, v[k]);
         }
         mid();
         lds_bar();
         {
             const f2 *r = imgB + rd_off;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = lds_ldv(r + 272 * k);
+            for (int k = 0; k < 16; ++k) v[k] = img_ld(r + 272 * k);
         }
         if constexpr (KEEP) {
 #pragma unroll
@@ -161,80 +174,60 @@ void k_filter_blk4096(Blk4096Args a) {
         dft16(v);
     };
 
-    // block -> workgroup: workgroups b, b + 8, .. share an XCD; neighbouring blocks (which share V samples)
-    // go to one XCD, the XCDs work side by side in a moving window
-    unsigned blk, bstride;
-    if constexpr (PF) {
-        const unsigned per_xcd = gridDim.x >> 3;  // grid: a multiple of 8
-        blk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-        bstride = gridDim.x;
-    } else {
-        constexpr unsigned W = 16;
-        const unsigned grp = blockIdx.x / (8 * W), rem = blockIdx.x % (8 * W);
-        blk = grp * 8 * W + (rem & 7) * W + (rem >> 3);
-        bstride = 0;
-    }
-    if (blk >= a.nblocks) return;
-
     const long n_clamp = a.n_in - 4096;  // PF: the launcher guarantees n_in >= 4096
-    f2 x[16];
-    if constexpr (PF) {
-        long b = a.e0 - a.V + (long)blk * hop;
+    const __amdgpu_buffer_rsrc_t rsG = rsrc_of(a.G, G16 ? 16384 : 32768);
+    f2 x[16];  // PF: the next block's samples
+    float4 gkeep[8];  // KEEPG: the lane's 16 G values are the same for every block
+    if constexpr (KEEPG) {
+#pragma unroll
+        for (int kp = 0; kp < 8; ++kp) {
+            if constexpr (G16) {
+                const f2 raw = buf_ld_f2<0>(rsG, 8u * j, 2048u * kp);
+                gkeep[kp] = float4{raw.x, raw.y, 0.f, 0.f};
+            } else {
+                gkeep[kp] = buf_ld_f4<0>(rsG, 16u * j, 4096u * kp);
+            }
+        }
+    }
+    auto request = [&](unsigned blk_, f2(&dst)[16]) {  // the 4096 samples of an interior block (clamped into the input)
+        long b = a.e0 - a.V + (long)blk_ * hop;
         b = b < 0 ? 0 : (b > n_clamp ? n_clamp : b);
         const __amdgpu_buffer_rsrc_t rs = rsrc_of(a.in + b, 32768);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = buf_ld_f2<2>(rs, 8u * j, 2048u * k);
-    }
-    const __amdgpu_buffer_rsrc_t rsG = rsrc_of(a.G, G16 ? 16384 : 32768);
-
-    bool first = true;
-    for (;;) {
-        // what stays in registers across blocks is decided here, not by invariant-code motion (which would
-        // hoist the 30 twiddle powers and every address, and then spill)
-        if constexpr (PF && !KEEP) asm volatile("" : "+v"(s1), "+v"(s2));
-        const long b0 = a.e0 - a.V + (long)blk * hop;
-        const bool interior = b0 >= 0 && b0 + 4096 <= a.n_in;
-        f2 v[16];
-        if (interior) {
-            if constexpr (PF) {
+        for (int k = 0; k < 16; ++k) dst[k] = buf_ld_f2<2>(rs, 8u * j, 2048u * k);
+    };
+    auto load_edge = [&](unsigned blk_, f2(&v)[16]) {
+        // edges: the previous chunk in front (none after a reset), nothing behind the input
+        const long b0 = a.e0 - a.V + (long)blk_ * hop;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) v[k] = x[k];
-            } else {
-                const __amdgpu_buffer_rsrc_t rs = rsrc_of(a.in + b0, 32768);
-#pragma unroll
-                for (int k = 0; k < 16; ++k) v[k] = buf_ld_f2<2>(rs, 8u * j, 2048u * k);
+        for (int k = 0; k < 16; ++k) {
+            const long pos = b0 + j + 256 * k;
+            float2 xv;
+            xv.x = 0.f;
+            xv.y = 0.f;
+            if (pos >= 0) {
+                if (pos < a.n_in) xv = a.in[pos];
+            } else if (pos >= -(long)a.hist_len) {
+                xv = a.hist[a.hist_len + pos];
             }
-        } else {
-            // edges: the previous chunk in front (none after a reset), nothing behind the input
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const long pos = b0 + j + 256 * k;
-                float2 xv;
-                xv.x = 0.f;
-                xv.y = 0.f;
-                if (pos >= 0) {
-                    if (pos < a.n_in) xv = a.in[pos];
-                } else if (pos >= -(long)a.hist_len) {
-                    xv = a.hist[a.hist_len + pos];
-                }
-                v[k] = (f2){xv.x, xv.y};
-            }
+            v[k] = (f2){xv.x, xv.y};
         }
-        const unsigned nblk = blk + bstride;
-        const bool more = PF && nblk < a.nblocks;
-        // In the middle of the forward transform: the block's 16 G values (8 reads of 16 or 8 bytes per lane), THEN
-        // the next block's samples.  Loads complete in order (vmcnt): requested behind the prefetch, a G value
-        // could not be waited for without waiting for the prefetch as well.  The prefetch is unconditional
-        // (clamped into the input), so that no later wait has to assume it might not have been issued.
-        auto prefetch_next = [&] {
-            long b = a.e0 - a.V + (long)(more ? nblk : blk) * hop;
-            b = b < 0 ? 0 : (b > n_clamp ? n_clamp : b);
-            const __amdgpu_buffer_rsrc_t rs = rsrc_of(a.in + b, 32768);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) x[k] = buf_ld_f2<2>(rs, 8u * j, 2048u * k);
-        };
+    };
+    // one block: forward transform, * G, forward transform again, reversed store.  PFN: request block `nblk`'s
+    // samples on the way (into x).
+    auto do_block = [&](auto PFN, f2(&v)[16], unsigned blk_, unsigned nblk, bool pre_barrier) {
+        constexpr bool pfn = decltype(PFN)::value;
+        // The block's 16 G values (8 reads of 16 or 8 bytes per lane) are requested in the middle of the forward
+        // transform, the next block's samples AFTER them: loads complete in order (vmcnt), so a G value requested
+        // behind the prefetch could not be waited for without waiting for the prefetch as well.  The prefetch is
+        // unconditional, so that no later wait has to assume it might not have been issued.
         float4 g4[8];
+        if constexpr (KEEPG) {
+#pragma unroll
+            for (int kp = 0; kp < 8; ++kp) g4[kp] = gkeep[kp];
+        }
         auto load_g = [&] {
+            if constexpr (KEEPG) return;
 #pragma unroll
             for (int kp = 0; kp < 8; ++kp) {
                 if constexpr (G16) {
@@ -246,10 +239,10 @@ void k_filter_blk4096(Blk4096Args a) {
             }
         };
         transform(
-            v, !first,
+            v, pre_barrier,
             [&] {
                 if constexpr (PF) load_g();
-                if constexpr (PF && PFEARLY) prefetch_next();
+                if constexpr (pfn && PFEARLY) request(nblk, x);
             },
             [&] {
                 if constexpr (!PF) load_g();
@@ -270,32 +263,78 @@ void k_filter_blk4096(Blk4096Args a) {
             v[2 * kp] = cmul(v[2 * kp], ga);
             v[2 * kp + 1] = cmul(v[2 * kp + 1], gb);
         }
-        if constexpr (PF && !PFEARLY) prefetch_next();
+        if constexpr (pfn && !PFEARLY) request(nblk, x);
         transform(v, true, [] {}, [] {});
-        first = false;
         // y[t] = v[k] with t = (4096 - (j + 256 k)) mod 4096; valid for t >= V: output mbase + t - V.
         // Offsets in the block's output window: (hop - j - 256 k) elements; t = 0 lands on `hop` (past the
         // window), t < V wraps to a huge offset: the descriptor's range check drops both.
-        {
-            const long mbase = (long)blk * hop;
-            const long left = a.n_out - mbase;
-            const unsigned recs = (unsigned)(left < hop ? left : hop) * (unsigned)esz;
-            char *obase = reinterpret_cast<char *>(a.out) + mbase * esz;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(obase, 0, recs, 0x00020000);
-            const unsigned lane_off = (unsigned)(hop - j) * (unsigned)esz;
+        const long mbase = (long)blk_ * hop;
+        const long left = a.n_out - mbase;
+        const unsigned recs = (unsigned)(left < hop ? left : hop) * (unsigned)esz;
+        char *obase = reinterpret_cast<char *>(a.out) + mbase * esz;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(obase, 0, recs, 0x00020000);
+        const unsigned lane_off = (unsigned)(hop - j) * (unsigned)esz;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const unsigned off = lane_off - (unsigned)(256 * k * esz);
-                if constexpr (OUT16) {
-                    const __half2 h = __floats2half2_rn(v[k].x, v[k].y);
-                    __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const unsigned *>(&h), rs, off, 0, 2);
-                } else {
-                    __builtin_amdgcn_raw_buffer_store_b64(v[k], rs, off, 0, 2);
-                }
+        for (int k = 0; k < 16; ++k) {
+            const unsigned off = lane_off - (unsigned)(256 * k * esz);
+            if constexpr (OUT16) {
+                const __half2 h = __floats2half2_rn(v[k].x, v[k].y);
+                __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const unsigned *>(&h), rs, off, 0, 2);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b64(v[k], rs, off, 0, 2);
             }
         }
-        if (!more) break;
-        blk = nblk;
+    };
+
+    if constexpr (!PF) {
+        // one block per workgroup.  Workgroups b, b + 8, .. share an XCD; neighbouring blocks (which share V
+        // samples) go to one XCD, the XCDs work side by side in a moving window of 8 x 16 blocks.
+        constexpr unsigned W = 16;
+        const unsigned grp = blockIdx.x / (8 * W), rem = blockIdx.x % (8 * W);
+        const unsigned blk = grp * 8 * W + (rem & 7) * W + (rem >> 3);
+        if (blk >= a.nblocks) return;
+        f2 v[16];
+        if (blk >= a.blk_lo && blk < a.blk_hi) request(blk, v);
+        else load_edge(blk, v);
+        do_block(std::false_type{}, v, blk, blk, false);
+    } else {
+        // Persistent workgroups over the interior blocks [blk_lo, blk_hi) - every sample inside the input - and one
+        // extra workgroup per edge block (it reaches into the history or past the end of the input).  The edge
+        // path has per-element conditions; kept out of the loop, the loop's waits stay counted (a join with
+        // conditional loads makes the compiler wait for everything, the previous block's stores included).
+        if (blockIdx.x >= a.npersist) {
+            const unsigned e = blockIdx.x - a.npersist;
+            const unsigned blk = e < a.blk_lo ? e : a.blk_hi + (e - a.blk_lo);
+            if (blk >= a.nblocks) return;
+            f2 v[16];
+            load_edge(blk, v);
+            do_block(std::false_type{}, v, blk, blk, false);
+            return;
+        }
+        // an XCD takes a contiguous run of every round's blocks
+        const unsigned per_xcd = a.npersist >> 3;  // npersist: a multiple of 8
+        unsigned blk = a.blk_lo + (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+        if (blk >= a.blk_hi) return;
+        request(blk, x);
+        // The first block's samples are waited for HERE (a use the compiler has to honour).  Entering the loop with
+        // them in flight, the wait at the top of the loop would have to serve two queue shapes - nothing behind the
+        // samples on this way in, sixteen stores behind them on the way round - and the compiler then waits for
+        // everything: every block would wait for the previous block's stores.
+        asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+        asm volatile("" : "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
+        for (;;) {
+            // what stays in registers across blocks is decided here, not by invariant-code motion (which would
+            // hoist the 30 twiddle powers and every address, and then spill)
+            if constexpr (!KEEP) asm volatile("" : "+v"(s1), "+v"(s2));
+            f2 v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = x[k];
+            const unsigned nblk = blk + a.npersist;
+            const bool more = nblk < a.blk_hi;
+            do_block(std::true_type{}, v, blk, more ? nblk : blk, true);
+            if (!more) break;
+            blk = nblk;
+        }
     }
 }
 
@@ -325,22 +364,36 @@ int launch_filter_blk4096(hipStream_t s, const void *hist, size_t hist_len, cons
     const size_t nblocks = (n_out + hop - 1) / hop;
     if (nblocks > 0x7ffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "Filter: too many blocks");
     a.nblocks = (unsigned)nblocks;
+    // blocks entirely inside the input: b0 = e0 - V + blk * hop >= 0 and b0 + 4096 <= n_in
+    {
+        const long first = e0 - a.V;
+        long lo = first >= 0 ? 0 : (-first + (long)hop - 1) / (long)hop;
+        long hi = ((long)n_in - 4096 - first) >= 0 ? ((long)n_in - 4096 - first) / (long)hop + 1 : 0;
+        if (hi > (long)nblocks) hi = (long)nblocks;
+        if (lo > hi) lo = hi;
+        a.blk_lo = (unsigned)lo;
+        a.blk_hi = (unsigned)hi;
+    }
     int mode = variant;
-    if (mode < 0 || mode > 2) mode = 1;
-    if (n_in < 4096 || nblocks < persist_min_blocks) mode = 0;  // the persistent forms prefetch whole blocks from inside the input
+    if (mode < 0 || mode > 3) mode = 1;
+    if (n_in < 4096 || nblocks < persist_min_blocks || a.blk_hi == a.blk_lo) mode = 0;  // the persistent forms prefetch whole blocks from inside the input
     unsigned grid;
+    a.npersist = 0;
     if (mode == 0) {
         grid = (unsigned)((nblocks + 127) / 128 * 128);
     } else {
-        const unsigned per_cu = mode == 1 ? 3 : 2;
-        grid = 256 * per_cu;
+        const unsigned per_cu = mode == 2 ? 2 : 3;
+        const size_t interior = a.blk_hi - a.blk_lo;
+        a.npersist = (unsigned)(interior < 256 * per_cu ? (interior + 7) / 8 * 8 : 256 * per_cu);
+        grid = a.npersist + (unsigned)(nblocks - interior);
     }
 #define RR_BLK_LAUNCH(O, GG, M) hipLaunchKernelGGL((k_filter_blk4096<O, GG, M>), dim3(grid), dim3(256), 0, s, a)
 #define RR_BLK_MODE(O, GG)                 \
     do {                                   \
         if (mode == 0) RR_BLK_LAUNCH(O, GG, 0); \
         else if (mode == 1) RR_BLK_LAUNCH(O, GG, 1); \
-        else RR_BLK_LAUNCH(O, GG, 2);      \
+        else if (mode == 2) RR_BLK_LAUNCH(O, GG, 2); \
+        else RR_BLK_LAUNCH(O, GG, 3);      \
     } while (0)
     if (out_f16) {
         if (g_f16) RR_BLK_MODE(true, true);

@@ -8,7 +8,7 @@ from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
 acc = defaultdict(lambda: defaultdict(list))
 for r in rows:
-    name = r.get("Kernel_Name", "?").split("(")[0][-60:]
+    name = r.get("Kernel_Name", "?").replace("(anonymous namespace)::", "").split("(")[0][-60:]
     acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for name, ctrs in sorted(acc.items()):
     n = max(len(v) for v in ctrs.values())

@@ -607,10 +607,10 @@ def test_filter_f16_output(rr, oracle, resp16):
 @pytest.mark.parametrize("n", [1024, 256, 2048])
 def test_filter_block4096_variants(rr, oracle, n, monkeypatch):
     """The 4096-point block kernel of the long Filters (rr_filter_ols.hip; BASELINE configs[4]: n = 1024 at
-    2 GS/s) in its three forms - one block per workgroup, persistent workgroups with the next block's samples
-    prefetched, and persistent with two LDS images - on one stream cut into calls of different sizes (first
+    2 GS/s) in its forms - one block per workgroup, persistent workgroups with the next block's samples
+    prefetched, persistent with two LDS images, persistent with the response kept in registers - on one stream cut into calls of different sizes (first
     chunk swallowed, calls shorter than a block, blocks reaching into the history and past the input), each
-    against the chunk-by-chunk oracle; the three forms do the same arithmetic in the same order, so their
+    against the chunk-by-chunk oracle; the forms do the same arithmetic in the same order, so their
     outputs are bit-equal.  RR_FILTER4K_MIN_BLOCKS=1 lets the persistent forms run on calls this small."""
     import torch
 
@@ -624,7 +624,8 @@ def test_filter_block4096_variants(rr, oracle, n, monkeypatch):
     d_in = torch.from_numpy(x).cuda()
     outs = {}
     monkeypatch.setenv("RR_FILTER4K_MIN_BLOCKS", "1")
-    for variant in (0, 1, 2, -1):
+    monkeypatch.setenv("RR_FILTER_KERNEL", "ols4096")  # (n = 256 would otherwise take k_filter_wave for the long calls)
+    for variant in (0, 1, 2, 3, -1):
         monkeypatch.setenv("RR_FILTER4K_VARIANT", str(variant))
         g = rr.Filter.new(lowpass(200e6))
         g.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -641,7 +642,7 @@ def test_filter_block4096_variants(rr, oracle, n, monkeypatch):
         assert not np.any(got[wrote:]), "wrote past the produced samples"
         check(got[:wrote], r64, r32)
         outs[variant] = got[:wrote]
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]) and np.array_equal(outs[0], outs[3])
 
 
 def test_filter_f16_unsupported(rr):
