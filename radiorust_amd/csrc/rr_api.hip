@@ -209,9 +209,6 @@ int rr_filter::design(double sample_rate, size_t len, const rr_c64 *resp, const 
         const char *e = std::getenv("RR_FILTER_KERNEL");  // "ols4096" / "fir" keep the older kernels (A/B runs, tests)
         use_wave = filter_wave_supported(dtype, len) && !(e && (!std::strcmp(e, "ols4096") || !std::strcmp(e, "fir")));
         if (e && !std::strcmp(e, "fir")) big_ols4096 = false;
-        const char *v = std::getenv("RR_FILTER4K_VARIANT"), *mb = std::getenv("RR_FILTER4K_MIN_BLOCKS");
-        blk_variant = v ? std::atoi(v) : 1;
-        blk_min_blocks = mb ? (size_t)std::atol(mb) : 2048;
     }
     if (use_wave) {
         std::vector<double> c(len);
@@ -286,9 +283,13 @@ int rr_filter::process_dev(double sample_rate, const void *d_in, size_t n_in, vo
         last_kernel = 3;
     } else if (produce && (use_ols4096 || (big_ols4096 && produce >= kFilterBigCall))) {
         last_kernel = 2;
-        RR_TRY(launch_filter_ols4096(stream, hist[cur].p, hist_valid ? n : 0, d_in, n_in, g_f16 ? d_G4096h.p : d_G4096.p,
-                                     d_tw4096.p, n, d_out, produce, hist_valid ? 0 : (long)n, out_f16, g_f16, blk_variant,
-                                     blk_min_blocks));
+        // (the kernel's last workgroup also leaves the next call's history)
+        RR_TRY(launch_filter_blk4096(stream, hist[cur].p, hist_valid ? n : 0, d_in, n_in, g_f16 ? d_G4096h.p : d_G4096.p,
+                                     d_tw4096.p, n, d_out, produce, hist_valid ? 0 : (long)n, out_f16, g_f16, hist[cur ^ 1].p, n));
+        cur ^= 1;
+        hist_valid = true;
+        if (n_out) *n_out = produce;
+        return RR_OK;
     } else if (produce && use_ols) {
         last_kernel = 1;
         RR_TRY(launch_filter_ols(dtype, stream, hist[cur].p, d_in, n, produce / n, hist_valid ? 0 : 1, d_H.p, d_olstw.p, d_out));

@@ -34,10 +34,8 @@ struct rr_filter : rr_block {
     bool use_wave = false;         // f32, n <= 385: k_filter_wave (a wave per 1024-block) for calls of >= 16384 outputs
     rr::DevBuf d_Hw, d_tww;        // its tables (DFT_1024(g) / 1024 pair-interleaved; twiddles + lane seeds)
     int wave_V = 0;
-    int last_kernel = 0;           // 0 k_fir, 1 k_filter_ols (2n-point), 2 k_filter_ols4096, 3 k_filter_wave
+    int last_kernel = 0;           // 0 k_fir, 1 k_filter_ols (2n-point), 2 k_filter_blk4096, 3 k_filter_wave
     rr::DevBuf d_G4096, d_tw4096;
-    int blk_variant = 1;           // which form of the 4096-block kernel runs (RR_FILTER4K_VARIANT at design time; -1: the first version)
-    size_t blk_min_blocks = 2048;  // calls of fewer blocks run one block per workgroup (RR_FILTER4K_MIN_BLOCKS)
     rr::DevBuf d_G4096h;           // the same table rounded to IEEE half (rr_filter_process_dev_f16's option)
     rr::DevBuf hist[2];            // previous_chunk (n samples), ping-pong
     int cur = 0;

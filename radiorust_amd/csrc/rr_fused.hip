@@ -31,7 +31,7 @@
 // Kernel 3   k_ols_decim4     the stage of kernel 1 by overlap-save, a workgroup per 4096-block
 // Kernel 3w  k_ols_wave       ... a WAVE per 1024-block: the default for 4x decimation
 // Kernel 3f  k_ols_frame      k_ols_wave's blocks + kernel 2 in one kernel (measured slower; on request)
-// Kernel 4   k_filter_ols4096 the Filter block alone by overlap-save (n = 256 .. 2048)
+// Kernel 4   k_filter_blk4096 (rr_filter_ols.hip) the Filter block alone by overlap-save (n = 256 .. 2048)
 // Kernel 4w  k_filter_wave    the Filter block alone, a wave per 1024-sample block (n <= 385)
 // Kernel 5   k_channelizer256 256-bin polyphase channelizer, a wave per run of frames
 //
@@ -47,7 +47,6 @@
 //   RR_V_WAVELDS  LDS elements per wave image (1176)
 //   RR_V_FRAMEWAVES, RR_V_FRAMEPF, RR_V_FRAMEOCC, RR_V_FRAMEWIN   kernel 3f: waves per frame (4), prefetch (0), frames per XCD in a window (1)
 //   RR_V_FFTPK, RR_V_FFTXCD, RR_V_FFTWIN   kernel 2: packed window copy + seeds up front + streaming hints (1), XCD mappings (0, 0)
-//   RR_V_FLTXCD   kernel 4: a contiguous eighth of the blocks per XCD (0)
 //   RR_V_FLTWOCC, RR_V_FLTWNT, RR_V_FLTWWIN   kernel 4w: register budget in waves per SIMD (3), streaming hints (3), window (64)
 //   RR_V_CHANRUN, RR_V_CHANWIN  kernel 5: frames per wave (16), runs per XCD in a window (4)
 //   RR_V_MFDWIN   kernel 1: tiles dealt in windows (0)
@@ -706,21 +705,21 @@ __global__ __launch_bounds__(64) void k_fft512(const float2 *__restrict__ head, 
     const float2 s1 = tw[8 * (l & 7)], s2 = tw[l];  // tw[k] = e^{-j 2 pi k / 512}
     dft8(a);  // pass 0 (Ns = 1): out 8 l + k
 #pragma unroll
-    for (int k = 0; k < 8; ++k) lds[pad8(8 * l + k)] = a[k];
+    for (int k = 0; k < 8; ++k) lds_st(lds + pad8(8 * l + k), a[k]);
     wave_sync();
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a[k] = lds[pad8(l + 64 * k)];
+    for (int k = 0; k < 8; ++k) a[k] = lds_ld(lds + pad8(l + 64 * k));
     twiddle8(a, (f2){s1.x, s1.y});  // pass 1 (Ns = 8): e^{-j 2 pi (l mod 8) k / 64}; out (l / 8) 64 + l % 8 + 8 k
     dft8(a);
     wave_sync();
     {
         const int b = (l >> 3) * 64 + (l & 7);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) lds[pad8(b + 8 * k)] = a[k];
+        for (int k = 0; k < 8; ++k) lds_st(lds + pad8(b + 8 * k), a[k]);
     }
     wave_sync();
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a[k] = lds[pad8(l + 64 * k)];
+    for (int k = 0; k < 8; ++k) a[k] = lds_ld(lds + pad8(l + 64 * k));
     twiddle8(a, (f2){s2.x, s2.y});  // pass 2 (Ns = 64): e^{-j 2 pi l k / 512}; out l + 64 k
     dft8(a);
     f2 *dst = reinterpret_cast<f2 *>(out) + (size_t)fr * 512;
@@ -761,10 +760,10 @@ __global__ __launch_bounds__(64) void k_fft64(const float2 *__restrict__ in, flo
     dft8(a);                  // pass 0 (Ns = 1): out 8 q + k
     f2 *img = lds + 72 * f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) img[pad8(8 * q + k)] = a[k];
+    for (int k = 0; k < 8; ++k) lds_st(img + pad8(8 * q + k), a[k]);
     wave_sync();
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a[k] = img[pad8(q + 8 * k)];
+    for (int k = 0; k < 8; ++k) a[k] = lds_ld(img + pad8(q + 8 * k));
     twiddle8(a, (f2){s1.x, s1.y});  // pass 1 (Ns = 8): e^{-j 2 pi q k / 64}; out q + 8 k
     dft8(a);
     if (!live) return;
@@ -789,12 +788,12 @@ __global__ __launch_bounds__(64) void k_fft128(const float2 *__restrict__ in, fl
     dft8(a);                      // pass 0 (Ns = 1): butterflies q over x[q + 16 k]; out 8 q + k
     f2 *img = lds + 144 * f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) img[pad8(8 * q + k)] = a[k];
+    for (int k = 0; k < 8; ++k) lds_st(img + pad8(8 * q + k), a[k]);
     wave_sync();
     // pass 1 (Ns = 8, radix 16): butterflies j < 8 over y[j + 8 k], k < 16; twiddle tw[j]^k; out j + 8 k
     f2 v[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = img[pad8((q & 7) + 8 * k)];
+    for (int k = 0; k < 16; ++k) v[k] = lds_ld(img + pad8((q & 7) + 8 * k));
     apply_twiddle_powers(v, (f2){s1.x, s1.y});
     dft16(v);
     if (!live || q >= 8) return;
@@ -860,18 +859,18 @@ __global__ __launch_bounds__(128) void k_fft2048(const float2 *__restrict__ head
     // pass 0 (Ns = 1, radix 16): butterflies t over x[t + 128 k]; out 16 t + k
     dft16(v);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) lds[pad16(16 * t + k)] = v[k];
+    for (int k = 0; k < 16; ++k) lds_st(lds + pad16(16 * t + k), v[k]);
     __syncthreads();
     // pass 1 (Ns = 16, radix 16): in y[t + 128 k]; out (t / 16) 256 + t % 16 + 16 k
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = lds[pad16(t + 128 * k)];
+    for (int k = 0; k < 16; ++k) v[k] = lds_ld(lds + pad16(t + 128 * k));
     apply_twiddle_powers(v, (f2){s1.x, s1.y});
     dft16(v);
     __syncthreads();
     {
         const int b = (t >> 4) * 256 + (t & 15);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) lds[pad16(b + 16 * k)] = v[k];
+        for (int k = 0; k < 16; ++k) lds_st(lds + pad16(b + 16 * k), v[k]);
     }
     __syncthreads();
     // pass 2 (Ns = 256, radix 8): butterflies j = t and t + 128 over z[j + 256 k]; out X[j + 256 k]
@@ -882,7 +881,7 @@ __global__ __launch_bounds__(128) void k_fft2048(const float2 *__restrict__ head
         const int j = t + 128 * sidx;
         f2 a[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) a[k] = lds[pad16(j + 256 * k)];
+        for (int k = 0; k < 8; ++k) a[k] = lds_ld(lds + pad16(j + 256 * k));
         const float2 sw = sidx ? s2b : s2a;
         const f2 w1 = {sw.x, sw.y};
         const f2 w2 = cmulf(w1, w1), w3 = cmulf(w2, w1), w4 = cmulf(w2, w2);
@@ -937,7 +936,7 @@ __global__ __launch_bounds__(256) void k_fft8192(const float2 *__restrict__ head
         }
         dft16(v[h]);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) lds[pad16(16 * j + k)] = v[h][k];
+        for (int k = 0; k < 16; ++k) lds_st(lds + pad16(16 * j + k), v[h][k]);
     }
     __syncthreads();
     // pass 1 (Ns = 16, radix 16): in y[j + 512 k]; twiddle e^{-j 2 pi (j mod 16) k / 256} = tw[32 (j mod 16)]^k;
@@ -948,7 +947,7 @@ __global__ __launch_bounds__(256) void k_fft8192(const float2 *__restrict__ head
         for (int h = 0; h < 2; ++h) {
             const int j = t + 256 * h;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[h][k] = lds[pad16(j + 512 * k)];
+            for (int k = 0; k < 16; ++k) v[h][k] = lds_ld(lds + pad16(j + 512 * k));
             apply_twiddle_powers(v[h], (f2){s1.x, s1.y});
             dft16(v[h]);
         }
@@ -959,7 +958,7 @@ __global__ __launch_bounds__(256) void k_fft8192(const float2 *__restrict__ head
         const int j = t + 256 * h;
         const int b = (j >> 4) * 256 + (j & 15);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) lds[pad16(b + 16 * k)] = v[h][k];
+        for (int k = 0; k < 16; ++k) lds_st(lds + pad16(b + 16 * k), v[h][k]);
     }
     __syncthreads();
     // pass 2 (Ns = 256, radix 32): butterfly t over z[t + 256 k], k < 32; twiddle tw[t]^k; out X[t + 256 k]
@@ -970,7 +969,7 @@ __global__ __launch_bounds__(256) void k_fft8192(const float2 *__restrict__ head
         const f2 w2 = cmulf(w, w);
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-            v[0][a] = lds[pad16(t + 256 * (2 * a))];
+            v[0][a] = lds_ld(lds + pad16(t + 256 * (2 * a)));
             v[1][a] = cmulf(lds[pad16(t + 256 * (2 * a + 1))], w);
         }
         apply_twiddle_powers(v[0], w2);
@@ -1012,10 +1011,10 @@ __device__ __forceinline__ void fft4096_regs(f2 (&v)[16], f2 *lds, const float2 
     // in: v[k] = x[j + 256 k]; out: v[k] = X[j + 256 k]
     dft16(v);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) lds[pad16(16 * j + k)] = v[k];
+    for (int k = 0; k < 16; ++k) lds_st(lds + pad16(16 * j + k), v[k]);
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = lds[pad16(j + 256 * k)];
+    for (int k = 0; k < 16; ++k) v[k] = lds_ld(lds + pad16(j + 256 * k));
     {
         const float2 t = tw[16 * (j & 15)];
         apply_twiddle_powers(v, (f2){t.x, t.y});
@@ -1025,11 +1024,11 @@ __device__ __forceinline__ void fft4096_regs(f2 (&v)[16], f2 *lds, const float2 
     {
         const int base = (j >> 4) * 256 + (j & 15);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) lds[pad16(base + 16 * k)] = v[k];
+        for (int k = 0; k < 16; ++k) lds_st(lds + pad16(base + 16 * k), v[k]);
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = lds[pad16(j + 256 * k)];
+    for (int k = 0; k < 16; ++k) v[k] = lds_ld(lds + pad16(j + 256 * k));
     {
         const float2 t = tw[j];
         apply_twiddle_powers(v, (f2){t.x, t.y});
@@ -1169,10 +1168,10 @@ __global__ __launch_bounds__(256) void k_ols_decim4(const float2 *__restrict__ x
         const int o = ((j - k) << 2) + k;  // (j / ns) * 4 ns + j mod ns
         if (pass == 0) __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 4; ++c) lds[pad16(o + c * ns)] = y[c];
+        for (int c = 0; c < 4; ++c) lds_st(lds + pad16(o + c * ns), y[c]);
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 4; ++c) y[c] = lds[pad16(j + 256 * c)];
+        for (int c = 0; c < 4; ++c) y[c] = lds_ld(lds + pad16(j + 256 * c));
     }
     // ---- store the valid part --------------------------------------------------------
     const long mbase = (long)blockIdx.x * per_block;
@@ -1810,7 +1809,7 @@ __device__ __forceinline__ void wave_block_transform(f2 (&v)[16], f2 (&y)[4], f2
             *reinterpret_cast<float4 *>(row + k) = (float4){v[k].x, v[k].y, v[k + 1].x, v[k + 1].y};
         wave_sync();
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = a_rd[72 * (k & 3) + 296 * (k >> 2)];
+        for (int k = 0; k < 16; ++k) v[k] = lds_ld(a_rd + (72 * (k & 3) + 296 * (k >> 2)));
     } else {
         // rows 0..31 (elements < 512) belong to lanes 0..31; a reader's k < 8 are its elements < 512
         f2 w[16];
@@ -1826,7 +1825,7 @@ __device__ __forceinline__ void wave_block_transform(f2 (&v)[16], f2 (&y)[4], f2
             }
             wave_sync();
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[8 * h + k] = a_rd[72 * (k & 3) + 296 * (k >> 2)];  // in[l + 64 (8 h + k)] - 512 h
+            for (int k = 0; k < 8; ++k) v[8 * h + k] = lds_ld(a_rd + (72 * (k & 3) + 296 * (k >> 2)));  // in[l + 64 (8 h + k)] - 512 h
             wave_sync();
         }
     }
@@ -1838,13 +1837,13 @@ __device__ __forceinline__ void wave_block_transform(f2 (&v)[16], f2 (&y)[4], f2
         {
             f2 *col = lds + (144 * (l >> 3) + 8 * (l >> 4) + (l & 7));
 #pragma unroll
-            for (int k = 0; k < 16; ++k) col[8 * k + 2 * (k >> 1)] = v[k];
+            for (int k = 0; k < 16; ++k) lds_st(col + (8 * k + 2 * (k >> 1)), v[k]);
         }
         wave_sync();
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) ain[m][c] = a_rd[72 * m + 144 * c + 8 * (c >> 1)];
+            for (int c = 0; c < 8; ++c) ain[m][c] = lds_ld(a_rd + (72 * m + 144 * c + 8 * (c >> 1)));
     } else {
         // elements 128 h' + p + 8 k with h' = l / 8 < 4 (lanes 0..31) are the lower 512; a reader's c < 4 too
         if constexpr (true) wave_sync();
@@ -1854,13 +1853,13 @@ __device__ __forceinline__ void wave_block_transform(f2 (&v)[16], f2 (&y)[4], f2
                 const int ll = l & 31;
                 f2 *col = lds + (144 * (ll >> 3) + 8 * (ll >> 4) + (ll & 7));
 #pragma unroll
-                for (int k = 0; k < 16; ++k) col[8 * k + 2 * (k >> 1)] = v[k];
+                for (int k = 0; k < 16; ++k) lds_st(col + (8 * k + 2 * (k >> 1)), v[k]);
             }
             wave_sync();
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) ain[m][4 * h + c] = a_rd[72 * m + 144 * c + 8 * (c >> 1)];
+                for (int c = 0; c < 4; ++c) ain[m][4 * h + c] = lds_ld(a_rd + (72 * m + 144 * c + 8 * (c >> 1)));
             wave_sync();
         }
     }
@@ -1904,7 +1903,7 @@ __device__ __forceinline__ void wave_block_transform(f2 (&v)[16], f2 (&y)[4], f2
 #pragma unroll
     for (int pass = 1; pass < 4; ++pass) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) y[c] = b_rd[80 * c];
+        for (int c = 0; c < 4; ++c) y[c] = lds_ld(b_rd + (80 * c));
         const f2 w1 = t_inv[pass - 1];
         const f2 w2 = cmul(w1, w1);
         const f2 w3 = cmul(w2, w1);
@@ -1917,11 +1916,11 @@ __device__ __forceinline__ void wave_block_transform(f2 (&v)[16], f2 (&y)[4], f2
         if (pass == 1) {
             f2 *col = lds + (20 * (l >> 2) + (l & 3));
 #pragma unroll
-            for (int c = 0; c < 4; ++c) col[4 * c] = y[c];
+            for (int c = 0; c < 4; ++c) lds_st(col + (4 * c), y[c]);
         } else {
             f2 *col = lds + (80 * g + q);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) col[20 * c] = y[c];
+            for (int c = 0; c < 4; ++c) lds_st(col + (20 * c), y[c]);
         }
         wave_sync();
     }
@@ -2342,14 +2341,14 @@ __device__ __forceinline__ void wave_dft1024(f2 (&v)[16], f2 (&X)[16], f2 *lds, 
     }
     wave_sync();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = a_rd[72 * (k & 3) + 296 * (k >> 2)];  // in[l + 64 k]
+    for (int k = 0; k < 16; ++k) v[k] = lds_ld(a_rd + (72 * (k & 3) + 296 * (k >> 2)));  // in[l + 64 k]
     twiddle16(v, t_p1);
     dft16(v);
     wave_sync();
     {
         f2 *col = lds + (144 * (l >> 3) + 8 * (l >> 4) + (l & 7));
 #pragma unroll
-        for (int k = 0; k < 16; ++k) col[8 * k + 2 * (k >> 1)] = v[k];
+        for (int k = 0; k < 16; ++k) lds_st(col + (8 * k + 2 * (k >> 1)), v[k]);
     }
     mid();
     wave_sync();
@@ -2357,7 +2356,7 @@ __device__ __forceinline__ void wave_dft1024(f2 (&v)[16], f2 (&X)[16], f2 *lds, 
     for (int m = 0; m < 2; ++m) {
         f2 a[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) a[c] = a_rd[72 * m + 144 * c + 8 * (c >> 1)];
+        for (int c = 0; c < 8; ++c) a[c] = lds_ld(a_rd + (72 * m + 144 * c + 8 * (c >> 1)));
         const f2 w1 = t_p2[m];
         const f2 w2 = cmul(w1, w1);
         const f2 w3 = cmul(w2, w1);
@@ -2400,19 +2399,19 @@ __device__ __forceinline__ void wave_dft1024_t(f2 (&Z)[16], f2 (&v)[16], f2 *lds
         a[6] = cmul(a[6], cmul(w4, w2));
         a[7] = cmul(a[7], cmul(w4, w3));
 #pragma unroll
-        for (int c = 0; c < 8; ++c) a_rd[72 * m + 144 * c + 8 * (c >> 1)] = a[c];
+        for (int c = 0; c < 8; ++c) lds_st(a_rd + (72 * m + 144 * c + 8 * (c >> 1)), a[c]);
     }
     wave_sync();
     {
         const f2 *col = lds + (144 * (l >> 3) + 8 * (l >> 4) + (l & 7));
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = col[8 * k + 2 * (k >> 1)];
+        for (int k = 0; k < 16; ++k) v[k] = lds_ld(col + (8 * k + 2 * (k >> 1)));
     }
     dft16(v);
     twiddle16(v, t_p1);
     wave_sync();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) a_rd[72 * (k & 3) + 296 * (k >> 2)] = v[k];
+    for (int k = 0; k < 16; ++k) lds_st(a_rd + (72 * (k & 3) + 296 * (k >> 2)), v[k]);
     wave_sync();
     {
         const f2 *row = lds + (18 * l + 8 * g);
@@ -2719,7 +2718,7 @@ __global__ __launch_bounds__(64) void k_channelizer256(const float2 *__restrict_
 #pragma unroll
         for (int pass = 1; pass < 4; ++pass) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) y[c] = b_rd[80 * c];
+            for (int c = 0; c < 4; ++c) y[c] = lds_ld(b_rd + (80 * c));
             const f2 w1 = seed[pass - 1];
             const f2 w2 = cmul(w1, w1);
             const f2 w3 = cmul(w2, w1);
@@ -2732,11 +2731,11 @@ __global__ __launch_bounds__(64) void k_channelizer256(const float2 *__restrict_
             if (pass == 1) {
                 f2 *col = lds + (20 * (l >> 2) + (l & 3));
 #pragma unroll
-                for (int c = 0; c < 4; ++c) col[4 * c] = y[c];
+                for (int c = 0; c < 4; ++c) lds_st(col + (4 * c), y[c]);
             } else {
                 f2 *col = lds + (80 * g + q);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) col[20 * c] = y[c];
+                for (int c = 0; c < 4; ++c) lds_st(col + (20 * c), y[c]);
             }
             wave_sync();
         }
@@ -2806,107 +2805,8 @@ int launch_ols_decim(hipStream_t s, const FusedFirArgs &a) {
     return RR_OK;
 }
 
-// ---------------------------------------------------------------------------
-// Kernel 4  k_filter_ols4096: the Filter block's fast convolution (filters.rs:240-259)
-// for n in {256, 512, 1024, 2048}, Complex<f32>, with 4096-point blocks:
-//   y = IDFT_4096(DFT_4096(x_block) * G),  G = DFT_4096(g) / 4096, overlap V >= n - 1,
-// i.e. the same linear convolution as the reference's 2n-point transforms (it differs by
-// rounding only), three 1024-sample chunks per block instead of one per 2048-point pair.
-// Forward and inverse transforms share one radix-16 x 3 routine (inverse = conj o DFT o conj).
-// ---------------------------------------------------------------------------
-// OUT16: outputs rounded to IEEE half (re, im) - 12 instead of 16 algorithmic bytes per sample;
-// G16: the response table held as halves (SURVEY 8(d) cfg5's second and third points).
-#ifndef RR_V_FLTXCD
-#define RR_V_FLTXCD 0  // a contiguous eighth of the blocks per XCD: no difference (0.327 / 0.326 ms)
-#endif
-template <bool OUT16, bool G16>
-__global__ __launch_bounds__(256) void k_filter_ols4096(const float2 *__restrict__ hist, int hist_len,
-                                                        const float2 *__restrict__ in, long n_in,
-                                                        const void *__restrict__ Gv, const float2 *__restrict__ tw,
-                                                        int V, void *__restrict__ outv, long n_out, long e0) {
-    __shared__ f2 lds[4096 + 256];
-    const int j = threadIdx.x;
-    const int hop = 4096 - V;
-#if RR_V_FLTXCD
-    // a contiguous eighth of the blocks per XCD (grid: a multiple of 8), see k_fft4096
-    const unsigned blk = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    if ((long)blk * hop >= n_out) return;
-#else
-    const unsigned blk = blockIdx.x;
-#endif
-    const long b0 = e0 - V + (long)blk * hop;
-    f2 v[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const long pos = b0 + j + 256 * k;
-        float2 x;
-        x.x = 0.f;
-        x.y = 0.f;
-        if (pos >= 0) {
-            if (pos < n_in) x = in[pos];
-        } else if (pos >= -(long)hist_len) {
-            x = hist[hist_len + pos];
-        }
-        v[k] = (f2){x.x, x.y};
-    }
-    fft4096_regs(v, lds, tw, j);
-    // G arrives pair-interleaved (Gp[kp][j] = {G[j + 512 kp], G[j + 512 kp + 256]}): 8 reads of 16 (8) bytes
-#pragma unroll
-    for (int kp = 0; kp < 8; ++kp) {
-        float4 g4;
-        if constexpr (G16) {
-            const uint2 raw = reinterpret_cast<const uint2 *>(Gv)[j + 256 * kp];
-            const __half2 a = *reinterpret_cast<const __half2 *>(&raw.x), b = *reinterpret_cast<const __half2 *>(&raw.y);
-            const float2 fa = __half22float2(a), fb = __half22float2(b);
-            g4 = float4{fa.x, fa.y, fb.x, fb.y};
-        } else {
-            g4 = reinterpret_cast<const float4 *>(Gv)[j + 256 * kp];
-        }
-        const f2 p0 = cmulf(v[2 * kp], (f2){g4.x, g4.y}), p1 = cmulf(v[2 * kp + 1], (f2){g4.z, g4.w});
-        v[2 * kp] = (f2){p0.x, -p0.y};  // conj: the inverse transform is conj(DFT(conj(.)))
-        v[2 * kp + 1] = (f2){p1.x, -p1.y};
-    }
-    __syncthreads();  // the forward transform's last LDS reads are done
-    fft4096_regs(v, lds, tw, j);
-    const long mbase = (long)blk * hop;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int t = j + 256 * k;
-        const long m = mbase + (t - V);
-        if (t >= V && m < n_out) {
-            if constexpr (OUT16) {
-                reinterpret_cast<__half2 *>(outv)[m] = __floats2half2_rn(v[k].x, -v[k].y);
-            } else {
-                float2 w;
-                w.x = v[k].x;
-                w.y = -v[k].y;
-                reinterpret_cast<float2 *>(outv)[m] = w;
-            }
-        }
-    }
-}
-
 bool filter_ols4096_supported(int dtype, size_t n) {
     return dtype == RR_F32 && (n == 256 || n == 512 || n == 1024 || n == 2048);
-}
-
-int launch_filter_ols4096(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *G,
-                          const void *tw4096, size_t n, void *out, size_t n_out, long e0, bool out_f16, bool g_f16, int variant,
-                          size_t persist_min_blocks) {
-    if (n_out == 0) return RR_OK;
-    // the rebuilt kernel (rr_filter_ols.hip) serves every call; variant -1 keeps this first version (A/B runs)
-    if (variant >= 0)
-        return launch_filter_blk4096(s, hist, hist_len, in, n_in, G, tw4096, n, out, n_out, e0, out_f16, g_f16, variant, persist_min_blocks);
-    const int V = (int)n;  // n is a multiple of 256 here, V >= n - 1
-    const size_t hop = 4096 - V;
-    const size_t nblocks = (n_out + hop - 1) / hop;
-    if (nblocks > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "Filter: too many blocks");
-    auto kern = out_f16 ? (g_f16 ? k_filter_ols4096<true, true> : k_filter_ols4096<true, false>)
-                        : (g_f16 ? k_filter_ols4096<false, true> : k_filter_ols4096<false, false>);
-    hipLaunchKernelGGL(kern, dim3(RR_V_FLTXCD ? (unsigned)((nblocks + 7) / 8 * 8) : (unsigned)nblocks), dim3(256), 0, s, (const float2 *)hist, (int)hist_len,
-                       (const float2 *)in, (long)n_in, G, (const float2 *)tw4096, V, out, (long)n_out, e0);
-    RR_HIP(hipGetLastError());
-    return RR_OK;
 }
 
 // tail drop on an interrupt: new[i] = old[i - drop] (zeros shifted in at the front)

@@ -43,20 +43,15 @@ bool ols_supported(int dtype, size_t n);
 int launch_filter_ols(int dtype, hipStream_t s, const void *hist, const void *in, size_t n, size_t nchunks,
                       int first_chunk, const void *H, const void *tw, void *out);
 
-// Filter fast convolution with 4096-point blocks (rr_fused.hip), Complex<f32>, n in {256..2048}:
-// out[m] = sum_k g[k] x[e0 + m - k] over [ hist | in ]; G = DFT_4096(g)/4096, tw4096 as above.
+// Filter fast convolution with 4096-point blocks (rr_filter_ols.hip), Complex<f32>, n in {256..2048} (V = n; any
+// n <= 2048 works): out[m] = sum_k g[k] x[e0 + m - k] over [ hist | in ]; G = DFT_4096(g)/4096 pair-interleaved
+// (f32, or f16 with g_f16), tw4096[k] = e^{-j 2 pi k / 4096}; out_f16: outputs as {half re, half im}.
+// hist_out (may be null) receives the last hist_out_len samples of [ hist | in ] - the next call's history -
+// written by the kernel itself (only when n_out > 0, i.e. when a kernel is launched).
 bool filter_ols4096_supported(int dtype, size_t n);
-int launch_filter_ols4096(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *G,
-                          const void *tw4096, size_t n, void *out, size_t n_out, long e0, bool out_f16 = false,
-                          bool g_f16 = false, int variant = 1, size_t persist_min_blocks = 2048);
-
-// the rebuilt 4096-point block kernel (rr_filter_ols.hip): same contract; V = n (any n <= 2048 works, the tables are
-// those of launch_filter_ols4096).  variant: 0 one block per workgroup, 1 persistent + prefetch (default), 2 persistent
-// with two LDS images and the twiddle powers kept in registers; calls of fewer than persist_min_blocks blocks
-// (or n_in < 4096) run variant 0.  (RR_FILTER4K_VARIANT / RR_FILTER4K_MIN_BLOCKS, read at design time.)
 int launch_filter_blk4096(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *G,
                           const void *tw4096, size_t n, void *out, size_t n_out, long e0, bool out_f16, bool g_f16,
-                          int variant, size_t persist_min_blocks);
+                          void *hist_out, size_t hist_out_len);
 
 // new_hist (H samples) = last H samples of [ zeros | old_hist (H) | in (n_in) ]
 int launch_update_hist(int dtype, hipStream_t s, const void *old_hist, void *new_hist, size_t H, const void *in,

@@ -210,7 +210,7 @@ __device__ __forceinline__ f2 lds_ldv(const f2 *p) { return *(const volatile lds
 __device__ __forceinline__ void lds_stv(f2 *p, f2 v) { *(volatile lds_f2 *)p = v; }
 // the same, switchable per build for A/B runs of the older kernels (RR_V_LDSVOL)
 #ifndef RR_V_LDSVOL
-#define RR_V_LDSVOL 0
+#define RR_V_LDSVOL 1
 #endif
 __device__ __forceinline__ f2 lds_ld(const f2 *p) {
 #if RR_V_LDSVOL

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""cfg5 (1024-tap Filter, 2^26 samples per call) for each form of the 4096-block kernel, one subprocess
-per form (the form is read at design time), interleaved rounds in one GPU session.
-usage: bench_cfg5_variants.py [rounds] [variants..]   (-1 = the first version k_filter_ols4096)"""
+"""cfg5 (1024-tap Filter, 2^26 samples per call; CFG5_N / CFG5_F16 change the case) for library variants, one
+subprocess per run, interleaved rounds in one GPU session.
+usage: bench_cfg5_variants.py [rounds] [variant ..]   variant = "-" (the product) or "name:ENV=value:.."
+       e.g. "-" "merge:RR_LIB=scripts/ubench/lib_f4kmerge.so" """
 import os, subprocess, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -31,11 +32,11 @@ torch.cuda.synchronize()
 print("MS", (time.perf_counter() - t) / K * 1e3)
 ''' % ROOT
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-variants = sys.argv[2:] or ["-1", "0", "1", "2"]
+variants = sys.argv[2:] or ["-"]
 res = {v: [] for v in variants}
 for r in range(rounds):
     for v in variants:
-        env = dict(os.environ, RR_FILTER4K_VARIANT=v.split(":")[0])
+        env = dict(os.environ)
         for kv in v.split(":")[1:]:
             k, _, val = kv.partition("=")
             env[k] = val

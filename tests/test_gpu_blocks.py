@@ -605,13 +605,11 @@ def test_filter_f16_output(rr, oracle, resp16):
 
 
 @pytest.mark.parametrize("n", [1024, 256, 2048])
-def test_filter_block4096_variants(rr, oracle, n, monkeypatch):
+def test_filter_block4096_ragged_calls(rr, oracle, n, monkeypatch):
     """The 4096-point block kernel of the long Filters (rr_filter_ols.hip; BASELINE configs[4]: n = 1024 at
-    2 GS/s) in its forms - one block per workgroup, persistent workgroups with the next block's samples
-    prefetched, persistent with two LDS images, persistent with the response kept in registers - on one stream cut into calls of different sizes (first
-    chunk swallowed, calls shorter than a block, blocks reaching into the history and past the input), each
-    against the chunk-by-chunk oracle; the forms do the same arithmetic in the same order, so their
-    outputs are bit-equal.  RR_FILTER4K_MIN_BLOCKS=1 lets the persistent forms run on calls this small."""
+    2 GS/s) on one stream cut into calls of different sizes (first chunk swallowed, calls shorter than a block,
+    blocks reaching into the history and past the input, the history handed from call to call by the kernel
+    itself), against the chunk-by-chunk oracle; nothing is written past the produced samples."""
     import torch
 
     fs = 2e9
@@ -622,27 +620,26 @@ def test_filter_block4096_variants(rr, oracle, n, monkeypatch):
     r64 = np.concatenate([o64.process(fs, x[i * n : (i + 1) * n]) for i in range(sum(ks))][1:])
     r32 = np.concatenate([o32.process(fs, x[i * n : (i + 1) * n]) for i in range(sum(ks))][1:])
     d_in = torch.from_numpy(x).cuda()
-    outs = {}
-    monkeypatch.setenv("RR_FILTER4K_MIN_BLOCKS", "1")
     monkeypatch.setenv("RR_FILTER_KERNEL", "ols4096")  # (n = 256 would otherwise take k_filter_wave for the long calls)
-    for variant in (0, 1, 2, 3, -1):
-        monkeypatch.setenv("RR_FILTER4K_VARIANT", str(variant))
-        g = rr.Filter.new(lowpass(200e6))
-        g.set_stream(torch.cuda.current_stream().cuda_stream)
-        d_out = torch.zeros_like(d_in)
-        off = wrote = 0
-        for k in ks:
-            made = g.process_dev(fs, n, d_in.data_ptr() + 8 * off, n * k, d_out.data_ptr() + 8 * wrote, n * k)
-            assert g.last_kernel() == (2 if made else 0)
-            wrote += made
-            off += n * k
-        torch.cuda.synchronize()
-        assert wrote == n * (sum(ks) - 1)
-        got = d_out.cpu().numpy()
-        assert not np.any(got[wrote:]), "wrote past the produced samples"
-        check(got[:wrote], r64, r32)
-        outs[variant] = got[:wrote]
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]) and np.array_equal(outs[0], outs[3])
+    g = rr.Filter.new(lowpass(200e6))
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_out = torch.zeros_like(d_in)
+    off = wrote = 0
+    for k in ks:
+        made = g.process_dev(fs, n, d_in.data_ptr() + 8 * off, n * k, d_out.data_ptr() + 8 * wrote, n * k)
+        assert g.last_kernel() == (2 if made else 0)
+        wrote += made
+        off += n * k
+    torch.cuda.synchronize()
+    assert wrote == n * (sum(ks) - 1)
+    got = d_out.cpu().numpy()
+    assert not np.any(got[wrote:]), "wrote past the produced samples"
+    check(got[:wrote], r64, r32)
+    # the seams between calls (history written by the previous call's kernel)
+    edge = 0
+    for k in ks[1:-1]:
+        edge += n * k
+        check(got[edge - n : edge + n], r64[edge - n : edge + n])
 
 
 def test_filter_f16_unsupported(rr):
