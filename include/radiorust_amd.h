@@ -225,8 +225,10 @@ int rr_downsampler_process_dev(rr_downsampler *h, double input_rate,
 int rr_downsampler_ir_len(const rr_downsampler *h, size_t *ir_len);
 /* Which kernel the last process call ran: 0 = k_fir (any ratio, any dtype); integer ratios 2, 4, 8
  * in f32 and calls of >= 4096 samples take the chain's fused kernels with an all-ones NCO table
- * (1 k_mix_fir_decim, 2 k_ols_decim4, 3 k_ols_wave): same result within rounding (tests: 1e-5 RMS
- * against the f64 oracle).  RR_DOWNSAMPLER_GENERIC=1 in the environment keeps k_fir. */
+ * (1 k_mix_fir_decim, 2 k_ols_decim4, 3 k_ols_wave); every other integer ratio P : 1 and rational
+ * ratios P : Q with Q <= 8 (both rates integral; e.g. 10 : 1, 8 : 3) take 5 = k_decim_poly (direct form,
+ * polyphase LDS layout): same result within rounding (tests: 1e-5 RMS against the f64 oracle).
+ * RR_DOWNSAMPLER_GENERIC=1 in the environment keeps k_fir. */
 int rr_downsampler_last_kernel(const rr_downsampler *h, int *kernel);
 int rr_downsampler_destroy(rr_downsampler *h);
 

@@ -370,35 +370,29 @@ int rr_downsampler::process_dev(double input_rate, const void *d_in, size_t n_in
     RR_TRY(select());
     RR_TRY(prepare(input_rate));
     if (n_in == 0) return RR_OK;
-    FirArgs a;
-    a.hist = hist[cur].p;
-    a.hist_len = L;
-    a.in = d_in;
-    a.n_in = n_in;
-    a.taps = d_ir.p;
-    a.K = (uint32_t)L;
-    a.complex_taps = false;
-    a.out = d_out;
-    a.n_out = produce;
-    if (sched.integer_ratio) {
-        a.e0 = sched.first_emit();
-        a.D = (uint32_t)sched.D;
-        if (sched.D > 0xffffffffull) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: decimation factor too large");
-        sched.advance(n_in, nullptr);
-    } else {
-        sched.advance(n_in, &emit);
-        if (produce) {
-            RR_TRY(d_emit.reserve(produce * sizeof(uint32_t)));
-            RR_HIP(hipMemcpyAsync(d_emit.p, emit.data(), produce * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-            RR_HIP(hipStreamSynchronize(stream));  // `emit` is reused by the next call
-        }
-        a.emit = d_emit.as<uint32_t>();
-        a.max_step = (uint32_t)std::ceil(input_rate / output_rate) + 1;
-    }
+    // The schedule (resampling.rs:110-112) is advanced on a COPY; `sched`, `cur` and the history are committed
+    // only after the last launch of this call has been accepted, so that a failing call (a reserve, an upload,
+    // a kernel's precondition) leaves the block where it was.
+    rr::Schedule next = sched;
     last_kernel = 0;
-    if (produce && sched.integer_ratio && n_in >= kFastMinSamples) {
+    if (produce && n_in >= kFastMinSamples) {
         RR_TRY(ensure_fast());
-        if (fast_kind != rr_chain::FK_NONE) {
+        if (fast_kind == rr_chain::FK_POLY) {
+            // any integer ratio, and rational ratios with a short period: k_decim_poly (rr_decim.hip)
+            int64_t e_first[8];
+            sched.first_emits((size_t)std::min<uint64_t>(sched.Q, produce), e_first);
+            for (uint64_t b = produce; b < sched.Q; ++b) e_first[b] = e_first[0];  // (fewer outputs than one period)
+            RR_TRY(ensure_poly_taps(e_first));
+            next.advance(n_in, nullptr);
+            RR_TRY(launch_decim_poly(stream, hist[cur].p, L, d_in, n_in, f_ctaps.p, sched.P, sched.Q, f_NC, L, e_first[0],
+                                     d_out, produce, hist[cur ^ 1].p, L));
+            sched = next;
+            cur ^= 1;
+            last_kernel = fast_kind;
+            if (n_out) *n_out = produce;
+            return RR_OK;
+        }
+        if (fast_kind != rr_chain::FK_NONE && sched.integer_ratio) {
             // the chain's kernels with every phasor = 1: out[m] = sum_i c[i] x[e0 + D m - i], c = reverse(ir);
             // the kernel's last workgroup leaves the last L samples as the next call's history
             FusedFirArgs f;
@@ -413,28 +407,72 @@ int rr_downsampler::process_dev(double input_rate, const void *d_in, size_t n_in
             f.Gp = f_Gp;
             f.out = d_out;
             f.n_out = produce;
-            f.e0 = (int64_t)a.e0;
-            f.D = a.D;
+            f.e0 = (int64_t)sched.first_emit();
+            f.D = (uint32_t)sched.D;
             f.xh_out = hist[cur ^ 1].p;
             f.H = f_H.p;
             f.tw4096 = f_tw.p;
             f.V = f_V;
+            next.advance(n_in, nullptr);
             if (fast_kind == rr_chain::FK_OLSW)
                 RR_TRY(launch_ols_wave(stream, f));
             else if (fast_kind == rr_chain::FK_OLS)
                 RR_TRY(launch_ols_decim(stream, f));
             else
                 RR_TRY(launch_fused_fir(stream, f));
+            sched = next;
             cur ^= 1;
             last_kernel = fast_kind;
             if (n_out) *n_out = produce;
             return RR_OK;
         }
     }
+    FirArgs a;
+    a.hist = hist[cur].p;
+    a.hist_len = L;
+    a.in = d_in;
+    a.n_in = n_in;
+    a.taps = d_ir.p;
+    a.K = (uint32_t)L;
+    a.complex_taps = false;
+    a.out = d_out;
+    a.n_out = produce;
+    if (sched.integer_ratio) {
+        a.e0 = sched.first_emit();
+        a.D = (uint32_t)sched.D;
+        if (sched.D > 0xffffffffull) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: decimation factor too large");
+        next.advance(n_in, nullptr);
+    } else {
+        next.advance(n_in, &emit);
+        if (produce) {
+            RR_TRY(d_emit.reserve(produce * sizeof(uint32_t)));
+            RR_HIP(hipMemcpyAsync(d_emit.p, emit.data(), produce * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            RR_HIP(hipStreamSynchronize(stream));  // `emit` is reused by the next call
+        }
+        a.emit = d_emit.as<uint32_t>();
+        a.max_step = (uint32_t)std::ceil(input_rate / output_rate) + 1;
+    }
     if (produce) RR_TRY(launch_fir(dtype, stream, a));
     RR_TRY(launch_update_hist(dtype, stream, hist[cur].p, hist[cur ^ 1].p, L, d_in, n_in));
+    sched = next;
     cur ^= 1;
     if (n_out) *n_out = produce;
+    return RR_OK;
+}
+
+// k_decim_poly's tap table depends on where in its period the schedule stands at the start of the call (the offsets
+// of the first Q emissions); rebuilt when that changes (calls of a whole number of periods keep it).
+int rr_downsampler::ensure_poly_taps(const int64_t *e_first) {
+    std::vector<int64_t> delta(sched.Q);
+    for (uint64_t b = 0; b < sched.Q; ++b) delta[b] = e_first[b] - e_first[0];
+    if (poly_version == design_version && delta == poly_delta) return RR_OK;
+    std::vector<float> T;
+    int nc = 0;
+    build_decim_poly_taps(ir_f64, sched.P, sched.Q, e_first, T, &nc);
+    RR_TRY(upload(f_ctaps, T.data(), T.size() * sizeof(float), stream));
+    f_NC = nc;
+    poly_delta.swap(delta);
+    poly_version = design_version;
     return RR_OK;
 }
 
@@ -444,10 +482,17 @@ int rr_downsampler::ensure_fast() {
     fast_version = design_version;
     fast_kind = rr_chain::FK_NONE;
     const char *e = std::getenv("RR_DOWNSAMPLER_GENERIC");
-    if (dtype != RR_F32 || !sched.integer_ratio || (e && std::atoi(e) != 0)) return RR_OK;
-    int kind = rr_chain::pick_fused_kernel(sched.D, L, true, 0);
+    if (dtype != RR_F32 || !sched.periodic || (e && std::atoi(e) != 0)) return RR_OK;
+    int kind = sched.integer_ratio ? rr_chain::pick_fused_kernel(sched.D, L, true, 0) : rr_chain::FK_NONE;
     if (kind == rr_chain::FK_OLSF) kind = rr_chain::FK_OLSW;
-    if (kind == rr_chain::FK_NONE) return RR_OK;
+    if (kind == rr_chain::FK_NONE) {
+        // every other integer ratio, and rational ratios with a short period (the tap table follows per call)
+        if (decim_poly_supported(dtype, sched.P, sched.Q, L)) {
+            fast_kind = rr_chain::FK_POLY;
+            poly_version = ~0ull;
+        }
+        return RR_OK;
+    }
     std::vector<double> c(L);
     std::vector<cd> cc(L);
     for (size_t i = 0; i < L; ++i) {

@@ -77,6 +77,11 @@ struct rr_downsampler : rr_block {
     uint64_t fast_version = ~0ull;
     rr::DevBuf f_ctaps, f_H, f_tw, f_one;
     int f_Gp = 0, f_V = 0;
+    // k_decim_poly (any integer ratio, short-period rational ratios): taps in f_ctaps, laid out for the schedule phase
+    int f_NC = 0;
+    uint64_t poly_version = ~0ull;
+    std::vector<int64_t> poly_delta;
+    int ensure_poly_taps(const int64_t *e_first);
     int last_kernel = 0;  // what the last call ran (rr_chain::FK_*, 0 = k_fir)
     int ensure_fast();
     int prepare(double input_rate);
@@ -224,7 +229,7 @@ struct rr_chain : rr_block {
     int ols_N = 4096;  // 4096: k_ols_decim4 (workgroup per block), 1024: k_ols_wave (wave per block)
     rr::DevBuf d_olsH, d_tw4096;
     bool fused_candidate(double sample_rate) const;
-    enum { FK_NONE = 0, FK_DIRECT, FK_OLS, FK_OLSW, FK_OLSF };
+    enum { FK_NONE = 0, FK_DIRECT, FK_OLS, FK_OLSW, FK_OLSF, FK_POLY };  // FK_POLY: k_decim_poly (Downsampler only)
     static int pick_fused_kernel(uint64_t D, size_t lc, bool real_taps, size_t fft_len);
     bool use_frame = false;      // FK_OLSF: k_ols_frame (FIR stage + Fourier in one kernel)
     rr::DevBuf pendbuf[2];       // its pending decimated samples, ping-pong

@@ -276,8 +276,21 @@ void Schedule::configure(double in_rate, double out_rate) {
     integer_ratio = false;
     D = 0;
     phase = 0;
-    if (is_integral(in_rate) && is_integral(out_rate) && out_rate >= 1.0) {
+    periodic = false;
+    ra = rb = P = Q = 0;
+    if (is_integral(in_rate) && is_integral(out_rate) && out_rate >= 1.0 && in_rate >= out_rate) {
         const uint64_t a = static_cast<uint64_t>(in_rate), b = static_cast<uint64_t>(out_rate);
+        uint64_t x = a, y = b;
+        while (y) {
+            const uint64_t t = x % y;
+            x = y;
+            y = t;
+        }
+        periodic = true;
+        ra = a;
+        rb = b;
+        P = a / x;
+        Q = b / x;
         if (a % b == 0) {
             integer_ratio = true;
             D = a / b;
@@ -286,8 +299,27 @@ void Schedule::configure(double in_rate, double out_rate) {
     }
 }
 
+// periodic schedules: pos is an integer in [0, ra); after n inputs pos + n rb has crossed ra that many times
+static inline unsigned __int128 sched_total(double pos, uint64_t rb, size_t n) {
+    return (unsigned __int128)static_cast<uint64_t>(pos) + (unsigned __int128)rb * n;
+}
+
+void Schedule::first_emits(size_t count, int64_t *e) const {
+    if (integer_ratio) {
+        for (size_t m = 0; m < count; ++m) e[m] = (int64_t)(phase + m * D);
+        return;
+    }
+    // output m is released by the first input t (0-based) with pos + (t + 1) rb >= (m + 1) ra
+    const uint64_t p0 = static_cast<uint64_t>(pos);
+    for (size_t m = 0; m < count; ++m) {
+        const unsigned __int128 need = (unsigned __int128)(m + 1) * ra - p0;
+        e[m] = (int64_t)((need + rb - 1) / rb) - 1;
+    }
+}
+
 size_t Schedule::count(size_t n_in) const {
     if (integer_ratio) return n_in > phase ? (n_in - 1 - phase) / D + 1 : 0;
+    if (periodic) return (size_t)(sched_total(pos, rb, n_in) / ra);
     double p = pos;
     size_t c = 0;
     for (size_t t = 0; t < n_in; ++t) {
@@ -312,6 +344,11 @@ size_t Schedule::advance(size_t n_in, std::vector<uint32_t> *emit) {
         phase = D - 1 - k;
         pos = static_cast<double>(k) * output_rate;
         return c;
+    }
+    if (periodic && !emit) {
+        const unsigned __int128 tot = sched_total(pos, rb, n_in);
+        pos = static_cast<double>((uint64_t)(tot % ra));
+        return (size_t)(tot / ra);
     }
     if (emit) emit->clear();
     size_t c = 0;

@@ -100,6 +100,12 @@ struct Schedule {
     size_t count(size_t n_in) const;  // like advance() without changing state
     // integer path only: index of the first emit for the next n_in inputs
     uint64_t first_emit() const { return phase; }
+    // Both rates integral (every f64 operation of resampling.rs:110-112 is then exact): the schedule is periodic,
+    // every P = in / g inputs release Q = out / g outputs (g = gcd).  count() and advance() without an emit list run
+    // in closed form; first_emits() gives the 0-based input indices that trigger the next `count` outputs.
+    bool periodic = false;
+    uint64_t ra = 0, rb = 0, P = 0, Q = 0;
+    void first_emits(size_t count, int64_t *e) const;
 };
 
 // The interpolation schedule of resampling.rs:248-265, run on the host: how many outputs each

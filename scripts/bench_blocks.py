@@ -47,6 +47,21 @@ os.environ.pop("RR_DOWNSAMPLER_GENERIC", None)
 ds8 = rr.Downsampler.new(4096, 48000.0, 40000.0)
 ds8.set_stream(st)
 run("Downsampler 384->48 kS/s L=288 (D=8)", 9, lambda: ds8.process_dev(384000.0, d_in.data_ptr(), N, d_out.data_ptr(), N))
+# the reference's own pipelines: bandwidth_meter/main.rs:56 (10 : 1, L = 145) and simple_receiver.rs:28 (8 : 3, L = 34)
+for name, fin, fout, bw, bps in (("Downsampler 1024->102.4 kS/s L=145 (10:1)", 1024000.0, 102400.0, 60000.0, 8.8),
+                                 ("Downsampler 1024->384 kS/s L=34 (8:3)", 1024000.0, 384000.0, 200000.0, 11.0),
+                                 ("Downsampler 300->100 kS/s (3:1)", 300000.0, 100000.0, 60000.0, 8 + 8 / 3),
+                                 ("Downsampler 48->32 kS/s (3:2)", 48000.0, 32000.0, 20000.0, 8 + 16 / 3)):
+    for generic in (False, True):
+        if generic:
+            os.environ["RR_DOWNSAMPLER_GENERIC"] = "1"
+        dsx = rr.Downsampler.new(4096, fout, bw)
+        dsx.set_stream(st)
+        run(name + (" (k_fir)" if generic else ""), round(bps, 2), lambda: dsx.process_dev(fin, d_in.data_ptr(), N, d_out.data_ptr(), N),
+            K=3 if generic else 10)
+        if not generic:
+            print("   kernel:", dsx.last_kernel(), " L =", dsx.ir_len())
+        os.environ.pop("RR_DOWNSAMPLER_GENERIC", None)
 fo = rr.Fourier.with_window(rr.Kaiser.with_null_at_bin(2.0))
 fo.set_stream(st)
 run("Fourier 4096 Kaiser(null@2)", 16, lambda: fo.process_dev(4096, d_in.data_ptr(), N, d_out.data_ptr(), N))

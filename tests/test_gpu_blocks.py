@@ -353,14 +353,23 @@ def test_downsampler_parity(rr, oracle, fin, fout, bw, q):
 
 
 # integer ratios 2, 4, 8 in f32: calls of >= 4096 samples run the chain's fused kernels with an all-ones
-# NCO table (rr_downsampler_last_kernel: 1 k_mix_fir_decim, 2 k_ols_decim4, 3 k_ols_wave), shorter
-# ones k_fir; the stream of outputs must not notice the switches
+# NCO table (rr_downsampler_last_kernel: 1 k_mix_fir_decim, 2 k_ols_decim4, 3 k_ols_wave), other periodic
+# schedules k_decim_poly (5), shorter calls k_fir; the stream of outputs must not notice the switches
 FAST_CASES = [
     (200e6, 50e6, 40e6, 3.0, 3),      # cfg2's Downsampler: L = 120, D = 4 -> k_ols_wave
     (200e6, 50e6, 47e6, 3.0, 2),      # L = 400: beyond k_ols_wave's overlap -> k_ols_decim4
     (200e6, 50e6, 30e6, 3.0, 1),      # L = 60: short -> k_mix_fir_decim
     (384000.0, 48000.0, 40000.0, 3.0, 1),   # the reference's simple_receiver second stage: D = 8, L = 288
     (96000.0, 48000.0, 30000.0, 3.0, 1),    # D = 2
+    # every other integer ratio and rational ratios with a short period: k_decim_poly (5), rr_decim.hip
+    (1024000.0, 102400.0, 60000.0, 3.0, 5),   # examples/bandwidth_meter/main.rs:56: 10 : 1, L = 145
+    (1024000.0, 384000.0, 200000.0, 3.0, 5),  # examples/simple_receiver.rs:28: 8 : 3, L = 34
+    (300000.0, 100000.0, 60000.0, 3.0, 5),    # 3 : 1
+    (48000.0, 32000.0, 20000.0, 2.0, 5),      # 3 : 2
+    (700000.0, 300000.0, 100000.0, 3.5, 5),   # 7 : 3
+    (2560000.0, 40000.0, 30000.0, 1.5, 5),    # 64 : 1, L = 768: tiles of 64 periods
+    (45000.0, 40000.0, 30000.0, 1.0, 5),      # 9 : 8, the longest period served
+    (48000.0, 44100.0, 30000.0, 2.0, 0),      # 160 : 147: period too long -> k_fir with the emission list
 ]
 
 
