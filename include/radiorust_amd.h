@@ -192,7 +192,7 @@ int rr_filter_process_dev(rr_filter *h, double sample_rate, const void *d_in,
  * rr_filter_process_dev, but d_out_f16 receives out_cap {half re, half im} pairs
  * (12 instead of 16 algorithmic bytes per sample); response_f16 != 0 also reads the
  * filter's frequency response from a table rounded to half.  Complex<f32> handles with
- * n in {256, 512, 1024, 2048} (the overlap-save kernel); RR_ERR_BAD_ARG otherwise. */
+ * n = 129 .. 2048 (the overlap-save kernel); RR_ERR_BAD_ARG otherwise. */
 int rr_filter_process_dev_f16(rr_filter *h, double sample_rate, const void *d_in,
                               size_t n_in, void *d_out_f16, size_t out_cap, size_t *n_out,
                               int response_f16);

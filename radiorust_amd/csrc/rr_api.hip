@@ -185,25 +185,35 @@ int rr_filter::design(double sample_rate, size_t len, const rr_c64 *resp, const 
     // shorter power-of-two filters: the same kernel for long calls (a 4096-block per 4096 - n outputs),
     // k_fir for short ones
     big_ols4096 = dtype == RR_F32 && (len == 64 || len == 128);
-    if (use_ols4096 || big_ols4096) {
-        std::vector<cd> gg(4096, cd(0, 0));
-        for (size_t i = 0; i < len; ++i) gg[i] = g[i];
-        fft_f64(gg, false);
-        std::vector<float> gb(2 * 4096), twb(2 * 4096);
+    // longer ones: partitions of 2048 taps, g = sum_p delay(g_p, 2048 p), one accumulating launch per partition
+    npart = (dtype == RR_F32 && len > 2048) ? (len + 2047) / 2048 : 0;
+    if (use_ols4096 || big_ols4096 || npart) {
+        const size_t parts = npart ? npart : 1;
+        std::vector<float> gb(parts * 2 * 4096), twb(2 * 4096);
+        for (size_t pt = 0; pt < parts; ++pt) {
+            std::vector<cd> gg(4096, cd(0, 0));
+            for (size_t i = 0; i < 2048 && pt * 2048 + i < len; ++i) gg[i] = g[pt * 2048 + i];
+            fft_f64(gg, false);
+            float *dst0 = gb.data() + pt * 2 * 4096;
+            for (size_t i = 0; i < 4096; ++i) {
+                // pair-interleaved for 16-byte reads: Gp[kp][j] = {G[j + 512 kp], G[j + 512 kp + 256]}, j < 256
+                const size_t kp = i / 512, r = i % 512, dst = (kp * 256 + r % 256) * 2 + r / 256;
+                dst0[2 * dst] = (float)(gg[i].real() / 4096.0);
+                dst0[2 * dst + 1] = (float)(gg[i].imag() / 4096.0);
+            }
+        }
         for (size_t i = 0; i < 4096; ++i) {
-            // pair-interleaved for 16-byte reads: Gp[kp][j] = {G[j + 512 kp], G[j + 512 kp + 256]}, j < 256
-            const size_t kp = i / 512, r = i % 512, dst = (kp * 256 + r % 256) * 2 + r / 256;
-            gb[2 * dst] = (float)(gg[i].real() / 4096.0);
-            gb[2 * dst + 1] = (float)(gg[i].imag() / 4096.0);
             const double ang = -2.0 * M_PI * (double)i / 4096.0;
             twb[2 * i] = (float)std::cos(ang);
             twb[2 * i + 1] = (float)std::sin(ang);
         }
         RR_TRY(upload(d_G4096, gb.data(), gb.size() * sizeof(float), stream));
         RR_TRY(upload(d_tw4096, twb.data(), twb.size() * sizeof(float), stream));
-        std::vector<uint16_t> gh(gb.size());
-        for (size_t i = 0; i < gb.size(); ++i) gh[i] = f32_to_f16_bits(gb[i]);
-        RR_TRY(upload(d_G4096h, gh.data(), gh.size() * sizeof(uint16_t), stream));
+        if (!npart) {
+            std::vector<uint16_t> gh(gb.size());
+            for (size_t i = 0; i < gb.size(); ++i) gh[i] = f32_to_f16_bits(gb[i]);
+            RR_TRY(upload(d_G4096h, gh.data(), gh.size() * sizeof(uint16_t), stream));
+        }
     }
     {
         const char *e = std::getenv("RR_FILTER_KERNEL");  // "ols4096" / "fir" keep the older kernels (A/B runs, tests)
@@ -219,7 +229,7 @@ int rr_filter::design(double sample_rate, size_t len, const rr_c64 *resp, const 
         RR_TRY(upload(d_tww, t.tw.data(), t.tw.size() * sizeof(float), stream));
         wave_V = t.V;
     }
-    use_ols = !use_ols4096 && !big_ols4096 && ols_supported(dtype, len);
+    use_ols = !use_ols4096 && !big_ols4096 && !npart && ols_supported(dtype, len);
     if (use_ols) {
         // the reference's extended response (filters.rs:220-238), transformed in f64 here
         std::vector<cd> ext(2 * len, cd(0, 0));
@@ -267,7 +277,7 @@ int rr_filter::process_dev(double sample_rate, const void *d_in, size_t n_in, vo
                            size_t *n_out, bool out_f16, bool g_f16) {
     if (n_out) *n_out = 0;
     if ((out_f16 || g_f16) && !(designed && use_ols4096))
-        RR_FAIL(RR_ERR_BAD_ARG, "Filter: half-precision output/response exists for Complex<f32>, n in {256, 512, 1024, 2048}");
+        RR_FAIL(RR_ERR_BAD_ARG, "Filter: half-precision output/response exists for Complex<f32>, n = 129 .. 2048");
     if (!designed || params_changed || sample_rate != rate)
         RR_FAIL(RR_ERR_NEED_DESIGN, "Filter: no design for sample rate %g (filters.rs:178-183)", sample_rate);
     if (n_in == 0) return RR_OK;
@@ -281,6 +291,19 @@ int rr_filter::process_dev(double sample_rate, const void *d_in, size_t n_in, vo
         RR_TRY(launch_filter_wave(stream, hist[cur].p, hist_valid ? n : 0, d_in, n_in, d_Hw.p, d_tww.p, wave_V, d_out, produce,
                                   hist_valid ? 0 : (long)n));
         last_kernel = 3;
+    } else if (produce && npart) {
+        last_kernel = 2;
+        // out[m] = sum_p sum_{k < 2048} g[2048 p + k] x[e0 + m - 2048 p - k]: partition p is the 2048-tap kernel run on
+        // the stream delayed by 2048 p; the last launch also leaves the next call's history
+        for (size_t pt = 0; pt < npart; ++pt)
+            RR_TRY(launch_filter_blk4096(stream, hist[cur].p, hist_valid ? n : 0, d_in, n_in,
+                                         static_cast<const char *>(d_G4096.p) + pt * 2 * 4096 * sizeof(float), d_tw4096.p, 2048,
+                                         d_out, produce, (hist_valid ? 0 : (long)n) - (long)(2048 * pt), false, false,
+                                         pt + 1 == npart ? hist[cur ^ 1].p : nullptr, n, pt > 0));
+        cur ^= 1;
+        hist_valid = true;
+        if (n_out) *n_out = produce;
+        return RR_OK;
     } else if (produce && (use_ols4096 || (big_ols4096 && produce >= kFilterBigCall))) {
         last_kernel = 2;
         // (the kernel's last workgroup also leaves the next call's history)
@@ -466,11 +489,11 @@ int rr_downsampler::ensure_poly_taps(const int64_t *e_first) {
     std::vector<int64_t> delta(sched.Q);
     for (uint64_t b = 0; b < sched.Q; ++b) delta[b] = e_first[b] - e_first[0];
     if (poly_version == design_version && delta == poly_delta) return RR_OK;
-    std::vector<float> T;
-    int nc = 0;
-    build_decim_poly_taps(ir_f64, sched.P, sched.Q, e_first, T, &nc);
-    RR_TRY(upload(f_ctaps, T.data(), T.size() * sizeof(float), stream));
-    f_NC = nc;
+    std::vector<uint32_t> T;
+    int lp = 0;
+    build_decim_poly_taps(ir_f64, sched.P, sched.Q, e_first, T, &lp);
+    RR_TRY(upload(f_ctaps, T.data(), T.size() * sizeof(uint32_t), stream));
+    f_NC = lp;
     poly_delta.swap(delta);
     poly_version = design_version;
     return RR_OK;

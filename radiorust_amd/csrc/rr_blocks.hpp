@@ -29,7 +29,8 @@ struct rr_filter : rr_block {
     rr::DevBuf d_taps;             // w[j] = g[n-1-j] as T or complex<T>
     bool use_ols = false;          // long power-of-two filters: overlap-save fast convolution
     rr::DevBuf d_H, d_olstw;       // H = FFT_2n([0 | g / 2n]) and e^{-j 2 pi k / 2n}, k < n
-    bool use_ols4096 = false;      // f32, n in {256..2048}: 4096-point blocks, radix-16 kernel
+    bool use_ols4096 = false;      // f32, n = 129 .. 2048: 4096-point blocks, radix-16 kernel
+    size_t npart = 0;              // f32, n > 2048: that kernel once per partition of 2048 taps, accumulating
     bool big_ols4096 = false;      // f32, n in {64, 128}: the same for calls of >= 16384 outputs
     bool use_wave = false;         // f32, n <= 385: k_filter_wave (a wave per 1024-block) for calls of >= 16384 outputs
     rr::DevBuf d_Hw, d_tww;        // its tables (DFT_1024(g) / 1024 pair-interleaved; twiddles + lane seeds)

@@ -17,9 +17,10 @@
 // in LDS in POLYPHASE layout: the sample at position p_ref + P c + r sits at row r, column c (row stride S).
 // Output (a, b) then reads, for the taps of row r, the columns a + c, c = 0 .. NC - 1: the 64 lanes of a wave
 // (consecutive a, one b) read 64 consecutive LDS elements — conflict-free for every P — at addresses
-// (lane term) + immediate.  The host lays the taps out to match, T[b][r][c] (zero where row r has no tap in
-// column c), so the tap stream of a wave is one contiguous array read through the scalar cache.
-// Per tap and lane: one 8-byte LDS read and one packed FMA.
+// (lane term) + a wave-uniform offset.  The host hands the taps over as a flat list per phase b,
+// T[b][j] = { ir[j], byte offset of (row, column) of tap j }, read through the scalar cache (8 taps per
+// s_load_dwordx16): exactly L taps per output whatever P is.  Per tap and lane: one 8-byte LDS read, one
+// address add and one packed FMA.
 //
 // LDS per workgroup: P (TA + NC) samples (10 : 1, L = 145: 21.8 KiB, 7 workgroups per CU).  HBM traffic:
 // 8 B read per input sample + 8 Q / P written = the algorithmic minimum; neighbouring tiles (which share
@@ -40,8 +41,8 @@ struct DecimArgs {
     int hist_len;
     const float2 *in;
     long n_in;
-    int P, Q, NC;
-    long p_ref;  // position (relative to in[0]) of tap 0 of output 0
+    int P, Q, NC, Lp;  // NC: tap columns (geometry only); Lp: taps per phase, padded to a multiple of 8
+    long p_ref;        // position (relative to in[0]) of tap 0 of output 0
     float2 *out;
     long n_out;
     int TA;  // periods per tile (a multiple of 64)
@@ -53,7 +54,7 @@ struct DecimArgs {
 
 // (T is a parameter of its own, const and restrict: only then does the compiler read the wave-uniform taps through
 //  the scalar cache; as a member of the argument struct they came as per-lane vector loads, waited for in every trip)
-__global__ __launch_bounds__(256) void k_decim_poly(DecimArgs a, const float *__restrict__ T) {
+__global__ __launch_bounds__(256) void k_decim_poly(DecimArgs a, const uint2 *__restrict__ T) {
     extern __shared__ __attribute__((aligned(16))) char decim_smem[];
     f2 *const xs = reinterpret_cast<f2 *>(decim_smem);  // P rows of S samples
     f2 *const ost = xs + (size_t)a.P * a.S;             // Q > 1: TA Q staged outputs
@@ -63,10 +64,10 @@ __global__ __launch_bounds__(256) void k_decim_poly(DecimArgs a, const float *__
     const unsigned grp = blockIdx.x / (8 * G), rem = blockIdx.x % (8 * G);
     const unsigned tile = grp * 8 * G + (rem & 7) * G + (rem >> 3);
     if (tile >= a.ntiles) return;
-    const int P = a.P, Q = a.Q, NC = a.NC, TA = a.TA, S = a.S;
+    const int P = a.P, Q = a.Q, TA = a.TA, S = a.S;
     const long a0 = (long)tile * TA;
     const long p_lo = a.p_ref + (long)P * a0;  // position of row 0, column 0
-    const int nld = P * (TA + NC);             // samples of the tile, row-major in time: q = P c + r
+    const int nld = P * (TA + a.NC);           // samples of the tile, row-major in time: q = P c + r
 
     if (a.hist_out && tile == a.ntiles - 1) {
         for (int i = t; i < a.hist_out_len; i += 256) {
@@ -80,23 +81,35 @@ __global__ __launch_bounds__(256) void k_decim_poly(DecimArgs a, const float *__
         }
     }
 
-    // ---- stage: coalesced 8-byte loads, polyphase scatter into LDS ---------------------------------------
+    // ---- stage: coalesced 8-byte loads (8 in flight per lane), polyphase scatter into LDS ------------------
     {
         int row = t % P, col = t / P;
         const int dr = 256 % P, dc = 256 / P;
+        auto step = [&] {
+            row += dr;
+            col += dc;
+            if (row >= P) {
+                row -= P;
+                ++col;
+            }
+        };
         const bool interior = p_lo >= 0 && p_lo + nld <= a.n_in;
         if (interior) {
             const f2 *src = reinterpret_cast<const f2 *>(a.in + p_lo);
-#pragma unroll 4
-            for (int q = t; q < nld; q += 256) {
-                const f2 v = __builtin_nontemporal_load(src + q);
-                xs[row * S + col] = v;
-                row += dr;
-                col += dc;
-                if (row >= P) {
-                    row -= P;
-                    ++col;
+            int q = t;
+            for (; q + 7 * 256 < nld; q += 8 * 256) {
+                f2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + q + 256 * u);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    xs[row * S + col] = v[u];
+                    step();
                 }
+            }
+            for (; q < nld; q += 256) {
+                xs[row * S + col] = __builtin_nontemporal_load(src + q);
+                step();
             }
         } else {
             // edges: the history in front (zeros before it), nothing behind the input
@@ -111,12 +124,7 @@ __global__ __launch_bounds__(256) void k_decim_poly(DecimArgs a, const float *__
                     xv = a.hist[a.hist_len + pos];
                 }
                 xs[row * S + col] = (f2){xv.x, xv.y};
-                row += dr;
-                col += dc;
-                if (row >= P) {
-                    row -= P;
-                    ++col;
-                }
+                step();
             }
         }
     }
@@ -128,20 +136,18 @@ __global__ __launch_bounds__(256) void k_decim_poly(DecimArgs a, const float *__
     for (int task = w; task < ntask; task += 4) {
         const int b = task / segs, seg = task - b * segs;
         const int al = seg * 64 + lane;
-        const f2 *base = xs + al;
-        const float *tb = T + (size_t)b * P * NC;
+        const char *base = reinterpret_cast<const char *>(xs + al);
+        const uint2 *tl = T + (size_t)b * a.Lp;
         f2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
-        for (int r = 0; r < P; ++r) {
-            const f2 *row = base + r * S;
-            const float *tr = tb + r * NC;
-#pragma unroll 4
-            for (int c = 0; c < NC; c += 4) {
-                const float4 t4 = *reinterpret_cast<const float4 *>(tr + c);  // uniform address: a scalar read
-                const f2 x0 = lds_ldv(row + c), x1 = lds_ldv(row + c + 1), x2 = lds_ldv(row + c + 2), x3 = lds_ldv(row + c + 3);
-                acc0 = __builtin_elementwise_fma(x0, (f2){t4.x, t4.x}, acc0);
-                acc1 = __builtin_elementwise_fma(x1, (f2){t4.y, t4.y}, acc1);
-                acc0 = __builtin_elementwise_fma(x2, (f2){t4.z, t4.z}, acc0);
-                acc1 = __builtin_elementwise_fma(x3, (f2){t4.w, t4.w}, acc1);
+        for (int i = 0; i < a.Lp; i += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                const uint2 e0 = tl[i + u], e1 = tl[i + u + 1];  // uniform addresses: scalar reads
+                const f2 x0 = lds_ldv(reinterpret_cast<const f2 *>(base + e0.y));
+                const f2 x1 = lds_ldv(reinterpret_cast<const f2 *>(base + e1.y));
+                const float t0 = __uint_as_float(e0.x), t1 = __uint_as_float(e1.x);
+                acc0 = __builtin_elementwise_fma(x0, (f2){t0, t0}, acc0);
+                acc1 = __builtin_elementwise_fma(x1, (f2){t1, t1}, acc1);
             }
         }
         const f2 acc = acc0 + acc1;
@@ -164,50 +170,57 @@ __global__ __launch_bounds__(256) void k_decim_poly(DecimArgs a, const float *__
 
 }  // namespace
 
-// LDS budget per workgroup: 4 or more workgroups per CU
-static constexpr size_t kDecimLds = 40 * 1024;
+// LDS per workgroup: tiles of about 24 KiB (6 workgroups per CU) where the period allows, never more than 64 KiB
+static constexpr size_t kDecimLdsTarget = 24 * 1024, kDecimLdsMax = 64 * 1024;
+
+static size_t decim_nc(uint64_t P, size_t L) { return (P - 1 + L + P - 1) / P; }  // tap columns for any phase offset
 
 static int decim_geometry(size_t P, size_t Q, size_t NC, int *TA, int *S) {
-    for (int ta : {256, 128, 64}) {
+    int best = 0;
+    for (int ta : {1024, 512, 256, 128, 64}) {
         int s = ta + (int)NC;
         if (!(s & 1)) ++s;  // odd row stride: the staging writes of neighbouring rows fall on different banks
         const size_t bytes = (P * (size_t)s + (Q > 1 ? (size_t)ta * Q : 0)) * 8;
-        if (bytes <= kDecimLds) {
+        if (bytes <= kDecimLdsTarget || (ta == 64 && bytes <= kDecimLdsMax)) {
             *TA = ta;
             *S = s;
-            return (int)bytes;
+            best = (int)bytes;
+            break;
         }
     }
-    return 0;
+    return best;
 }
 
 bool decim_poly_supported(int dtype, uint64_t P, uint64_t Q, size_t L) {
     if (dtype != RR_F32 || P < 2 || P > 512 || Q < 1 || Q > 8 || Q >= P || L < 1) return false;
-    const size_t NC = ((P - 1 + L + P - 1) / P + 3) / 4 * 4;
     int ta, s;
-    return decim_geometry(P, Q, NC, &ta, &s) != 0;
+    return decim_geometry(P, Q, decim_nc(P, L), &ta, &s) != 0;
 }
 
-// taps in the kernel's order: T[b][r][c] = ir[j] for (delta_b + j) = P c + r, zero elsewhere; delta_b = e[b] - e[0]
-void build_decim_poly_taps(const std::vector<double> &ir, uint64_t P, uint64_t Q, const int64_t *e_first, std::vector<float> &T,
-                           int *NC_out) {
-    const size_t L = ir.size();
-    size_t maxd = 0;
-    for (uint64_t b = 0; b < Q; ++b) maxd = std::max(maxd, (size_t)(e_first[b] - e_first[0]));
-    const size_t NC = ((maxd + L + P - 1) / P + 3) / 4 * 4;
-    T.assign((size_t)Q * P * NC, 0.f);
+// taps in the kernel's order: T[b][j] = { ir[j], byte offset of tap j's (row, column) }, (delta_b + j) = P column + row,
+// delta_b = e[b] - e[0]; padded to a multiple of 8 taps per phase with { 0, 0 }
+void build_decim_poly_taps(const std::vector<double> &ir, uint64_t P, uint64_t Q, const int64_t *e_first, std::vector<uint32_t> &T,
+                           int *Lp_out) {
+    const size_t L = ir.size(), Lp = (L + 7) / 8 * 8;
+    int ta = 0, S = 0;
+    decim_geometry(P, Q, decim_nc(P, L), &ta, &S);
+    T.assign((size_t)Q * Lp * 2, 0u);
     for (uint64_t b = 0; b < Q; ++b) {
         const size_t d = (size_t)(e_first[b] - e_first[0]);
         for (size_t j = 0; j < L; ++j) {
             const size_t idx = d + j, r = idx % P, c = idx / P;
-            T[((size_t)b * P + r) * NC + c] = (float)ir[j];
+            const float tap = (float)ir[j];
+            uint32_t bits;
+            std::memcpy(&bits, &tap, 4);
+            T[((size_t)b * Lp + j) * 2] = bits;
+            T[((size_t)b * Lp + j) * 2 + 1] = (uint32_t)((r * (size_t)S + c) * 8);
         }
     }
-    *NC_out = (int)NC;
+    *Lp_out = (int)Lp;
 }
 
 int launch_decim_poly(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *T,
-                      uint64_t P, uint64_t Q, int NC, size_t L, int64_t e_first0, void *out, size_t n_out, void *hist_out,
+                      uint64_t P, uint64_t Q, int Lp, size_t L, int64_t e_first0, void *out, size_t n_out, void *hist_out,
                       size_t hist_out_len) {
     if (n_out == 0) return RR_OK;
     DecimArgs a;
@@ -217,21 +230,22 @@ int launch_decim_poly(hipStream_t s, const void *hist, size_t hist_len, const vo
     a.n_in = (long)n_in;
     a.P = (int)P;
     a.Q = (int)Q;
-    a.NC = NC;
+    a.NC = (int)decim_nc(P, L);
+    a.Lp = Lp;
     a.p_ref = (long)e_first0 - (long)(L - 1);
     a.out = (float2 *)out;
     a.n_out = (long)n_out;
     a.hist_out = (float2 *)hist_out;
     a.hist_out_len = (int)hist_out_len;
-    const int lds = decim_geometry(P, Q, (size_t)NC, &a.TA, &a.S);
+    const int lds = decim_geometry(P, Q, (size_t)a.NC, &a.TA, &a.S);
     if (!lds) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: %llu : %llu with %d tap columns does not fit the LDS tile",
-                      (unsigned long long)P, (unsigned long long)Q, NC);
+                      (unsigned long long)P, (unsigned long long)Q, a.NC);
     const size_t per_tile = (size_t)a.TA * Q;
     const size_t ntiles = (n_out + per_tile - 1) / per_tile;
     if (ntiles > 0x7ffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: too many tiles");
     a.ntiles = (unsigned)ntiles;
     const unsigned grid = (unsigned)((ntiles + 63) / 64 * 64);
-    hipLaunchKernelGGL(k_decim_poly, dim3(grid), dim3(256), (size_t)lds, s, a, (const float *)T);  // T: [Q][P][NC] taps
+    hipLaunchKernelGGL(k_decim_poly, dim3(grid), dim3(256), (size_t)lds, s, a, (const uint2 *)T);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }

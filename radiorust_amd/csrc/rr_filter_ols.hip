@@ -89,7 +89,9 @@ struct Blk4096Args {
     int hist_out_len;
 };
 
-template <bool OUT16, bool G16>
+// ACC: the block's results are added to what `out` holds (responses longer than 2048 taps run as partitions of 2048,
+// one launch each, the later ones delayed by 2048 p samples and accumulating).
+template <bool OUT16, bool G16, bool ACC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_filter_blk4096(Blk4096Args a) {
     __shared__ __attribute__((aligned(16))) f2 img[kImg];
     __shared__ __attribute__((aligned(16))) f2 tab[kTab];
@@ -237,6 +239,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     char *obase = reinterpret_cast<char *>(a.out) + mbase * esz;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(obase, 0, recs, 0x00020000);
     const unsigned lane_off = (unsigned)(hop - j) * (unsigned)esz;
+    if constexpr (ACC && !OUT16) {
+        f2 old[16];  // (lanes outside the block's valid part read zeros and store nothing)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) old[k] = buf_ld_f2<0>(rs, lane_off - (unsigned)(256 * k * esz), 0);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] += old[k];
+    }
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const unsigned off = lane_off - (unsigned)(256 * k * esz);
@@ -253,8 +262,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 int launch_filter_blk4096(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *G,
                           const void *tw4096, size_t n, void *out, size_t n_out, long e0, bool out_f16, bool g_f16,
-                          void *hist_out, size_t hist_out_len) {
+                          void *hist_out, size_t hist_out_len, bool accumulate) {
     if (n_out == 0) return RR_OK;
+    if (accumulate && (out_f16 || g_f16)) RR_FAIL(RR_ERR_BAD_ARG, "Filter: partitions accumulate in f32");
     Blk4096Args a;
     a.hist = (const float2 *)hist;
     a.hist_len = (int)hist_len;
@@ -283,12 +293,14 @@ int launch_filter_blk4096(hipStream_t s, const void *hist, size_t hist_len, cons
         a.blk_hi = (unsigned)hi;
     }
     const unsigned grid = (unsigned)((nblocks + 127) / 128 * 128);
-    if (out_f16) {
-        if (g_f16) hipLaunchKernelGGL((k_filter_blk4096<true, true>), dim3(grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((k_filter_blk4096<true, false>), dim3(grid), dim3(256), 0, s, a);
+    if (accumulate) {
+        hipLaunchKernelGGL((k_filter_blk4096<false, false, true>), dim3(grid), dim3(256), 0, s, a);
+    } else if (out_f16) {
+        if (g_f16) hipLaunchKernelGGL((k_filter_blk4096<true, true, false>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_filter_blk4096<true, false, false>), dim3(grid), dim3(256), 0, s, a);
     } else {
-        if (g_f16) hipLaunchKernelGGL((k_filter_blk4096<false, true>), dim3(grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((k_filter_blk4096<false, false>), dim3(grid), dim3(256), 0, s, a);
+        if (g_f16) hipLaunchKernelGGL((k_filter_blk4096<false, true, false>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_filter_blk4096<false, false, false>), dim3(grid), dim3(256), 0, s, a);
     }
     RR_HIP(hipGetLastError());
     return RR_OK;

@@ -2805,9 +2805,7 @@ int launch_ols_decim(hipStream_t s, const FusedFirArgs &a) {
     return RR_OK;
 }
 
-bool filter_ols4096_supported(int dtype, size_t n) {
-    return dtype == RR_F32 && (n == 256 || n == 512 || n == 1024 || n == 2048);
-}
+bool filter_ols4096_supported(int dtype, size_t n) { return dtype == RR_F32 && n >= 129 && n <= 2048; }
 
 // tail drop on an interrupt: new[i] = old[i - drop] (zeros shifted in at the front)
 __global__ void k_drop_tail(const float2 *__restrict__ oldh, float2 *__restrict__ newh, int H, int drop) {

@@ -168,71 +168,89 @@ __global__ __launch_bounds__(256) void k_fir(const v2<T> *__restrict__ hist, lon
                                              const v2<T> *__restrict__ in, long n_in,
                                              const typename TapType<T, CT>::type *__restrict__ taps, int K,
                                              v2<T> *__restrict__ out, size_t n_out, unsigned long long e0, uint32_t D,
-                                             const uint32_t *__restrict__ emit, uint32_t outs_per_block) {
+                                             const uint32_t *__restrict__ emit, uint32_t outs_per_block, int Kc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     v2<T> *xs = reinterpret_cast<v2<T> *>(smem);
     const size_t m0 = (size_t)blockIdx.x * outs_per_block;
     if (m0 >= n_out) return;
     const size_t m1 = (m0 + outs_per_block < n_out) ? m0 + outs_per_block : n_out;
     auto e_of = [&](size_t m) -> long { return LIST ? (long)emit[m] : (long)(e0 + m * (unsigned long long)D); };
-    const long lo = e_of(m0) - (K - 1);
     const long hi = e_of(m1 - 1);
-    for (long i = lo + threadIdx.x; i <= hi; i += blockDim.x) {
-        v2<T> v;
-        v.x = 0;
-        v.y = 0;
-        if (i >= 0) {
-            if (i < n_in) v = in[i];
-        } else if (i >= -hist_len) {
-            v = hist[hist_len + i];
-        }
-        xs[i - lo] = v;
-    }
-    __syncthreads();
-    for (size_t mb = m0 + threadIdx.x; mb < m1; mb += (size_t)blockDim.x * R) {
-        int base[R];
-        v2<T> acc[R];
+    // Long responses are taken Kc taps at a time (Kc = K when the whole span fits the LDS tile): per pass the
+    // tile holds the samples those taps touch, the partial sums stay in registers.  With more than one pass a
+    // workgroup has at most 256 R outputs (the launcher's duty), i.e. one round of the output loop.
+    const bool one_pass = Kc >= K;
+    v2<T> acc_keep[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const size_t m = mb + (size_t)r * blockDim.x;
-            base[r] = (m < m1) ? (int)(e_of(m) - (K - 1) - lo) : 0;
-            acc[r].x = 0;
-            acc[r].y = 0;
+    for (int r = 0; r < R; ++r) {
+        acc_keep[r].x = 0;
+        acc_keep[r].y = 0;
+    }
+    for (int jc = 0; jc < K; jc += Kc) {
+        const int kc = (jc + Kc < K) ? Kc : K - jc;  // taps of this pass: jc .. jc + kc - 1
+        const long lo = e_of(m0) - (K - 1) + jc;      // position of tap jc of output m0
+        if (jc) __syncthreads();                      // the previous pass has been read
+        for (long i = lo + threadIdx.x; i <= hi - (K - 1) + jc + kc - 1; i += blockDim.x) {
+            v2<T> v;
+            v.x = 0;
+            v.y = 0;
+            if (i >= 0) {
+                if (i < n_in) v = in[i];
+            } else if (i >= -hist_len) {
+                v = hist[hist_len + i];
+            }
+            xs[i - lo] = v;
         }
-        // two-level summation: partial sums over 64 taps keep the rounding error
-        // of long filters (n = 4096) at the level of the FFT-based reference
-        for (int j0 = 0; j0 < K; j0 += 64) {
-            v2<T> part[R];
+        __syncthreads();
+        for (size_t mb = m0 + threadIdx.x; mb < m1; mb += (size_t)blockDim.x * R) {
+            int base[R];
+            v2<T> acc[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                part[r].x = 0;
-                part[r].y = 0;
+                const size_t m = mb + (size_t)r * blockDim.x;
+                base[r] = (m < m1) ? (int)(e_of(m) - (K - 1) + jc - lo) : 0;
+                acc[r] = acc_keep[r];
             }
-            const int j1 = (j0 + 64 < K) ? j0 + 64 : K;
-            for (int j = j0; j < j1; ++j) {
-                const auto w = taps[j];
+            // two-level summation: partial sums over 64 taps keep the rounding error
+            // of long filters (n = 4096) at the level of the FFT-based reference
+            for (int j0 = 0; j0 < kc; j0 += 64) {
+                v2<T> part[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const v2<T> x = xs[base[r] + j];
-                    if constexpr (CT) {
-                        part[r].x += w.x * x.x - w.y * x.y;
-                        part[r].y += w.x * x.y + w.y * x.x;
-                    } else {
-                        part[r].x += x.x * w;
-                        part[r].y += x.y * w;
+                    part[r].x = 0;
+                    part[r].y = 0;
+                }
+                const int j1 = (j0 + 64 < kc) ? j0 + 64 : kc;
+                for (int j = j0; j < j1; ++j) {
+                    const auto w = taps[jc + j];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const v2<T> x = xs[base[r] + j];
+                        if constexpr (CT) {
+                            part[r].x += w.x * x.x - w.y * x.y;
+                            part[r].y += w.x * x.y + w.y * x.x;
+                        } else {
+                            part[r].x += x.x * w;
+                            part[r].y += x.y * w;
+                        }
                     }
                 }
-            }
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                acc[r].x += part[r].x;
-                acc[r].y += part[r].y;
+                for (int r = 0; r < R; ++r) {
+                    acc[r].x += part[r].x;
+                    acc[r].y += part[r].y;
+                }
             }
-        }
+            if (one_pass || jc + kc >= K) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const size_t m = mb + (size_t)r * blockDim.x;
-            if (m < m1) out[m] = acc[r];
+                for (int r = 0; r < R; ++r) {
+                    const size_t m = mb + (size_t)r * blockDim.x;
+                    if (m < m1) out[m] = acc[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc_keep[r] = acc[r];
+            }
         }
     }
 }
@@ -244,15 +262,23 @@ static int launch_fir_t(hipStream_t s, const FirArgs &a) {
     const size_t budget = kFirLdsBytes / esz;  // samples
     if (a.K == 0) RR_FAIL(RR_ERR_BAD_ARG, "fir: no taps");
     const uint64_t step = LIST ? a.max_step : a.D;
-    if ((uint64_t)a.K + 63 * step + 1 > budget)
-        RR_FAIL(RR_ERR_BAD_ARG, "fir: %u taps with step %llu exceed the LDS tile (%zu samples)", a.K,
-                (unsigned long long)step, budget);
-    uint64_t opb = (budget - a.K) / (step ? step : 1) + 1;
-    if (opb > 2048) opb = 2048;
-    // keep >= ~4 workgroups per CU when the problem is large enough
-    while (opb > 256 && (a.n_out + opb - 1) / opb < 1024) opb /= 2;
-    if (opb > 64) opb &= ~uint64_t(63);
-    const size_t span = (opb - 1) * step + a.K;
+    uint64_t opb, Kc = a.K;
+    if ((uint64_t)a.K + 63 * step + 1 > budget) {
+        // the response alone does not fit the tile: 64 .. 1024 outputs per workgroup, the taps in passes
+        opb = 256;
+        while (opb > 64 && (opb - 1) * step + 64 > budget / 2) opb /= 2;
+        if ((opb - 1) * step + 64 > budget)
+            RR_FAIL(RR_ERR_BAD_ARG, "fir: an output step of %llu samples exceeds the LDS tile (%zu samples)",
+                    (unsigned long long)step, budget);
+        Kc = (budget - (opb - 1) * step) & ~uint64_t(63);
+    } else {
+        opb = (budget - a.K) / (step ? step : 1) + 1;
+        if (opb > 2048) opb = 2048;
+        // keep >= ~4 workgroups per CU when the problem is large enough
+        while (opb > 256 && (a.n_out + opb - 1) / opb < 1024) opb /= 2;
+        if (opb > 64) opb &= ~uint64_t(63);
+    }
+    const size_t span = (opb - 1) * step + (Kc < a.K ? Kc : a.K);
     const size_t lds = span * esz;
     auto fn = k_fir<T, CT, LIST, R>;
     RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));
@@ -260,7 +286,7 @@ static int launch_fir_t(hipStream_t s, const FirArgs &a) {
     if (blocks > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fir: too many workgroups");
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), lds, s, (const v2<T> *)a.hist, (long)a.hist_len,
                        (const v2<T> *)a.in, (long)a.n_in, (const typename TapType<T, CT>::type *)a.taps, (int)a.K,
-                       (v2<T> *)a.out, a.n_out, (unsigned long long)a.e0, a.D, a.emit, (uint32_t)opb);
+                       (v2<T> *)a.out, a.n_out, (unsigned long long)a.e0, a.D, a.emit, (uint32_t)opb, (int)Kc);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }

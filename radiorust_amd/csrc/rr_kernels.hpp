@@ -43,24 +43,24 @@ bool ols_supported(int dtype, size_t n);
 int launch_filter_ols(int dtype, hipStream_t s, const void *hist, const void *in, size_t n, size_t nchunks,
                       int first_chunk, const void *H, const void *tw, void *out);
 
-// Filter fast convolution with 4096-point blocks (rr_filter_ols.hip), Complex<f32>, n in {256..2048} (V = n; any
-// n <= 2048 works): out[m] = sum_k g[k] x[e0 + m - k] over [ hist | in ]; G = DFT_4096(g)/4096 pair-interleaved
+// Filter fast convolution with 4096-point blocks (rr_filter_ols.hip), Complex<f32>, any n <= 2048 (V = n; longer
+// responses: one launch per partition of 2048 taps, e0 moved back by 2048 p, accumulate = true from the second on): out[m] = sum_k g[k] x[e0 + m - k] over [ hist | in ]; G = DFT_4096(g)/4096 pair-interleaved
 // (f32, or f16 with g_f16), tw4096[k] = e^{-j 2 pi k / 4096}; out_f16: outputs as {half re, half im}.
 // hist_out (may be null) receives the last hist_out_len samples of [ hist | in ] - the next call's history -
 // written by the kernel itself (only when n_out > 0, i.e. when a kernel is launched).
 bool filter_ols4096_supported(int dtype, size_t n);
 int launch_filter_blk4096(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *G,
                           const void *tw4096, size_t n, void *out, size_t n_out, long e0, bool out_f16, bool g_f16,
-                          void *hist_out, size_t hist_out_len);
+                          void *hist_out, size_t hist_out_len, bool accumulate = false);
 
 // Downsampler for any integer ratio P : 1 and rational ratios P : Q with Q <= 8 (rr_decim.hip), Complex<f32>:
 // out[Q a + b] = sum_j ir[j] x[e_first[b] + P a - (L - 1) + j] over [ hist | in ]; T = build_decim_poly_taps' table.
 // hist_out (may be null) receives the last hist_out_len samples of [ hist | in ].
 bool decim_poly_supported(int dtype, uint64_t P, uint64_t Q, size_t L);
-void build_decim_poly_taps(const std::vector<double> &ir, uint64_t P, uint64_t Q, const int64_t *e_first, std::vector<float> &T,
-                           int *NC_out);
+void build_decim_poly_taps(const std::vector<double> &ir, uint64_t P, uint64_t Q, const int64_t *e_first, std::vector<uint32_t> &T,
+                           int *Lp_out);
 int launch_decim_poly(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *T,
-                      uint64_t P, uint64_t Q, int NC, size_t L, int64_t e_first0, void *out, size_t n_out, void *hist_out,
+                      uint64_t P, uint64_t Q, int Lp, size_t L, int64_t e_first0, void *out, size_t n_out, void *hist_out,
                       size_t hist_out_len);
 
 // new_hist (H samples) = last H samples of [ zeros | old_hist (H) | in (n_in) ]

@@ -143,7 +143,10 @@ def test_freqshifter_errors(rr):
 
 
 # ---------------------------------------------------------------- Filter
-FILTER_CASES = [(64, 200e6, 20e6, 40), (1024, 2e9, 200e6, 6), (4096, 48000.0, 16e3, 3), (48, 48000.0, 4e3, 9), (33, 48000.0, 5e3, 9)]
+FILTER_CASES = [(64, 200e6, 20e6, 40), (1024, 2e9, 200e6, 6), (4096, 48000.0, 16e3, 3), (48, 48000.0, 4e3, 9), (33, 48000.0, 5e3, 9),
+                (1000, 48000.0, 6e3, 5), (1537, 96000.0, 9e3, 4),          # any length up to 2048: the 4096-point block kernel
+                (3000, 48000.0, 7e3, 4), (8192, 1024000.0, 100e3, 4),      # longer: partitions of 2048 taps
+                (16384, 1024000.0, 100e3, 3)]                             # examples/simple_receiver.rs:28-37: chunks of 16384
 
 
 @pytest.mark.parametrize("n,fs,cut,chunks", FILTER_CASES)
@@ -223,6 +226,25 @@ def test_filter_complex_taps_and_windows(rr, oracle):
                 t64.append(r64)
                 t32.append(r32)
         check(np.concatenate(got), np.concatenate(t64), np.concatenate(t32))
+
+
+@pytest.mark.parametrize("n", [8192, 16384])
+def test_filter_f64_long(rr, oracle, n):
+    """Complex<f64> responses beyond one LDS tile of the direct-form kernel (6144 taps): the taps are taken in
+    several passes.  The reference has no limit on the chunk length."""
+    fs = 1024000.0
+    x = oracle.synth_iq(9, 0, n * 3).astype(np.complex128)
+    g = rr.Filter.new(lowpass(100e3), dtype=np.float64)
+    o = oracle.Filter(lowpass(100e3), flt=np.float64)
+    got, ref = [], []
+    for i in range(3):
+        out = g.process(rr.Samples(fs, x[i * n : (i + 1) * n]))
+        r = o.process(fs, x[i * n : (i + 1) * n])
+        if out:
+            got.append(out[0].chunk)
+            ref.append(r)
+    assert len(got) == 2
+    assert rms_rel(np.concatenate(got), np.concatenate(ref)) < 1e-12
 
 
 def test_filter_f64(rr, oracle):
