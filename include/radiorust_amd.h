@@ -282,6 +282,11 @@ int rr_chain_filter_design(rr_chain *h, double sample_rate, const rr_c64 *resp,
  * history (filters.rs:262-265); FreqShifter, Downsampler and Fourier keep their
  * state (transform.rs:357-359, resampling.rs:135-137, analysis.rs:122-124). */
 int rr_chain_interrupt(rr_chain *h);
+/* Samples the Rechunker in front of the Filter holds (its patchwork, chunks.rs:62-64).  The reference's Rechunker
+ * drops them and sends a SamplesLost event - which is an interrupt for the Filter behind it - when an event arrives
+ * or the sample rate changes while it holds some (chunks.rs:72-92): the host layer asks here, calls
+ * rr_chain_interrupt and emits the event.  rr_chain_filter_design for another sample rate drops them too. */
+int rr_chain_pending(const rr_chain *h, size_t *n);
 /* Spectra this call will emit for n_in more input samples. */
 int rr_chain_peek(rr_chain *h, double sample_rate, size_t n_in, size_t *n_frames);
 /* Consumes n_in samples; writes n_frames*fft_len spectrum bins (n_out). */
@@ -350,6 +355,8 @@ int rr_stft_create(int dtype, size_t chunk_len, size_t chunk_count, const rr_win
 /* Any event (and a change of sample rate) makes the Rechunker drop its patchwork
  * and the Overlapper its history (chunks.rs:72-88, 225-233). */
 int rr_stft_reset(rr_stft *h);
+/* Samples the Rechunker holds (chunks.rs:62-64); see rr_chain_pending. */
+int rr_stft_pending(const rr_stft *h, size_t *n);
 int rr_stft_peek(const rr_stft *h, size_t n_in, size_t *n_out);
 int rr_stft_process(rr_stft *h, const void *in, size_t n_in, void *out, size_t out_cap,
                     size_t *n_out);

@@ -129,6 +129,7 @@ SIGNATURES = {
     "rr_chain_filter_mark_params_changed": (_i, [_vp]),
     "rr_chain_filter_design": (_i, [_vp, _d, _vp, _vp]),
     "rr_chain_interrupt": (_i, [_vp]),
+    "rr_chain_pending": (_i, [_vp, _psz]),
     "rr_chain_peek": (_i, [_vp, _d, _sz, _psz]),
     "rr_chain_process": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
     "rr_chain_enqueue": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
@@ -147,6 +148,7 @@ SIGNATURES = {
     "rr_channelizer_destroy": (_i, [_vp]),
     "rr_stft_create": (_i, [_i, _sz, _sz, C.POINTER(Window), _i, _i, C.POINTER(_vp)]),
     "rr_stft_reset": (_i, [_vp]),
+    "rr_stft_pending": (_i, [_vp, _psz]),
     "rr_stft_peek": (_i, [_vp, _sz, _psz]),
     "rr_stft_process": (_i, [_vp, _vp, _sz, _vp, _sz, _psz]),
     "rr_stft_process_dev": (_i, [_vp, _vp, _sz, _vp, _sz, _psz]),

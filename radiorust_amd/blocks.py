@@ -434,6 +434,7 @@ class Chain(_Block):
         self.filter_len = int(filter_len)
         self.fft_len = int(fft_len)
         self.output_rate = float(output_rate)
+        self._rate = None  # sample rate of the last Samples message (what the Rechunker's patchwork carries)
         p = _lib.ChainParams(self._code, float(precision), float(shift), self.filter_len, float(output_rate),
                              float(bandwidth), float(quality), self.fft_len, spec, int(bool(center_dc)),
                              int(bool(allow_fused)))
@@ -476,14 +477,35 @@ class Chain(_Block):
         _lib.check(_lib.lib().rr_chain_last_path(self._h, C.byref(v)))
         return ["", "k_mix_fir_decim", "k_ols_decim4", "k_ols_wave", "k_ols_frame"][v.value]
 
+    def pending(self) -> int:
+        """Samples the Rechunker in front of the Filter holds (chunks.rs:62-64)."""
+        n = C.c_size_t()
+        _lib.check(_lib.lib().rr_chain_pending(self._h, C.byref(n)))
+        return n.value
+
     def process(self, signal):
+        """One message through the four blocks.  The Rechunker in front of the Filter drops its leftover samples and
+        sends SamplesLost - an interrupt for the Filter - when an event arrives or the sample rate changes while it
+        holds some (chunks.rs:72-92); an interrupting event resets the Filter (filters.rs:262-265)."""
+        from .signal import SamplesLost
+
         if signal.is_event():
-            if signal.event.is_interrupt():
+            out = []
+            if self.pending():
                 self.interrupt()
-            return [signal]
-        frames = self.peek(signal.sample_rate, len(signal.chunk))
-        y = self._host_call(_lib.lib().rr_chain_process, (float(signal.sample_rate),), signal.chunk, frames * self.fft_len)
-        return [Samples(self.output_rate, y[i * self.fft_len : (i + 1) * self.fft_len]) for i in range(frames)]
+                out.append(EventSignal(SamplesLost()))
+            elif signal.event.is_interrupt():
+                self.interrupt()
+            return out + [signal]
+        pre = []
+        rate = float(signal.sample_rate)
+        if self._rate is not None and rate != self._rate and self.pending():
+            self.interrupt()
+            pre = [EventSignal(SamplesLost())]
+        self._rate = rate
+        frames = self.peek(rate, len(signal.chunk))
+        y = self._host_call(_lib.lib().rr_chain_process, (rate,), signal.chunk, frames * self.fft_len)
+        return pre + [Samples(self.output_rate, y[i * self.fft_len : (i + 1) * self.fft_len]) for i in range(frames)]
 
     def process_dev(self, sample_rate, d_in: int, n_in: int, d_out: int, cap: int) -> int:
         self._ensure_design(float(sample_rate))
@@ -544,6 +566,7 @@ class Stft(_Block):
         self._code, self._cdt = _dtype_code(dtype)
         self.chunk_len, self.chunk_count = int(chunk_len), int(chunk_count)
         self._rate = None
+        self._rates = []  # sample rates of the chunks in the Overlapper's history
         w = window if window is not None else Rectangular()
         spec = w._spec()
         if spec is None:
@@ -551,24 +574,55 @@ class Stft(_Block):
         _lib.check(_lib.lib().rr_stft_create(self._code, self.chunk_len, self.chunk_count, spec, int(bool(center_dc)),
                                              device, C.byref(self._h)))
 
+    def pending(self) -> int:
+        """Samples the Rechunker holds (chunks.rs:62-64)."""
+        n = C.c_size_t()
+        _lib.check(_lib.lib().rr_stft_pending(self._h, C.byref(n)))
+        return n.value
+
     def process(self, signal):
-        """One output message per overlapped chunk (chunk_len * chunk_count bins).  Any event resets the
-        overlap history and is preceded by SamplesLost, as the Overlapper does (chunks.rs:225-233)."""
+        """One output message per overlapped chunk (chunk_len * chunk_count bins), events as the composition
+        Rechunker -> Overlapper -> Fourier passes them on:
+        * an event: the Rechunker sends SamplesLost first if it holds samples, and drops them (chunks.rs:80-88); the
+          Overlapper answers EVERY event with a reset of its history and a SamplesLost of its own in front of it
+          (chunks.rs:225-233);
+        * a new sample rate: the Rechunker drops what it holds - if it holds anything - and sends SamplesLost
+          (chunks.rs:72-79), which resets the Overlapper; with nothing pending nothing is lost, the Overlapper keeps
+          its history and labels each output with the length-weighted average rate of its chunks (chunks.rs:207-213)."""
         from .signal import SamplesLost
 
         if signal.is_event():
+            out = []
+            if self.pending():
+                out += [EventSignal(SamplesLost()), EventSignal(SamplesLost())]  # the Overlapper's, the Rechunker's
             _lib.check(_lib.lib().rr_stft_reset(self._h))
-            return [EventSignal(SamplesLost()), signal]
+            self._rates = []
+            return out + [EventSignal(SamplesLost()), signal]
         pre = []
-        if self._rate is not None and signal.sample_rate != self._rate:  # chunks.rs:72-79
+        rate = float(signal.sample_rate)
+        if self._rate is not None and rate != self._rate and self.pending():
             _lib.check(_lib.lib().rr_stft_reset(self._h))
-            pre = [EventSignal(SamplesLost())]
-        self._rate = signal.sample_rate
+            self._rates = []
+            pre = [EventSignal(SamplesLost()), EventSignal(SamplesLost())]
+        self._rate = rate
+        chunks = (self.pending() + len(signal.chunk)) // self.chunk_len  # chunks this message completes
         n_out = C.c_size_t()
         _lib.check(_lib.lib().rr_stft_peek(self._h, len(signal.chunk), C.byref(n_out)))
         y = self._host_call(_lib.lib().rr_stft_process, (), signal.chunk, n_out.value)
         N = self.chunk_len * self.chunk_count
-        return pre + [Samples(signal.sample_rate, y[i * N : (i + 1) * N]) for i in range(len(y) // N)]
+        out, k = [], 0
+        for _ in range(chunks):
+            self._rates.append(rate)
+            if len(self._rates) >= self.chunk_count:
+                acc, cnt = 0.0, 0
+                for r in self._rates:  # chunks.rs:207-213, same order of operations
+                    cnt += self.chunk_len
+                    acc += r * float(self.chunk_len)
+                out.append(Samples(acc / float(cnt), y[k * N : (k + 1) * N]))
+                k += 1
+                self._rates.pop(0)
+        assert k == len(y) // N
+        return pre + out
 
     def process_dev(self, d_in: int, n_in: int, d_out: int, cap: int) -> int:
         n_out = C.c_size_t()

@@ -1833,6 +1833,12 @@ int rr_stft_reset(rr_stft *h) {
     h->carry_len = 0;    // chunks.rs:80-88
     return RR_OK;
 }
+int rr_stft_pending(const rr_stft *h, size_t *n) {
+    RR_CHECK_HANDLE(h, K_STFT);
+    if (!n) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    *n = h->carry_len;
+    return RR_OK;
+}
 int rr_stft_peek(const rr_stft *h, size_t n_in, size_t *n_out) {
     RR_CHECK_HANDLE(h, K_STFT);
     if (!n_out) RR_FAIL(RR_ERR_BAD_ARG, "null");
@@ -2159,6 +2165,17 @@ int rr_chain_filter_design(rr_chain *h, double sample_rate, const rr_c64 *resp, 
     RR_CHECK_HANDLE(h, K_CHAIN);
     // the Downsampler keeps running across a Filter redesign: give it its ring back first
     RR_TRY(h->materialize());
+    if (h->fl->designed && sample_rate != h->fl->rate && h->carry_len) {
+        // the Rechunker drops a patchwork of another sample rate (chunks.rs:72-79); those samples were mixed with the
+        // old NCO table and must not be prepended to the new-rate stream
+        if (h->HX) {
+            RR_TRY(h->select());
+            RR_TRY(launch_drop_tail(h->stream, h->xh[h->xh_cur].p, h->xh[h->xh_cur ^ 1].p, h->HX, h->carry_len));
+            h->xh_cur ^= 1;
+            h->xh_count = h->xh_count > h->carry_len ? h->xh_count - h->carry_len : 0;
+        }
+        h->carry_len = 0;
+    }
     RR_TRY(h->fl->design(sample_rate, h->p.filter_len, resp, window_rel));
     h->zrun = 0;
     return RR_OK;
@@ -2182,6 +2199,12 @@ int rr_chain_interrupt(rr_chain *h) {
     h->zrun = 0;
     return RR_OK;
     RR_GUARD_END
+}
+int rr_chain_pending(const rr_chain *h, size_t *n) {
+    RR_CHECK_HANDLE(h, K_CHAIN);
+    if (!n) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    *n = h->carry_len;
+    return RR_OK;
 }
 int rr_chain_peek(rr_chain *h, double sample_rate, size_t n_in, size_t *n_frames) {
     RR_CHECK_HANDLE(h, K_CHAIN);

@@ -84,7 +84,9 @@ def test_chain_interrupt_and_retune(rr, oracle, allow_fused):
     g = make(rr, oracle, CFG2, allow_fused)
     out = g.process(rr.Samples(fs, x[:100000]))  # 100000 = 1562 chunks + 32 leftover
     ev = rr.EventSignal(rr.SamplesLost())
-    assert g.process(ev) == [ev]
+    mid = g.process(ev)  # the Rechunker holds 32 samples: it reports them lost in front of the event (chunks.rs:80-88)
+    assert len(mid) == 2 and mid[0].is_event() and mid[0].event.is_interrupt() and mid[1] is ev
+    assert g.pending() == 0 and g.process(ev) == [ev]  # nothing pending: the event alone
     g.set_shift(-12.5e6)
     out += g.process(rr.Samples(fs, x[100000:]))
     # oracle: same message sequence through the four blocks + a Rechunker(64)
@@ -109,6 +111,47 @@ def test_chain_interrupt_and_retune(rr, oracle, allow_fused):
     assert len(out) == len(ref) and len(ref) >= 17
     for a, b in zip(out, ref):
         assert rms_rel(a.chunk, b) <= 1e-5
+
+
+@pytest.mark.parametrize("allow_fused", [False, True])
+def test_chain_sample_rate_change(rr, oracle, allow_fused):
+    """A new sample rate while the Rechunker in front of the Filter holds samples: they are dropped behind a
+    SamplesLost (chunks.rs:72-79) - they were mixed with the old rate's NCO table -, the FreqShifter rebuilds its
+    table keeping the phase (transform.rs:318-340), Filter and Downsampler redesign (filters.rs:178-187,
+    resampling.rs:75-102); the partly filled output chunk of the Downsampler carries on."""
+    fs1, fs2 = 200e6, 100e6
+    x = oracle.synth_iq(5, 0, 260000)
+    g = make(rr, oracle, CFG2, allow_fused)
+    out = g.process(rr.Samples(fs1, x[:100000]))  # 1562 chunks of 64 + 32 leftover
+    assert g.pending() == 32
+    out2 = g.process(rr.Samples(fs2, x[100000:]))
+    assert out2[0].is_event() and isinstance(out2[0].event, rr.SamplesLost) and not out2[1].is_event()
+    out += out2[1:]
+    assert g.pending() == (260000 - 100000) % 64
+    sh = oracle.FreqShifter(1.0, 25e6, flt=np.float64)
+    fl = oracle.Filter(lowpass(20e6), flt=np.float64)
+    ds = oracle.Downsampler(4096, 50e6, 40e6, flt=np.float64)
+    fo = oracle.Fourier(oracle.Kaiser.with_null_at_bin(2.0), flt=np.float64)
+    ref = []
+
+    def feed(fs, mixed):
+        for off in range(0, len(mixed) - 63, 64):
+            z = fl.process(fs, mixed[off : off + 64])
+            if z is not None:
+                for c in ds.feed(fs, z):
+                    ref.append(fo.process(c))
+
+    m1 = sh.process(fs1, x[:100000])
+    feed(fs1, m1[: 100000 // 64 * 64])  # the 32 leftover samples are dropped by the Rechunker
+    fl.interrupt()                      # its SamplesLost is an interrupt for the Filter
+    feed(fs2, sh.process(fs2, x[100000:]))
+    assert len(out) == len(ref) and len(ref) >= 20
+    for a, b in zip(out, ref):
+        assert rms_rel(a.chunk, b) <= 1e-5
+    # a rate change with nothing pending loses nothing
+    g2 = make(rr, oracle, CFG2, allow_fused)
+    g2.process(rr.Samples(fs1, x[:64000]))
+    assert g2.pending() == 0 and not any(s.is_event() for s in g2.process(rr.Samples(fs2, x[64000:128000])))
 
 
 @pytest.mark.parametrize("allow_fused", [False, True])

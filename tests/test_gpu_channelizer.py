@@ -187,8 +187,38 @@ def test_stft_rechunks_arbitrary_input(rr, oracle):
     assert len(got) == len(ref) == 8 and all(len(s.chunk) == M * P for s in got)
     for s, r in zip(got, ref):
         assert rms_rel(s.chunk, r) <= 1e-5
+    assert g.pending() == 300
     out = g.process(rr.Samples(2.0, x[: 3 * M]))  # new rate: 300 pending samples and the history are dropped
-    assert out[0].is_event() and len(out) == 1 + 2
+    # the Rechunker's SamplesLost (chunks.rs:72-79) reaches the Overlapper as an event: it sends one of its own first
+    assert out[0].is_event() and out[1].is_event() and len(out) == 2 + 2
     ref2, _ = overlapped_spectra(oracle, chunks[:3], P, oracle.Rectangular(), False, np.float64)
-    for s, r in zip(out[1:], ref2):
+    for s, r in zip(out[2:], ref2):
         assert s.sample_rate == 2.0 and rms_rel(s.chunk, r) <= 1e-5
+
+
+def test_stft_rate_change_and_events_like_the_composition(rr, oracle):
+    """Rechunker -> Overlapper -> Fourier, message by message (chunks.rs:62-92, 207-233):
+    a new sample rate with NOTHING pending loses nothing - the Overlapper keeps its history and labels each
+    output with the length-weighted average rate of its chunks; an event while samples are pending is preceded
+    by the Rechunker's SamplesLost, and the Overlapper puts a SamplesLost of its own in front of every event."""
+    M, P = 256, 4
+    x = oracle.synth_iq(25, 0, M * 10 + 100)
+    chunks = [x[i * M : (i + 1) * M] for i in range(10)]
+    ref, _ = overlapped_spectra(oracle, chunks, P, oracle.Rectangular(), False, np.float64)
+    g = rr.Stft(M, P)
+    a = g.process(rr.Samples(1000.0, x[: 5 * M]))           # chunks 0 .. 4 at rate 1000: spectra 0, 1
+    assert g.pending() == 0
+    b = g.process(rr.Samples(2000.0, x[5 * M : 10 * M]))    # chunks 5 .. 9 at rate 2000: spectra 2 .. 6, nothing lost
+    assert not any(s.is_event() for s in a + b) and len(a) == 2 and len(b) == 5
+    for s, r in zip(a + b, ref):
+        assert rms_rel(s.chunk, r) <= 1e-5
+    # rates: windows (2,3,4,5), (3,4,5,6), (4,5,6,7) mix the two rates
+    assert [s.sample_rate for s in a + b] == [1000.0, 1000.0, 1250.0, 1500.0, 1750.0, 2000.0, 2000.0]
+    c = g.process(rr.Samples(2000.0, x[10 * M :]))           # 100 samples: no chunk yet
+    assert c == [] and g.pending() == 100
+    ev = rr.EventSignal(rr.Disconnection())
+    out = g.process(ev)
+    assert [s.is_event() for s in out] == [True] * 4 and out[3] is ev and g.pending() == 0
+    assert all(isinstance(s.event, rr.SamplesLost) for s in out[:3])
+    again = g.process(rr.Samples(2000.0, x[: 4 * M]))       # the history is gone: P chunks for the first spectrum
+    assert len(again) == 1 and rms_rel(again[0].chunk, ref[0]) <= 1e-5
