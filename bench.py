@@ -150,7 +150,13 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="rank logic rehearsal only: all ranks share cuda:0 and line up over gloo (RCCL refuses two ranks on one GPU)")
     ap.add_argument("--traffic-json", default=None, help="file holding measured HBM bytes per launch (PMC pass)")
+    ap.add_argument("--profile", action="store_true",
+                    help="profiler runs: only the chain's own launches (no block-by-block replay, no copy benchmark, no extra "
+                         "timing steps, no CPU baseline), so that a rocprofv3 --kernel-trace --stats of this command averages "
+                         "exactly the launches the line reports")
     args = ap.parse_args()
+    if args.profile:
+        args.no_cpu_baseline = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # the driver's form `python bench.py --gpus N`: this process only starts the ranks (fresh child
@@ -237,7 +243,7 @@ def main():
     # kernels and compare the last step's spectra; together with the first-spectrum check against
     # the f64 oracle above this ties the fused kernels to the oracle at the benchmark size.
     fused_vs_blocks = None
-    if rank == 0 and fused and not args.no_fused:
+    if rank == 0 and fused and not args.no_fused and not args.profile:
         ref_chain = rr.Chain(shift=25e6, filter_len=64, freq_resp=lowpass20, output_rate=50e6, bandwidth=40e6,
                              fft_len=4096, fft_window=rr.Kaiser.with_null_at_bin(2.0), device=local_rank,
                              allow_fused=False)
@@ -254,7 +260,7 @@ def main():
     # the "measured-copy" denominator next to the 8 TB/s spec -- a device-to-device
     # copy of 1 GiB (read + write counted), median of 10, timed with events on the same stream
     copy_gbs = None
-    if rank == 0:
+    if rank == 0 and not args.profile:
         a = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
         b = torch.empty_like(a)
         b.copy_(a)
@@ -284,7 +290,7 @@ def main():
 
     timed_stages = read_stages()
     other = {}
-    if not args.no_fused:  # the remaining kernels, outside the timed region
+    if not args.no_fused and not args.profile:  # the remaining kernels, outside the timed region
         lib.rr_chain_timing_enable(chain._h, 1)
         lib.rr_chain_timing_reset(chain._h)
         for _ in range(20):
@@ -357,6 +363,8 @@ def main():
             line["cpu_baseline"], ref0 = cpu_baseline()
             line["parity_first_spectrum_rms"] = float(np.sqrt(np.sum(np.abs(first_spectrum - ref0) ** 2) / np.sum(np.abs(ref0) ** 2)))
         assert first_frames >= 0
+        if args.profile:
+            line["profile_run"] = "chain launches only: no replay, no copy benchmark, no extra timing steps"
         if args.rehearse_on_one_gpu:
             line["rehearsal"] = "all ranks shared cuda:0 over gloo: not a measurement"
         print(json.dumps(line))

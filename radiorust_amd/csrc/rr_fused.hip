@@ -35,23 +35,10 @@
 // Kernel 4w  k_filter_wave    the Filter block alone, a wave per 1024-sample block (n <= 385)
 // Kernel 5   k_channelizer256 256-bin polyphase channelizer, a wave per run of frames
 //
-// Build-time switches (all default to the measured-best setting; scripts/build_variant.sh builds
-// a second library with other values for A/B runs in one GPU session, scripts/ab_bench.py):
-//   RR_V_STAGGER, RR_V_CUSTAG, RR_V_WGPCU, RR_V_R4, RR_V_T256, RR_V_CONTIG   variants of kernel 1 (all slower)
-//   RR_V_WAVEWG   independent waves per workgroup of kernel 3w (1)
-//   RR_V_WAVEWIN  kernel 3w: blocks dealt to the XCDs in a moving window, that many per XCD (64; 0: an eighth of the stream per XCD)
-//   RR_V_WAVEBUFST  kernel 3w: outputs as buffer stores with out-of-range lanes dropped (1)
-//   RR_V_WAVELOOP, RR_V_WAVEOCCL, RR_V_WAVERUN, RR_V_WAVELOOPWIN   persistent one-wave forms of kernel 3w (0: one block per wave)
-//   RR_V_WAVECUR, RR_V_WAVECU, RR_V_WAVECUPF   persistent CU-resident workgroups with H in LDS (0)
-//   RR_V_WAVENT   streaming hint on the sample loads/stores of kernel 3w (1; no measurable effect)
-//   RR_V_WAVELDS  LDS elements per wave image (1176)
-//   RR_V_FRAMEWAVES, RR_V_FRAMEPF, RR_V_FRAMEOCC, RR_V_FRAMEWIN   kernel 3f: waves per frame (4), prefetch (0), frames per XCD in a window (1)
-//   RR_V_FFTPK, RR_V_FFTXCD, RR_V_FFTWIN   kernel 2: packed window copy + seeds up front + streaming hints (1), XCD mappings (0, 0)
-//   RR_V_FLTWOCC, RR_V_FLTWNT, RR_V_FLTWWIN   kernel 4w: register budget in waves per SIMD (3), streaming hints (3), window (64)
-//   RR_V_CHANRUN, RR_V_CHANWIN  kernel 5: frames per wave (16), runs per XCD in a window (4)
-//   RR_V_MFDWIN   kernel 1: tiles dealt in windows (0)
-//   RR_STAMP      s_memtime stamps per phase (scripts/stamp_run.py, stamp_wave.py)
-//   RR_ABLATE, RR_OLS_ABLATE, RR_WAVE_ABLATE   measurement builds that skip a phase (results are WRONG)
+// The tunables below (#define RR_V_*) carry the measured-best setting and the measurement in their comment; the
+// variants that lost (persistent forms, staggering, other tile shapes, ablation and stamp builds) are in the
+// repository's history (commit 28a7624) and in DESIGN.md 4, not in this file.  RR_V_LDSVOL (rr_wave_math.hpp)
+// is the one build-time switch left for A/B runs (scripts/build_variant.sh).
 #include "rr_blocks.hpp"
 #include "rr_wave_math.hpp"
 
@@ -83,24 +70,6 @@ constexpr int kNPF = 18;  // R*D = 32 samples per lane row
 // generic: enough 16-B pairs per lane for a tile of T rows of RD samples plus up to 16 halo rows
 constexpr int npf_for(int RD) { return RD * 9 / 16; }
 
-#ifdef RR_STAMP
-// diagnostic build: per-phase cycle sums (s_memtime), summed over all waves
-__device__ unsigned long long g_stamp[8];
-__device__ __forceinline__ unsigned long long stamp() {
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-#define RR_STAMP_T(var) const unsigned long long var = stamp()
-#define RR_STAMP_ADD(i, a, b) st_acc[i] += (b) - (a)
-constexpr unsigned kWaveStampBlocks = 90000;
-__device__ unsigned g_wstamp[8 * kWaveStampBlocks];  // k_ols_wave: one record per block
-#else
-#define RR_STAMP_T(var)
-#define RR_STAMP_ADD(i, a, b)
-#endif
 
 __device__ __forceinline__ void lds_barrier() {
     // Measured on MI355X: the plain barrier, which also drains vmcnt, is 8 % FASTER here than
@@ -108,9 +77,6 @@ __device__ __forceinline__ void lds_barrier() {
     __syncthreads();
 }
 
-#ifndef RR_V_MFDWIN
-#define RR_V_MFDWIN 0
-#endif
 template <int D, int R, int T>
 __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict__ xh, int hx,
                                                         const float2 *__restrict__ in, long n_in, int in_aligned16,
@@ -145,15 +111,6 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
         const unsigned b = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, rmd = nwg & 7, xcd = b & 7;
         chunk = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (b >> 3);
     }
-#if RR_V_MFDWIN
-    // every round of the grid covers one contiguous window of tiles, an eighth of the window per XCD
-    // (the mapping of k_freqshift; grid: multiple of 8)
-    const unsigned tstride = gridDim.x;
-    const unsigned tile_begin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const unsigned tile_end = ntiles;
-    (void)tiles_per_wg;
-    (void)chunk;
-#elif !defined(RR_V_CONTIG)
     // an XCD owns a contiguous range of tiles and its workgroups take them round robin, so that the
     // tiles in flight at any moment are neighbours in memory (grid: multiple of 8); contiguous runs
     // per workgroup (RR_V_CONTIG) measured 3 % slower
@@ -163,12 +120,6 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
     unsigned tile_end = ((blockIdx.x & 7) + 1) * per_xcd_t;
     if (tile_end > ntiles) tile_end = ntiles;
     (void)tiles_per_wg;
-#else
-    const unsigned tstride = 1;
-    const unsigned tile_begin = chunk * tiles_per_wg;
-    unsigned tile_end = tile_begin + tiles_per_wg;
-    if (tile_end > ntiles) tile_end = ntiles;
-#endif
     // The workgroup that owns the last run of tiles also leaves the mixed-sample
     // history for the next call: xh_out = the last hx_out mixed samples of this call.
     if (xh_out && chunk == gridDim.x - 1) {
@@ -216,49 +167,14 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
 
     f4 x[NPF];
     auto prefetch = [&](long tlo) {
-#if defined(RR_ABLATE) && (RR_ABLATE == 2 || RR_ABLATE == 4)  // diagnostic: no global loads
-#pragma unroll
-        for (int u = 0; u < NPF; ++u) x[u] = (f4){1.f, 2.f, 3.f, (float)tlo};
-#else
         const f4 *src = reinterpret_cast<const f4 *>(in + (tlo - odd)) + threadIdx.x;
 #pragma unroll
         for (int u = 0; u < NPF; ++u) x[u] = src[u * T];
-#endif
     };
     bool cur_interior = interior_of(tile_lo);
     if (cur_interior) prefetch(tile_lo);
-#ifdef RR_V_CUSTAG
-    // All CUs start their tiles at the same time, so the HBM sees one burst per tile period
-    // and idles in between.  Offset the workgroups of each CU by a CU-dependent fraction of
-    // the period (hardware CU id) to turn the bursts into a steady stream.
-    {
-        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID
-        const unsigned cu = (hw >> 8) & 7;
-        for (unsigned k = 0; k < cu; ++k) __builtin_amdgcn_s_sleep(RR_V_CUSTAG);
-    }
-#endif
-#ifdef RR_V_STAGGER
-    // The two waves that share a SIMD (hardware wave slots 0 and 1) belong to two
-    // different workgroups.  Delay the workgroup whose first wave sits in an odd slot by
-    // about half a tile period, so that one wave's load/stage/store phases overlap the
-    // other's FIR loop instead of both doing the same thing at the same time.
-    {
-        __shared__ int stagger_flag;
-        if (threadIdx.x == 0) {
-            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID
-            stagger_flag = (int)(hw & 1);                                                // wave_id[0]
-        }
-        __syncthreads();
-        if (stagger_flag)
-            for (int k = 0; k < RR_V_STAGGER; ++k) __builtin_amdgcn_s_sleep(64);  // 64 * 64 cycles each
-    }
-#endif
 
-#ifdef RR_STAMP
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
     for (unsigned tile = tile_begin; tile < tile_end; tile += tstride) {
-        RR_STAMP_T(ts0);
         // ---- stage: (prefetched) raw samples -> mix -> LDS; each prefetch slot is
         //      re-issued for the next tile as soon as it has been consumed ----------
         const long next_lo = tile_lo + (long)D * OUTS * tstride;
@@ -322,13 +238,10 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
             }
             if (next_interior) prefetch(next_lo);
         }
-        RR_STAMP_T(ts1);
         lds_barrier();
-        RR_STAMP_T(ts2);
         // prefetch the next tile once the stage barrier is passed (re-issuing each slot inside
         // the stage loop, or in slices between FIR rounds, measured 4-14 % slower)
         if (cur_interior && next_interior) prefetch(next_lo);
-        RR_STAMP_T(ts3);
 
         // ---- FIR: rotating register window, packed FMAs --------------------------
         f2 acc[R];
@@ -383,11 +296,7 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
                     }
                 }
             };
-#if defined(RR_ABLATE) && (RR_ABLATE == 1 || RR_ABLATE == 4)  // diagnostic: one round of tap groups instead of all
-            const int nouter = 1, rem = 0;
-#else
             const int nouter = Gp / R, rem = Gp % R;
-#endif
             float ca[HT], cb[HT];
             load_taps(tap_lds, ca);
             for (int to = 0; to < nouter; ++to) {
@@ -414,9 +323,7 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
                 }(std::make_integer_sequence<int, R / 2 - 1>{});
             }
         }
-        RR_STAMP_T(ts4);
         lds_barrier();  // every wave is done reading this tile's samples
-        RR_STAMP_T(ts5);
 
         // ---- store: R consecutive outputs per lane ---------------------------------
         {
@@ -437,24 +344,11 @@ __global__ __launch_bounds__(T, 2) void k_mix_fir_decim(const float2 *__restrict
                     }
             }
         }
-        RR_STAMP_T(ts6);
-        RR_STAMP_ADD(0, ts0, ts1);  // stage
-        RR_STAMP_ADD(1, ts1, ts2);  // barrier after stage
-        RR_STAMP_ADD(2, ts2, ts3);  // prefetch issue
-        RR_STAMP_ADD(3, ts3, ts4);  // FIR loop
-        RR_STAMP_ADD(4, ts4, ts5);  // barrier after FIR
-        RR_STAMP_ADD(5, ts5, ts6);  // store
         tile_lo = next_lo;
         cur_interior = next_interior;
         rbase += tstep;
         if (rbase >= denom) rbase -= denom;
     }
-#ifdef RR_STAMP
-    if ((threadIdx.x & 63) == 0) {
-        for (int i = 0; i < 6; ++i) atomicAdd(&g_stamp[i], st_acc[i]);
-        atomicAdd(&g_stamp[7], 1ull);
-    }
-#endif
 }
 
 template <int D, int R, int T>
@@ -471,20 +365,10 @@ static int launch_mfd(hipStream_t s, const FusedFirArgs &a) {
     const size_t ntiles = (a.n_out + OUTS - 1) / OUTS;
     if (ntiles > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fused FIR: too many tiles");
     // persistent grid: 8 waves per CU (LDS-limited), 256 CUs
-#ifdef RR_V_WGPCU
-    size_t nwg = 256 * RR_V_WGPCU;
-#else
     size_t nwg = 256 * (512 / T) * (32 / G::RD);  // LDS-limited: 8 waves/CU at 32 samples per lane, 12-16 at 16
-#endif
-#ifndef RR_V_CONTIG
     if (nwg > ntiles) nwg = ntiles;
     nwg = (nwg + 7) / 8 * 8;
     const size_t tpw = 0;
-#else
-    if (nwg > ntiles) nwg = ntiles;
-    const size_t tpw = (ntiles + nwg - 1) / nwg;
-    nwg = (ntiles + tpw - 1) / tpw;
-#endif
     const int in_al = (reinterpret_cast<uintptr_t>(a.in) % 16 == 0) ? 1 : 0;
     const int out_al = (reinterpret_cast<uintptr_t>(a.out) % 16 == 0) ? 1 : 0;
     hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(T), lds, s, (const float2 *)a.xh, (int)a.hx, (const float2 *)a.in,
@@ -507,11 +391,7 @@ bool fused_fir_supported(uint64_t D, size_t Lc) {
 int fused_fir_R(uint64_t D) {
     switch (D) {
         case 2: return 16;
-#ifdef RR_V_R4
-        case 4: return 4;
-#else
         case 4: return 8;
-#endif
         case 8: return 4;
     }
     return 0;
@@ -521,13 +401,7 @@ int launch_fused_fir(hipStream_t s, const FusedFirArgs &a) {
     if (a.n_out == 0) return RR_OK;
     switch (a.D) {
         case 2: return launch_mfd<2, 16, 128>(s, a);
-#if defined(RR_V_R4)
-        case 4: return launch_mfd<4, 4, 128>(s, a);
-#elif defined(RR_V_T256)
-        case 4: return launch_mfd<4, 8, 256>(s, a);
-#else
         case 4: return launch_mfd<4, 8, 128>(s, a);
-#endif
         case 8: return launch_mfd<8, 4, 128>(s, a);
     }
     RR_FAIL(RR_ERR_BAD_ARG, "fused FIR: decimation %u not instantiated", a.D);
@@ -538,38 +412,18 @@ int launch_fused_fir(hipStream_t s, const FusedFirArgs &a) {
 // ---------------------------------------------------------------------------
 // The input stream of frames is [ head (n_head samples) | in ]: the head is the
 // Downsampler's partly filled output chunk left over by the previous call.
-#ifndef RR_V_FFTPK
-#define RR_V_FFTPK 1
-#endif
-#ifndef RR_V_FFTWIN
-#define RR_V_FFTWIN 0  // > 0: frames dealt to the XCDs in a moving window, that many neighbouring frames per XCD
-#endif
-#ifndef RR_V_FFTXCD
-#define RR_V_FFTXCD 0  // a contiguous eighth of the frames per XCD: measured slower here (0.181 against 0.176 ms per 2^26 samples)
-#endif
+// (frames round robin over the XCDs: a contiguous eighth per XCD measured 0.181 against 0.176 ms per 2^26 samples, a
+//  moving window no gain)
 __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head, long n_head,
                                                  const float2 *__restrict__ in, float2 *__restrict__ out,
                                                  const float *__restrict__ window, const float2 *__restrict__ tw,
                                                  int center_dc, long hop, unsigned count) {
     __shared__ f2 lds[4096 + 256];
     const int j = threadIdx.x;
-#if RR_V_FFTWIN > 0
-    const unsigned fr = blockIdx.x / (8 * RR_V_FFTWIN) * (8 * RR_V_FFTWIN) + (blockIdx.x % (8 * RR_V_FFTWIN) & 7) * RR_V_FFTWIN + (blockIdx.x % (8 * RR_V_FFTWIN) >> 3);
-    if (fr >= count) return;
-#elif RR_V_FFTXCD
-    // workgroups b, b + 8, .. share an XCD: every XCD takes a contiguous eighth of the frames (grid: a multiple
-    // of 8).  That mapping took k_freqshift (4 KiB per workgroup and trip) from 4.7 to 5.4 TB/s; with a whole
-    // 32 KiB frame per workgroup it does not pay.
-    const unsigned per_xcd = gridDim.x >> 3;
-    const unsigned fr = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (fr >= count) return;
-#else
     const unsigned fr = blockIdx.x;
-#endif
     const long base = (long)fr * hop - n_head;  // index into `in` of this frame's first sample
     float2 *dst = out + (size_t)fr * 4096;
     f2 v[16];
-#if RR_V_FFTPK
     // the lane's 16 window values as 4 loads of 16 bytes (packed copy behind the table), its two twiddle
     // seeds up front, the frame's samples with the streaming hint when frames do not overlap
     float wv[16];
@@ -599,15 +453,6 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
             v[k] = (f2){x.x * wv[k], x.y * wv[k]};
         }
     }
-#else
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const long i = base + j + 256 * k;
-        const float2 x = (i >= 0) ? in[i] : head[n_head + i];
-        const float w = window[j + 256 * k];
-        v[k] = (f2){x.x * w, x.y * w};
-    }
-#endif
     // pass 0 (Ns = 1): no twiddles; out index 16 j + k
     dft16(v);
 #pragma unroll
@@ -619,11 +464,7 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
     {
         // e^{-j 2 pi k (j mod 16) / 256} = w^k with w = tw[16 (j mod 16)]: one
         // table read, powers by a depth-4 product tree (error ~4 ulp, not 15)
-#if RR_V_FFTPK
         const float2 t = s1;
-#else
-        const float2 t = tw[16 * (j & 15)];
-#endif
         apply_twiddle_powers(v, (f2){t.x, t.y});
     }
     dft16(v);
@@ -638,11 +479,7 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = lds_ld(lds + pad16(j + 256 * k));
     {
-#if RR_V_FFTPK
         const float2 t = s2;
-#else
-        const float2 t = tw[j];  // e^{-j 2 pi j / 4096}, coalesced
-#endif
         apply_twiddle_powers(v, (f2){t.x, t.y});
     }
     dft16(v);
@@ -650,14 +487,7 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int o = (j + 256 * k + rot) & 4095;
-#if RR_V_FFTPK
         __builtin_nontemporal_store(v[k], reinterpret_cast<f2 *>(dst) + o);
-#else
-        float2 w;
-        w.x = v[k].x;
-        w.y = v[k].y;
-        dst[o] = w;
-#endif
     }
 }
 
@@ -666,8 +496,7 @@ int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *i
                    hipEvent_t ev_stop) {
     if (count == 0) return RR_OK;
     if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fft4096: too many frames");
-    const unsigned grid = RR_V_FFTWIN > 0 ? (unsigned)((count + 8 * RR_V_FFTWIN - 1) / (8 * RR_V_FFTWIN) * (8 * RR_V_FFTWIN))
-                                         : (RR_V_FFTXCD ? (unsigned)((count + 7) / 8 * 8) : (unsigned)count);
+    const unsigned grid = (unsigned)count;
     if (ev_start && ev_stop)
         hipExtLaunchKernelGGL(k_fft4096, dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, (const float2 *)head,
                               (long)n_head, (const float2 *)in, (float2 *)out, (const float *)window,
@@ -1208,142 +1037,38 @@ __global__ __launch_bounds__(256) void k_ols_decim4(const float2 *__restrict__ x
 // patterns of the radix 8 x 16 x 8 transform).  Image B (256-point inverse) uses B(i) = i + 4 (i >> 4).
 // Every access pattern below is (lane term) + (compile-time offset), spelled out so that the
 // offsets land in the instructions' immediate fields instead of per-access address arithmetic.
-#ifndef RR_V_WAVELDS
-#define RR_V_WAVELDS 1176
-#endif
-constexpr int kWaveLds = RR_V_WAVELDS;  // A(1023) + 1 = 1174, rounded up to a multiple of 8
+constexpr int kWaveLds = 1176;  // A(1023) + 1 = 1174, rounded up to a multiple of 8
 
-
-#ifndef RR_V_WAVELOOPWIN
-#define RR_V_WAVELOOPWIN 1  // persistent forms: 1 = the grid's rounds cover contiguous windows, 0 = a contiguous eighth of the blocks per XCD
-#endif
-#ifndef RR_V_WAVEWIN
-#define RR_V_WAVEWIN 64  // > 0: blocks dealt to the XCDs in a moving window, that many neighbouring blocks per XCD (0: one contiguous eighth of the stream per XCD; measured 0.1375 -> 0.135 ms, G = 16 .. 1024 alike, 2 .. 8 no gain)
-#endif
-#ifndef RR_V_WAVEWG
-#define RR_V_WAVEWG 1  // independent waves (blocks) per workgroup (LOOP = false only)
-#endif
-#ifndef RR_V_WAVERUN
-#define RR_V_WAVERUN 0  // persistent form: 0 = round-robin blocks with prefetch; R > 0 = runs of R neighbouring blocks, tables loaded once
-#endif
-#ifndef RR_V_WAVEOCCL
-#define RR_V_WAVEOCCL 3  // waves per SIMD of the persistent form (register budget 512 / n)
-#endif
-#ifndef RR_WAVE_ABLATE
-#define RR_WAVE_ABLATE 0  // measurement builds: 1 = load/mix/store only, 2 = no inverse, 3 = no forward
-#endif
-// Stamps (RR_STAMP build, LOOP = false) showed a block at 14.0k cycles of which 7.3k are the wait
-// for its own 8 KiB of samples (HBM latency under load ~3 us) and 5.6k the transforms.
-// LOOP = true: persistent waves, each a contiguous run of blocks; the next block's samples are
-// requested as soon as the current ones have been mixed, so that latency runs under the
-// transforms.  That costs 32 registers through the whole block: 3 waves per SIMD instead of 4.
-// The sample stream passes through once: with the streaming hint it does not displace the
-// 16 KiB of H / twiddle tables from the CU's 32 KiB L1.
-#ifndef RR_V_WAVENT
-#define RR_V_WAVENT 1
-#endif
-#if RR_V_WAVENT
+// Measured and dropped (the bodies are in the history, commit 28a7624): persistent one-wave
+// workgroups that request the next block's samples while the current one is transformed (0.143-0.150 ms against
+// 0.135: 32 more registers, 3 instead of 4 waves per SIMD), CU-resident workgroups of 12-16 waves with H staged in
+// LDS (0.149-0.19 ms), runs of neighbouring blocks per wave (0.155-0.160 ms), several waves per workgroup.
+// Stamps showed a block at 14.0k cycles of which 7.3k are the wait for its own 8 KiB of samples (HBM latency under
+// load ~3 us) and 5.6k the transforms; four such waves per SIMD hide each other's waits.
 typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));  // two complex samples, 8-byte aligned
+// (the sample stream passes through once: with the streaming hint it does not displace the 16 KiB of H / twiddle
+//  tables from the CU's 32 KiB L1)
 __device__ __forceinline__ f4u ld_stream(const f4u *p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ void st_stream(float2 *p, float2 v) {
-    __builtin_nontemporal_store((f2){v.x, v.y}, reinterpret_cast<f2 *>(p));
-}
-#define RR_WAVE_LDX(p) ld_stream(p)
-#define RR_WAVE_STY(p, v) st_stream(p, v)
-#else
-#define RR_WAVE_LDX(p) (*(p))
-#define RR_WAVE_STY(p, v) (*(p) = (v))
-#endif
-// MODE 0: one block per wave.  MODE 1 (LOOP): persistent one-wave workgroups.  MODE 2 (CUR): persistent
-// workgroups of kCuWaves waves, one per CU, with H staged in LDS once per workgroup: per block and lane
-// the vector-memory instructions shrink from 24 (8 samples, 8 H, 3 seeds, 1 NCO, 4 stores) to 12-13.
-#ifndef RR_V_WAVECU
-#define RR_V_WAVECU 16  // waves of a CU-resident workgroup (MODE 2): 16 x 9408 B images + 8 KiB of H = 155 KiB of LDS
-#endif
-#ifndef RR_V_WAVEBUFST
-#define RR_V_WAVEBUFST 1  // the block's outputs leave as buffer stores with out-of-range lanes dropped (no branch)
-#endif
-#ifndef RR_V_WAVECUPF
-#define RR_V_WAVECUPF 1  // MODE 2: request the next block's samples while the current block is transformed
-#endif
-constexpr int kCuWaves = RR_V_WAVECU;
-template <int MODE>
-__global__ __launch_bounds__(MODE == 2 ? 64 * kCuWaves : (MODE == 1 ? 64 : 64 * RR_V_WAVEWG))
-    __attribute__((amdgpu_waves_per_eu(MODE == 2 ? kCuWaves / 4 : (MODE == 1 ? RR_V_WAVEOCCL : 4),
-                                       MODE == 2 ? kCuWaves / 4 : (MODE == 1 ? RR_V_WAVEOCCL : 4)))) void k_ols_wave(
-        const float2 *__restrict__ xh, int hx, const float2 *__restrict__ in, long n_in, const float2 *__restrict__ nco,
-        unsigned denom, unsigned idx0, const float2 *__restrict__ H, const float2 *__restrict__ tw, int V,
-        float2 *__restrict__ out, long n_out, long e0, float2 *__restrict__ xh_out, int hx_out, unsigned nblocks,
-        unsigned ph0, unsigned hopm, unsigned hopm_run, unsigned kstep, double inv_denom) {
-    constexpr bool LOOP = MODE != 0, CUR = MODE == 2;
-    __shared__ __attribute__((aligned(16))) f2 lds_all[CUR ? kCuWaves : (LOOP ? 1 : RR_V_WAVEWG)][kWaveLds];
-    __shared__ __attribute__((aligned(16))) float4 Hs[CUR ? 512 : 1];
-    f2 *const lds = lds_all[MODE == 1 ? 0 : (threadIdx.x >> 6)];
-    const int l = threadIdx.x & 63;
-    if constexpr (CUR) {  // the pair-interleaved response, once per workgroup (before any wave leaves)
-        for (int i = threadIdx.x; i < 512; i += 64 * kCuWaves) Hs[i] = reinterpret_cast<const float4 *>(H)[i];
-        __syncthreads();
-    }
-    // Workgroups b, b+8, .. share an XCD.  Blocks are dealt so that neighbouring blocks run on one
-    // XCD (and, with LOOP, in one wave): the V samples two neighbours share come from HBM once.
-    unsigned blk, cnt, bstride;
-    if constexpr (LOOP) {
-        // XCD x owns the contiguous range of blocks [x * per_xcd, (x + 1) * per_xcd); its waves take
-        // them round robin (wave i: i, i + wpx, ..), so that the blocks in flight at any moment are
-        // neighbours in memory, as with one block per wave.  Contiguous runs per wave were measured
-        // slower (0.146 vs 0.128 ms for the bare load/store loop): 3072 separate streams.
-        const unsigned wpw = CUR ? kCuWaves : 1;  // waves per workgroup
-        const unsigned wpx = (gridDim.x >> 3) * wpw, xcd = blockIdx.x & 7;  // grid: multiple of 8
-        const unsigned i = (blockIdx.x >> 3) * wpw + (CUR ? (threadIdx.x >> 6) : 0);
-#if RR_V_WAVERUN > 0
-        // run mode: RR_V_WAVERUN neighbouring blocks per wave, H and the seeds loaded once per run
-        // (fewer vector-memory instructions per block), no prefetch
-        blk = (xcd * wpx + i) * RR_V_WAVERUN;
-        bstride = 1;
-        if (blk >= nblocks) return;
-        cnt = nblocks - blk < RR_V_WAVERUN ? nblocks - blk : RR_V_WAVERUN;
-#else
-#if RR_V_WAVELOOPWIN
-        // every round of the grid covers one contiguous window of blocks, an eighth of the window per XCD
-        blk = xcd * wpx + i;
-        bstride = 8 * wpx;
-        if (blk >= nblocks) return;
-        cnt = (nblocks - blk + bstride - 1) / bstride;
-#else
-        const unsigned per_xcd = (nblocks + 7) >> 3;
-        const unsigned lo = xcd * per_xcd, hi = lo + per_xcd < nblocks ? lo + per_xcd : nblocks;
-        blk = lo + i;
-        bstride = wpx;
-        if (blk >= hi) return;
-        cnt = (hi - blk + wpx - 1) / wpx;
-#endif
-#endif
-    } else {
-#if RR_V_WAVEWIN > 0
-        // windowed: the XCDs work side by side in a moving window of 8 G blocks, G neighbouring blocks each
-        // (instead of one far-apart eighth of the stream per XCD)
-        static_assert(RR_V_WAVEWG == 1, "the windowed mapping deals one-wave workgroups");
-        constexpr unsigned G = RR_V_WAVEWIN;
-        const unsigned grp = blockIdx.x / (8 * G), rem = blockIdx.x % (8 * G);
-        blk = grp * 8 * G + (rem & 7) * G + (rem >> 3);
-        cnt = 1;
-        bstride = 1;
-        if (blk >= nblocks) return;
-#else
-        const unsigned per_xcd = (nblocks + 7) >> 3;
-        const unsigned within = (blockIdx.x >> 3) * RR_V_WAVEWG + (threadIdx.x >> 6);
-        blk = (blockIdx.x & 7) * per_xcd + within;
-        cnt = 1;
-        bstride = 1;
-        if (blk >= nblocks || within >= per_xcd) return;
-#endif
-    }
+constexpr unsigned kWaveWin = 64;  // blocks dealt to the XCDs in a moving window, that many neighbouring blocks per XCD
+                                   // (one contiguous eighth of the stream per XCD: 0.1375 -> 0.135 ms; 16 .. 1024 alike)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ols_wave(
+    const float2 *__restrict__ xh, int hx, const float2 *__restrict__ in, long n_in, const float2 *__restrict__ nco,
+    unsigned denom, unsigned idx0, const float2 *__restrict__ H, const float2 *__restrict__ tw, int V,
+    float2 *__restrict__ out, long n_out, long e0, float2 *__restrict__ xh_out, int hx_out, unsigned nblocks,
+    unsigned ph0, unsigned hopm, unsigned kstep, double inv_denom) {
+    __shared__ __attribute__((aligned(16))) f2 lds[kWaveLds];
+    const int l = threadIdx.x;
+    // Workgroups b, b+8, .. share an XCD.  Blocks are dealt so that neighbouring blocks run on one XCD - the V
+    // samples two neighbours share come from HBM once -, and the XCDs work side by side in a moving window of
+    // 8 G blocks (instead of one far-apart eighth of the stream per XCD).
+    constexpr unsigned G = kWaveWin;
+    const unsigned grp = blockIdx.x / (8 * G), rem = blockIdx.x % (8 * G);
+    const unsigned blk = grp * 8 * G + (rem & 7) * G + (rem >> 3);
+    if (blk >= nblocks) return;
     const int hop = 1024 - V, per_block = hop >> 2;
-    const long bhop = (long)bstride * hop;  // distance between two blocks of this wave
-    long b0 = e0 - V + (long)blk * hop;
-    RR_STAMP_T(ws0);
+    const long b0 = e0 - V + (long)blk * hop;
 
-    if (xh_out && blk + (cnt - 1) * bstride == nblocks - 1) {  // mixed-sample history for the next call
+    if (xh_out && blk == nblocks - 1) {  // mixed-sample history for the next call
         for (int i = l; i < hx_out; i += 64) {
             const long pos = n_in - hx_out + i;
             float2 v;
@@ -1359,7 +1084,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 * kCuWaves : (MODE == 1 ? 64 : 64 * 
         }
     }
 
-    // ---- NCO phase of the run's first sample: (idx0 + b0) mod denom ---------------------------
+    // ---- NCO phase of the block's first sample: (idx0 + b0) mod denom -------------------------
     // ph0 = (idx0 + e0 - V) mod denom and hopm = hop mod denom come from the host; the block's
     // term blk * hopm < 2^53 is reduced in f64 (exact) instead of a 64-bit integer division.
     unsigned base = ph0;
@@ -1379,11 +1104,11 @@ __global__ __launch_bounds__(MODE == 2 ? 64 * kCuWaves : (MODE == 1 ? 64 : 64 * 
     // (measured), so everything comes in 16-byte pieces: lane l takes the sample pairs
     // x[2 l + 128 k' .. + 1], k' < 8, and its 6 twiddle seeds as 3 packed entries.
     f4u x[8];
-    constexpr bool PF = LOOP && RR_V_WAVERUN == 0 && (!CUR || RR_V_WAVECUPF);  // prefetching form
-    if (!LOOP && b0 >= 0 && b0 + 1024 <= n_in) {
+    const bool interior = b0 >= 0 && b0 + 1024 <= n_in;
+    if (interior) {
         const f4u *src = reinterpret_cast<const f4u *>(in + b0) + l;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = RR_WAVE_LDX(src + 64 * k);
+        for (int k = 0; k < 8; ++k) x[k] = ld_stream(src + 64 * k);
     }
     const int g = l >> 4, q = l & 15;
     // seeds: pass 1 tw[8 (l mod 8)]; pass 2 tw[l], tw[l + 64]; inverse tw[64 (l mod 4)], tw[16 (l mod 16)], tw[4 l]
@@ -1400,348 +1125,192 @@ __global__ __launch_bounds__(MODE == 2 ? 64 * kCuWaves : (MODE == 1 ? 64 : 64 * 
     }
     f2 *const a_rd = lds + (l + 2 * g);  // A(l + 64 m + 256 c) = a_rd + 72 m + 296 c
     f2 *const b_rd = lds + (l + 4 * g);  // B(l + 64 c) = b_rd + 80 c
-    size_t zoff = 0;
-    float2 hv[16];
-    auto lane_phase = [&](unsigned bs) {  // (bs + 2 l) mod denom, bs < denom
-        unsigned r = bs + 2u * (unsigned)l;
-        if (denom >= 128u) {
-            if (r >= denom) r -= denom;
-        } else if ((denom & (denom - 1u)) == 0u) {
-            r &= denom - 1u;
-        } else {
-            r %= denom;
-        }
-        return r;
-    };
-    // the lane's phasor pair at the block start.  The prefetching form requests the next block's pair
-    // together with its samples: asked for at the block start it would sit behind the previous block's
-    // stores in the in-order vmcnt queue, a full round trip in front of every block's first product.
-    f4u pp_next;
-    if constexpr (PF) {
-        // The first block's pair and samples are waited for HERE, in front of the loop.  Entering the loop
-        // with them in flight, the wait at the top of the loop would have to serve both ways in - the newest
-        // operations of the queue on this way, four stores behind them on the way round - and the
-        // compiler then takes vmcnt(0): every block would wait for the previous block's stores.
-        pp_next = *reinterpret_cast<const f4u *>(nco + lane_phase(base));
-        const long bs = b0 < 0 ? 0 : (b0 > n_in - 1024 ? n_in - 1024 : b0);
-        const f4u *src = reinterpret_cast<const f4u *>(in + bs) + l;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = RR_WAVE_LDX(src + 64 * k);
-        asm volatile("" : "+v"(t_p1), "+v"(t_p2[0]), "+v"(t_p2[1]), "+v"(t_inv[0]), "+v"(t_inv[1]), "+v"(t_inv[2]));
-        asm volatile("" : "+v"(pp_next), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+    // ---- phase of the lane's first sample (2 l into the block): (base + 2 l) mod denom -----------
+    unsigned r = base + 2u * (unsigned)l;
+    if (denom >= 128u) {
+        if (r >= denom) r -= denom;
+    } else if ((denom & (denom - 1u)) == 0u) {
+        r &= denom - 1u;
+    } else {
+        r %= denom;
     }
-#if RR_V_WAVERUN > 0
-    if constexpr (LOOP) {
-#pragma unroll
-        for (int kp = 0; kp < 8; ++kp) {
-            const float4 h4 = reinterpret_cast<const float4 *>(H)[l + 64 * kp];
-            hv[2 * kp] = float2{h4.x, h4.y};
-            hv[2 * kp + 1] = float2{h4.z, h4.w};
-        }
-    }
-#endif
-
-    for (unsigned it = 0; it < cnt; ++it, blk += bstride, b0 += bhop) {
-        RR_STAMP_T(wt0);
-        if constexpr (LOOP && !PF) {
-            if (b0 >= 0 && b0 + 1024 <= n_in) {
-                const f4u *src = reinterpret_cast<const f4u *>(in + b0) + l;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) x[k] = RR_WAVE_LDX(src + 64 * k);
-            }
-        }
-        if constexpr (LOOP) {
-            // What stays in registers across blocks is decided here, not by invariant-code motion
-            // (which would hoist the 60 derived twiddles and the 16 H values, and then spill): the
-            // 6 twiddle seeds stay, their powers and H (L1/L2 hits) are redone per block.
-            asm volatile("" : "+v"(t_p1), "+v"(t_p2[0]), "+v"(t_p2[1]), "+v"(t_inv[0]), "+v"(t_inv[1]), "+v"(t_inv[2]));
-            asm volatile("" : "+s"(zoff));  // an opaque 0 added to H below
-        }
-        // ---- phase of the lane's first sample (2 l into the block) -------------------------------
-        unsigned r = lane_phase(base);
-        base += hopm_run;  // (bstride * hop) mod denom
-        if (base >= denom) base -= denom;
-        // ---- mix: v[2 k' + j] = xs[b0 + 2 l + j + 128 k'] ------------------------------------------
-        // (the NCO table carries entry 0 once more behind entry denom - 1, so the pair r, r + 1 is one 16-byte read)
-        f2 v[16];
-        if (b0 >= 0 && b0 + 1024 <= n_in) {
-            f4u pp;
-            if constexpr (PF) pp = pp_next;
-            else pp = *reinterpret_cast<const f4u *>(nco + r);
-            if (kstep == 0) {  // the period divides 128: one pair of phasors per lane
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    v[2 * k] = cmul((f2){x[k].x, x[k].y}, (f2){pp.x, pp.y});
-                    v[2 * k + 1] = cmul((f2){x[k].z, x[k].w}, (f2){pp.z, pp.w});
-                }
-            } else {
-                // general period: the lane's pair at the block start from the table, the seven
-                // 128-sample steps by the rotations kept behind the table (one product each; a
-                // last-bit difference from the table's own entries, far inside the chain's 1e-5)
-                const f2 p0 = {pp.x, pp.y}, p1 = {pp.z, pp.w};
-                v[0] = cmul((f2){x[0].x, x[0].y}, p0);
-                v[1] = cmul((f2){x[0].z, x[0].w}, p1);
-#pragma unroll
-                for (int k = 1; k < 8; ++k) {
-                    const float2 rt = nco[denom + 1 + k];  // uniform address: a scalar read
-                    const f2 rot = {rt.x, rt.y};
-                    v[2 * k] = cmul((f2){x[k].x, x[k].y}, cmul(p0, rot));
-                    v[2 * k + 1] = cmul((f2){x[k].z, x[k].w}, cmul(p1, rot));
-                }
-            }
-        } else {
-            // edges: history (already mixed) in front, nothing behind the input.  Every lane reads
-            // some valid address and selects afterwards.
+    // ---- mix: v[2 k' + j] = xs[b0 + 2 l + j + 128 k'] ------------------------------------------
+    // (the NCO table carries entry 0 once more behind entry denom - 1, so the pair r, r + 1 is one 16-byte read)
+    f2 v[16];
+    if (interior) {
+        const f4u pp = *reinterpret_cast<const f4u *>(nco + r);
+        if (kstep == 0) {  // the period divides 128: one pair of phasors per lane
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const f4u pp = *reinterpret_cast<const f4u *>(nco + r);
+                v[2 * k] = cmul((f2){x[k].x, x[k].y}, (f2){pp.x, pp.y});
+                v[2 * k + 1] = cmul((f2){x[k].z, x[k].w}, (f2){pp.z, pp.w});
+            }
+        } else {
+            // general period: the lane's pair at the block start from the table, the seven
+            // 128-sample steps by the rotations kept behind the table (one product each; a
+            // last-bit difference from the table's own entries, far inside the chain's 1e-5)
+            const f2 p0 = {pp.x, pp.y}, p1 = {pp.z, pp.w};
+            v[0] = cmul((f2){x[0].x, x[0].y}, p0);
+            v[1] = cmul((f2){x[0].z, x[0].w}, p1);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const long pos = b0 + 2 * l + j + 128 * k;
-                    const bool inr = pos >= 0 && pos < n_in;
-                    const bool hst = pos < 0 && pos >= -(long)hx;
-                    const float2 *ptr = inr ? in + pos : xh + (hst ? hx + pos : 0);
-                    const float2 xx = *ptr;
-                    const f2 p = j ? (f2){pp.z, pp.w} : (f2){pp.x, pp.y};
-                    const f2 pk = {inr ? p.x : (hst ? 1.f : 0.f), inr ? p.y : 0.f};
-                    const f2 xv = {(inr || hst) ? xx.x : 0.f, (inr || hst) ? xx.y : 0.f};
-                    v[2 * k + j] = cmul(xv, pk);
-                }
-                r += kstep;
-                if (r >= denom) r -= denom;
+            for (int k = 1; k < 8; ++k) {
+                const float2 rt = nco[denom + 1 + k];  // uniform address: a scalar read
+                const f2 rot = {rt.x, rt.y};
+                v[2 * k] = cmul((f2){x[k].x, x[k].y}, cmul(p0, rot));
+                v[2 * k + 1] = cmul((f2){x[k].z, x[k].w}, cmul(p1, rot));
             }
         }
-        // the 16 H values of the lane, used in pass 2.  Requested BEFORE the next block's samples:
-        // loads complete in order (vmcnt), so waiting for a load issued after the prefetch would
-        // wait for the prefetch as well.
-        // (H arrives pair-interleaved from the host, Hp[kp][l] = {H[l + 128 kp], H[l + 128 kp + 64]}:
-        //  8 loads of 16 bytes per lane; measured cost of vector-memory traffic here is per
-        //  instruction, not per byte)
-        if constexpr (!(LOOP && RR_V_WAVERUN > 0) && !CUR) {
-#pragma unroll
-            for (int kp = 0; kp < 8; ++kp) {
-                const float4 h4 = reinterpret_cast<const float4 *>(H + zoff)[l + 64 * kp];
-                hv[2 * kp] = float2{h4.x, h4.y};
-                hv[2 * kp + 1] = float2{h4.z, h4.w};
-            }
-        }
-        // ---- request the next block ---------------------------------------------------------------
-        // Unconditional (the position is clamped into the input, n_in >= 1024 is the launcher's
-        // duty): with the loads under a condition, the compiler must assume at every later wait
-        // that they were NOT issued, and then each wait for an H value also waits for them.
-        if constexpr (PF) {
-            __builtin_amdgcn_sched_barrier(0);
-            pp_next = *reinterpret_cast<const f4u *>(nco + lane_phase(base));  // base: already the next block's
-            long nb = b0 + bhop;
-            nb = nb < 0 ? 0 : (nb > n_in - 1024 ? n_in - 1024 : nb);
-            const f4u *src = reinterpret_cast<const f4u *>(in + nb) + l;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) x[k] = RR_WAVE_LDX(src + 64 * k);
-        }
-        RR_STAMP_T(ws1);
-        f2 y[4];
-#if RR_WAVE_ABLATE == 1 || RR_WAVE_ABLATE == 3 || RR_WAVE_ABLATE == 7 || RR_WAVE_ABLATE == 8
-#pragma unroll
-        for (int m = 0; m < 4; ++m) y[m] = v[m] + v[m + 4] + v[m + 8] + v[m + 12];
-#if RR_WAVE_ABLATE == 7  // + the 16 H loads (8 bytes per lane each)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) y[k & 3] += (f2){hv[k].x, hv[k].y};
-#elif RR_WAVE_ABLATE == 8  // + the same H bytes as 8 loads of 16 bytes per lane
+    } else {
+        // edges: history (already mixed) in front, nothing behind the input.  Every lane reads
+        // some valid address and selects afterwards.
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float4 h4 = reinterpret_cast<const float4 *>(H + zoff)[l + 64 * k];
-            y[k & 3] += (f2){h4.x + h4.z, h4.y + h4.w};
-        }
-#endif
-#else
-        // ---- forward DFT_1024 = radix 8 x 16 x 8 (Stockham) -------------------------------------------
-        // pass 0 (Ns = 1): butterflies 2 l + j over x[2 l + j + 128 k']; out 8 (2 l + j) + r = 16 l + 8 j + r
-        {
-            f2 e0[8], e1[8];
+            const f4u pp = *reinterpret_cast<const f4u *>(nco + r);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                e0[k] = v[2 * k];
-                e1[k] = v[2 * k + 1];
+            for (int j = 0; j < 2; ++j) {
+                const long pos = b0 + 2 * l + j + 128 * k;
+                const bool inr = pos >= 0 && pos < n_in;
+                const bool hst = pos < 0 && pos >= -(long)hx;
+                const float2 *ptr = inr ? in + pos : xh + (hst ? hx + pos : 0);
+                const float2 xx = *ptr;
+                const f2 p = j ? (f2){pp.z, pp.w} : (f2){pp.x, pp.y};
+                const f2 pk = {inr ? p.x : (hst ? 1.f : 0.f), inr ? p.y : 0.f};
+                const f2 xv = {(inr || hst) ? xx.x : 0.f, (inr || hst) ? xx.y : 0.f};
+                v[2 * k + j] = cmul(xv, pk);
             }
-            dft8(e0);
-            dft8(e1);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                v[k] = e0[k];
-                v[8 + k] = e1[k];
-            }
+            r += kstep;
+            if (r >= denom) r -= denom;
         }
-        if constexpr (LOOP) wave_sync();  // the previous block's last reads of image B are done
-#if RR_WAVE_ABLATE != 4
-        {
-            f2 *row = lds + (18 * l + 8 * g);  // A(16 l + e) = 18 l + 8 g + e
+    }
+    // the 16 H values of the lane, used in pass 2 (H arrives pair-interleaved from the host,
+    // Hp[kp][l] = {H[l + 128 kp], H[l + 128 kp + 64]}: 8 loads of 16 bytes per lane)
+    float2 hv[16];
 #pragma unroll
-            for (int k = 0; k < 16; k += 2)
-                *reinterpret_cast<float4 *>(row + k) = (float4){v[k].x, v[k].y, v[k + 1].x, v[k + 1].y};
+    for (int kp = 0; kp < 8; ++kp) {
+        const float4 h4 = reinterpret_cast<const float4 *>(H)[l + 64 * kp];
+        hv[2 * kp] = float2{h4.x, h4.y};
+        hv[2 * kp + 1] = float2{h4.z, h4.w};
+    }
+    f2 y[4];
+    // ---- forward DFT_1024 = radix 8 x 16 x 8 (Stockham) -------------------------------------------
+    // pass 0 (Ns = 1): butterflies 2 l + j over x[2 l + j + 128 k']; out 8 (2 l + j) + r = 16 l + 8 j + r
+    {
+        f2 e0[8], e1[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            e0[k] = v[2 * k];
+            e1[k] = v[2 * k + 1];
         }
-        wave_sync();
+        dft8(e0);
+        dft8(e1);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = lds_ld(a_rd + (72 * (k & 3) + 296 * (k >> 2)));  // in[l + 64 k]
-#endif
-        RR_STAMP_T(ws2);
-        // pass 1 (Ns = 8, radix 16): twiddle e^{-j 2 pi k (l mod 8) / 128}; out 128 (l / 8) + l % 8 + 8 k
-#if RR_WAVE_ABLATE != 5
-        twiddle16(v, t_p1);
-#endif
-        dft16(v);
-        RR_STAMP_T(ws3);
-#if RR_WAVE_ABLATE != 4
-        wave_sync();
-        {
-            // A(128 h + p + 8 k), h = l / 8, p = l % 8: 144 h + 8 (h / 2) + p + 8 k + 2 (k / 2)
-            f2 *col = lds + (144 * (l >> 3) + 8 * (l >> 4) + (l & 7));
-#pragma unroll
-            for (int k = 0; k < 16; ++k) lds_st(col + (8 * k + 2 * (k >> 1)), v[k]);
+        for (int k = 0; k < 8; ++k) {
+            v[k] = e0[k];
+            v[8 + k] = e1[k];
         }
-        wave_sync();
-#endif
-        // pass 2 (Ns = 128, radix 8): butterflies t = l + 64 m over in[t + 128 c]; out X[t + 128 r],
-        // i.e. X[l + 64 k] with k = m + 2 r
-        f2 X[16];
+    }
+    {
+        f2 *row = lds + (18 * l + 8 * g);  // A(16 l + e) = 18 l + 8 g + e
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            f2 a[8];
-#if RR_WAVE_ABLATE == 4
+        for (int k = 0; k < 16; k += 2)
+            *reinterpret_cast<float4 *>(row + k) = (float4){v[k].x, v[k].y, v[k + 1].x, v[k + 1].y};
+    }
+    wave_sync();
 #pragma unroll
-            for (int c = 0; c < 8; ++c) a[c] = v[m + 2 * c];
-#else
-            // A(l + 64 m + 128 c) = a_rd + 72 m + 144 c + 8 (c / 2)
+    for (int k = 0; k < 16; ++k) v[k] = lds_ld(a_rd + (72 * (k & 3) + 296 * (k >> 2)));  // in[l + 64 k]
+    // pass 1 (Ns = 8, radix 16): twiddle e^{-j 2 pi k (l mod 8) / 128}; out 128 (l / 8) + l % 8 + 8 k
+    twiddle16(v, t_p1);
+    dft16(v);
+    wave_sync();
+    {
+        // A(128 h + p + 8 k), h = l / 8, p = l % 8: 144 h + 8 (h / 2) + p + 8 k + 2 (k / 2)
+        f2 *col = lds + (144 * (l >> 3) + 8 * (l >> 4) + (l & 7));
 #pragma unroll
-            for (int c = 0; c < 8; ++c) a[c] = lds_ld(a_rd + (72 * m + 144 * c + 8 * (c >> 1)));
-#endif
-#if RR_WAVE_ABLATE != 5
-            const f2 w1 = t_p2[m];
-            const f2 w2 = cmul(w1, w1);
-            const f2 w3 = cmul(w2, w1);
-            const f2 w4 = cmul(w2, w2);
-            a[1] = cmul(a[1], w1);
-            a[2] = cmul(a[2], w2);
-            a[3] = cmul(a[3], w3);
-            a[4] = cmul(a[4], w4);
-            a[5] = cmul(a[5], cmul(w4, w1));
-            a[6] = cmul(a[6], cmul(w4, w2));
-            a[7] = cmul(a[7], cmul(w4, w3));
-#endif
-            dft8(a);
+        for (int k = 0; k < 16; ++k) lds_st(col + (8 * k + 2 * (k >> 1)), v[k]);
+    }
+    wave_sync();
+    // pass 2 (Ns = 128, radix 8): butterflies t = l + 64 m over in[t + 128 c]; out X[t + 128 r],
+    // i.e. X[l + 64 k] with k = m + 2 r
+    f2 X[16];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) X[m + 2 * c] = a[c];
-        }
-        // * H and fold the four 256-bin quarters: Y[l + 64 m] = sum_q X[l + 64 (m + 4 q)] H[l + 64 (m + 4 q)]
-        if constexpr (CUR) {
-            int hl = l;
-            asm volatile("" : "+v"(hl));  // read here, in every block: hoisted out of the loop the 16 values cost 32 registers
+    for (int m = 0; m < 2; ++m) {
+        f2 a[8];
+        // A(l + 64 m + 128 c) = a_rd + 72 m + 144 c + 8 (c / 2)
 #pragma unroll
-            for (int kp = 0; kp < 8; ++kp) {
-                const float4 h4 = Hs[hl + 64 * kp];
-                hv[2 * kp] = float2{h4.x, h4.y};
-                hv[2 * kp + 1] = float2{h4.z, h4.w};
-            }
-        }
+        for (int c = 0; c < 8; ++c) a[c] = lds_ld(a_rd + (72 * m + 144 * c + 8 * (c >> 1)));
+        const f2 w1 = t_p2[m];
+        const f2 w2 = cmul(w1, w1);
+        const f2 w3 = cmul(w2, w1);
+        const f2 w4 = cmul(w2, w2);
+        a[1] = cmul(a[1], w1);
+        a[2] = cmul(a[2], w2);
+        a[3] = cmul(a[3], w3);
+        a[4] = cmul(a[4], w4);
+        a[5] = cmul(a[5], cmul(w4, w1));
+        a[6] = cmul(a[6], cmul(w4, w2));
+        a[7] = cmul(a[7], cmul(w4, w3));
+        dft8(a);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            f2 acc = cmul(X[m], (f2){hv[m].x, hv[m].y});
-            acc = cmac(acc, X[m + 4], (f2){hv[m + 4].x, hv[m + 4].y});
-            acc = cmac(acc, X[m + 8], (f2){hv[m + 8].x, hv[m + 8].y});
-            acc = cmac(acc, X[m + 12], (f2){hv[m + 12].x, hv[m + 12].y});
-            y[m] = acc;
-        }
-#endif
-        RR_STAMP_T(ws4);
-#if RR_WAVE_ABLATE == 0 || (RR_WAVE_ABLATE >= 3 && RR_WAVE_ABLATE < 7)
-        // ---- inverse DFT_256, Stockham radix 4 x 4: butterfly l reads in[l + 64 c] ------------------
-        // pass 0 (Ns = 1): no twiddle; out 4 l + c: B = 4 l + 4 (l >> 2) + c
+        for (int c = 0; c < 8; ++c) X[m + 2 * c] = a[c];
+    }
+    // * H and fold the four 256-bin quarters: Y[l + 64 m] = sum_q X[l + 64 (m + 4 q)] H[l + 64 (m + 4 q)]
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        f2 acc = cmul(X[m], (f2){hv[m].x, hv[m].y});
+        acc = cmac(acc, X[m + 4], (f2){hv[m + 4].x, hv[m + 4].y});
+        acc = cmac(acc, X[m + 8], (f2){hv[m + 8].x, hv[m + 8].y});
+        acc = cmac(acc, X[m + 12], (f2){hv[m + 12].x, hv[m + 12].y});
+        y[m] = acc;
+    }
+    // ---- inverse DFT_256, Stockham radix 4 x 4: butterfly l reads in[l + 64 c] ------------------
+    // pass 0 (Ns = 1): no twiddle; out 4 l + c: B = 4 l + 4 (l >> 2) + c
+    idft4(y[0], y[1], y[2], y[3]);
+    wave_sync();  // the forward image has been read
+    {
+        f2 *row = lds + (4 * l + 4 * (l >> 2));
+        *reinterpret_cast<float4 *>(row) = (float4){y[0].x, y[0].y, y[1].x, y[1].y};
+        *reinterpret_cast<float4 *>(row + 2) = (float4){y[2].x, y[2].y, y[3].x, y[3].y};
+    }
+    wave_sync();
+#pragma unroll
+    for (int pass = 1; pass < 4; ++pass) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) y[c] = lds_ld(b_rd + (80 * c));
+        // twiddles e^{+j 2 pi c (l mod ns) / (4 ns)} = conj(tw[(l mod ns) 256 / ns])^c, ns = 4^pass
+        const f2 w1 = t_inv[pass - 1];
+        const f2 w2 = cmul(w1, w1);
+        const f2 w3 = cmul(w2, w1);
+        y[1] = cmul_conj(y[1], w1);
+        y[2] = cmul_conj(y[2], w2);
+        y[3] = cmul_conj(y[3], w3);
         idft4(y[0], y[1], y[2], y[3]);
-        wave_sync();  // the forward image has been read
-        {
-            f2 *row = lds + (4 * l + 4 * (l >> 2));
-            *reinterpret_cast<float4 *>(row) = (float4){y[0].x, y[0].y, y[1].x, y[1].y};
-            *reinterpret_cast<float4 *>(row + 2) = (float4){y[2].x, y[2].y, y[3].x, y[3].y};
+        if (pass == 3) break;  // natural order: y[c] = result[l + 64 c]
+        wave_sync();
+        if (pass == 1) {  // out 16 (l >> 2) + (l & 3) + 4 c: B = 20 (l >> 2) + (l & 3) + 4 c
+            f2 *col = lds + (20 * (l >> 2) + (l & 3));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) lds_st(col + (4 * c), y[c]);
+        } else {  // out 64 g + q + 16 c: B = 80 g + q + 20 c
+            f2 *col = lds + (80 * g + q);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) lds_st(col + (20 * c), y[c]);
         }
         wave_sync();
+    }
+    // ---- store the valid part -----------------------------------------------------------------
+    // Buffer stores: the lanes outside the block's valid part (and behind the end of the output)
+    // carry an out-of-range offset and are dropped by the address check - four stores in
+    // straight-line code, with the streaming hint.
+    const int first = V >> 2;
+    const long mb = (long)blk * per_block;
+    const long left = n_out - mb;
+    const unsigned recs = (unsigned)(left < per_block ? left : per_block) * 8u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + mb, 0, recs, 0x00020000);
 #pragma unroll
-        for (int pass = 1; pass < 4; ++pass) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) y[c] = lds_ld(b_rd + (80 * c));
-            // twiddles e^{+j 2 pi c (l mod ns) / (4 ns)} = conj(tw[(l mod ns) 256 / ns])^c, ns = 4^pass
-            const f2 w1 = t_inv[pass - 1];
-            const f2 w2 = cmul(w1, w1);
-            const f2 w3 = cmul(w2, w1);
-            y[1] = cmul_conj(y[1], w1);
-            y[2] = cmul_conj(y[2], w2);
-            y[3] = cmul_conj(y[3], w3);
-            idft4(y[0], y[1], y[2], y[3]);
-            if (pass == 3) break;  // natural order: y[c] = result[l + 64 c]
-            wave_sync();
-            if (pass == 1) {  // out 16 (l >> 2) + (l & 3) + 4 c: B = 20 (l >> 2) + (l & 3) + 4 c
-                f2 *col = lds + (20 * (l >> 2) + (l & 3));
-#pragma unroll
-                for (int c = 0; c < 4; ++c) lds_st(col + (4 * c), y[c]);
-            } else {  // out 64 g + q + 16 c: B = 80 g + q + 20 c
-                f2 *col = lds + (80 * g + q);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) lds_st(col + (20 * c), y[c]);
-            }
-            wave_sync();
-        }
-#endif
-        RR_STAMP_T(ws5);
-        // ---- store the valid part -----------------------------------------------------------------
-        const int first = V >> 2;
-#if RR_V_WAVEBUFST
-        {
-            // Buffer stores: the lanes outside the block's valid part (and behind the end of the output)
-            // carry an out-of-range offset and are dropped by the address check - four stores in
-            // straight-line code.  Under a condition the compiler has to assume at the next wait for a
-            // load that they were not issued, and waits for everything instead (vmcnt counts in order).
-            const long mb = (long)__builtin_amdgcn_readfirstlane((int)blk) * per_block;
-            const long left = n_out - mb;
-            const unsigned recs = (unsigned)(left < per_block ? left : per_block) * 8u;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + mb, 0, recs, 0x00020000);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int tau = l + 64 * c;
-                const unsigned off = tau >= first ? (unsigned)(tau - first) * 8u : 0xffffffffu;
-                __builtin_amdgcn_raw_buffer_store_b64(y[c], rs, off, 0, RR_V_WAVENT ? 2 : 0);
-            }
-        }
-#else
-        const long mbase = (long)blk * per_block;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int tau = l + 64 * c;
-            const long m = mbase + (tau - first);
-            if (tau >= first && m < n_out) {
-                float2 w;
-                w.x = y[c].x;
-                w.y = y[c].y;
-                RR_WAVE_STY(out + m, w);
-            }
-        }
-#endif
-#if defined(RR_STAMP) && RR_WAVE_ABLATE == 0
-        {
-            RR_STAMP_T(ws6);
-            // one record per block, no atomics (80k waves x 7 atomics on 7 addresses distort everything)
-            if (l == 0 && b0 >= 0 && b0 + 1024 <= n_in && blk < kWaveStampBlocks) {
-                unsigned *rec = g_wstamp + 8 * (size_t)blk;
-                rec[0] = (unsigned)(ws1 - (LOOP ? wt0 : ws0));  // (prologue,) wait for the samples, mix
-                rec[1] = (unsigned)(ws2 - ws1);  // pass 0 + exchange 1
-                rec[2] = (unsigned)(ws3 - ws2);  // pass 1 (twiddles + radix 16)
-                rec[3] = (unsigned)(ws4 - ws3);  // exchange 2 + pass 2 + H
-                rec[4] = (unsigned)(ws5 - ws4);  // inverse
-                rec[5] = (unsigned)(ws6 - ws5);  // store
-                rec[6] = (unsigned)ws1;          // time (low bits)
-                unsigned hwid;
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-                rec[7] = hwid;
-            }
-        }
-#endif
+    for (int c = 0; c < 4; ++c) {
+        const int tau = l + 64 * c;
+        const unsigned off = tau >= first ? (unsigned)(tau - first) * 8u : 0xffffffffu;
+        __builtin_amdgcn_raw_buffer_store_b64(y[c], rs, off, 0, 2);
     }
 }
 
@@ -1765,12 +1334,8 @@ __global__ __launch_bounds__(MODE == 2 ? 64 * kCuWaves : (MODE == 1 ? 64 : 64 * 
 // history for the next call.
 // ---------------------------------------------------------------------------
 int ols_wave_overlap(size_t Lc);
-#ifndef RR_V_FRAMEWIN
 #define RR_V_FRAMEWIN 1  // frames round robin over the XCDs: 0.1915 ms; a contiguous eighth per XCD (0): 0.1965
-#endif
-#ifndef RR_V_FRAMEWAVES
 #define RR_V_FRAMEWAVES 4  // measured (full-size images): 4 waves 0.233 ms, 5 waves 0.30 (one workgroup per CU), 8 waves 0.26, 10 waves 0.28
-#endif
 constexpr int kFrameWaves = RR_V_FRAMEWAVES, kFrameBlocks = 20;
 
 // the transforms of one 1024-sample block: v = mixed samples in the pair layout of k_ols_wave;
@@ -1952,21 +1517,15 @@ struct FrameArgs {
     unsigned nfr;           // full frames
 };
 
-#ifndef RR_V_FRAMEOCC
 #define RR_V_FRAMEOCC 4
-#endif
-#ifndef RR_V_FRAMEOCCMIN
 #define RR_V_FRAMEOCCMIN 3  // 12 waves per CU need <= 168 VGPRs
-#endif
 __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_eu(RR_V_FRAMEOCCMIN, RR_V_FRAMEOCC))) void k_ols_frame(FrameArgs a_) {
     // The fields used once per workgroup (pending buffers, spectra, window ..) are re-read from the
     // kernel-argument segment where they are needed: held in SGPRs through the block loop they push
     // the kernel one VGPR (of spilled SGPRs) over the 128 that two 5-wave workgroups per CU need.
     const FrameArgs &a = a_;
     const FrameArgs *ka = (const FrameArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-#ifndef RR_V_FRAMEHALF
 #define RR_V_FRAMEHALF 1  // half-size wave images: 3 workgroups per CU instead of 2
-#endif
     constexpr int kImg = RR_V_FRAMEHALF ? kWaveLdsHalf : kWaveLds;
     // the frame (+ the surplus of block 19); once every lane holds its 16 frame samples it becomes the
     // padded exchange image of the DFT_4096
@@ -1974,14 +1533,9 @@ __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_e
     __shared__ __attribute__((aligned(16))) f2 img[kFrameWaves * kImg];  // wave images
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     // frames dealt so that an XCD owns a contiguous range (grid: multiple of 8)
-#if RR_V_FRAMEWIN > 0
     // frames dealt to the XCDs in a moving window, RR_V_FRAMEWIN neighbouring frames per XCD
     const unsigned f = blockIdx.x / (8 * RR_V_FRAMEWIN) * (8 * RR_V_FRAMEWIN) + (blockIdx.x % (8 * RR_V_FRAMEWIN) & 7) * RR_V_FRAMEWIN +
                        (blockIdx.x % (8 * RR_V_FRAMEWIN) >> 3);
-#else
-    const unsigned per_xcd = gridDim.x >> 3;
-    const unsigned f = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-#endif
     if (f > a.nfr) return;
     const bool tail = f == a.nfr;  // the frame that does not fill: goes to pend_out
     const long F0 = 4096l * f - a.pl;  // decimated index (of this call) of the frame's first sample
@@ -2034,17 +1588,7 @@ __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_e
     const long n_clamp = a.n_in - 1024;  // the launcher guarantees n_in >= 1024
     auto block_b0 = [&](int jb) { return a.e0 - a.V + 4 * (F0 + (long)per_block * jb); };
     [[maybe_unused]] auto clampb = [&](long b) { return b < 0 ? 0 : (b > n_clamp ? n_clamp : b); };
-#ifndef RR_V_FRAMEPF
-#define RR_V_FRAMEPF 0  // 1: request the next block's samples while the current block is transformed
-#endif
     f4u x[8];
-#if RR_V_FRAMEPF
-    {
-        const f4u *src = reinterpret_cast<const f4u *>(a.in + clampb(block_b0(w))) + l;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = RR_WAVE_LDX(src + 64 * k);
-    }
-#endif
     for (int jb = w; jb < kFrameBlocks; jb += kFrameWaves) {
         asm volatile("" : "+v"(t_p1), "+v"(t_p2[0]), "+v"(t_p2[1]), "+v"(t_inv[0]), "+v"(t_inv[1]), "+v"(t_inv[2]));
         asm volatile("" : "+s"(zoff));
@@ -2069,13 +1613,11 @@ __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_e
         }
         f2 v[16];
         if (b0 >= 0 && b0 <= n_clamp) {
-#if !RR_V_FRAMEPF
             {
                 const f4u *src = reinterpret_cast<const f4u *>(a.in + b0) + l;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) x[k] = RR_WAVE_LDX(src + 64 * k);
+                for (int k = 0; k < 8; ++k) x[k] = ld_stream(src + 64 * k);
             }
-#endif
             if (a.kstep == 0) {
                 const f4u pp = *reinterpret_cast<const f4u *>(a.nco + r);
 #pragma unroll
@@ -2121,15 +1663,6 @@ __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_e
             hv[2 * kp] = float2{h4.x, h4.y};
             hv[2 * kp + 1] = float2{h4.z, h4.w};
         }
-#if RR_V_FRAMEPF
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const int jn = jb + kFrameWaves < kFrameBlocks ? jb + kFrameWaves : jb;
-            const f4u *src = reinterpret_cast<const f4u *>(a.in + clampb(block_b0(jn))) + l;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) x[k] = RR_WAVE_LDX(src + 64 * k);
-        }
-#endif
         f2 y[4];
         wave_block_transform<RR_V_FRAMEHALF != 0>(v, y, lds, l, t_p1, t_p2, t_inv, hv);
         // valid results tau = l + 64 c >= first; frame-relative index i = per_block * jb + tau - first
@@ -2217,11 +1750,7 @@ int launch_ols_frame(hipStream_t s, const FusedFirArgs &a, const void *pend_in, 
     f.kstep = (unsigned)(128 % den);
     f.inv_denom = 1.0 / (double)den;
     f.nfr = (unsigned)nfr;
-#if RR_V_FRAMEWIN > 0
     const unsigned grid = (unsigned)((nfr + 1 + 8 * RR_V_FRAMEWIN - 1) / (8 * RR_V_FRAMEWIN) * (8 * RR_V_FRAMEWIN));
-#else
-    const unsigned grid = (unsigned)((nfr + 1 + 7) / 8 * 8);
-#endif
     hipLaunchKernelGGL(k_ols_frame, dim3(grid), dim3(64 * kFrameWaves), 0, s, f);
     RR_HIP(hipGetLastError());
     return RR_OK;
@@ -2243,61 +1772,18 @@ int launch_ols_wave(hipStream_t s, const FusedFirArgs &a) {
     int64_t ph = ((int64_t)a.idx0 + a.e0 - a.V) % den;
     if (ph < 0) ph += den;
     const unsigned hopm = (unsigned)((int64_t)(1024 - a.V) % den), kstep = (unsigned)(128 % den);
-#ifndef RR_V_WAVECUR
-#define RR_V_WAVECUR 0  // > 0: CU-resident persistent workgroups (k_ols_wave<2>), that many per CU
-#endif
-#ifndef RR_V_WAVELOOP
-#define RR_V_WAVELOOP 0  // 0: one block per wave (measured faster: 0.144 vs 0.168 ms); G > 0: persistent waves, G resident sets
-#endif
-#if RR_V_WAVELOOP > 0
-    // one resident set = 256 CUs x 4 SIMDs x RR_V_WAVEOCCL waves; the grid must be a multiple of 8
-#if RR_V_WAVERUN > 0
-    unsigned grid = (unsigned)(((nblocks + RR_V_WAVERUN - 1) / RR_V_WAVERUN + 7) / 8 * 8), threads = 64;
-#else
-    const size_t cap = (size_t)1024 * RR_V_WAVEOCCL * RR_V_WAVELOOP;
-    unsigned grid = (unsigned)(nblocks < cap ? (nblocks + 7) / 8 * 8 : cap), threads = 64;
-#endif
-    auto kern = k_ols_wave<1>;
-    unsigned wpw = 1;
-    if (a.n_in < 1024) {  // the persistent form prefetches whole blocks from inside the input
-        kern = k_ols_wave<0>;
-        grid = (unsigned)((nblocks + 7) / 8 * 8);
-    }
-#elif RR_V_WAVECUR > 0
-    // CU-resident workgroups: RR_V_WAVECUR per CU's worth of LDS (1), 256 CUs
-    unsigned grid = 256 * RR_V_WAVECUR, threads = 64 * kCuWaves, wpw = kCuWaves;
-    auto kern = k_ols_wave<2>;
-    if (a.n_in < 1024 || nblocks < 4096) {
-        const size_t per_xcd = (nblocks + 7) / 8;
-        kern = k_ols_wave<0>;
-        grid = (unsigned)((per_xcd + RR_V_WAVEWG - 1) / RR_V_WAVEWG * 8);
-        threads = 64 * RR_V_WAVEWG;
-        wpw = 1;
-    }
-#else
-    const size_t per_xcd = (nblocks + 7) / 8;
-#if RR_V_WAVEWIN > 0
-    const unsigned grid = (unsigned)((nblocks + 8 * RR_V_WAVEWIN - 1) / (8 * RR_V_WAVEWIN) * (8 * RR_V_WAVEWIN)), threads = 64, wpw = 1;
-    (void)per_xcd;
-#else
-    const unsigned grid = (unsigned)((per_xcd + RR_V_WAVEWG - 1) / RR_V_WAVEWG * 8), threads = 64 * RR_V_WAVEWG, wpw = 1;
-#endif
-    auto kern = k_ols_wave<0>;
-#endif
-    const bool looped = kern != k_ols_wave<0>;
-    const unsigned hopm_run = (looped && RR_V_WAVERUN == 0) ? (unsigned)((int64_t)(grid / 8) * wpw * (RR_V_WAVELOOPWIN ? 8 : 1) * (1024 - a.V) % den) : hopm;
+    const unsigned grid = (unsigned)((nblocks + 8 * kWaveWin - 1) / (8 * kWaveWin) * (8 * kWaveWin));
     if (a.ev_start && a.ev_stop)
-        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, s, a.ev_start, a.ev_stop, 0, (const float2 *)a.xh, (int)a.hx,
+        hipExtLaunchKernelGGL(k_ols_wave, dim3(grid), dim3(64), 0, s, a.ev_start, a.ev_stop, 0, (const float2 *)a.xh, (int)a.hx,
                               (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0,
                               (const float2 *)a.H, (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out,
-                              (long)a.e0, (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, hopm_run,
-                              kstep, 1.0 / (double)den);
+                              (long)a.e0, (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, kstep,
+                              1.0 / (double)den);
     else
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, s, (const float2 *)a.xh, (int)a.hx,
+        hipLaunchKernelGGL(k_ols_wave, dim3(grid), dim3(64), 0, s, (const float2 *)a.xh, (int)a.hx,
                            (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0,
                            (const float2 *)a.H, (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out, (long)a.e0,
-                           (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, hopm_run, kstep,
-                           1.0 / (double)den);
+                           (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, kstep, 1.0 / (double)den);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
@@ -2434,15 +1920,9 @@ __device__ __forceinline__ void wave_dft1024_t(f2 (&Z)[16], f2 (&v)[16], f2 *lds
     }
 }
 
-#ifndef RR_V_FLTWWIN
 #define RR_V_FLTWWIN 64
-#endif
-#ifndef RR_V_FLTWNT
 #define RR_V_FLTWNT 3  // bit 0: streaming stores, bit 1: streaming loads (measured n = 64: 0.203 / 0.196 / 0.202 / 0.193 ms for 0 / 1 / 2 / 3)
-#endif
-#ifndef RR_V_FLTWOCC
 #define RR_V_FLTWOCC 3  // waves per SIMD the register budget is cut for (140 registers; at 4 the kernel spills 12)
-#endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_FLTWOCC, RR_V_FLTWOCC))) void k_filter_wave(
     const float2 *__restrict__ hist, int hist_len, const float2 *__restrict__ in, long n_in,
     const float2 *__restrict__ H, const float2 *__restrict__ tw, int V, float2 *__restrict__ out, long n_out, long e0,
@@ -2450,16 +1930,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_FLTWOCC
     __shared__ __attribute__((aligned(16))) f2 lds[kWaveLds];
     const int l = threadIdx.x;
     // workgroups b, b + 8, .. share an XCD: neighbouring blocks (which share V samples) on one XCD
-#if RR_V_FLTWWIN > 0
     // (in a moving window of 8 G blocks, G neighbouring blocks per XCD, as k_ols_wave)
     constexpr unsigned G = RR_V_FLTWWIN;
     const unsigned blk = blockIdx.x / (8 * G) * (8 * G) + (blockIdx.x % (8 * G) & 7) * G + (blockIdx.x % (8 * G) >> 3);
     if (blk >= nblocks) return;
-#else
-    const unsigned per_xcd = (nblocks + 7) >> 3, within = blockIdx.x >> 3;
-    const unsigned blk = (blockIdx.x & 7) * per_xcd + within;
-    if (blk >= nblocks || within >= per_xcd) return;
-#endif
     const int hop = 1024 - V;
     const long b0 = e0 - V + (long)blk * hop;
     f2 v[16];
@@ -2622,11 +2096,7 @@ int launch_filter_wave(hipStream_t s, const void *hist, size_t hist_len, const v
     const size_t hop = 1024 - V;
     const size_t nblocks = (n_out + hop - 1) / hop;
     if (nblocks > 0x7ffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "Filter: too many blocks");
-#if RR_V_FLTWWIN > 0
     const size_t grid = (nblocks + 8 * RR_V_FLTWWIN - 1) / (8 * RR_V_FLTWWIN) * (8 * RR_V_FLTWWIN);
-#else
-    const size_t grid = (nblocks + 7) / 8 * 8;
-#endif
     hipLaunchKernelGGL(k_filter_wave, dim3((unsigned)grid), dim3(64), 0, s, (const float2 *)hist, (int)hist_len,
                        (const float2 *)in, (long)n_in, (const float2 *)H, (const float2 *)tw, V, (float2 *)out, (long)n_out,
                        e0, (unsigned)nblocks);
@@ -2642,9 +2112,7 @@ int launch_filter_wave(hipStream_t s, const void *hist, size_t hist_len, const v
 // chunks in registers and loads one new chunk (4 loads) per frame; the window values of the lane
 // (4 P) and the three twiddle seeds stay in registers for the whole run.
 // ---------------------------------------------------------------------------
-#ifndef RR_V_CHANWIN
 #define RR_V_CHANWIN 4  // cfg3: one contiguous eighth of the runs per XCD 0.250 ms; windows of 1 .. 6 and 64 runs per XCD 0.222-0.226; 8: 0.232, 16: 0.265, 32: 0.233
-#endif
 template <int P>
 __global__ __launch_bounds__(64) void k_channelizer256(const float2 *__restrict__ hist, long hist_len,
                                                        const float2 *__restrict__ in, long base0,
@@ -2654,15 +2122,10 @@ __global__ __launch_bounds__(64) void k_channelizer256(const float2 *__restrict_
     __shared__ __attribute__((aligned(16))) f2 lds[320];  // B(i) = i + 4 (i >> 4), i < 256
     const int l = threadIdx.x, g = l >> 4, q = l & 15;
     // workgroups b, b + 8, .. share an XCD: neighbouring runs on one XCD (grid: multiple of 8)
-#if RR_V_CHANWIN > 0
     // runs dealt to the XCDs in a moving window: RR_V_CHANWIN neighbouring runs per XCD (as k_ols_wave's blocks)
     const unsigned rb = blockIdx.x / (8 * RR_V_CHANWIN) * (8 * RR_V_CHANWIN) + (blockIdx.x % (8 * RR_V_CHANWIN) & 7) * RR_V_CHANWIN +
                         (blockIdx.x % (8 * RR_V_CHANWIN) >> 3);
     const unsigned f0 = rb * run;
-#else
-    const unsigned wpx = gridDim.x >> 3;
-    const unsigned f0 = ((blockIdx.x & 7) * wpx + (blockIdx.x >> 3)) * run;
-#endif
     if (f0 >= nframes) return;
     const unsigned cnt = nframes - f0 < run ? nframes - f0 : run;
 
@@ -2758,15 +2221,9 @@ int launch_channelizer256(hipStream_t s, const void *hist, size_t hist_len, cons
                           size_t nframes, const void *window, const void *tw, void *out) {
     if (nframes == 0) return RR_OK;
     if (nframes > 0x7ffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: too many frames in one call");
-#ifndef RR_V_CHANRUN
 #define RR_V_CHANRUN 16
-#endif
     const unsigned run = RR_V_CHANRUN;
-#if RR_V_CHANWIN > 0
     const unsigned grid = (unsigned)(((nframes + run - 1) / run + 8 * RR_V_CHANWIN - 1) / (8 * RR_V_CHANWIN) * (8 * RR_V_CHANWIN));
-#else
-    const unsigned grid = (unsigned)(((nframes + run - 1) / run + 7) / 8 * 8);
-#endif
 #define RR_CHAN_LAUNCH(PP)                                                                                        \
     hipLaunchKernelGGL(k_channelizer256<PP>, dim3(grid), dim3(64), 0, s, (const float2 *)hist, (long)hist_len,    \
                        (const float2 *)in, base0, (const float *)window, (const float2 *)tw, (float2 *)out,      \
@@ -2818,22 +2275,6 @@ __global__ void k_drop_tail(const float2 *__restrict__ oldh, float2 *__restrict_
     newh[i] = v;
 }
 
-#ifdef RR_STAMP
-extern "C" int rr_debug_read_wave_stamps(unsigned *out, unsigned nblocks) {
-    if (nblocks > kWaveStampBlocks) nblocks = kWaveStampBlocks;
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wstamp), (size_t)nblocks * 8 * sizeof(unsigned)) != hipSuccess;
-}
-extern "C" int rr_debug_read_stamps(unsigned long long *out8, int reset) {
-    unsigned long long h[8];
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp), sizeof h) != hipSuccess) return 1;
-    for (int i = 0; i < 8; ++i) out8[i] = h[i];
-    if (reset) {
-        unsigned long long z[8] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof z) != hipSuccess) return 1;
-    }
-    return 0;
-}
-#endif
 
 int launch_drop_tail(hipStream_t s, const void *oldh, void *newh, size_t H, size_t drop) {
     if (H == 0) return RR_OK;

@@ -22,7 +22,8 @@ run pytest 900 python -m pytest tests -m gpu -q --timeout 300 ${PYTEST_ARGS:-}
 run bench 600 python bench.py "$@"
 grep -h '^{' "$OUT/bench.log" > "$OUT/bench.json" || true
 export TMPDIR=/tmp
-run rocprof 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 bench.py "$@" --no-cpu-baseline
+run rocprof 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 bench.py "$@" --profile
+grep -h '^{' "$OUT/rocprof.log" > "$OUT/bench_profiled.json" || true
 find "$OUT/prof" -name '*kernel_stats*.csv' | head -1 | xargs -r -I{} cp {} "$OUT/kernel_stats.csv"
 [ -f "$OUT/kernel_stats.csv" ] && head -15 "$OUT/kernel_stats.csv"
 find "$OUT/prof" -name '*kernel_trace*.csv' -size +20M -delete || true
