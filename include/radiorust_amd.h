@@ -328,6 +328,12 @@ const char *rr_chain_timing_stage_name(int stage); /* NULL past the last stage *
 typedef struct rr_channelizer rr_channelizer;
 int rr_channelizer_create(int dtype, size_t bins, size_t taps_per_branch,
                           const rr_window *window, int device, rr_channelizer **out);
+/* The general form: any number of bins (the bins-point transforms run through the Fourier machinery: fast kernels,
+ * four-step or Bluestein) and an OVERSAMPLED filterbank with `hop` < bins samples between frames (hop must divide
+ * bins * taps_per_branch; 0 = bins) = the composition Rechunker(hop) -> Overlapper(bins * taps_per_branch / hop) ->
+ * Fourier::with_window -> every taps_per_branch-th bin.  Input: whole chunks of `hop` samples. */
+int rr_channelizer_create_ex(int dtype, size_t bins, size_t taps_per_branch, size_t hop,
+                             const rr_window *window, int device, rr_channelizer **out);
 /* Any event makes the Overlapper drop its history (chunks.rs:225-233). */
 int rr_channelizer_reset(rr_channelizer *h);
 int rr_channelizer_peek(const rr_channelizer *h, size_t n_in, size_t *n_out);

@@ -141,6 +141,7 @@ SIGNATURES = {
     "rr_chain_timing_read": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(C.c_uint64)]),
     "rr_chain_timing_stage_name": (C.c_char_p, [_i]),
     "rr_channelizer_create": (_i, [_i, _sz, _sz, C.POINTER(Window), _i, C.POINTER(_vp)]),
+    "rr_channelizer_create_ex": (_i, [_i, _sz, _sz, _sz, C.POINTER(Window), _i, C.POINTER(_vp)]),
     "rr_channelizer_reset": (_i, [_vp]),
     "rr_channelizer_peek": (_i, [_vp, _sz, _psz]),
     "rr_channelizer_process": (_i, [_vp, _vp, _sz, _vp, _sz, _psz]),

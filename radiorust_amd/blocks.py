@@ -518,19 +518,24 @@ class Channelizer(_Block):
     """Polyphase FFT channelizer (BASELINE configs[2]): the reference composition
     Rechunker(bins) -> Overlapper(taps_per_branch) -> Fourier.with_window(window) ->
     every taps_per_branch-th bin (chunks.rs:42-242, analysis.rs:60-132) as one
-    fold + `bins`-point FFT per hop.  Input chunks must be multiples of `bins`."""
+    fold + `bins`-point FFT per hop.  Input chunks must be multiples of the hop.
+    hop < bins: the oversampled filterbank = Rechunker(hop) -> Overlapper(bins * taps_per_branch / hop) -> the same
+    Fourier and bin selection; any number of bins works (powers of two with hop = bins take the fused kernels)."""
 
     _destroy = "rr_channelizer_destroy"
 
-    def __init__(self, bins: int, taps_per_branch: int, window: Window | None = None, dtype=np.float32, device: int = 0):
+    def __init__(self, bins: int, taps_per_branch: int, window: Window | None = None, dtype=np.float32, device: int = 0,
+                 hop: int | None = None):
         super().__init__()
         self._code, self._cdt = _dtype_code(dtype)
         self.bins, self.taps_per_branch = int(bins), int(taps_per_branch)
+        self.hop = int(hop) if hop else self.bins
         w = window if window is not None else Kaiser.with_null_at_bin(float(taps_per_branch))
         spec = w._spec()
         if spec is None:
             raise TypeError("Channelizer needs a built-in window (Rectangular or Kaiser)")
-        _lib.check(_lib.lib().rr_channelizer_create(self._code, self.bins, self.taps_per_branch, spec, device, C.byref(self._h)))
+        _lib.check(_lib.lib().rr_channelizer_create_ex(self._code, self.bins, self.taps_per_branch, self.hop, spec, device,
+                                                       C.byref(self._h)))
 
     def process(self, signal):
         """Each output message is one frame of `bins` channel samples; the frame rate is

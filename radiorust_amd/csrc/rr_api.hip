@@ -705,6 +705,15 @@ int rr_fmdemod::process_dev(double sample_rate, const void *d_in, size_t n_in, v
 // ---------------------------------------------------------------------------
 // Fourier
 // ---------------------------------------------------------------------------
+// Which kernel family transforms a chunk of `len` points:
+//   fast     the radix-8/16 register kernels of rr_fused.hip (f32: 64 .. 8192) and the LDS radix-2 kernel (<= 8192 f32,
+//            <= 4096 f64) for powers of two
+//   big      powers of two beyond that, up to 2^24: four-step through HBM (launch_fft_big)
+//   bluestein any other length >= 32 (either dtype): two power-of-two transforms of M >= 2 len - 1 points by a nested
+//            rectangular-window Fourier (which is `fast` or `big` itself)
+//   direct   other lengths below 32: the O(n^2) kernel
+static bool is_pow2_sz(size_t n) { return n && (n & (n - 1)) == 0; }
+
 int rr_fourier::prepare(size_t len) {
     if (len == n) return RR_OK;
     RR_TRY(fourier_supported(dtype, len));
@@ -718,84 +727,110 @@ int rr_fourier::prepare(size_t len) {
     }
     std::vector<double> vals(len);
     RR_TRY(fourier_design_window(len, rel.data(), vals.data()));
-    const size_t ntw = len;  // the radix-2 kernel uses the first half, radix-16 and direct all of it
-    std::vector<double> tw(2 * ntw);
-    for (size_t k = 0; k < ntw; ++k) {
-        const double ang = -2.0 * M_PI * (double)k / (double)len;
-        tw[2 * k] = std::cos(ang);
-        tw[2 * k + 1] = std::sin(ang);
-    }
+    const bool pow2 = is_pow2_sz(len);
+    const bool generic = [] { const char *e = std::getenv("RR_FOURIER_GENERIC"); return e && std::atoi(e) != 0; }();
+    const bool use_big = pow2 && !fourier_pow2_path(dtype, len);
+    const bool use_bs = !pow2 && len >= 32 && !(generic && len <= 16384);
+    auto cast = [&](const std::vector<double> &src, std::vector<unsigned char> &dst) {
+        if (dtype == RR_F32) cast_to<float>(src.data(), src.size(), dst);
+        else cast_to<double>(src.data(), src.size(), dst);
+    };
     std::vector<unsigned char> wb, tb;
-    if (dtype == RR_F32) {
-        cast_to<float>(vals.data(), len, wb);
-        cast_to<float>(tw.data(), tw.size(), tb);
-    } else {
-        cast_to<double>(vals.data(), len, wb);
-        cast_to<double>(tw.data(), tw.size(), tb);
-    }
-    if (dtype == RR_F32 && (len == 4096 || len == 2048)) {
-        // k_fft4096 / k_fft2048 read the 16 window values of a lane (w[j + T k], k < 16, T = len / 16 lanes) as four
-        // 16-byte pieces from a second copy behind the table: wp[16 j + k] = w[j + T k]
-        const size_t T = len / 16;
-        std::vector<float> both(2 * len);
-        std::memcpy(both.data(), wb.data(), len * sizeof(float));
-        for (size_t j = 0; j < T; ++j)
-            for (size_t k = 0; k < 16; ++k) both[len + 16 * j + k] = both[j + T * k];
-        RR_TRY(upload(d_window, both.data(), both.size() * sizeof(float), stream));
-    } else {
+    cast(vals, wb);
+    if (use_big) {
+        // half tables e^{-j 2 pi k / N1}, e^{-j 2 pi k / N2} of the four-step split, one behind the other
+        size_t N1, N2;
+        fft_big_split(len, &N1, &N2);
+        std::vector<double> tw(N1 + N2);  // (N1 / 2 + N2 / 2) complex
+        for (size_t k = 0; k < N1 / 2; ++k) {
+            const double ang = -2.0 * M_PI * (double)k / (double)N1;
+            tw[2 * k] = std::cos(ang);
+            tw[2 * k + 1] = std::sin(ang);
+        }
+        for (size_t k = 0; k < N2 / 2; ++k) {
+            const double ang = -2.0 * M_PI * (double)k / (double)N2;
+            tw[N1 + 2 * k] = std::cos(ang);
+            tw[N1 + 2 * k + 1] = std::sin(ang);
+        }
+        cast(tw, tb);
         RR_TRY(upload(d_window, wb.data(), wb.size(), stream));
-    }
-    if (dtype == RR_F32 && len == 1024) {  // k_fft1024 finds its lane seeds behind the table
-        std::vector<float> twb(2 * 1024);
-        std::memcpy(twb.data(), tb.data(), twb.size() * sizeof(float));
-        append_wave1024_seeds(twb);
-        RR_TRY(upload(d_tw, twb.data(), twb.size() * sizeof(float), stream));
-    } else {
         RR_TRY(upload(d_tw, tb.data(), tb.size(), stream));
+    } else if (use_bs) {
+        RR_TRY(upload(d_window, wb.data(), wb.size(), stream));  // (kept for symmetry; Bluestein folds the window into c)
+    } else {
+        const size_t ntw = len;  // the radix-2 kernel uses the first half, radix-16 and direct all of it
+        std::vector<double> tw(2 * ntw);
+        for (size_t k = 0; k < ntw; ++k) {
+            const double ang = -2.0 * M_PI * (double)k / (double)len;
+            tw[2 * k] = std::cos(ang);
+            tw[2 * k + 1] = std::sin(ang);
+        }
+        cast(tw, tb);
+        if (dtype == RR_F32 && (len == 4096 || len == 2048)) {
+            // k_fft4096 / k_fft2048 read the 16 window values of a lane (w[j + T k], k < 16, T = len / 16 lanes) as four
+            // 16-byte pieces from a second copy behind the table: wp[16 j + k] = w[j + T k]
+            const size_t T = len / 16;
+            std::vector<float> both(2 * len);
+            std::memcpy(both.data(), wb.data(), len * sizeof(float));
+            for (size_t j = 0; j < T; ++j)
+                for (size_t k = 0; k < 16; ++k) both[len + 16 * j + k] = both[j + T * k];
+            RR_TRY(upload(d_window, both.data(), both.size() * sizeof(float), stream));
+        } else {
+            RR_TRY(upload(d_window, wb.data(), wb.size(), stream));
+        }
+        if (dtype == RR_F32 && len == 1024) {  // k_fft1024 finds its lane seeds behind the table
+            std::vector<float> twb(2 * 1024);
+            std::memcpy(twb.data(), tb.data(), twb.size() * sizeof(float));
+            append_wave1024_seeds(twb);
+            RR_TRY(upload(d_tw, twb.data(), twb.size() * sizeof(float), stream));
+        } else {
+            RR_TRY(upload(d_tw, tb.data(), tb.size(), stream));
+        }
     }
     window_f64.swap(vals);
     n = len;
     bs_M = 0;
-    {
-        const char *e = std::getenv("RR_FOURIER_GENERIC");
-        const bool pow2 = (len & (len - 1)) == 0;
-        if (dtype == RR_F32 && !pow2 && len >= 32 && len <= 4096 && !(e && std::atoi(e) != 0)) {
-            size_t M = 512;
-            while (M < 2 * len - 1) M *= 2;
-            // chirp w_m = e^{+j pi m^2 / n}, the phase reduced exactly (m^2 mod 2n) before it is evaluated
-            std::vector<cd> w(len);
-            for (size_t m = 0; m < len; ++m) {
-                const uint64_t r = (uint64_t)m * m % (2 * len);
-                const double ang = M_PI * (double)r / (double)len;
-                w[m] = cd(std::cos(ang), std::sin(ang));
-            }
-            std::vector<cd> bb(M, cd(0, 0));
-            bb[0] = w[0];
-            for (size_t m = 1; m < len; ++m) bb[m] = bb[M - m] = w[m];
-            fft_f64(bb, false);
-            std::vector<float> cf(2 * len), wf(2 * len), Bf(2 * M);
-            for (size_t m = 0; m < len; ++m) {
-                const cd c = std::conj(w[m]) * window_f64[m];
-                cf[2 * m] = (float)c.real();
-                cf[2 * m + 1] = (float)c.imag();
-                wf[2 * m] = (float)w[m].real();
-                wf[2 * m + 1] = (float)w[m].imag();
-            }
-            for (size_t m = 0; m < M; ++m) {
-                Bf[2 * m] = (float)(bb[m].real() / (double)M);
-                Bf[2 * m + 1] = (float)(bb[m].imag() / (double)M);
-            }
-            RR_TRY(upload(d_bs_c, cf.data(), cf.size() * sizeof(float), stream));
-            RR_TRY(upload(d_bs_w, wf.data(), wf.size() * sizeof(float), stream));
-            RR_TRY(upload(d_bs_B, Bf.data(), Bf.size() * sizeof(float), stream));
-            if (!bs_fft) {
-                bs_fft = new rr_fourier;
-                RR_TRY(bs_fft->init_base(K_FOURIER, RR_F32, device));
-            }
-            bs_fft->stream = stream;
-            RR_TRY(bs_fft->prepare(M));  // rectangular window: all ones
-            bs_M = M;
+    big = use_big;
+    if (use_bs) {
+        size_t M = 64;
+        while (M < 2 * len - 1) M *= 2;
+        // chirp w_m = e^{+j pi m^2 / n}, the phase reduced exactly (m^2 mod 2n) before it is evaluated
+        std::vector<cd> w(len);
+        for (size_t m = 0; m < len; ++m) {
+            const uint64_t r = (uint64_t)(((unsigned __int128)m * m) % (2 * len));
+            const double ang = M_PI * (double)r / (double)len;
+            w[m] = cd(std::cos(ang), std::sin(ang));
         }
+        std::vector<cd> bb(M, cd(0, 0));
+        bb[0] = w[0];
+        for (size_t m = 1; m < len; ++m) bb[m] = bb[M - m] = w[m];
+        fft_f64(bb, false);
+        std::vector<double> cf(2 * len), wf(2 * len), Bf(2 * M);
+        for (size_t m = 0; m < len; ++m) {
+            const cd c = std::conj(w[m]) * window_f64[m];
+            cf[2 * m] = c.real();
+            cf[2 * m + 1] = c.imag();
+            wf[2 * m] = w[m].real();
+            wf[2 * m + 1] = w[m].imag();
+        }
+        for (size_t m = 0; m < M; ++m) {
+            Bf[2 * m] = bb[m].real() / (double)M;
+            Bf[2 * m + 1] = bb[m].imag() / (double)M;
+        }
+        std::vector<unsigned char> cb, wwb, Bb;
+        cast(cf, cb);
+        cast(wf, wwb);
+        cast(Bf, Bb);
+        RR_TRY(upload(d_bs_c, cb.data(), cb.size(), stream));
+        RR_TRY(upload(d_bs_w, wwb.data(), wwb.size(), stream));
+        RR_TRY(upload(d_bs_B, Bb.data(), Bb.size(), stream));
+        if (!bs_fft) {
+            bs_fft = new rr_fourier;
+            RR_TRY(bs_fft->init_base(K_FOURIER, dtype, device));
+        }
+        bs_fft->stream = stream;
+        RR_TRY(bs_fft->prepare(M));  // rectangular window: all ones
+        bs_M = M;
     }
     return RR_OK;
 }
@@ -803,11 +838,32 @@ int rr_fourier::prepare(size_t len) {
 rr_fourier::~rr_fourier() { delete bs_fft; }
 
 int rr_fourier::transform_dev(const void *head, size_t n_head, const void *in, void *out, size_t hop, size_t count) {
+    const size_t esz = elem_size(dtype);
+    if (big) {
+        if (hop != n || n_head) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: overlapping chunks of more than 8192 points are not supported");
+        // passes of at most 2^24 workspace elements
+        size_t per_pass = ((size_t)1 << 24) / n;
+        if (per_pass < 1) per_pass = 1;
+        if (per_pass > 65535) per_pass = 65535;
+        if (per_pass > count) per_pass = count;
+        RR_TRY(big_ws.reserve(per_pass * n * esz));
+        size_t N1, N2;
+        fft_big_split(n, &N1, &N2);
+        const char *tw2 = d_tw.as<char>() + (N1 / 2) * esz;
+        for (size_t f0 = 0; f0 < count; f0 += per_pass) {
+            const size_t F = count - f0 < per_pass ? count - f0 : per_pass;
+            RR_TRY(launch_fft_big(dtype, stream, static_cast<const char *>(in) + f0 * n * esz, static_cast<char *>(out) + f0 * n * esz,
+                                  big_ws.p, n, F, d_window.p, d_tw.p, tw2, center_dc));
+        }
+        return RR_OK;
+    }
     if (!bs_M) return launch_fourier_overlapped(dtype, stream, head, n_head, in, out, n, hop, count, d_window.p, d_tw.p, center_dc);
-    const size_t M = bs_M, esz = elem_size(dtype);
-    // passes of at most 2^22 workspace elements per buffer (32 MiB each)
+    const size_t M = bs_M;
+    // passes of at most 2^22 workspace elements per buffer (32 MiB each in f32)
     size_t per_pass = ((size_t)1 << 22) / M;
+    if (per_pass < 1) per_pass = 1;
     if (per_pass > 65535) per_pass = 65535;
+    if (per_pass > count) per_pass = count;
     RR_TRY(bs_ws[0].reserve(per_pass * M * esz));
     RR_TRY(bs_ws[1].reserve(per_pass * M * esz));
     bs_fft->stream = stream;
@@ -825,11 +881,11 @@ int rr_fourier::transform_dev(const void *head, size_t n_head, const void *in, v
             hd += skip * esz;
             nh = n_head - skip;
         }
-        RR_TRY(launch_bs_pre(stream, hd, nh, src, hop, n, M, d_bs_c.p, bs_ws[0].p, F));
-        RR_TRY(launch_fourier(RR_F32, stream, bs_ws[0].p, bs_ws[1].p, M, F, bs_fft->d_window.p, bs_fft->d_tw.p, false));
-        RR_TRY(launch_bs_mul(stream, bs_ws[1].p, d_bs_B.p, M, F));
-        RR_TRY(launch_fourier(RR_F32, stream, bs_ws[1].p, bs_ws[0].p, M, F, bs_fft->d_window.p, bs_fft->d_tw.p, false));
-        RR_TRY(launch_bs_post(stream, bs_ws[0].p, d_bs_w.p, n, M, static_cast<char *>(out) + f0 * n * esz, center_dc, F));
+        RR_TRY(launch_bs_pre(dtype, stream, hd, nh, src, hop, n, M, d_bs_c.p, bs_ws[0].p, F));
+        RR_TRY(bs_fft->transform_dev(nullptr, 0, bs_ws[0].p, bs_ws[1].p, M, F));
+        RR_TRY(launch_bs_mul(dtype, stream, bs_ws[1].p, d_bs_B.p, M, F));
+        RR_TRY(bs_fft->transform_dev(nullptr, 0, bs_ws[1].p, bs_ws[0].p, M, F));
+        RR_TRY(launch_bs_post(dtype, stream, bs_ws[0].p, d_bs_w.p, n, M, static_cast<char *>(out) + f0 * n * esz, center_dc, F));
     }
     return RR_OK;
 }
@@ -850,27 +906,46 @@ int rr_fourier::process_dev(size_t chunk_len, const void *d_in, size_t n_in, voi
 // ---------------------------------------------------------------------------
 // Channelizer
 // ---------------------------------------------------------------------------
+rr_channelizer::~rr_channelizer() { delete fo; }
+
 int rr_channelizer::process_dev(const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out) {
     if (n_out) *n_out = 0;
-    if (n_in % M) RR_FAIL(RR_ERR_BAD_ARG, "Channelizer: %zu samples is not a whole number of %zu-sample chunks", n_in, M);
+    if (n_in % hop) RR_FAIL(RR_ERR_BAD_ARG, "Channelizer: %zu samples is not a whole number of %zu-sample chunks", n_in, hop);
     const size_t produce = peek(n_in);
     if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Channelizer: out_cap %zu < %zu", cap, produce);
     if (n_in == 0) return RR_OK;
     RR_TRY(select());
-    const size_t chunks = n_in / M, H = (P - 1) * M;
+    const size_t chunks = n_in / hop, K = span_chunks(), H = P * M - hop;
     const size_t frames = produce / M;
     if (frames) {
-        // frame 0 ends with the chunk that completes the history: it starts (have_chunks) chunks before in[0]
-        // when the history is full, later when it is still filling
-        const size_t first_complete = (have_chunks >= P - 1) ? 0 : (P - 1 - have_chunks);  // index of the chunk that ends frame 0
-        const long base0 = ((long)first_complete - (long)(P - 1)) * (long)M;
-        RR_TRY(launch_channelizer(dtype, stream, hist[cur].p, H, d_in, base0, M, P, frames, d_window.p, d_tw.p, d_out));
+        // frame 0 ends with the chunk that completes the history: it starts (K - 1) chunks before that chunk
+        const size_t first_complete = (have_chunks >= K - 1) ? 0 : (K - 1 - have_chunks);  // index of the chunk that ends frame 0
+        const long base0 = ((long)first_complete - (long)(K - 1)) * (long)hop;
+        if (!fo) {
+            RR_TRY(launch_channelizer(dtype, stream, hist[cur].p, H, d_in, base0, M, P, frames, d_window.p, d_tw.p, d_out));
+        } else {
+            // general form: fold every frame into the workspace, then the M-point transforms (any M)
+            const size_t esz = elem_size(dtype);
+            size_t per_pass = ((size_t)1 << 24) / M;
+            if (per_pass < 1) per_pass = 1;
+            if (per_pass > 65535) per_pass = 65535;
+            if (per_pass > frames) per_pass = frames;
+            RR_TRY(fold_ws.reserve(per_pass * M * esz));
+            fo->stream = stream;
+            RR_TRY(fo->prepare(M));
+            for (size_t f0 = 0; f0 < frames; f0 += per_pass) {
+                const size_t F = frames - f0 < per_pass ? frames - f0 : per_pass;
+                RR_TRY(launch_chan_fold(dtype, stream, hist[cur].p, H, d_in, base0 + (long)(f0 * hop), hop, M, P, F, d_window.p,
+                                        fold_ws.p));
+                RR_TRY(fo->transform_dev(nullptr, 0, fold_ws.p, static_cast<char *>(d_out) + f0 * M * esz, M, F));
+            }
+        }
     }
     if (H) {
         RR_TRY(launch_update_hist(dtype, stream, hist[cur].p, hist[cur ^ 1].p, H, d_in, n_in));
         cur ^= 1;
     }
-    have_chunks = (have_chunks + chunks > P - 1) ? P - 1 : have_chunks + chunks;
+    have_chunks = (have_chunks + chunks > K - 1) ? K - 1 : have_chunks + chunks;
     if (n_out) *n_out = produce;
     return RR_OK;
 }
@@ -2283,16 +2358,21 @@ int rr_chain_destroy(rr_chain *h) {
     return RR_OK;
 }
 
-int rr_channelizer_create(int dtype, size_t bins, size_t taps_per_branch, const rr_window *window, int device,
-                          rr_channelizer **out) {
+int rr_channelizer_create_ex(int dtype, size_t bins, size_t taps_per_branch, size_t hop, const rr_window *window, int device,
+                             rr_channelizer **out) {
     RR_GUARD_BEGIN
     if (!out || !window) RR_FAIL(RR_ERR_BAD_ARG, "null");
     *out = nullptr;
     if (taps_per_branch == 0) RR_FAIL(RR_ERR_CONTRACT, "chunk count must be positive");  // chunks.rs:195
-    if (bins < 2 || (bins & (bins - 1)) || bins > (dtype == RR_F32 ? 8192u : 4096u))
-        RR_FAIL(RR_ERR_BAD_ARG, "Channelizer: bins must be a power of two in [2, %u]", dtype == RR_F32 ? 8192u : 4096u);
+    if (hop == 0) hop = bins;
+    if (bins < 2 || bins > ((size_t)1 << 20)) RR_FAIL(RR_ERR_BAD_ARG, "Channelizer: bins must be in [2, 2^20]");
+    if (hop > bins || (bins * taps_per_branch) % hop)
+        RR_FAIL(RR_ERR_BAD_ARG, "Channelizer: the hop (%zu) must divide bins * taps_per_branch (%zu) and not exceed bins", hop,
+                bins * taps_per_branch);
     if (window->kind != RR_WIN_RECTANGULAR && window->kind != RR_WIN_KAISER)
         RR_FAIL(RR_ERR_BAD_ARG, "Channelizer: window must be a built-in window");
+    const bool pow2 = (bins & (bins - 1)) == 0;
+    const bool fast = hop == bins && pow2 && bins <= (dtype == RR_F32 ? 8192u : 4096u);  // one fused fold + FFT kernel
     auto *h = new rr_channelizer;
     int st = h->init_base(K_CHANNELIZER, dtype, device);
     if (st != RR_OK) {
@@ -2301,6 +2381,7 @@ int rr_channelizer_create(int dtype, size_t bins, size_t taps_per_branch, const 
     }
     h->M = bins;
     h->P = taps_per_branch;
+    h->hop = hop;
     const size_t n = bins * taps_per_branch;
     std::vector<double> rel(n), vals(n), tw(bins);
     st = window_sample(window, n, rel.data());
@@ -2320,9 +2401,14 @@ int rr_channelizer_create(int dtype, size_t bins, size_t taps_per_branch, const 
     }
     if (st == RR_OK) st = upload(h->d_window, wb.data(), wb.size(), h->stream);
     if (st == RR_OK) st = upload(h->d_tw, tb.data(), tb.size(), h->stream);
-    const size_t hb = (taps_per_branch - 1) * bins * elem_size(dtype);
+    const size_t hb = (n - hop) * elem_size(dtype);
     if (st == RR_OK) st = h->hist[0].reserve(hb ? hb : 16);
     if (st == RR_OK) st = h->hist[1].reserve(hb ? hb : 16);
+    if (st == RR_OK && !fast) {
+        h->fo = new rr_fourier;  // rectangular window (all ones), no DC centring: the bare M-point transform
+        st = h->fo->init_base(K_FOURIER, dtype, device);
+        if (st == RR_OK) st = fourier_supported(dtype, bins);
+    }
     if (st != RR_OK) {
         delete h;
         return st;
@@ -2330,6 +2416,10 @@ int rr_channelizer_create(int dtype, size_t bins, size_t taps_per_branch, const 
     *out = h;
     return RR_OK;
     RR_GUARD_END
+}
+int rr_channelizer_create(int dtype, size_t bins, size_t taps_per_branch, const rr_window *window, int device,
+                          rr_channelizer **out) {
+    return rr_channelizer_create_ex(dtype, bins, taps_per_branch, 0, window, device, out);
 }
 int rr_channelizer_reset(rr_channelizer *h) {
     RR_CHECK_HANDLE(h, K_CHANNELIZER);
@@ -2339,7 +2429,7 @@ int rr_channelizer_reset(rr_channelizer *h) {
 int rr_channelizer_peek(const rr_channelizer *h, size_t n_in, size_t *n_out) {
     RR_CHECK_HANDLE(h, K_CHANNELIZER);
     if (!n_out) RR_FAIL(RR_ERR_BAD_ARG, "null");
-    if (n_in % h->M) RR_FAIL(RR_ERR_BAD_ARG, "Channelizer: input must be whole chunks of %zu samples", h->M);
+    if (n_in % h->hop) RR_FAIL(RR_ERR_BAD_ARG, "Channelizer: input must be whole chunks of %zu samples", h->hop);
     *n_out = h->peek(n_in);
     return RR_OK;
 }
@@ -2354,7 +2444,7 @@ int rr_channelizer_process(rr_channelizer *h, const void *in, size_t n_in, void 
     RR_GUARD_BEGIN
     RR_CHECK_HANDLE(h, K_CHANNELIZER);
     if (n_out) *n_out = 0;
-    if (n_in % h->M) RR_FAIL(RR_ERR_BAD_ARG, "Channelizer: input must be whole chunks of %zu samples", h->M);
+    if (n_in % h->hop) RR_FAIL(RR_ERR_BAD_ARG, "Channelizer: input must be whole chunks of %zu samples", h->hop);
     const size_t produce = h->peek(n_in);
     if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Channelizer: out_cap %zu < %zu", cap, produce);
     size_t got = 0;

@@ -145,7 +145,10 @@ struct rr_fourier : rr_block {
     size_t sampled_n = 0;
     std::vector<double> window_f64;  // scaled window of the current design
     rr::DevBuf d_window, d_tw;
-    // Bluestein for lengths that are not powers of two (f32, 32 <= n <= 4096): two transforms of bs_M points
+    // powers of two beyond the LDS kernels (up to 2^24): four-step through a workspace in HBM
+    bool big = false;
+    rr::DevBuf big_ws;
+    // Bluestein for lengths that are not powers of two (n >= 32, either dtype): two transforms of bs_M points
     // by a nested rectangular-window Fourier, tables c = window * conj(chirp), B = F(chirp) / M, w = chirp
     size_t bs_M = 0;
     rr_fourier *bs_fft = nullptr;
@@ -160,13 +163,20 @@ struct rr_fourier : rr_block {
 // Channelizer — Overlapper's history (chunks.rs:200-223) + Fourier's window (analysis.rs:67-73)
 struct rr_channelizer : rr_block {
     size_t M = 0, P = 0;
-    size_t have_chunks = 0;  // chunks in the Overlapper's history, < P
-    rr::DevBuf hist[2];      // the last (P-1)*M samples
+    size_t hop = 0;          // samples between frames: M (critically sampled) or a divisor of P M (oversampled)
+    size_t have_chunks = 0;  // chunks of `hop` samples in the Overlapper's history, < P M / hop
+    rr::DevBuf hist[2];      // the last P M - hop samples
     int cur = 0;
     rr::DevBuf d_window, d_tw;
+    // general form (hop != M, or M not a power of two): fold to a workspace, then M-point transforms by a
+    // rectangular-window Fourier (any M)
+    rr_fourier *fo = nullptr;
+    rr::DevBuf fold_ws;
+    ~rr_channelizer() override;
+    size_t span_chunks() const { return P * M / hop; }  // the Overlapper's chunk count
     size_t peek(size_t n_in) const {
-        const size_t chunks = n_in / M, total = have_chunks + chunks;
-        return total >= P ? (total - (P - 1)) * M : 0;
+        const size_t chunks = n_in / hop, total = have_chunks + chunks, K = span_chunks();
+        return total >= K ? (total - (K - 1)) * M : 0;
     }
     int process_dev(const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
 };

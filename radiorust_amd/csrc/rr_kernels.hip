@@ -517,12 +517,12 @@ constexpr size_t kDirectLimit = 16384;
 
 bool fourier_pow2_path(int dtype, size_t n) { return is_pow2(n) && n >= 2 && n <= pow2_limit(dtype); }
 
+// any length up to 2^23 (Bluestein over power-of-two transforms of up to 2^24 points), powers of two up to 2^24
 int fourier_supported(int dtype, size_t n) {
+    (void)dtype;
     if (n == 0) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: empty chunk");
-    if (fourier_pow2_path(dtype, n)) return RR_OK;
-    if (n <= kDirectLimit) return RR_OK;
-    RR_FAIL(RR_ERR_BAD_ARG, "Fourier: chunk length %zu is not supported yet (power of two <= %zu, or any length <= %zu)",
-            n, pow2_limit(dtype), kDirectLimit);
+    if (is_pow2(n) ? n <= ((size_t)1 << 24) : n <= ((size_t)1 << 23)) return RR_OK;
+    RR_FAIL(RR_ERR_BAD_ARG, "Fourier: chunk length %zu is not supported (powers of two up to 2^24, any length up to 2^23)", n);
 }
 
 template <class T>
@@ -559,64 +559,212 @@ static int launch_fourier_t(hipStream_t s, const void *head, size_t n_head, cons
 //   ->  F again (= conj of the inverse transform)  ->  X[k] = conj(result[k] * w_k).
 // Three elementwise kernels around the two transforms; rr_fourier::transform_dev drives them.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bs_pre(const float2 *__restrict__ head, long n_head, const float2 *__restrict__ in,
-                                                long hop, int n, int M, const float2 *__restrict__ c, float2 *__restrict__ ws) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+template <class T>
+__global__ __launch_bounds__(256) void k_bs_pre(const v2<T> *__restrict__ head, long n_head, const v2<T> *__restrict__ in,
+                                                long hop, long n, long M, const v2<T> *__restrict__ c, v2<T> *__restrict__ ws) {
+    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
-    float2 v;
-    v.x = 0.f;
-    v.y = 0.f;
+    v2<T> v;
+    v.x = 0;
+    v.y = 0;
     if (m < n) {
         const long i = (long)blockIdx.y * hop - n_head + m;
-        const float2 x = (i >= 0) ? in[i] : head[n_head + i];
-        v = cmul<float>(x, c[m]);
+        const v2<T> x = (i >= 0) ? in[i] : head[n_head + i];
+        v = cmul<T>(x, c[m]);
     }
     ws[(size_t)blockIdx.y * M + m] = v;
 }
-__global__ __launch_bounds__(256) void k_bs_mul(float2 *__restrict__ ws, const float2 *__restrict__ B, int M) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+template <class T>
+__global__ __launch_bounds__(256) void k_bs_mul(v2<T> *__restrict__ ws, const v2<T> *__restrict__ B, long M) {
+    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
-    float2 *p = ws + (size_t)blockIdx.y * M + m;
-    const float2 v = cmul<float>(*p, B[m]);
-    float2 o;
+    v2<T> *p = ws + (size_t)blockIdx.y * M + m;
+    const v2<T> v = cmul<T>(*p, B[m]);
+    v2<T> o;
     o.x = v.x;
     o.y = -v.y;
     *p = o;
 }
-__global__ __launch_bounds__(256) void k_bs_post(const float2 *__restrict__ ws, const float2 *__restrict__ w, int n, int M,
-                                                 float2 *__restrict__ out, int center_dc) {
-    const int kk = blockIdx.x * blockDim.x + threadIdx.x;
+template <class T>
+__global__ __launch_bounds__(256) void k_bs_post(const v2<T> *__restrict__ ws, const v2<T> *__restrict__ w, long n, long M,
+                                                 v2<T> *__restrict__ out, int center_dc) {
+    const long kk = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (kk >= n) return;
-    const float2 v = cmul<float>(ws[(size_t)blockIdx.y * M + kk], w[kk]);
-    int o = kk + (center_dc ? n / 2 : 0);  // rotate_right(n / 2)
+    const v2<T> v = cmul<T>(ws[(size_t)blockIdx.y * M + kk], w[kk]);
+    long o = kk + (center_dc ? n / 2 : 0);  // rotate_right(n / 2)
     if (o >= n) o -= n;
-    float2 r;
+    v2<T> r;
     r.x = v.x;
     r.y = -v.y;
     out[(size_t)blockIdx.y * n + o] = r;
 }
-int launch_bs_pre(hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n, size_t M,
+int launch_bs_pre(int dtype, hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n, size_t M,
                   const void *c, void *ws, size_t frames) {
     if (frames == 0) return RR_OK;
     if (frames > 65535) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: too many frames in one Bluestein pass");
-    hipLaunchKernelGGL(k_bs_pre, dim3((unsigned)((M + 255) / 256), (unsigned)frames), dim3(256), 0, s, (const float2 *)head,
-                       (long)n_head, (const float2 *)in, (long)hop, (int)n, (int)M, (const float2 *)c, (float2 *)ws);
+    const dim3 grid((unsigned)((M + 255) / 256), (unsigned)frames);
+    if (dtype == RR_F32)
+        hipLaunchKernelGGL(k_bs_pre<float>, grid, dim3(256), 0, s, (const float2 *)head, (long)n_head, (const float2 *)in,
+                           (long)hop, (long)n, (long)M, (const float2 *)c, (float2 *)ws);
+    else
+        hipLaunchKernelGGL(k_bs_pre<double>, grid, dim3(256), 0, s, (const double2 *)head, (long)n_head, (const double2 *)in,
+                           (long)hop, (long)n, (long)M, (const double2 *)c, (double2 *)ws);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
-int launch_bs_mul(hipStream_t s, void *ws, const void *B, size_t M, size_t frames) {
+int launch_bs_mul(int dtype, hipStream_t s, void *ws, const void *B, size_t M, size_t frames) {
     if (frames == 0) return RR_OK;
-    hipLaunchKernelGGL(k_bs_mul, dim3((unsigned)((M + 255) / 256), (unsigned)frames), dim3(256), 0, s, (float2 *)ws,
-                       (const float2 *)B, (int)M);
+    const dim3 grid((unsigned)((M + 255) / 256), (unsigned)frames);
+    if (dtype == RR_F32)
+        hipLaunchKernelGGL(k_bs_mul<float>, grid, dim3(256), 0, s, (float2 *)ws, (const float2 *)B, (long)M);
+    else
+        hipLaunchKernelGGL(k_bs_mul<double>, grid, dim3(256), 0, s, (double2 *)ws, (const double2 *)B, (long)M);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
-int launch_bs_post(hipStream_t s, const void *ws, const void *w, size_t n, size_t M, void *out, bool center_dc, size_t frames) {
+int launch_bs_post(int dtype, hipStream_t s, const void *ws, const void *w, size_t n, size_t M, void *out, bool center_dc,
+                   size_t frames) {
     if (frames == 0) return RR_OK;
-    hipLaunchKernelGGL(k_bs_post, dim3((unsigned)((n + 255) / 256), (unsigned)frames), dim3(256), 0, s, (const float2 *)ws,
-                       (const float2 *)w, (int)n, (int)M, (float2 *)out, (int)center_dc);
+    const dim3 grid((unsigned)((n + 255) / 256), (unsigned)frames);
+    if (dtype == RR_F32)
+        hipLaunchKernelGGL(k_bs_post<float>, grid, dim3(256), 0, s, (const float2 *)ws, (const float2 *)w, (long)n, (long)M,
+                           (float2 *)out, (int)center_dc);
+    else
+        hipLaunchKernelGGL(k_bs_post<double>, grid, dim3(256), 0, s, (const double2 *)ws, (const double2 *)w, (long)n, (long)M,
+                           (double2 *)out, (int)center_dc);
     RR_HIP(hipGetLastError());
     return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Power-of-two lengths beyond one LDS tile (n = 2^14 .. 2^24; analysis.rs:82-115 accepts any length): the
+// four-step decomposition n = N1 N2 through HBM, two launches of one batched, strided radix-2 kernel:
+//   A: for every n2: Y[k1][n2] = W_n^(n2 k1) * DFT_N1 over n1 of (window x)[N2 n1 + n2]     (workspace, [k1][n2])
+//   B: for every k1: X[k1 + N1 k2] = DFT_N2 over n2 of Y[k1][n2]
+// A workgroup takes C neighbouring sequences, so that every access touches C (A) or N2 (B) contiguous elements.
+// The twiddles W_n^(n2 k1) are evaluated in f64 (sincospi of the exactly reduced phase), whatever the data type.
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_fft_bs(const v2<T> *__restrict__ in, v2<T> *__restrict__ out, int N, int C,
+                                                long in_seq, long in_el, long out_seq, long out_el, long chunk_stride,
+                                                const T *__restrict__ window, const v2<T> *__restrict__ tw, long tw_M,
+                                                int rot) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v2<T> *a = reinterpret_cast<v2<T> *>(smem);
+    v2<T> *b = a + (size_t)C * N;
+    const long s0 = (long)blockIdx.x * C;
+    const v2<T> *src = in + (size_t)blockIdx.y * chunk_stride;
+    v2<T> *dst = out + (size_t)blockIdx.y * chunk_stride;
+    const int total = C * N;
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        int sq, i;
+        if (in_seq == 1) {
+            i = idx / C;
+            sq = idx - i * C;
+        } else {
+            sq = idx / N;
+            i = idx - sq * N;
+        }
+        const long off = (s0 + sq) * in_seq + (long)i * in_el;
+        v2<T> v = src[off];
+        if (window) {
+            const T w = window[off];
+            v.x *= w;
+            v.y *= w;
+        }
+        a[sq * N + i] = v;
+    }
+    __syncthreads();
+    const int half = N >> 1;
+    for (int ns = 1; ns < N; ns <<= 1) {
+        const int tstride = half / ns;
+        for (int jj = threadIdx.x; jj < C * half; jj += blockDim.x) {
+            const int sq = jj / half, j = jj - sq * half;
+            const int k = j & (ns - 1);
+            const v2<T> *as = a + sq * N;
+            v2<T> *bs = b + sq * N;
+            const v2<T> u = as[j];
+            const v2<T> v = cmul<T>(as[j + half], tw[k * tstride]);
+            const int j0 = ((j - k) << 1) + k;
+            v2<T> sm, df;
+            sm.x = u.x + v.x;
+            sm.y = u.y + v.y;
+            df.x = u.x - v.x;
+            df.y = u.y - v.y;
+            bs[j0] = sm;
+            bs[j0 + ns] = df;
+        }
+        __syncthreads();
+        v2<T> *t = a;
+        a = b;
+        b = t;
+    }
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        int sq, k;
+        if (out_seq == 1) {
+            k = idx / C;
+            sq = idx - k * C;
+        } else {
+            sq = idx / N;
+            k = idx - sq * N;
+        }
+        v2<T> v = a[sq * N + k];
+        if (tw_M) {
+            const long ph = ((s0 + sq) * (long)k) % tw_M;  // < 2^48: exact
+            double sn, cs;
+            sincospi(-2.0 * (double)ph / (double)tw_M, &sn, &cs);
+            v2<T> w;
+            w.x = (T)cs;
+            w.y = (T)sn;
+            v = cmul<T>(v, w);
+        }
+        int ko = k + rot;
+        if (ko >= N) ko -= N;
+        dst[(s0 + sq) * out_seq + (long)ko * out_el] = v;
+    }
+}
+
+bool fft_big_supported(size_t n) { return is_pow2_n(n) && n >= 4 && n <= ((size_t)1 << 24); }
+void fft_big_split(size_t n, size_t *N1, size_t *N2) {
+    int lg = 0;
+    while (((size_t)1 << lg) < n) ++lg;
+    *N1 = (size_t)1 << (lg / 2);
+    *N2 = n / *N1;
+}
+
+// in, out: `count` chunks of n = N1 N2 elements each; ws: workspace of count * n elements; tw1 / tw2: e^{-j 2 pi k / N1}
+// (N1 / 2 entries) and e^{-j 2 pi k / N2} (N2 / 2 entries); window: n reals or null
+template <class T>
+static int launch_fft_big_t(hipStream_t s, const void *in, void *out, void *ws, size_t n, size_t count, const void *window,
+                            const void *tw1, const void *tw2, bool center_dc) {
+    size_t N1, N2;
+    fft_big_split(n, &N1, &N2);
+    auto fn = k_fft_bs<T>;
+    const size_t esz = sizeof(v2<T>), budget = 64 * 1024;
+    auto tile = [&](size_t N, size_t nseq) {
+        size_t c = budget / (2 * N * esz);
+        if (c < 1) c = 1;
+        if (c > 32) c = 32;
+        while (c > nseq) c /= 2;
+        return c;
+    };
+    const size_t CA = tile(N1, N2), CB = tile(N2, N1);
+    const size_t ldsA = 2 * CA * N1 * esz, ldsB = 2 * CB * N2 * esz;
+    RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), ldsA > ldsB ? ldsA : ldsB));
+    if (count > 65535) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: too many chunks in one call");
+    hipLaunchKernelGGL(fn, dim3((unsigned)(N2 / CA), (unsigned)count), dim3(256), ldsA, s, (const v2<T> *)in, (v2<T> *)ws, (int)N1,
+                       (int)CA, 1L, (long)N2, 1L, (long)N2, (long)n, (const T *)window, (const v2<T> *)tw1, (long)n, 0);
+    hipLaunchKernelGGL(fn, dim3((unsigned)(N1 / CB), (unsigned)count), dim3(256), ldsB, s, (const v2<T> *)ws, (v2<T> *)out, (int)N2,
+                       (int)CB, (long)N2, 1L, 1L, (long)N1, (long)n, (const T *)nullptr, (const v2<T> *)tw2, 0L,
+                       center_dc ? (int)(N2 / 2) : 0);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+int launch_fft_big(int dtype, hipStream_t s, const void *in, void *out, void *ws, size_t n, size_t count, const void *window,
+                   const void *tw1, const void *tw2, bool center_dc) {
+    if (count == 0) return RR_OK;
+    if (dtype == RR_F32) return launch_fft_big_t<float>(s, in, out, ws, n, count, window, tw1, tw2, center_dc);
+    return launch_fft_big_t<double>(s, in, out, ws, n, count, window, tw1, tw2, center_dc);
 }
 
 int launch_fourier_overlapped(int dtype, hipStream_t s, const void *head, size_t n_head, const void *in, void *out,
@@ -647,6 +795,45 @@ int launch_fourier_overlapped(int dtype, hipStream_t s, const void *head, size_t
 int launch_fourier(int dtype, hipStream_t s, const void *in, void *out, size_t n, size_t count, const void *window,
                    const void *twiddle, bool center_dc) {
     return launch_fourier_overlapped(dtype, s, nullptr, 0, in, out, n, n, count, window, twiddle, center_dc);
+}
+
+// ---------------------------------------------------------------------------
+// Channelizer, general form (any number of bins, any hop that divides P M): the fold alone,
+//   y[f][r] = sum_{p < P} w[r + M p] x[base0 + hop f + r + M p],  r < M,
+// written frame by frame to a workspace; the M-point transforms follow through rr_fourier (any M).
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_chan_fold(const v2<T> *__restrict__ hist, long hist_len, const v2<T> *__restrict__ in,
+                                                   long base0, long hop, int M, int P, const T *__restrict__ window,
+                                                   v2<T> *__restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= M) return;
+    const long base = base0 + (long)blockIdx.y * hop + r;
+    v2<T> acc;
+    acc.x = 0;
+    acc.y = 0;
+    for (int p = 0; p < P; ++p) {
+        const long i = base + (long)M * p;
+        const v2<T> x = (i >= 0) ? in[i] : hist[hist_len + i];
+        const T w = window[r + M * p];
+        acc.x += x.x * w;
+        acc.y += x.y * w;
+    }
+    out[(size_t)blockIdx.y * M + r] = acc;
+}
+int launch_chan_fold(int dtype, hipStream_t s, const void *hist, size_t hist_len, const void *in, long base0, size_t hop,
+                     size_t M, size_t P, size_t frames, const void *window, void *out) {
+    if (frames == 0) return RR_OK;
+    if (frames > 65535) RR_FAIL(RR_ERR_BAD_ARG, "Channelizer: too many frames in one pass");
+    const dim3 grid((unsigned)((M + 255) / 256), (unsigned)frames);
+    if (dtype == RR_F32)
+        hipLaunchKernelGGL(k_chan_fold<float>, grid, dim3(256), 0, s, (const float2 *)hist, (long)hist_len, (const float2 *)in,
+                           base0, (long)hop, (int)M, (int)P, (const float *)window, (float2 *)out);
+    else
+        hipLaunchKernelGGL(k_chan_fold<double>, grid, dim3(256), 0, s, (const double2 *)hist, (long)hist_len, (const double2 *)in,
+                           base0, (long)hop, (int)M, (int)P, (const double *)window, (double2 *)out);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
 }
 
 // ---------------------------------------------------------------------------

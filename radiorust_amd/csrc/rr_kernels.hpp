@@ -131,10 +131,17 @@ int launch_fused_fir(hipStream_t s, const FusedFirArgs &a);
 // 4096-point windowed forward DFT (radix 16 x 3); tw4096[k] = e^{-j 2 pi k / 4096}, 4096 entries
 // frames are cut from the stream [ head (n_head samples) | in ]
 // Bluestein's elementwise stages (rr_kernels.hip), f32: frames <= 65535 per launch
-int launch_bs_pre(hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n, size_t M,
+int launch_bs_pre(int dtype, hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n, size_t M,
                   const void *c, void *ws, size_t frames);
-int launch_bs_mul(hipStream_t s, void *ws, const void *B, size_t M, size_t frames);
-int launch_bs_post(hipStream_t s, const void *ws, const void *w, size_t n, size_t M, void *out, bool center_dc, size_t frames);
+int launch_bs_mul(int dtype, hipStream_t s, void *ws, const void *B, size_t M, size_t frames);
+int launch_bs_post(int dtype, hipStream_t s, const void *ws, const void *w, size_t n, size_t M, void *out, bool center_dc,
+                   size_t frames);
+// power-of-two transforms beyond one LDS tile (up to 2^24 points): four-step through a workspace of count * n elements;
+// tw1 / tw2 = e^{-j 2 pi k / N1}, e^{-j 2 pi k / N2} (half tables) for the split of fft_big_split
+bool fft_big_supported(size_t n);
+void fft_big_split(size_t n, size_t *N1, size_t *N2);
+int launch_fft_big(int dtype, hipStream_t s, const void *in, void *out, void *ws, size_t n, size_t count, const void *window,
+                   const void *tw1, const void *tw2, bool center_dc);
 // k_fft8192: 256 lanes per 8192-sample frame, 32 values per lane (plain window and twiddle tables)
 int launch_fft8192(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
                    const void *window, const void *tw8192, bool center_dc, size_t hop);
@@ -161,6 +168,9 @@ int launch_drop_tail(hipStream_t s, const void *oldh, void *newh, size_t H, size
 // base0 = index (relative to in[0], may be negative) of the first sample of frame 0.
 int launch_channelizer(int dtype, hipStream_t s, const void *hist, size_t hist_len, const void *in, long base0,
                        size_t M, size_t P, size_t nframes, const void *window, const void *tw, void *out);
+// the fold alone for any M and any hop (frames written to `out`, M values each); the transforms follow through rr_fourier
+int launch_chan_fold(int dtype, hipStream_t s, const void *hist, size_t hist_len, const void *in, long base0, size_t hop,
+                     size_t M, size_t P, size_t frames, const void *window, void *out);
 // f32, M = 256, P in {1, 2, 3, 4, 6, 8}: one wave per run of frames, sliding window of chunks in
 // registers, radix-4 DFT_256 with wave-local exchanges (rr_fused.hip)
 bool channelizer256_supported(int dtype, size_t M, size_t P);

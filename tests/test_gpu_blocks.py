@@ -490,7 +490,9 @@ def test_fourier_reference_kat_on_gpu(rr):
 
 
 @pytest.mark.parametrize("n,center", [(4096, False), (4096, True), (8192, False), (8192, True), (256, True), (256, False), (1024, False),
-                                      (1024, True), (2048, False), (2048, True), (2, False), (1, True), (1000, True), (7, True), (4095, False), (12000, False)])
+                                      (1024, True), (2048, False), (2048, True), (2, False), (1, True), (1000, True), (7, True), (4095, False), (12000, False),
+                                      (16384, True), (65536, False), (65536, True), (1 << 18, False),   # four-step through HBM
+                                      (20000, False), (20000, True), (5000, False), (31, True)])         # Bluestein beyond 4096 points; direct below 32
 def test_fourier_parity(rr, oracle, n, center):
     x = oracle.synth_iq(12, 0, n)
     gw, ow = rr.Kaiser.with_null_at_bin(2.0), oracle.Kaiser.with_null_at_bin(2.0)
@@ -499,6 +501,18 @@ def test_fourier_parity(rr, oracle, n, center):
     t64 = oracle.Fourier(ow, center, flt=np.float64).process(x)
     t32 = oracle.Fourier(ow, center, flt=np.float32).process(x)
     check(out.chunk, t64, t32)
+
+
+@pytest.mark.parametrize("n,center", [(1000, True), (20000, False), (8192, False), (32768, True), (65536, False), (33, False)])
+def test_fourier_f64_lengths(rr, oracle, n, center):
+    """Complex<f64>: powers of two beyond the LDS kernel (4096) by the four-step transform, every other length >= 32 by
+    Bluestein over f64 power-of-two transforms (the twiddles of the four-step split are evaluated in f64 with the
+    phase reduced exactly)."""
+    x = oracle.synth_iq(13, 0, n).astype(np.complex128)
+    g = rr.Fourier(rr.Kaiser.with_null_at_bin(2.0), center, dtype=np.float64)
+    (out,) = g.process(rr.Samples(1e6, x))
+    ref = oracle.Fourier(oracle.Kaiser.with_null_at_bin(2.0), center, flt=np.float64).process(x)
+    assert rms_rel(out.chunk, ref) < 1e-11
 
 
 def test_fourier_custom_window_and_length_change(rr, oracle):
@@ -554,7 +568,7 @@ def test_fourier_wave_kernels_batched(rr, oracle, n, center, monkeypatch):
 
 @pytest.mark.parametrize("n,center,k", [(1000, True, 2100), (33, False, 500), (1500, False, 64), (4095, True, 9), (100, True, 300)])
 def test_fourier_bluestein_batched(rr, oracle, n, center, k):
-    """Chunk lengths that are not powers of two (f32, 32 .. 4096) run Bluestein's algorithm over the power-of-two
+    """Chunk lengths that are not powers of two (32 and more) run Bluestein's algorithm over the power-of-two
     kernels, in passes of at most 2^22 workspace elements (n = 1000: 2048 chunks per pass, so 2100 chunks take
     two): chunks from the start, the pass boundary and the end against the f64 oracle."""
     import torch
@@ -580,7 +594,7 @@ def test_fourier_errors(rr):
     with pytest.raises(BackendError):
         g.process(rr.Samples(1.0, np.zeros(0, dtype=np.complex64)))
     with pytest.raises(BackendError):
-        g.process(rr.Samples(1.0, np.zeros(20000, dtype=np.complex64)))  # unsupported length says so
+        g.process(rr.Samples(1.0, np.zeros((1 << 23) + 1, dtype=np.complex64)))  # beyond 2^23 points: says so
 
 
 # ---------------------------------------------------------------- async + pinned

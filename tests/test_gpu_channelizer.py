@@ -61,6 +61,33 @@ def test_channelizer_parity(rr, oracle, M, P, dtype, tol):
         assert rms_rel(a.chunk, b) <= tol
 
 
+@pytest.mark.parametrize("M,P,hop,dtype,tol", [(256, 4, 128, np.float32, 1e-5), (256, 4, 64, np.float32, 1e-5),
+                                               (64, 3, 32, np.float64, 1e-12), (1024, 2, 512, np.float32, 1e-5),
+                                               (100, 4, 100, np.float32, 1e-5), (100, 4, 50, np.float32, 1e-5),
+                                               (1000, 2, 250, np.float64, 1e-11), (16384, 2, 8192, np.float32, 1e-5)])
+def test_channelizer_oversampled_and_any_bins(rr, oracle, M, P, hop, dtype, tol):
+    """The general form (rr_channelizer_create_ex): `hop` < bins samples between frames - the oversampled
+    filterbank - and bin counts that are not powers of two, against the composition it is defined by:
+    Rechunker(hop) -> Overlapper(P M / hop) -> Fourier::with_window(Kaiser null-at-bin P) over P M samples ->
+    every P-th bin (chunks.rs:194-242, analysis.rs:60-132)."""
+    K = P * M // hop
+    nchunks = 3 * K + 5
+    x = oracle.synth_iq(26, 0, hop * nchunks)
+    if dtype == np.float64:
+        x = x.astype(np.complex128)
+    chunks = [x[i * hop : (i + 1) * hop] for i in range(nchunks)]
+    fo = oracle.Fourier(oracle.Kaiser.with_null_at_bin(float(P)), flt=np.float64)
+    ref = [fo.process(np.concatenate(chunks[i : i + K]))[::P] for i in range(nchunks - K + 1)]
+    g = rr.Channelizer(M, P, dtype=dtype, hop=hop)
+    got = []
+    cuts = [0, 1, 2, K + 1, K + 2, 2 * K + 3, nchunks]  # ragged multiples of the hop per call
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        got += g.process(rr.Samples(1e9, x[a * hop : b * hop]))
+    assert len(got) == len(ref) and all(len(s.chunk) == M for s in got)
+    for a, b in zip(got, ref):
+        assert rms_rel(a.chunk, b) <= tol
+
+
 def test_channelizer_event_resets_history(rr, oracle):
     M, P = 256, 4
     x = oracle.synth_iq(22, 0, M * 12)
@@ -101,7 +128,9 @@ def test_channelizer_device_batch_and_errors(rr, oracle):
     with pytest.raises(BackendError):
         g.process(rr.Samples(1e9, x[: M + 1]))  # not whole chunks
     with pytest.raises(BackendError):
-        rr.Channelizer(100, 4)  # bins must be a power of two
+        rr.Channelizer(256, 4, hop=96)  # the hop must divide bins * taps_per_branch
+    with pytest.raises(BackendError):
+        rr.Channelizer(256, 4, hop=512)  # .. and not exceed bins
 
 
 def overlapped_spectra(oracle, chunks, P, window, center_dc, flt, history=None):
