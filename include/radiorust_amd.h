@@ -100,6 +100,9 @@ double rr_kaiser_rel_with_beta(double beta, double x);  /* math.rs:26-28 */
 double rr_kaiser_alpha_to_beta(double alpha);           /* math.rs:31-33 */
 double rr_kaiser_null_at_bin_to_beta(double n);         /* math.rs:37-39 */
 double rr_sinc(double x);                               /* math.rs:42-49 */
+/* blocks::filters::deemphasis_factor (filters.rs:20-27): the complex amplification 1 / (1 + j tau 2 pi f) of a passive
+ * first-order RC low-pass (tau e.g. 50e-6), what examples/relm_app/simple_receiver.rs:43-49 builds its second Filter from. */
+int rr_deemphasis_factor(double tau, double frequency, rr_c64 *out);
 /* out[i] = window.relative_value_at(2 (i + 0.5) / n - 1) for a built-in window
  * (the sampling positions of filters.rs:209-212 and analysis.rs:93-94). */
 int rr_window_sample(const rr_window *w, size_t n, double *out);

@@ -62,6 +62,16 @@ double rro_sinc(double x)
     return sin(t) / t;
 }
 
+/* filters.rs:20-27: Complex { re: 1.0, im: tau * TAU * frequency }.finv(); num-complex 0.4 (Cargo.toml:18):
+ * finv(self) = self.conj() / norm / norm with norm = re.hypot(im) */
+void rro_deemphasis_factor(double tau, double frequency, double *out)
+{
+    const double re = 1.0, im = tau * (2.0 * M_PI) * frequency;
+    const double norm = hypot(re, im);
+    out[0] = re / norm / norm;
+    out[1] = -im / norm / norm;
+}
+
 /* windowing.rs:14-20 (Rectangular), 24-51 (Kaiser), 58-67 (CustomWindow) */
 double rro_window_value(const rro_window *w, double x)
 {

@@ -48,6 +48,7 @@ double rro_kaiser_rel_with_beta(double beta, double x); /* math.rs:26-28 */
 double rro_kaiser_alpha_to_beta(double alpha);          /* math.rs:31-33 */
 double rro_kaiser_null_at_bin_to_beta(double n);        /* math.rs:37-39 */
 double rro_sinc(double x);                              /* math.rs:42-49 */
+void rro_deemphasis_factor(double tau, double frequency, double *out); /* filters.rs:20-27, out = {re, im} */
 
 /* ---- windows (windowing.rs) ------------------------------------------ */
 enum { RRO_WIN_RECT = 0, RRO_WIN_KAISER = 1, RRO_WIN_CUSTOM = 2 };

@@ -147,6 +147,8 @@ def _bind(L):
     for name in ("rro_bessel_i0", "rro_kaiser_alpha_to_beta", "rro_kaiser_null_at_bin_to_beta", "rro_sinc"):
         getattr(L, name).restype = d
         getattr(L, name).argtypes = [d]
+    L.rro_deemphasis_factor.restype = None
+    L.rro_deemphasis_factor.argtypes = [d, d, C.POINTER(d)]
     L.rro_kaiser_rel_with_beta.restype = d
     L.rro_kaiser_rel_with_beta.argtypes = [d, d]
     L.rro_window_value.restype = d
@@ -242,6 +244,12 @@ def bessel_I0(x: float) -> float:
 
 def sinc(x: float) -> float:
     return lib().rro_sinc(float(x))
+
+
+def deemphasis_factor(tau: float, frequency: float) -> complex:
+    out = (C.c_double * 2)()
+    lib().rro_deemphasis_factor(float(tau), float(frequency), out)
+    return complex(out[0], out[1])
 
 
 def kaiser_rel_with_beta(beta: float, x: float) -> float:

@@ -83,6 +83,7 @@ SIGNATURES = {
     "rr_kaiser_alpha_to_beta": (_d, [_d]),
     "rr_kaiser_null_at_bin_to_beta": (_d, [_d]),
     "rr_sinc": (_d, [_d]),
+    "rr_deemphasis_factor": (_i, [_d, _d, _vp]),
     "rr_window_sample": (_i, [C.POINTER(Window), _sz, _vp]),
     "rr_freqshifter_ratio": (_i, [_d, _d, _d, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rr_freqshifter_table": (_i, [_i, C.c_int64, C.c_int64, _d, _vp]),

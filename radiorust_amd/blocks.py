@@ -127,6 +127,13 @@ class FreqShifter(_Block):
         return n_out.value
 
 
+def deemphasis_factor(tau: float, frequency: float) -> complex:
+    """blocks::filters::deemphasis_factor (filters.rs:20-27): 1 / (1 + j tau 2 pi f)."""
+    out = (C.c_double * 2)()
+    _lib.check(_lib.lib().rr_deemphasis_factor(float(tau), float(frequency), out))
+    return complex(out[0], out[1])
+
+
 def sample_freq_resp(freq_resp, n: int, sample_rate: float) -> np.ndarray:
     """Evaluates the user's closure exactly where the reference does
     (filters.rs:188-199): bins 0..=(n-1)/2 and their negatives; for even n the

@@ -651,11 +651,15 @@ int rr_upsampler::process_dev(double input_rate, const void *d_in, size_t n_in, 
     RR_TRY(select());
     RR_TRY(prepare(input_rate));
     if (n_in == 0) return RR_OK;
+    // The schedule is advanced on a copy and the kept-input offsets are prepared aside: `sched`, `before_hist`, `cur`
+    // change only after both launches have been accepted (a failing call leaves the block where it was).
+    rr::UpSchedule next = sched;
+    std::vector<int32_t> next_before_hist;
     const int32_t *d_bef = nullptr;
     if (sched.integer_ratio) {
-        sched.advance(n_in, nullptr);
+        next.advance(n_in, nullptr);
     } else {
-        sched.advance(n_in, &before);
+        next.advance(n_in, &before);
         std::vector<int32_t> all(Hn + n_in);
         std::copy(before_hist.begin(), before_hist.end(), all.begin());
         std::copy(before.begin(), before.end(), all.begin() + Hn);
@@ -664,14 +668,17 @@ int rr_upsampler::process_dev(double input_rate, const void *d_in, size_t n_in, 
         RR_HIP(hipStreamSynchronize(stream));  // `all` dies here
         d_bef = d_before.as<int32_t>();
         // the kept inputs of the next call, relative to its first output
+        next_before_hist.resize(Hn);
         for (size_t i = 0; i < Hn; ++i) {
             const int64_t v = (int64_t)all[n_in + i] - (int64_t)produce;
-            before_hist[i] = (int32_t)std::max<int64_t>(v, -(int64_t(1) << 30));
+            next_before_hist[i] = (int32_t)std::max<int64_t>(v, -(int64_t(1) << 30));
         }
     }
     RR_TRY(launch_upsample(dtype, stream, hist[cur].p, Hn, d_in, n_in, d_ir.p, L, sched.integer_ratio ? sched.U : 0, d_bef,
                            d_out, produce));
     RR_TRY(launch_update_hist(dtype, stream, hist[cur].p, hist[cur ^ 1].p, Hn, d_in, n_in));
+    sched = next;
+    if (!sched.integer_ratio) before_hist.swap(next_before_hist);
     cur ^= 1;
     if (n_out) *n_out = produce;
     return RR_OK;
@@ -1545,6 +1552,15 @@ double rr_kaiser_rel_with_beta(double beta, double x) { return rr::kaiser_rel_wi
 double rr_kaiser_alpha_to_beta(double alpha) { return alpha * M_PI; }
 double rr_kaiser_null_at_bin_to_beta(double n) { return std::sqrt(n * n - 1.0); }
 double rr_sinc(double x) { return rr::sinc(x); }
+int rr_deemphasis_factor(double tau, double frequency, rr_c64 *out) {
+    if (!out) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    // Complex { re: 1.0, im: tau * TAU * frequency }.finv(); num-complex 0.4: finv = conj / norm / norm, norm = hypot(re, im)
+    const double re = 1.0, im = tau * (2.0 * M_PI) * frequency;
+    const double norm = std::hypot(re, im);
+    out->re = re / norm / norm;
+    out->im = -im / norm / norm;
+    return RR_OK;
+}
 int rr_window_sample(const rr_window *w, size_t n, double *out) { return rr::window_sample(w, n, out); }
 
 int rr_freqshifter_ratio(double sample_rate, double precision, double shift, int64_t *numer, int64_t *denom) {

@@ -247,6 +247,33 @@ def test_filter_f64_long(rr, oracle, n):
     assert rms_rel(np.concatenate(got), np.concatenate(ref)) < 1e-12
 
 
+def test_filter_deemphasis_of_simple_receiver(rr, oracle):
+    """examples/relm_app/simple_receiver.rs:43-49: the audio Filter behind the FM demodulator - rectangular window,
+    complex response built from blocks::filters::deemphasis_factor(50e-6, f) on 20 Hz .. 16 kHz, DC bin blocked -
+    at 384 kS/s in chunks of 16384 (the Downsampler in front of it emits those): complex taps through the
+    partitioned block kernel."""
+    n, fs = 16384, 384000.0
+
+    def make_resp(mod):
+        return lambda b, f: (mod.deemphasis_factor(50e-6, f) if abs(b) >= 1 and 20.0 <= abs(f) <= 16000.0 else 0.0)
+
+    x = oracle.synth_iq(31, 0, n * 3)
+    g = rr.Filter.new_rectangular(make_resp(rr))
+    o64 = oracle.Filter(make_resp(oracle), oracle.Rectangular(), flt=np.float64)
+    o32 = oracle.Filter(make_resp(oracle), oracle.Rectangular(), flt=np.float32)
+    got, t64, t32 = [], [], []
+    for i in range(3):
+        c = x[i * n : (i + 1) * n]
+        out = g.process(rr.Samples(fs, c))
+        r64, r32 = o64.process(fs, c), o32.process(fs, c)
+        if out:
+            got.append(out[0].chunk)
+            t64.append(r64)
+            t32.append(r32)
+    assert len(got) == 2
+    check(np.concatenate(got), np.concatenate(t64), np.concatenate(t32))
+
+
 def test_filter_f64(rr, oracle):
     n, fs = 64, 200e6
     x = oracle.synth_iq(7, 0, n * 6).astype(np.complex128)

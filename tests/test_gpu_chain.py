@@ -397,3 +397,42 @@ def test_handles_run_concurrently_from_different_threads(rr, oracle):
         assert len(a) == len(g_) == 7
         for u, v in zip(a, g_):
             assert np.array_equal(u.view(np.uint32), v.view(np.uint32))
+
+
+def test_chain_one_call_of_2_pow_28_samples(rr, oracle):
+    """Index arithmetic at a size the other tests do not reach (BASELINE's timing batch is 2^26 per step): ONE chain call
+    over 2^28 samples (2 GiB in, 16383 spectra out).  The first 256 spectra against the C oracle; every spectrum against
+    the same stream fed in 16 calls of 2^24 samples (a size-independent property: the cut of a stream into calls must not
+    show), compared on the device."""
+    import torch
+
+    n, fs = 1 << 28, 200e6
+    st = torch.cuda.current_stream().cuda_stream
+    d_in = torch.empty(n, dtype=torch.complex64, device="cuda")
+    rr.synth_iq_dev(0, st, 3, 0, n, d_in.data_ptr())
+    g = make(rr, oracle, CFG2, True)
+    g.set_stream(st)
+    frames = g.peek(fs, n)
+    assert frames == 16383
+    d_out = torch.empty(frames * 4096, dtype=torch.complex64, device="cuda")
+    assert g.process_dev(fs, d_in.data_ptr(), n, d_out.data_ptr(), d_out.numel()) == frames * 4096
+    K = 256
+    x = d_in[: (K + 2) * 16384].cpu().numpy()
+    ref = oracle.run_chain_c(x, fs, shift=25e6, filter_len=64, freq_resp=lowpass(20e6), output_rate=50e6, bandwidth=40e6,
+                             fft_len=4096, fft_window=oracle.Kaiser.with_null_at_bin(2.0), flt=np.float64, threads=4,
+                             max_frames=K + 1)[0][:K]
+    y = d_out[: K * 4096].cpu().numpy().reshape(K, 4096)
+    for a, b in zip(y, ref):
+        assert rms_rel(a, b) <= 1e-5
+    g2 = make(rr, oracle, CFG2, True)
+    g2.set_stream(st)
+    d_out2 = torch.empty_like(d_out)
+    off = wrote = 0
+    step = 1 << 24
+    while off < n:
+        wrote += g2.process_dev(fs, d_in.data_ptr() + 8 * off, step, d_out2.data_ptr() + 8 * wrote, d_out2.numel() - wrote)
+        off += step
+    assert wrote == frames * 4096
+    a, b = d_out.view(frames, 4096), d_out2.view(frames, 4096)
+    err = (torch.linalg.vector_norm(a - b, dim=1) / torch.linalg.vector_norm(b, dim=1)).max().item()
+    assert err <= 2e-6, err

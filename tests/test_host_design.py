@@ -47,6 +47,18 @@ def test_math_bit_equal_to_oracle(L, oracle):
     assert L.rr_kaiser_alpha_to_beta(1.25) == oracle.kaiser_alpha_to_beta(1.25)
 
 
+def test_deemphasis_factor(oracle):
+    """blocks::filters::deemphasis_factor (filters.rs:20-27): product == oracle bit for bit, both == 1 / (1 + j tau 2 pi f)."""
+    import radiorust_amd as rr
+
+    for tau, f in ((50e-6, 0.0), (50e-6, 20.0), (50e-6, 3183.1), (75e-6, -16000.0), (50e-6, 1e9), (1e-3, 1e-3)):
+        a, b = rr.deemphasis_factor(tau, f), oracle.deemphasis_factor(tau, f)
+        assert a == b
+        exact = 1.0 / complex(1.0, tau * 2.0 * math.pi * f)
+        assert abs(a - exact) <= 4e-16 * abs(exact)
+    assert rr.deemphasis_factor(50e-6, 0.0) == 1.0
+
+
 @pytest.mark.parametrize("fs,prec,shift", [(48000.0, 1.0, 700.0), (200e6, 1.0, 25e6), (200e6, 1e3, 12.345e6),
                                            (48000.0, 1.0, -700.0), (48000.0, 1.0, 0.0), (1024000.0, 1.0, 200e3),
                                            (44100.0, 0.5, 1234.56)])
