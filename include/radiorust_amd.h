@@ -374,6 +374,45 @@ int rr_stft_process_dev(rr_stft *h, const void *d_in, size_t n_in, void *d_out,
 int rr_stft_destroy(rr_stft *h);
 
 /* ------------------------------------------------------------------------ */
+/* Meter — the reference's own hot-path caller in ITS order                       */
+/* (examples/bandwidth_meter/main.rs:53-69):                                      */
+/*   FreqShifter -> Downsampler::with_quality(chunk_len, output_rate, bandwidth,  */
+/*   quality) -> Filter (it receives the Downsampler's chunks: chunk_len samples   */
+/*   at output_rate) -> Overlapper(overlap) -> Fourier::with_window               */
+/* on one device without host hops; output: frames of chunk_len * overlap bins    */
+/* (feed them to rr_bandwidth_dev for the example's last step).  Any input length; */
+/* any integer or short-period rational decimation runs the fast kernels.          */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    int dtype;
+    double precision;      /* FreqShifter                                        */
+    double shift;
+    double output_rate;    /* Downsampler                                        */
+    double bandwidth;
+    double quality;
+    size_t chunk_len;      /* Downsampler output_chunk_len = Filter chunk length  */
+    size_t overlap;        /* Overlapper chunk count                              */
+    rr_window fft_window;  /* built-in kinds only                                 */
+    int center_dc;
+} rr_meter_params;
+typedef struct rr_meter rr_meter;
+int rr_meter_create(const rr_meter_params *p, int device, rr_meter **out);
+int rr_meter_set_shift(rr_meter *h, double shift);
+/* The Filter always sees (output_rate, chunk_len): one design, arguments as for rr_filter_design_taps with
+ * n = chunk_len and the closure sampled at i * output_rate / chunk_len. */
+int rr_meter_filter_design(rr_meter *h, const rr_c64 *resp, const double *window_rel);
+/* An event travelling down the pipeline: an interrupting one resets the Filter (filters.rs:262-265), every event
+ * the Overlapper (chunks.rs:225-233; the host layer sends its SamplesLost); the Downsampler's partly filled output
+ * chunk stays (resampling.rs:135-137). */
+int rr_meter_event(rr_meter *h, int is_interrupt);
+int rr_meter_peek(rr_meter *h, double sample_rate, size_t n_in, size_t *n_frames);
+int rr_meter_process(rr_meter *h, double sample_rate, const void *in, size_t n_in, void *out,
+                     size_t out_cap, size_t *n_out);
+int rr_meter_process_dev(rr_meter *h, double sample_rate, const void *d_in, size_t n_in,
+                         void *d_out, size_t out_cap, size_t *n_out);
+int rr_meter_destroy(rr_meter *h);
+
+/* ------------------------------------------------------------------------ */
 /* Upsampler — src/blocks/resampling.rs:147-280.          */
 /* The reference adds every input, scaled by the impulse response, into a ring  */
 /* buffer and releases output_rate / input_rate outputs per input (:237-267);   */

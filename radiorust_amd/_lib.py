@@ -63,6 +63,21 @@ class ChainParams(C.Structure):
     ]
 
 
+class MeterParams(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int),
+        ("precision", C.c_double),
+        ("shift", C.c_double),
+        ("output_rate", C.c_double),
+        ("bandwidth", C.c_double),
+        ("quality", C.c_double),
+        ("chunk_len", C.c_size_t),
+        ("overlap", C.c_size_t),
+        ("fft_window", Window),
+        ("center_dc", C.c_int),
+    ]
+
+
 _vp, _sz, _d, _i = C.c_void_p, C.c_size_t, C.c_double, C.c_int
 _psz = C.POINTER(C.c_size_t)
 
@@ -151,6 +166,14 @@ SIGNATURES = {
     "rr_stft_create": (_i, [_i, _sz, _sz, C.POINTER(Window), _i, _i, C.POINTER(_vp)]),
     "rr_stft_reset": (_i, [_vp]),
     "rr_stft_pending": (_i, [_vp, _psz]),
+    "rr_meter_create": (_i, [C.POINTER(MeterParams), _i, C.POINTER(_vp)]),
+    "rr_meter_set_shift": (_i, [_vp, _d]),
+    "rr_meter_filter_design": (_i, [_vp, _vp, _vp]),
+    "rr_meter_event": (_i, [_vp, _i]),
+    "rr_meter_peek": (_i, [_vp, _d, _sz, _psz]),
+    "rr_meter_process": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
+    "rr_meter_process_dev": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
+    "rr_meter_destroy": (_i, [_vp]),
     "rr_stft_peek": (_i, [_vp, _sz, _psz]),
     "rr_stft_process": (_i, [_vp, _vp, _sz, _vp, _sz, _psz]),
     "rr_stft_process_dev": (_i, [_vp, _vp, _sz, _vp, _sz, _psz]),

@@ -642,6 +642,64 @@ class Stft(_Block):
         return n_out.value
 
 
+class Meter(_Block):
+    """The reference's own hot-path caller in ITS order (examples/bandwidth_meter/main.rs:53-69) on one device without
+    host hops: FreqShifter(shift) -> Downsampler(chunk_len, output_rate, bandwidth, quality) -> Filter(freq_resp; it
+    sees chunks of chunk_len at output_rate) -> Overlapper(overlap) -> Fourier.with_window(fft_window).  Output: one
+    message per overlapped spectrum (chunk_len * overlap bins) at the output rate; `metering.bandwidth` on each of
+    them is the example's last step (rr_bandwidth_dev keeps that on the device too)."""
+
+    _destroy = "rr_meter_destroy"
+
+    def __init__(self, *, shift: float, precision: float = 1.0, output_rate: float, bandwidth: float, quality: float = 3.0,
+                 chunk_len: int, freq_resp, filter_window: Window | None = None, overlap: int, fft_window: Window | None = None,
+                 center_dc: bool = False, dtype=np.float32, device: int = 0):
+        super().__init__()
+        self._code, self._cdt = _dtype_code(dtype)
+        fw = fft_window if fft_window is not None else Rectangular()
+        spec = fw._spec()
+        if spec is None:
+            raise TypeError("Meter needs a built-in fft_window (Rectangular or Kaiser)")
+        self.chunk_len, self.overlap, self.output_rate = int(chunk_len), int(overlap), float(output_rate)
+        p = _lib.MeterParams(self._code, float(precision), float(shift), float(output_rate), float(bandwidth), float(quality),
+                             self.chunk_len, self.overlap, spec, int(bool(center_dc)))
+        _lib.check(_lib.lib().rr_meter_create(p, device, C.byref(self._h)))
+        self._filter_window = filter_window if filter_window is not None else Kaiser.with_null_at_bin(2.0)
+        self.update_filter(freq_resp)
+
+    def set_shift(self, shift: float):
+        _lib.check(_lib.lib().rr_meter_set_shift(self._h, float(shift)))
+
+    def update_filter(self, freq_resp, window: Window | None = None):
+        """Filter::update / update_with_window: the closure is sampled at the rate and chunk length the Filter sees."""
+        if window is not None:
+            self._filter_window = window
+        resp = sample_freq_resp(freq_resp, self.chunk_len, self.output_rate)
+        win = self._filter_window.sample(self.chunk_len)
+        _lib.check(_lib.lib().rr_meter_filter_design(self._h, resp.ctypes.data, win.ctypes.data))
+
+    def peek(self, sample_rate, n_in: int) -> int:
+        n = C.c_size_t()
+        _lib.check(_lib.lib().rr_meter_peek(self._h, float(sample_rate), n_in, C.byref(n)))
+        return n.value
+
+    def process(self, signal):
+        from .signal import SamplesLost
+
+        if signal.is_event():
+            _lib.check(_lib.lib().rr_meter_event(self._h, int(signal.event.is_interrupt())))
+            return [EventSignal(SamplesLost()), signal]  # the Overlapper's answer to every event (chunks.rs:225-233)
+        frames = self.peek(signal.sample_rate, len(signal.chunk))
+        N = self.chunk_len * self.overlap
+        y = self._host_call(_lib.lib().rr_meter_process, (float(signal.sample_rate),), signal.chunk, frames * N)
+        return [Samples(self.output_rate, y[i * N : (i + 1) * N]) for i in range(frames)]
+
+    def process_dev(self, sample_rate, d_in: int, n_in: int, d_out: int, cap: int) -> int:
+        n_out = C.c_size_t()
+        _lib.check(_lib.lib().rr_meter_process_dev(self._h, float(sample_rate), d_in, n_in, d_out, cap, C.byref(n_out)))
+        return n_out.value
+
+
 def synth_iq_dev(device: int, hip_stream: int | None, seed: int, t0: int, n: int, d_out: int):
     """Fills n complex64 samples of the synthetic IQ source on the device."""
     _lib.check(_lib.lib().rr_synth_iq_dev(device, C.c_void_p(hip_stream or 0), seed, t0, n, d_out))

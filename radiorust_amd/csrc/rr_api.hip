@@ -958,6 +958,71 @@ int rr_channelizer::process_dev(const void *d_in, size_t n_in, void *d_out, size
 }
 
 // ---------------------------------------------------------------------------
+// Meter: FreqShifter -> Downsampler -> Filter -> Overlapper -> Fourier (examples/bandwidth_meter/main.rs:53-69)
+// ---------------------------------------------------------------------------
+rr_meter::~rr_meter() {
+    delete fs;
+    delete ds;
+    delete fl;
+    delete st;
+}
+
+void rr_meter::set_streams() {
+    fs->stream = ds->stream = fl->stream = st->stream = stream;
+    if (st->fo) st->fo->stream = stream;
+}
+
+int rr_meter::peek(double sample_rate, size_t n_in, size_t *n_frames) {
+    size_t m = 0;
+    RR_TRY(ds->peek(sample_rate, n_in, &m));
+    const size_t whole = (dec_len + m) / chunk_len * chunk_len;
+    const size_t k = fl->designed ? fl->peek(whole) : 0;
+    *n_frames = st->peek(k) / (chunk_len * overlap);
+    return RR_OK;
+}
+
+int rr_meter::process_dev(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out) {
+    if (n_out) *n_out = 0;
+    if (!fl->designed) RR_FAIL(RR_ERR_NEED_DESIGN, "Meter: the Filter has no design yet (rr_meter_filter_design)");
+    size_t frames = 0;
+    RR_TRY(peek(sample_rate, n_in, &frames));
+    const size_t N = chunk_len * overlap;
+    if (frames * N > cap) RR_FAIL(RR_ERR_CAPACITY, "Meter: out_cap %zu < %zu", cap, frames * N);
+    if (n_in == 0) return RR_OK;
+    RR_TRY(select());
+    set_streams();
+    const size_t esz = elem_size(dtype);
+    size_t m = 0;
+    RR_TRY(ds->peek(sample_rate, n_in, &m));
+    // room first (nothing has changed state yet); `dec` keeps the pending samples when it has to grow
+    RR_TRY(mixed.reserve(n_in * esz));
+    if ((dec_len + m) * esz > dec.cap) {
+        rr::DevBuf bigger;
+        RR_TRY(bigger.reserve((dec_len + m) * esz + chunk_len * esz));
+        if (dec_len) RR_HIP(hipMemcpyAsync(bigger.p, dec.p, dec_len * esz, hipMemcpyDeviceToDevice, stream));
+        RR_HIP(hipStreamSynchronize(stream));  // the old buffer is freed below
+        std::swap(dec.p, bigger.p);
+        std::swap(dec.cap, bigger.cap);
+    }
+    RR_TRY(filt.reserve((dec_len + m + 1) * esz));
+    size_t got = 0;
+    RR_TRY(fs->process_dev(sample_rate, d_in, n_in, mixed.p, n_in, &got));
+    RR_TRY(ds->process_dev(sample_rate, mixed.p, n_in, dec.as<char>() + dec_len * esz, m, &got));
+    const size_t total = dec_len + got, whole = total / chunk_len * chunk_len, left = total - whole;
+    size_t wrote = 0;
+    if (whole) {
+        size_t k = 0;
+        RR_TRY(fl->process_dev(output_rate, dec.p, whole, filt.p, whole, &k));
+        if (k) RR_TRY(st->process_dev(filt.p, k, d_out, cap, &wrote));
+        // the samples of the chunk that is still filling move to the front (left < chunk_len <= whole: no overlap)
+        if (left) RR_HIP(hipMemcpyAsync(dec.p, dec.as<char>() + whole * esz, left * esz, hipMemcpyDeviceToDevice, stream));
+    }
+    dec_len = left;
+    if (n_out) *n_out = wrote;
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
 // stage timers
 // ---------------------------------------------------------------------------
 int StageTimers::begin(int stage, hipStream_t s) {
@@ -1890,9 +1955,10 @@ int rr_stft_create(int dtype, size_t chunk_len, size_t chunk_count, const rr_win
     if (chunk_len == 0) RR_FAIL(RR_ERR_CONTRACT, "chunk length must be positive");    // chunks.rs:56
     if (chunk_count == 0) RR_FAIL(RR_ERR_CONTRACT, "chunk count must be positive");   // chunks.rs:195
     const size_t N = chunk_len * chunk_count;
-    // overlapped frames: the power-of-two kernels, or Bluestein over them (f32, 32 .. 4096 points)
-    if (!fourier_pow2_path(dtype, N) && !(dtype == RR_F32 && N >= 32 && N <= 4096))
-        RR_FAIL(RR_ERR_BAD_ARG, "Stft: chunk_len * chunk_count = %zu: powers of two, or 32 .. 4096 for Complex<f32>", N);
+    // overlapped frames: the power-of-two kernels of one LDS tile, or Bluestein over power-of-two transforms (>= 32 points)
+    if (!fourier_pow2_path(dtype, N) && !(N >= 32 && (N & (N - 1)) != 0 && N <= ((size_t)1 << 23)))
+        RR_FAIL(RR_ERR_BAD_ARG, "Stft: chunk_len * chunk_count = %zu: powers of two up to %u, or any other length of 32 .. 2^23", N,
+                dtype == RR_F32 ? 8192u : 4096u);
     if (window->kind != RR_WIN_RECTANGULAR && window->kind != RR_WIN_KAISER)
         RR_FAIL(RR_ERR_BAD_ARG, "Stft: window must be a built-in window");
     auto *h = new rr_stft;
@@ -2476,6 +2542,105 @@ int rr_channelizer_process(rr_channelizer *h, const void *in, size_t n_in, void 
 int rr_channelizer_destroy(rr_channelizer *h) {
     if (!h) return RR_OK;
     RR_CHECK_HANDLE(h, K_CHANNELIZER);
+    (void)hipSetDevice(h->device);
+    delete h;
+    return RR_OK;
+}
+
+int rr_meter_create(const rr_meter_params *p, int device, rr_meter **out) {
+    RR_GUARD_BEGIN
+    if (!out || !p) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    *out = nullptr;
+    if (p->chunk_len == 0) RR_FAIL(RR_ERR_CONTRACT, "chunk length must be positive");
+    if (p->overlap == 0) RR_FAIL(RR_ERR_CONTRACT, "chunk count must be positive");  // chunks.rs:195
+    if (!(p->output_rate >= 0.0)) RR_FAIL(RR_ERR_CONTRACT, "output sample rate must be positive");  // resampling.rs:51-56
+    if (!(p->bandwidth >= 0.0)) RR_FAIL(RR_ERR_CONTRACT, "bandwidth must be positive");
+    if (!(p->bandwidth < p->output_rate)) RR_FAIL(RR_ERR_CONTRACT, "bandwidth must be smaller than output sample rate");
+    rr_stft *st = nullptr;
+    RR_TRY(rr_stft_create(p->dtype, p->chunk_len, p->overlap, &p->fft_window, p->center_dc, device, &st));
+    auto *h = new rr_meter;
+    h->st = st;
+    int s = h->init_base(K_METER, p->dtype, device);
+    if (s == RR_OK) {
+        h->fs = new rr_freqshifter;
+        s = h->fs->init_base(K_FREQSHIFTER, p->dtype, device);
+    }
+    if (s == RR_OK) {
+        h->ds = new rr_downsampler;
+        s = h->ds->init_base(K_DOWNSAMPLER, p->dtype, device);
+    }
+    if (s == RR_OK) {
+        h->fl = new rr_filter;
+        s = h->fl->init_base(K_FILTER, p->dtype, device);
+    }
+    if (s != RR_OK) {
+        delete h;
+        return s;
+    }
+    h->fs->precision = p->precision;
+    h->fs->shift = p->shift;
+    h->ds->output_rate = p->output_rate;
+    h->ds->bandwidth = p->bandwidth;
+    h->ds->quality = p->quality;
+    h->chunk_len = p->chunk_len;
+    h->overlap = p->overlap;
+    h->output_rate = p->output_rate;
+    *out = h;
+    return RR_OK;
+    RR_GUARD_END
+}
+int rr_meter_set_shift(rr_meter *h, double shift) {
+    RR_CHECK_HANDLE(h, K_METER);
+    h->fs->shift = shift;
+    h->fs->shift_changed = true;
+    return RR_OK;
+}
+int rr_meter_filter_design(rr_meter *h, const rr_c64 *resp, const double *window_rel) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_METER);
+    h->set_streams();
+    return h->fl->design(h->output_rate, h->chunk_len, resp, window_rel);
+    RR_GUARD_END
+}
+int rr_meter_event(rr_meter *h, int is_interrupt) {
+    RR_CHECK_HANDLE(h, K_METER);
+    if (is_interrupt) h->fl->hist_valid = false;  // filters.rs:262-265
+    h->st->have_chunks = 0;                       // the Overlapper drops its history at any event (chunks.rs:225-233)
+    h->st->carry_len = 0;
+    return RR_OK;
+}
+int rr_meter_peek(rr_meter *h, double sample_rate, size_t n_in, size_t *n_frames) {
+    RR_CHECK_HANDLE(h, K_METER);
+    if (!n_frames) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    return h->peek(sample_rate, n_in, n_frames);
+}
+int rr_meter_process_dev(rr_meter *h, double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_METER);
+    return h->process_dev(sample_rate, d_in, n_in, d_out, cap, n_out);
+    RR_GUARD_END
+}
+int rr_meter_process(rr_meter *h, double sample_rate, const void *in, size_t n_in, void *out, size_t cap, size_t *n_out) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_METER);
+    if (n_out) *n_out = 0;
+    size_t frames = 0;
+    RR_TRY(h->peek(sample_rate, n_in, &frames));
+    const size_t produce = frames * h->chunk_len * h->overlap;
+    if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Meter: out_cap %zu < %zu", cap, produce);
+    size_t got = 0;
+    RR_TRY(host_io(h, in, n_in, out, produce, true, [&](void *di, void *dout, size_t *p) {
+        int s = h->process_dev(sample_rate, di, n_in, dout, produce, p);
+        got = *p;
+        return s;
+    }));
+    if (n_out) *n_out = got;
+    return RR_OK;
+    RR_GUARD_END
+}
+int rr_meter_destroy(rr_meter *h) {
+    if (!h) return RR_OK;
+    RR_CHECK_HANDLE(h, K_METER);
     (void)hipSetDevice(h->device);
     delete h;
     return RR_OK;

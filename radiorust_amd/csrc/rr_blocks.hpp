@@ -111,6 +111,25 @@ struct rr_stft : rr_block {
     int process_dev(const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
 };
 
+// The reference's own hot-path caller in its own order (examples/bandwidth_meter/main.rs:53-69):
+//   FreqShifter -> Downsampler(chunk_len, ..) -> Filter (chunks of chunk_len at the output rate) -> Overlapper(overlap)
+//   -> Fourier, on one device without host hops: four block handles, intermediates in device buffers.
+struct rr_meter : rr_block {
+    rr_freqshifter *fs = nullptr;
+    rr_downsampler *ds = nullptr;
+    rr_filter *fl = nullptr;
+    rr_stft *st = nullptr;
+    size_t chunk_len = 0, overlap = 0;
+    double output_rate = 0;
+    rr::DevBuf mixed, dec, filt;
+    size_t dec_len = 0;  // decimated samples waiting for the rest of their chunk: the Downsampler's partly filled output
+                         // chunk (resampling.rs:121-131); it survives events and rate changes like the reference's
+    ~rr_meter() override;
+    void set_streams();
+    int peek(double sample_rate, size_t n_in, size_t *n_frames);
+    int process_dev(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
+};
+
 struct rr_upsampler : rr_block {
     double output_rate = 0, bandwidth = 0, quality = 3.0;
     bool have_rate = false;

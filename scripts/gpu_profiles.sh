@@ -1,0 +1,53 @@
+#!/usr/bin/env bash
+# One GPU-box session that produces every file profiles/ keeps for a round (scripts/collect_profiles.py copies them):
+#   bench.json                      python bench.py (the driver's command, defaults)
+#   bench_profiled.json + kernel_stats.csv   rocprofv3 --kernel-trace --stats -- python3 bench.py --profile
+#   pmc_{sq1,sq2,fetch,write}.summary.txt    separate --pmc passes of `bench.py --profile` (chain launches only)
+#   cfg5_kernel_stats.csv, cfg5_pmc_*.summary.txt   the same for BASELINE configs[4] (scripts/prof_cfg5.py)
+#   blocks.txt, cfg5.txt, cfg3.txt   scripts/bench_blocks.py, bench_cfg5.py, bench_cfg3.py
+# usage: scripts/gpu_profiles.sh TAG
+set -u -o pipefail
+TAG="${1:-prof}"
+OUT="$GRAFT_REPO_ROOT/gpurun_out/$TAG"
+mkdir -p "$OUT"
+cd "$GRAFT_REPO_ROOT"
+export TMPDIR=/tmp
+step() { # name timeout cmd...
+  local name="$1" to="$2"; shift 2
+  echo "=== $name"
+  timeout -k 10 "$to" "$@" > "$OUT/$name.log" 2>&1
+  local rc=$?
+  echo "=== $name rc=$rc"; tail -n 4 "$OUT/$name.log"
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "!!! $name timed out/killed: stopping"; exit $rc; fi
+}
+pmc() { # name script-and-args... ; counters in $CTRS
+  local name="$1"; shift
+  step "$name" 300 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d "$OUT/$name" -- python3 "$@"
+  local f; f=$(find "$OUT/$name" -name '*counter_collection.csv' | head -1)
+  [ -n "$f" ] && python3 scripts/pmc_summary.py "$f" > "$OUT/$name.summary.txt"
+  find "$OUT/$name" -name '*.csv' -size +8M -delete
+}
+SQ1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+SQ2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE"
+step bench 600 python3 bench.py
+grep -h '^{' "$OUT/bench.log" > "$OUT/bench.json" || true
+step rocprof 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 bench.py --profile
+grep -h '^{' "$OUT/rocprof.log" > "$OUT/bench_profiled.json" || true
+find "$OUT/prof" -name '*kernel_stats*.csv' | head -1 | xargs -r -I{} cp {} "$OUT/kernel_stats.csv"
+find "$OUT/prof" -name '*kernel_trace*.csv' -size +20M -delete || true
+B="bench.py --profile --steps 20 --warmup 3 --settle-ms 0"
+CTRS="$SQ1" pmc pmc_sq1 $B
+CTRS="$SQ2" pmc pmc_sq2 $B
+CTRS="FETCH_SIZE" pmc pmc_fetch $B
+CTRS="WRITE_SIZE" pmc pmc_write $B
+step cfg5prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg5prof" -- python3 scripts/prof_cfg5.py 40
+find "$OUT/cfg5prof" -name '*kernel_stats*.csv' | head -1 | xargs -r -I{} cp {} "$OUT/cfg5_kernel_stats.csv"
+CTRS="$SQ1" pmc cfg5_pmc_sq1 scripts/prof_cfg5.py
+CTRS="$SQ2" pmc cfg5_pmc_sq2 scripts/prof_cfg5.py
+CTRS="FETCH_SIZE" pmc cfg5_pmc_fetch scripts/prof_cfg5.py
+CTRS="WRITE_SIZE" pmc cfg5_pmc_write scripts/prof_cfg5.py
+step blocks 400 python3 scripts/bench_blocks.py
+step fftsizes 300 python3 scripts/fft_sizes_probe.py
+step cfg5 300 python3 scripts/bench_cfg5.py
+step cfg3 300 python3 scripts/bench_cfg3.py
+echo "=== done"

@@ -410,12 +410,14 @@ def test_chain_one_call_of_2_pow_28_samples(rr, oracle):
     st = torch.cuda.current_stream().cuda_stream
     d_in = torch.empty(n, dtype=torch.complex64, device="cuda")
     rr.synth_iq_dev(0, st, 3, 0, n, d_in.data_ptr())
+    torch.cuda.synchronize()
     g = make(rr, oracle, CFG2, True)
     g.set_stream(st)
     frames = g.peek(fs, n)
     assert frames == 16383
     d_out = torch.empty(frames * 4096, dtype=torch.complex64, device="cuda")
     assert g.process_dev(fs, d_in.data_ptr(), n, d_out.data_ptr(), d_out.numel()) == frames * 4096
+    torch.cuda.synchronize()  # (torch's default stream is the null stream: the handle then runs on its own)
     K = 256
     x = d_in[: (K + 2) * 16384].cpu().numpy()
     ref = oracle.run_chain_c(x, fs, shift=25e6, filter_len=64, freq_resp=lowpass(20e6), output_rate=50e6, bandwidth=40e6,
@@ -433,6 +435,61 @@ def test_chain_one_call_of_2_pow_28_samples(rr, oracle):
         wrote += g2.process_dev(fs, d_in.data_ptr() + 8 * off, step, d_out2.data_ptr() + 8 * wrote, d_out2.numel() - wrote)
         off += step
     assert wrote == frames * 4096
+    torch.cuda.synchronize()
     a, b = d_out.view(frames, 4096), d_out2.view(frames, 4096)
     err = (torch.linalg.vector_norm(a - b, dim=1) / torch.linalg.vector_norm(b, dim=1)).max().item()
     assert err <= 2e-6, err
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 1e-5), (np.float64, 1e-11)])
+def test_meter_is_the_bandwidth_meter_example(rr, oracle, dtype, tol):
+    """rr_meter_*: the reference's own pipeline in its own order (examples/bandwidth_meter/main.rs:53-69) -
+    FreqShifter -> Downsampler(1024, 102400, max_bw) (10 : 1, L = 145) -> Filter(|f| <= max_bw / 2) on the Downsampler's
+    1024-sample chunks -> Overlapper(4) -> Fourier(Kaiser null at bin 4) -> metering::bandwidth(0.01, ..) - on the device
+    without host hops, fed in ragged pieces, against the same blocks of the oracle message by message; an event in the
+    middle resets Filter and Overlapper but not the Downsampler's partly filled chunk."""
+    from radiorust_amd import metering
+
+    fs, out_rate, max_bw, quality = 1024000.0, 102400.0, 60e3, 4
+    resp = lambda _b, f: 1.0 if abs(f) <= max_bw / 2 else 0.0  # noqa: E731
+    x = oracle.synth_iq(41, 0, 300000)
+    if dtype == np.float64:
+        x = x.astype(np.complex128)
+    g = rr.Meter(shift=12.5e3, output_rate=out_rate, bandwidth=max_bw, chunk_len=1024, freq_resp=resp, overlap=quality,
+                 fft_window=rr.Kaiser.with_null_at_bin(float(quality)), dtype=dtype)
+    sh = oracle.FreqShifter(1.0, 12.5e3, flt=np.float64)
+    ds = oracle.Downsampler(1024, out_rate, max_bw, flt=np.float64)
+    fl = oracle.Filter(resp, flt=np.float64)
+    fo = oracle.Fourier(oracle.Kaiser.with_null_at_bin(float(quality)), flt=np.float64)
+    hist, ref, got = [], [], []
+
+    def feed(piece):
+        for c in ds.feed(fs, sh.process(fs, piece)):
+            z = fl.process(out_rate, c)
+            if z is not None:
+                hist.append(z)
+                if len(hist) >= quality:
+                    ref.append(fo.process(np.concatenate(hist[-quality:])))
+                    del hist[: len(hist) - (quality - 1)]
+
+    cuts = [0, 5000, 5001, 60000, 131072, 200000]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        out = g.process(rr.Samples(fs, x[a:b]))
+        assert all(s.sample_rate == out_rate and len(s.chunk) == 1024 * quality for s in out)
+        got += out
+        feed(x[a:b])
+    assert len(got) == len(ref) and len(ref) >= 12
+    # an interrupting event: SamplesLost first, Filter and Overlapper start over, the Downsampler's chunk carries on
+    ev = rr.EventSignal(rr.Disconnection())
+    mid = g.process(ev)
+    assert len(mid) == 2 and isinstance(mid[0].event, rr.SamplesLost) and mid[1] is ev
+    fl.interrupt()
+    hist.clear()
+    got += g.process(rr.Samples(fs, x[200000:]))
+    feed(x[200000:])
+    assert len(got) == len(ref) and len(ref) >= 17
+    for a, b in zip(got, ref):
+        assert rms_rel(a.chunk, b) <= tol
+        bw_ref = oracle.bandwidth(0.01, out_rate, b, flt=np.float64)
+        bw_got = metering.bandwidth(0.01, out_rate, a.chunk)
+        assert abs(bw_got - bw_ref) <= 1e-3 * bw_ref + 1e-6
