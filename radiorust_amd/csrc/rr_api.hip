@@ -508,6 +508,11 @@ int rr_downsampler::ensure_fast() {
     if (dtype != RR_F32 || !sched.periodic || (e && std::atoi(e) != 0)) return RR_OK;
     int kind = sched.integer_ratio ? rr_chain::pick_fused_kernel(sched.D, L, true, 0) : rr_chain::FK_NONE;
     if (kind == rr_chain::FK_OLSF) kind = rr_chain::FK_OLSW;
+    {
+        // RR_DOWNSAMPLER_POLY=1: k_decim_poly also where a fused kernel applies (A/B runs)
+        const char *pe = std::getenv("RR_DOWNSAMPLER_POLY");
+        if (pe && std::atoi(pe) != 0 && decim_poly_supported(dtype, sched.P, sched.Q, L)) kind = rr_chain::FK_NONE;
+    }
     if (kind == rr_chain::FK_NONE) {
         // every other integer ratio, and rational ratios with a short period (the tap table follows per call)
         if (decim_poly_supported(dtype, sched.P, sched.Q, L)) {

@@ -491,5 +491,5 @@ def test_meter_is_the_bandwidth_meter_example(rr, oracle, dtype, tol):
     for a, b in zip(got, ref):
         assert rms_rel(a.chunk, b) <= tol
         bw_ref = oracle.bandwidth(0.01, out_rate, b, flt=np.float64)
-        bw_got = metering.bandwidth(0.01, out_rate, a.chunk)
+        bw_got = metering.bandwidth(0.01, out_rate, a.chunk, dtype=dtype)
         assert abs(bw_got - bw_ref) <= 1e-3 * bw_ref + 1e-6

@@ -150,7 +150,8 @@ def overlapped_spectra(oracle, chunks, P, window, center_dc, flt, history=None):
                                                   (4096, 1, False, np.float32, 1e-5), (2048, 2, True, np.float32, 1e-5),
                                                   (64, 8, False, np.float64, 1e-12), (512, 16, False, np.float32, 1e-5),
                                                   (512, 2, False, np.float32, 1e-5), (256, 1, False, np.float32, 1e-5),
-                                                  (1024, 1, True, np.float32, 1e-5), (1024, 2, False, np.float32, 1e-5), (512, 4, True, np.float32, 1e-5), (128, 4, True, np.float32, 1e-5), (256, 2, False, np.float32, 1e-5), (2048, 4, True, np.float32, 1e-5), (250, 4, True, np.float32, 1e-5), (100, 3, False, np.float32, 1e-5)])
+                                                  (1024, 1, True, np.float32, 1e-5), (1024, 2, False, np.float32, 1e-5), (512, 4, True, np.float32, 1e-5), (128, 4, True, np.float32, 1e-5), (256, 2, False, np.float32, 1e-5), (2048, 4, True, np.float32, 1e-5), (250, 4, True, np.float32, 1e-5), (100, 3, False, np.float32, 1e-5),
+                                                  (100, 3, True, np.float64, 1e-11), (1500, 4, False, np.float32, 1e-5)])
 def test_stft_parity(rr, oracle, M, P, center, dtype, tol):
     """rr_stft_*: Rechunker -> Overlapper -> Fourier on the device (4096-point spans run k_fft4096
     with a hop, the others the generic power-of-two kernel) against the oracle composition."""
@@ -196,9 +197,9 @@ def test_stft_contract(rr):
     with pytest.raises(ContractViolation):
         rr.Stft(64, 0)
     with pytest.raises(BackendError):
-        rr.Stft(5, 3)  # 15 points: overlapping chunks need a power-of-two span or, in f32, 32 .. 4096 points (Bluestein)
+        rr.Stft(5, 3)  # 15 points: overlapping chunks need a power-of-two span (one LDS tile) or 32 points and more (Bluestein)
     with pytest.raises(BackendError):
-        rr.Stft(100, 3, dtype=np.float64)
+        rr.Stft(4096, 4)  # 16384 points: a power of two beyond the overlapped kernels
 
 
 def test_stft_rechunks_arbitrary_input(rr, oracle):
