@@ -410,6 +410,9 @@ int rr_meter_process(rr_meter *h, double sample_rate, const void *in, size_t n_i
                      size_t out_cap, size_t *n_out);
 int rr_meter_process_dev(rr_meter *h, double sample_rate, const void *d_in, size_t n_in,
                          void *d_out, size_t out_cap, size_t *n_out);
+/* 1 when the last process call ran FreqShifter and Downsampler as ONE kernel (Complex<f32>, calls of >= 4096 samples,
+ * any integer or short-period rational ratio: k_decim_poly with the phase table riding along), else 0. */
+int rr_meter_last_path(const rr_meter *h, int *front_fused);
 int rr_meter_destroy(rr_meter *h);
 
 /* ------------------------------------------------------------------------ */

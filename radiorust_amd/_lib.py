@@ -173,6 +173,7 @@ SIGNATURES = {
     "rr_meter_peek": (_i, [_vp, _d, _sz, _psz]),
     "rr_meter_process": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
     "rr_meter_process_dev": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
+    "rr_meter_last_path": (_i, [_vp, C.POINTER(_i)]),
     "rr_meter_destroy": (_i, [_vp]),
     "rr_stft_peek": (_i, [_vp, _sz, _psz]),
     "rr_stft_process": (_i, [_vp, _vp, _sz, _vp, _sz, _psz]),

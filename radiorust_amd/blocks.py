@@ -694,6 +694,12 @@ class Meter(_Block):
         y = self._host_call(_lib.lib().rr_meter_process, (float(signal.sample_rate),), signal.chunk, frames * N)
         return [Samples(self.output_rate, y[i * N : (i + 1) * N]) for i in range(frames)]
 
+    def front_fused(self) -> bool:
+        """True when the last call ran FreqShifter + Downsampler as one kernel."""
+        v = C.c_int()
+        _lib.check(_lib.lib().rr_meter_last_path(self._h, C.byref(v)))
+        return bool(v.value)
+
     def process_dev(self, sample_rate, d_in: int, n_in: int, d_out: int, cap: int) -> int:
         n_out = C.c_size_t()
         _lib.check(_lib.lib().rr_meter_process_dev(self._h, float(sample_rate), d_in, n_in, d_out, cap, C.byref(n_out)))

@@ -383,8 +383,16 @@ int rr_downsampler::peek(double input_rate, size_t n_in, size_t *n_out) {
     return RR_OK;
 }
 
+// true when a call of n_in samples at this rate would run k_decim_poly, which can take a FreqShifter's table along
+bool rr_downsampler::can_fuse_mixer(double input_rate, size_t n_in) {
+    size_t produce = 0;
+    if (dtype != RR_F32 || n_in < kFastMinSamples || peek(input_rate, n_in, &produce) != RR_OK || !produce) return false;
+    if (select() != RR_OK || prepare(input_rate) != RR_OK || ensure_fast() != RR_OK) return false;
+    return fast_kind == rr_chain::FK_POLY;
+}
+
 int rr_downsampler::process_dev(double input_rate, const void *d_in, size_t n_in, void *d_out, size_t cap,
-                                size_t *n_out) {
+                                size_t *n_out, const void *nco, uint32_t nco_denom, uint32_t nco_idx0) {
     if (n_out) *n_out = 0;
     size_t produce = 0;
     RR_TRY(peek(input_rate, n_in, &produce));
@@ -408,13 +416,14 @@ int rr_downsampler::process_dev(double input_rate, const void *d_in, size_t n_in
             RR_TRY(ensure_poly_taps(e_first));
             next.advance(n_in, nullptr);
             RR_TRY(launch_decim_poly(stream, hist[cur].p, L, d_in, n_in, f_ctaps.p, sched.P, sched.Q, f_NC, L, e_first[0],
-                                     d_out, produce, hist[cur ^ 1].p, L));
+                                     d_out, produce, hist[cur ^ 1].p, L, nco, nco_denom, nco_idx0));
             sched = next;
             cur ^= 1;
             last_kernel = fast_kind;
             if (n_out) *n_out = produce;
             return RR_OK;
         }
+        if (nco) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: a mixer can only ride along with k_decim_poly (can_fuse_mixer)");
         if (fast_kind != rr_chain::FK_NONE && sched.integer_ratio) {
             // the chain's kernels with every phasor = 1: out[m] = sum_i c[i] x[e0 + D m - i], c = reverse(ir);
             // the kernel's last workgroup leaves the last L samples as the next call's history
@@ -450,6 +459,7 @@ int rr_downsampler::process_dev(double input_rate, const void *d_in, size_t n_in
             return RR_OK;
         }
     }
+    if (nco) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: a mixer can only ride along with k_decim_poly (can_fuse_mixer)");
     FirArgs a;
     a.hist = hist[cur].p;
     a.hist_len = L;
@@ -1000,7 +1010,6 @@ int rr_meter::process_dev(double sample_rate, const void *d_in, size_t n_in, voi
     size_t m = 0;
     RR_TRY(ds->peek(sample_rate, n_in, &m));
     // room first (nothing has changed state yet); `dec` keeps the pending samples when it has to grow
-    RR_TRY(mixed.reserve(n_in * esz));
     if ((dec_len + m) * esz > dec.cap) {
         rr::DevBuf bigger;
         RR_TRY(bigger.reserve((dec_len + m) * esz + chunk_len * esz));
@@ -1011,8 +1020,20 @@ int rr_meter::process_dev(double sample_rate, const void *d_in, size_t n_in, voi
     }
     RR_TRY(filt.reserve((dec_len + m + 1) * esz));
     size_t got = 0;
-    RR_TRY(fs->process_dev(sample_rate, d_in, n_in, mixed.p, n_in, &got));
-    RR_TRY(ds->process_dev(sample_rate, mixed.p, n_in, dec.as<char>() + dec_len * esz, m, &got));
+    if (ds->can_fuse_mixer(sample_rate, n_in)) {
+        // FreqShifter and Downsampler in ONE pass over the input (k_decim_poly with the phase table riding along): the
+        // mixed stream is never written; the Downsampler's history holds mixed samples either way
+        RR_TRY(fs->prepare(sample_rate));  // table for this rate and shift, phase kept (transform.rs:318-340)
+        RR_TRY(ds->process_dev(sample_rate, d_in, n_in, dec.as<char>() + dec_len * esz, m, &got, fs->d_table.p, (uint32_t)fs->denom,
+                               (uint32_t)fs->phase_idx));
+        fs->phase_idx = (fs->phase_idx + n_in % (uint64_t)fs->denom) % (uint64_t)fs->denom;
+        last_front_fused = true;
+    } else {
+        RR_TRY(mixed.reserve(n_in * esz));
+        RR_TRY(fs->process_dev(sample_rate, d_in, n_in, mixed.p, n_in, &got));
+        RR_TRY(ds->process_dev(sample_rate, mixed.p, n_in, dec.as<char>() + dec_len * esz, m, &got));
+        last_front_fused = false;
+    }
     const size_t total = dec_len + got, whole = total / chunk_len * chunk_len, left = total - whole;
     size_t wrote = 0;
     if (whole) {
@@ -2642,6 +2663,12 @@ int rr_meter_process(rr_meter *h, double sample_rate, const void *in, size_t n_i
     if (n_out) *n_out = got;
     return RR_OK;
     RR_GUARD_END
+}
+int rr_meter_last_path(const rr_meter *h, int *front_fused) {
+    RR_CHECK_HANDLE(h, K_METER);
+    if (!front_fused) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    *front_fused = h->last_front_fused ? 1 : 0;
+    return RR_OK;
 }
 int rr_meter_destroy(rr_meter *h) {
     if (!h) return RR_OK;

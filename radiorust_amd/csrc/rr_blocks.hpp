@@ -87,7 +87,11 @@ struct rr_downsampler : rr_block {
     int ensure_fast();
     int prepare(double input_rate);
     int peek(double input_rate, size_t n_in, size_t *n_out);
-    int process_dev(double input_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
+    // nco != null (only after can_fuse_mixer() said yes): in[pos] * nco[(nco_idx0 + pos) mod nco_denom] is what gets
+    // filtered - a FreqShifter in front fused into k_decim_poly; the history then holds mixed samples
+    int process_dev(double input_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out,
+                    const void *nco = nullptr, uint32_t nco_denom = 0, uint32_t nco_idx0 = 0);
+    bool can_fuse_mixer(double input_rate, size_t n_in);
 };
 
 // Fourier — analysis.rs:67-73 (previous_chunk_len, fft, window_values)
@@ -122,6 +126,7 @@ struct rr_meter : rr_block {
     size_t chunk_len = 0, overlap = 0;
     double output_rate = 0;
     rr::DevBuf mixed, dec, filt;
+    bool last_front_fused = false;  // the last call ran FreqShifter + Downsampler as one kernel
     size_t dec_len = 0;  // decimated samples waiting for the rest of their chunk: the Downsampler's partly filled output
                          // chunk (resampling.rs:121-131); it survives events and rate changes like the reference's
     ~rr_meter() override;

@@ -50,6 +50,10 @@ struct DecimArgs {
     unsigned ntiles;
     float2 *hist_out;  // receives the last hist_out_len samples of [ hist | in ] (may be null)
     int hist_out_len;
+    // optional mixer in front (FreqShifter fused, transform.rs:341-348): samples of `in` are multiplied by
+    // nco[(idx0 + pos) mod denom] as they are staged; `hist` and `hist_out` then hold MIXED samples.  denom = 0: no mixer
+    const float2 *nco;
+    unsigned denom, idx0;
 };
 
 // (T is a parameter of its own, const and restrict: only then does the compiler read the wave-uniform taps through
@@ -75,8 +79,17 @@ __global__ __launch_bounds__(256) void k_decim_poly(DecimArgs a, const uint2 *__
             float2 h;
             h.x = 0.f;
             h.y = 0.f;
-            if (pos >= 0) h = a.in[pos];
-            else if (pos >= -(long)a.hist_len) h = a.hist[a.hist_len + pos];
+            if (pos >= 0) {
+                h = a.in[pos];
+                if (a.denom) {
+                    const float2 pp = a.nco[(unsigned)(((long)a.idx0 + pos) % (long)a.denom)];
+                    const float2 x = h;
+                    h.x = x.x * pp.x - x.y * pp.y;
+                    h.y = x.x * pp.y + x.y * pp.x;
+                }
+            } else if (pos >= -(long)a.hist_len) {
+                h = a.hist[a.hist_len + pos];
+            }
             a.hist_out[i] = h;
         }
     }
@@ -94,6 +107,20 @@ __global__ __launch_bounds__(256) void k_decim_poly(DecimArgs a, const uint2 *__
             }
         };
         const bool interior = p_lo >= 0 && p_lo + nld <= a.n_in;
+        // NCO phase of this lane's first sample and its step per 256 samples (interior tiles: every sample is in `in`)
+        unsigned ph = 0, dph = 0;
+        if (a.denom) {
+            long r0 = ((long)a.idx0 + p_lo + t) % (long)a.denom;
+            if (r0 < 0) r0 += a.denom;
+            ph = (unsigned)r0;
+            dph = 256u % a.denom;
+        }
+        auto mix = [&](f2 v) {
+            const float2 pp = a.nco[ph];
+            ph += dph;
+            if (ph >= a.denom) ph -= a.denom;
+            return cmul(v, (f2){pp.x, pp.y});
+        };
         if (interior) {
             const f2 *src = reinterpret_cast<const f2 *>(a.in + p_lo);
             int q = t;
@@ -103,12 +130,13 @@ __global__ __launch_bounds__(256) void k_decim_poly(DecimArgs a, const uint2 *__
                 for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + q + 256 * u);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    xs[row * S + col] = v[u];
+                    xs[row * S + col] = a.denom ? mix(v[u]) : v[u];
                     step();
                 }
             }
             for (; q < nld; q += 256) {
-                xs[row * S + col] = __builtin_nontemporal_load(src + q);
+                const f2 v = __builtin_nontemporal_load(src + q);
+                xs[row * S + col] = a.denom ? mix(v) : v;
                 step();
             }
         } else {
@@ -119,9 +147,17 @@ __global__ __launch_bounds__(256) void k_decim_poly(DecimArgs a, const uint2 *__
                 xv.x = 0.f;
                 xv.y = 0.f;
                 if (pos >= 0) {
-                    if (pos < a.n_in) xv = a.in[pos];
+                    if (pos < a.n_in) {
+                        xv = a.in[pos];
+                        if (a.denom) {
+                            const float2 pp = a.nco[(unsigned)(((long)a.idx0 + pos) % (long)a.denom)];
+                            const float2 x = xv;
+                            xv.x = x.x * pp.x - x.y * pp.y;
+                            xv.y = x.x * pp.y + x.y * pp.x;
+                        }
+                    }
                 } else if (pos >= -(long)a.hist_len) {
-                    xv = a.hist[a.hist_len + pos];
+                    xv = a.hist[a.hist_len + pos];  // (already mixed)
                 }
                 xs[row * S + col] = (f2){xv.x, xv.y};
                 step();
@@ -221,7 +257,7 @@ void build_decim_poly_taps(const std::vector<double> &ir, uint64_t P, uint64_t Q
 
 int launch_decim_poly(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *T,
                       uint64_t P, uint64_t Q, int Lp, size_t L, int64_t e_first0, void *out, size_t n_out, void *hist_out,
-                      size_t hist_out_len) {
+                      size_t hist_out_len, const void *nco, uint32_t denom, uint32_t idx0) {
     if (n_out == 0) return RR_OK;
     DecimArgs a;
     a.hist = (const float2 *)hist;
@@ -237,6 +273,9 @@ int launch_decim_poly(hipStream_t s, const void *hist, size_t hist_len, const vo
     a.n_out = (long)n_out;
     a.hist_out = (float2 *)hist_out;
     a.hist_out_len = (int)hist_out_len;
+    a.nco = (const float2 *)nco;
+    a.denom = nco ? denom : 0;
+    a.idx0 = idx0;
     const int lds = decim_geometry(P, Q, (size_t)a.NC, &a.TA, &a.S);
     if (!lds) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: %llu : %llu with %d tap columns does not fit the LDS tile",
                       (unsigned long long)P, (unsigned long long)Q, a.NC);

@@ -55,13 +55,14 @@ int launch_filter_blk4096(hipStream_t s, const void *hist, size_t hist_len, cons
 
 // Downsampler for any integer ratio P : 1 and rational ratios P : Q with Q <= 8 (rr_decim.hip), Complex<f32>:
 // out[Q a + b] = sum_j ir[j] x[e_first[b] + P a - (L - 1) + j] over [ hist | in ]; T = build_decim_poly_taps' table.
-// hist_out (may be null) receives the last hist_out_len samples of [ hist | in ].
+// hist_out (may be null) receives the last hist_out_len samples of [ hist | in ].  nco != null: the FreqShifter fused in
+// front - in[pos] * nco[(idx0 + pos) mod denom] -, hist / hist_out then hold mixed samples.
 bool decim_poly_supported(int dtype, uint64_t P, uint64_t Q, size_t L);
 void build_decim_poly_taps(const std::vector<double> &ir, uint64_t P, uint64_t Q, const int64_t *e_first, std::vector<uint32_t> &T,
                            int *Lp_out);
 int launch_decim_poly(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *T,
                       uint64_t P, uint64_t Q, int Lp, size_t L, int64_t e_first0, void *out, size_t n_out, void *hist_out,
-                      size_t hist_out_len);
+                      size_t hist_out_len, const void *nco = nullptr, uint32_t denom = 0, uint32_t idx0 = 0);
 
 // new_hist (H samples) = last H samples of [ zeros | old_hist (H) | in (n_in) ]
 int launch_update_hist(int dtype, hipStream_t s, const void *old_hist, void *new_hist, size_t H, const void *in,

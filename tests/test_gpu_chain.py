@@ -476,6 +476,8 @@ def test_meter_is_the_bandwidth_meter_example(rr, oracle, dtype, tol):
     for a, b in zip(cuts[:-1], cuts[1:]):
         out = g.process(rr.Samples(fs, x[a:b]))
         assert all(s.sample_rate == out_rate and len(s.chunk) == 1024 * quality for s in out)
+        # f32 calls of >= 4096 samples: mixer and decimator as one kernel; the 1-sample call and f64: two steps
+        assert g.front_fused() == (dtype == np.float32 and b - a >= 4096)
         got += out
         feed(x[a:b])
     assert len(got) == len(ref) and len(ref) >= 12
