@@ -12,7 +12,8 @@
 //! | `blocks::filters::Filter` | [`Filter`] | `rr_filter` |
 //! | `blocks::resampling::Downsampler` | [`Downsampler`] | `rr_downsampler` |
 //! | `blocks::analysis::Fourier` | [`Fourier`] | `rr_fourier` |
-//! | the four wired in a row (`examples/bandwidth_meter`) | [`Chain`] | `rr_chain` |
+//! | shift → filter → decimate → Fourier in a row | [`Chain`] | `rr_chain` |
+//! | `examples/bandwidth_meter`: shift → decimate → filter → overlap → Fourier | [`Meter`] | `rr_meter` |
 //!
 //! To add this to radiorust: copy this directory to `src/blocks/gpu/`, `build.rs` next to `Cargo.toml`, and
 //! add `#[cfg(feature = "mi355x")] pub mod gpu;` to `src/blocks/mod.rs` (feature `mi355x = []`).
@@ -26,12 +27,14 @@ pub mod ffi;
 pub mod filter;
 pub mod fourier;
 pub mod freq_shifter;
+pub mod meter;
 
 pub use chain::Chain;
 pub use downsampler::Downsampler;
 pub use filter::Filter;
 pub use fourier::Fourier;
 pub use freq_shifter::FreqShifter;
+pub use meter::Meter;
 
 use crate::numbers::Float;
 use crate::windowing::Window;
