@@ -377,7 +377,7 @@ class FreqShifter:
         return out
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             getattr(lib(), f"rro_freqshifter_free_{self._suf}")(self._h)
             self._h = None
 
@@ -431,7 +431,7 @@ class Filter:
         return out
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             getattr(lib(), f"rro_filter_free_{self._suf}")(self._h)
             self._h = None
 
@@ -481,7 +481,7 @@ class Downsampler:
         return out
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             getattr(lib(), f"rro_downsampler_free_{self._suf}")(self._h)
             self._h = None
 
@@ -529,7 +529,7 @@ class Upsampler:
         return out
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             getattr(lib(), f"rro_upsampler_free_{self._suf}")(self._h)
             self._h = None
 
@@ -554,7 +554,7 @@ class FmDemod:
         return y
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             getattr(lib(), f"rro_fmdemod_free_{self._suf}")(self._h)
             self._h = None
 
@@ -582,7 +582,7 @@ class Fourier:
         return out
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             getattr(lib(), f"rro_fourier_free_{self._suf}")(self._h)
             self._h = None
 

@@ -1184,14 +1184,13 @@ int rr_chain::ensure_xh() {
 // Three fused mix + FIR + decimate implementations (measured on cfg2, 2^26 samples, Lc = 183):
 //   direct  k_mix_fir_decim  direct form, real taps, D in {2, 4, 8}; cost ~ Lc           0.222 ms
 //   ols     k_ols_decim4     overlap-save, workgroup per 4096-block, D = 4, any taps       0.21 ms
-//   olsw    k_ols_wave       overlap-save, wave per 1024-block, D = 4, any taps, Lc <= 513 0.144 ms
-//                            (chosen up to Lc = 385)
+//   olsw    k_ols_wave<D>    overlap-save, wave per 1024-block, D in {2, 4, 8}, any taps, Lc <= 513   0.132 ms
 //   olsf    k_ols_frame      olsw's blocks + the 4096-point Fourier stage in one kernel (a workgroup
 //                            per frame), D = 4, 129 <= Lc <= 193, fft_len = 4096; 0.233 ms for BOTH
 //                            stages against olsw + k_fft4096 = 0.207: on request only
-// Unforced: olsw unless the filter is so short (Lc < 112) that the direct form is at its load/store
-// floor anyway.  RR_FUSED_KERNEL = direct | ols | olsw | olsf forces one of
-// them where it applies (A/B runs and tests).
+// Unforced: olsw wherever it applies (D in {2, 4, 8}, Lc <= 513), ols beyond an overlap of 384 at D = 4, the direct
+// form for what is left.  RR_FUSED_KERNEL = direct | ols | olsw | olsf forces one of them where it applies (A/B
+// runs and tests).
 int rr_chain::pick_fused_kernel(uint64_t D, size_t lc, bool real_taps, size_t fft_len) {
     const bool can_direct = real_taps && fused_fir_supported(D, lc);
     const bool can_ols = ols_decim_supported(D, lc), can_wave = ols_wave_supported(D, lc);
@@ -1203,12 +1202,13 @@ int rr_chain::pick_fused_kernel(uint64_t D, size_t lc, bool real_taps, size_t ff
         if (!std::strcmp(e, "olsw") && can_wave) return FK_OLSW;
         if (!std::strcmp(e, "olsf") && can_frame) return FK_OLSF;
     }
-    // 4x decimation: overlap-save unless the filter is short; beyond an overlap of 384 of the 1024 samples
-    // (Lc > 385) the 4096-blocks are ahead (measured: Lc = 455: 0.252 against 0.259 ms per step, the direct
-    // form 0.54; Lc = 375: 0.250 against 0.222)
-    const bool long_enough = lc >= 112 || !can_direct;
-    if (can_wave && long_enough && (ols_wave_overlap(lc) <= 384 || !can_ols)) return FK_OLSW;
-    if (can_ols && long_enough) return FK_OLS;
+    // Overlap-save with a wave per 1024-block for every ratio it folds (2, 4, 8) and every length it reaches: since
+    // round 2 it is ahead of the direct form for short responses too (scripts/bench_decim_ab.py, ms per 2^26 samples:
+    // 2 : 1 L = 32 0.149 against 0.173, 4 : 1 L = 60 0.121 against 0.144, 8 : 1 L = 83 0.117 against 0.129).  Beyond an
+    // overlap of 384 of the 1024 samples (Lc > 385) the 4096-blocks are ahead at 4 : 1 (measured: Lc = 455: 0.252
+    // against 0.259 ms per step; Lc = 375: 0.250 against 0.222).
+    if (can_wave && (ols_wave_overlap(lc) <= 384 || !can_ols)) return FK_OLSW;
+    if (can_ols) return FK_OLS;
     if (can_direct) return FK_DIRECT;
     if (can_wave) return FK_OLSW;
     if (can_ols) return FK_OLS;

@@ -1051,6 +1051,11 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));  // two compl
 __device__ __forceinline__ f4u ld_stream(const f4u *p) { return __builtin_nontemporal_load(p); }
 constexpr unsigned kWaveWin = 64;  // blocks dealt to the XCDs in a moving window, that many neighbouring blocks per XCD
                                    // (one contiguous eighth of the stream per XCD: 0.1375 -> 0.135 ms; 16 .. 1024 alike)
+// D = 4 is the benchmark's form.  D = 2 and D = 8 fold the spectrum into 2 resp. 8 parts instead of 4 (decimation =
+// aliasing in frequency: Y[i] = sum_q X[i + (1024 / D) q] H[..]) and differ in the inverse only: 512 points as the
+// forward radix 8 x 8 x 8 routine of k_fft512 with the result index reversed (IDFT(Z)[t] = DFT(Z)[(N - t) mod N]),
+// 128 points as radix 2 x 4 x 4 x 4 on the lower half of the wave.
+template <int D>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ols_wave(
     const float2 *__restrict__ xh, int hx, const float2 *__restrict__ in, long n_in, const float2 *__restrict__ nco,
     unsigned denom, unsigned idx0, const float2 *__restrict__ H, const float2 *__restrict__ tw, int V,
@@ -1065,7 +1070,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const unsigned grp = blockIdx.x / (8 * G), rem = blockIdx.x % (8 * G);
     const unsigned blk = grp * 8 * G + (rem & 7) * G + (rem >> 3);
     if (blk >= nblocks) return;
-    const int hop = 1024 - V, per_block = hop >> 2;
+    static_assert(D == 2 || D == 4 || D == 8, "fold 2, 4 or 8");
+    constexpr int ND = 16 / D;  // bins per lane behind the fold
+    const int hop = 1024 - V, per_block = hop / D;
     const long b0 = e0 - V + (long)blk * hop;
 
     if (xh_out && blk == nblocks - 1) {  // mixed-sample history for the next call
@@ -1111,17 +1118,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         for (int k = 0; k < 8; ++k) x[k] = ld_stream(src + 64 * k);
     }
     const int g = l >> 4, q = l & 15;
-    // seeds: pass 1 tw[8 (l mod 8)]; pass 2 tw[l], tw[l + 64]; inverse tw[64 (l mod 4)], tw[16 (l mod 16)], tw[4 l]
+    // seeds: pass 1 tw[8 (l mod 8)]; pass 2 tw[l], tw[l + 64]; inverse (D = 4) tw[64 (l mod 4)], tw[16 (l mod 16)], tw[4 l];
+    // D = 8: tw[128 (l mod 2)], tw[32 (l mod 8)], tw[8 (l mod 32)]; D = 2: tw[16 (l mod 8)], tw[2 l]  (append_wave1024_seeds)
     f2 t_p1, t_p2[2], t_inv[3];
     {
         const float4 *tl = reinterpret_cast<const float4 *>(tw + 1024) + l;
-        const float4 s0 = tl[0], s1 = tl[64], s2 = tl[128];
+        const float4 s0 = tl[0], s1 = tl[64];
         t_p1 = (f2){s0.x, s0.y};
         t_p2[0] = (f2){s0.z, s0.w};
         t_p2[1] = (f2){s1.x, s1.y};
-        t_inv[0] = (f2){s1.z, s1.w};
-        t_inv[1] = (f2){s2.x, s2.y};
-        t_inv[2] = (f2){s2.z, s2.w};
+        if (D == 4) {
+            const float4 s2 = tl[128];
+            t_inv[0] = (f2){s1.z, s1.w};
+            t_inv[1] = (f2){s2.x, s2.y};
+            t_inv[2] = (f2){s2.z, s2.w};
+        } else if (D == 8) {
+            const float4 s3 = tl[192], s4 = tl[256];
+            t_inv[0] = (f2){s3.x, s3.y};
+            t_inv[1] = (f2){s3.z, s3.w};
+            t_inv[2] = (f2){s4.x, s4.y};
+        } else {
+            const float4 s4 = tl[256], s5 = tl[320];
+            t_inv[0] = (f2){s4.z, s4.w};
+            t_inv[1] = (f2){s5.x, s5.y};
+            t_inv[2] = t_inv[1];
+        }
     }
     f2 *const a_rd = lds + (l + 2 * g);  // A(l + 64 m + 256 c) = a_rd + 72 m + 296 c
     f2 *const b_rd = lds + (l + 4 * g);  // B(l + 64 c) = b_rd + 80 c
@@ -1191,7 +1212,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         hv[2 * kp] = float2{h4.x, h4.y};
         hv[2 * kp + 1] = float2{h4.z, h4.w};
     }
-    f2 y[4];
+    f2 y[ND];
     // ---- forward DFT_1024 = radix 8 x 16 x 8 (Stockham) -------------------------------------------
     // pass 0 (Ns = 1): butterflies 2 l + j over x[2 l + j + 128 k']; out 8 (2 l + j) + r = 16 l + 8 j + r
     {
@@ -1253,64 +1274,134 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
         for (int c = 0; c < 8; ++c) X[m + 2 * c] = a[c];
     }
-    // * H and fold the four 256-bin quarters: Y[l + 64 m] = sum_q X[l + 64 (m + 4 q)] H[l + 64 (m + 4 q)]
+    // * H and fold the D parts of 1024 / D bins: Y[l + 64 m] = sum_q X[l + 64 (m + ND q)] H[l + 64 (m + ND q)]
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < ND; ++m) {
         f2 acc = cmul(X[m], (f2){hv[m].x, hv[m].y});
-        acc = cmac(acc, X[m + 4], (f2){hv[m + 4].x, hv[m + 4].y});
-        acc = cmac(acc, X[m + 8], (f2){hv[m + 8].x, hv[m + 8].y});
-        acc = cmac(acc, X[m + 12], (f2){hv[m + 12].x, hv[m + 12].y});
+#pragma unroll
+        for (int q2 = 1; q2 < D; ++q2) acc = cmac(acc, X[m + ND * q2], (f2){hv[m + ND * q2].x, hv[m + ND * q2].y});
         y[m] = acc;
     }
-    // ---- inverse DFT_256, Stockham radix 4 x 4: butterfly l reads in[l + 64 c] ------------------
-    // pass 0 (Ns = 1): no twiddle; out 4 l + c: B = 4 l + 4 (l >> 2) + c
-    idft4(y[0], y[1], y[2], y[3]);
-    wave_sync();  // the forward image has been read
-    {
-        f2 *row = lds + (4 * l + 4 * (l >> 2));
-        *reinterpret_cast<float4 *>(row) = (float4){y[0].x, y[0].y, y[1].x, y[1].y};
-        *reinterpret_cast<float4 *>(row + 2) = (float4){y[2].x, y[2].y, y[3].x, y[3].y};
-    }
-    wave_sync();
-#pragma unroll
-    for (int pass = 1; pass < 4; ++pass) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) y[c] = lds_ld(b_rd + (80 * c));
-        // twiddles e^{+j 2 pi c (l mod ns) / (4 ns)} = conj(tw[(l mod ns) 256 / ns])^c, ns = 4^pass
-        const f2 w1 = t_inv[pass - 1];
-        const f2 w2 = cmul(w1, w1);
-        const f2 w3 = cmul(w2, w1);
-        y[1] = cmul_conj(y[1], w1);
-        y[2] = cmul_conj(y[2], w2);
-        y[3] = cmul_conj(y[3], w3);
-        idft4(y[0], y[1], y[2], y[3]);
-        if (pass == 3) break;  // natural order: y[c] = result[l + 64 c]
-        wave_sync();
-        if (pass == 1) {  // out 16 (l >> 2) + (l & 3) + 4 c: B = 20 (l >> 2) + (l & 3) + 4 c
-            f2 *col = lds + (20 * (l >> 2) + (l & 3));
-#pragma unroll
-            for (int c = 0; c < 4; ++c) lds_st(col + (4 * c), y[c]);
-        } else {  // out 64 g + q + 16 c: B = 80 g + q + 20 c
-            f2 *col = lds + (80 * g + q);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) lds_st(col + (20 * c), y[c]);
-        }
-        wave_sync();
-    }
-    // ---- store the valid part -----------------------------------------------------------------
-    // Buffer stores: the lanes outside the block's valid part (and behind the end of the output)
-    // carry an out-of-range offset and are dropped by the address check - four stores in
-    // straight-line code, with the streaming hint.
-    const int first = V >> 2;
+    const int first = V / D;
     const long mb = (long)blk * per_block;
     const long left = n_out - mb;
     const unsigned recs = (unsigned)(left < per_block ? left : per_block) * 8u;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + mb, 0, recs, 0x00020000);
+    if constexpr (D == 4) {
+        // ---- inverse DFT_256, Stockham radix 4 x 4: butterfly l reads in[l + 64 c] ------------------
+        // pass 0 (Ns = 1): no twiddle; out 4 l + c: B = 4 l + 4 (l >> 2) + c
+        idft4(y[0], y[1], y[2], y[3]);
+        wave_sync();  // the forward image has been read
+        {
+            f2 *row = lds + (4 * l + 4 * (l >> 2));
+            *reinterpret_cast<float4 *>(row) = (float4){y[0].x, y[0].y, y[1].x, y[1].y};
+            *reinterpret_cast<float4 *>(row + 2) = (float4){y[2].x, y[2].y, y[3].x, y[3].y};
+        }
+        wave_sync();
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int tau = l + 64 * c;
-        const unsigned off = tau >= first ? (unsigned)(tau - first) * 8u : 0xffffffffu;
-        __builtin_amdgcn_raw_buffer_store_b64(y[c], rs, off, 0, 2);
+        for (int pass = 1; pass < 4; ++pass) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) y[c] = lds_ld(b_rd + (80 * c));
+            // twiddles e^{+j 2 pi c (l mod ns) / (4 ns)} = conj(tw[(l mod ns) 256 / ns])^c, ns = 4^pass
+            const f2 w1 = t_inv[pass - 1];
+            const f2 w2 = cmul(w1, w1);
+            const f2 w3 = cmul(w2, w1);
+            y[1] = cmul_conj(y[1], w1);
+            y[2] = cmul_conj(y[2], w2);
+            y[3] = cmul_conj(y[3], w3);
+            idft4(y[0], y[1], y[2], y[3]);
+            if (pass == 3) break;  // natural order: y[c] = result[l + 64 c]
+            wave_sync();
+            if (pass == 1) {  // out 16 (l >> 2) + (l & 3) + 4 c: B = 20 (l >> 2) + (l & 3) + 4 c
+                f2 *col = lds + (20 * (l >> 2) + (l & 3));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) lds_st(col + (4 * c), y[c]);
+            } else {  // out 64 g + q + 16 c: B = 80 g + q + 20 c
+                f2 *col = lds + (80 * g + q);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) lds_st(col + (20 * c), y[c]);
+            }
+            wave_sync();
+        }
+        // ---- store the valid part -----------------------------------------------------------------
+        // Buffer stores: the lanes outside the block's valid part (and behind the end of the output)
+        // carry an out-of-range offset and are dropped by the address check - four stores in
+        // straight-line code, with the streaming hint.
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int tau = l + 64 * c;
+            const unsigned off = tau >= first ? (unsigned)(tau - first) * 8u : 0xffffffffu;
+            __builtin_amdgcn_raw_buffer_store_b64(y[c], rs, off, 0, 2);
+        }
+    } else if constexpr (D == 2) {
+        // ---- inverse DFT_512 as the forward radix 8 x 8 x 8 (k_fft512's passes) with the result index reversed ----
+        dft8(y);  // pass 0 (Ns = 1): butterfly l over Y[l + 64 c]; out 8 l + c
+        wave_sync();  // the forward image has been read
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lds_st(lds + pad8(8 * l) + k, y[k]);
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y[k] = lds_ld(lds + (l + (l >> 3)) + 72 * k);  // pad8(l + 64 k)
+        twiddle8(y, t_inv[0]);  // pass 1 (Ns = 8): e^{-j 2 pi (l mod 8) k / 64}; out (l / 8) 64 + l % 8 + 8 k
+        dft8(y);
+        wave_sync();
+        {
+            f2 *col = lds + (72 * (l >> 3) + (l & 7));  // pad8(64 h + p + 8 k) = 72 h + p + 9 k
+#pragma unroll
+            for (int k = 0; k < 8; ++k) lds_st(col + 9 * k, y[k]);
+        }
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y[k] = lds_ld(lds + (l + (l >> 3)) + 72 * k);
+        twiddle8(y, t_inv[1]);  // pass 2 (Ns = 64): e^{-j 2 pi l k / 512}; out l + 64 k
+        dft8(y);
+        // y[k] = DFT(Y)[l + 64 k] = result[(512 - l - 64 k) mod 512]
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int tau = (512 - l - 64 * k) & 511;
+            const unsigned off = tau >= first ? (unsigned)(tau - first) * 8u : 0xffffffffu;
+            __builtin_amdgcn_raw_buffer_store_b64(y[k], rs, off, 0, 2);
+        }
+    } else {
+        // ---- inverse DFT_128, Stockham radix 2 x 4 x 4 x 4; the radix-4 passes on lanes 0 .. 31 ------------------
+        // pass 0 (radix 2, Ns = 1): butterfly l over Y[l], Y[l + 64]; out 2 l + c
+        {
+            const f2 s0 = y[0] + y[1], s1 = y[0] - y[1];
+            wave_sync();  // the forward image has been read
+            *reinterpret_cast<float4 *>(lds + 2 * l) = (float4){s0.x, s0.y, s1.x, s1.y};
+        }
+        wave_sync();
+        const int j = l & 31;
+        f2 z[4];
+#pragma unroll
+        for (int pass = 1; pass < 4; ++pass) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) z[c] = lds_ld(lds + j + 32 * c);
+            // twiddles e^{+j 2 pi c (j mod ns) / (4 ns)}, ns = 2, 8, 32
+            const f2 w1 = t_inv[pass - 1];
+            const f2 w2 = cmul(w1, w1);
+            const f2 w3 = cmul(w2, w1);
+            z[1] = cmul_conj(z[1], w1);
+            z[2] = cmul_conj(z[2], w2);
+            z[3] = cmul_conj(z[3], w3);
+            idft4(z[0], z[1], z[2], z[3]);
+            if (pass == 3) break;  // natural order: z[c] = result[j + 32 c]
+            wave_sync();
+            if (l < 32) {
+                // pass 1: out 8 (j >> 1) + (j & 1) + 2 c;  pass 2: out 32 (j >> 3) + (j & 7) + 8 c
+                f2 *col = pass == 1 ? lds + (8 * (j >> 1) + (j & 1)) : lds + (32 * (j >> 3) + (j & 7));
+                const int st = pass == 1 ? 2 : 8;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) lds_st(col + st * c, z[c]);
+            }
+            wave_sync();
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int tau = j + 32 * c;
+            const unsigned off = (l < 32 && tau >= first) ? (unsigned)(tau - first) * 8u : 0xffffffffu;
+            __builtin_amdgcn_raw_buffer_store_b64(z[c], rs, off, 0, 2);
+        }
     }
 }
 
@@ -1761,11 +1852,11 @@ int ols_wave_overlap(size_t Lc) {  // V: multiple of 64 covering the Lc - 1 wrap
     return v == 0 ? 64 : (int)v;
 }
 
-bool ols_wave_supported(uint64_t D, size_t Lc) { return D == 4 && Lc >= 1 && Lc - 1 <= 512; }
+bool ols_wave_supported(uint64_t D, size_t Lc) { return (D == 2 || D == 4 || D == 8) && Lc >= 1 && Lc - 1 <= 512; }
 
-int launch_ols_wave(hipStream_t s, const FusedFirArgs &a) {
-    if (a.n_out == 0) return RR_OK;
-    const int per_block = (1024 - a.V) / 4;
+template <int D>
+static int launch_ols_wave_d(hipStream_t s, const FusedFirArgs &a) {
+    const int per_block = (1024 - a.V) / D;
     const size_t nblocks = (a.n_out + per_block - 1) / per_block;
     if (nblocks > 0x7ffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS: too many blocks");
     const int64_t den = (int64_t)a.denom;
@@ -1774,18 +1865,28 @@ int launch_ols_wave(hipStream_t s, const FusedFirArgs &a) {
     const unsigned hopm = (unsigned)((int64_t)(1024 - a.V) % den), kstep = (unsigned)(128 % den);
     const unsigned grid = (unsigned)((nblocks + 8 * kWaveWin - 1) / (8 * kWaveWin) * (8 * kWaveWin));
     if (a.ev_start && a.ev_stop)
-        hipExtLaunchKernelGGL(k_ols_wave, dim3(grid), dim3(64), 0, s, a.ev_start, a.ev_stop, 0, (const float2 *)a.xh, (int)a.hx,
+        hipExtLaunchKernelGGL(k_ols_wave<D>, dim3(grid), dim3(64), 0, s, a.ev_start, a.ev_stop, 0, (const float2 *)a.xh, (int)a.hx,
                               (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0,
                               (const float2 *)a.H, (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out,
                               (long)a.e0, (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, kstep,
                               1.0 / (double)den);
     else
-        hipLaunchKernelGGL(k_ols_wave, dim3(grid), dim3(64), 0, s, (const float2 *)a.xh, (int)a.hx,
+        hipLaunchKernelGGL(k_ols_wave<D>, dim3(grid), dim3(64), 0, s, (const float2 *)a.xh, (int)a.hx,
                            (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0,
                            (const float2 *)a.H, (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out, (long)a.e0,
                            (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, kstep, 1.0 / (double)den);
     RR_HIP(hipGetLastError());
     return RR_OK;
+}
+
+int launch_ols_wave(hipStream_t s, const FusedFirArgs &a) {
+    if (a.n_out == 0) return RR_OK;
+    switch (a.D) {
+    case 2: return launch_ols_wave_d<2>(s, a);
+    case 4: return launch_ols_wave_d<4>(s, a);
+    case 8: return launch_ols_wave_d<8>(s, a);
+    }
+    RR_FAIL(RR_ERR_BAD_ARG, "fused OLS: decimation %u not instantiated", a.D);
 }
 
 // ---------------------------------------------------------------------------
@@ -2076,15 +2177,22 @@ void append_wave1024_seeds(std::vector<float> &twb) {
         dst[0] = twb[2 * i];
         dst[1] = twb[2 * i + 1];
     };
-    twb.resize(2 * (N + 2 * 3 * 64));
+    twb.resize(2 * (N + 2 * 6 * 64));
     for (size_t l = 0; l < 64; ++l) {
-        float *e0 = &twb[2 * N + 4 * l], *e1 = e0 + 4 * 64, *e2 = e1 + 4 * 64;
+        float *e0 = &twb[2 * N + 4 * l], *e1 = e0 + 4 * 64, *e2 = e1 + 4 * 64, *e3 = e2 + 4 * 64, *e4 = e3 + 4 * 64,
+              *e5 = e4 + 4 * 64;
         twv(8 * (l & 7), e0);         // pass 1
         twv(l, e0 + 2);               // pass 2, m = 0
         twv(l + 64, e1);              // pass 2, m = 1
         twv(64 * (l & 3), e1 + 2);    // inverse pass 1
         twv(16 * (l & 15), e2);       // inverse pass 2
         twv(4 * l, e2 + 2);           // inverse pass 3
+        twv(128 * (l & 1), e3);       // k_ols_wave<8>: inverse DFT_128, passes 1 .. 3
+        twv(32 * (l & 7), e3 + 2);
+        twv(8 * (l & 31), e4);
+        twv(16 * (l & 7), e4 + 2);    // k_ols_wave<2>: DFT_512, passes 1 and 2
+        twv(2 * l, e5);
+        e5[2] = e5[3] = 0.f;
     }
 }
 

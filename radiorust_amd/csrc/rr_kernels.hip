@@ -264,9 +264,10 @@ static int launch_fir_t(hipStream_t s, const FirArgs &a) {
     const uint64_t step = LIST ? a.max_step : a.D;
     uint64_t opb, Kc = a.K;
     if ((uint64_t)a.K + 63 * step + 1 > budget) {
-        // the response alone does not fit the tile: 64 .. 1024 outputs per workgroup, the taps in passes
+        // the response alone does not fit the tile: up to 256 outputs per workgroup (fewer when the outputs lie
+        // far apart: 512 : 1 leaves 8), the taps in passes
         opb = 256;
-        while (opb > 64 && (opb - 1) * step + 64 > budget / 2) opb /= 2;
+        while (opb > 1 && (opb - 1) * step + 64 > budget / 2) opb /= 2;
         if ((opb - 1) * step + 64 > budget)
             RR_FAIL(RR_ERR_BAD_ARG, "fir: an output step of %llu samples exceeds the LDS tile (%zu samples)",
                     (unsigned long long)step, budget);

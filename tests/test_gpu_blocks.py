@@ -407,9 +407,12 @@ def test_downsampler_parity(rr, oracle, fin, fout, bw, q):
 FAST_CASES = [
     (200e6, 50e6, 40e6, 3.0, 3),      # cfg2's Downsampler: L = 120, D = 4 -> k_ols_wave
     (200e6, 50e6, 47e6, 3.0, 2),      # L = 400: beyond k_ols_wave's overlap -> k_ols_decim4
-    (200e6, 50e6, 30e6, 3.0, 1),      # L = 60: short -> k_mix_fir_decim
-    (384000.0, 48000.0, 40000.0, 3.0, 1),   # the reference's simple_receiver second stage: D = 8, L = 288
-    (96000.0, 48000.0, 30000.0, 3.0, 1),    # D = 2
+    (200e6, 50e6, 30e6, 3.0, 3),      # L = 60: short responses too (k_mix_fir_decim only on request since round 2)
+    (384000.0, 48000.0, 40000.0, 3.0, 3),   # the reference's simple_receiver second stage: D = 8, L = 288 -> k_ols_wave<8>
+    (384000.0, 48000.0, 43000.0, 3.0, 3),   # D = 8, L = 461: overlap 512 of 1024
+    (96000.0, 48000.0, 30000.0, 3.0, 3),    # D = 2, L = 32
+    (96000.0, 48000.0, 44000.0, 3.0, 3),    # D = 2, L = 144 -> k_ols_wave<2>
+    (96000.0, 48000.0, 46500.0, 3.0, 3),    # D = 2, L = 384
     # every other integer ratio and rational ratios with a short period: k_decim_poly (5), rr_decim.hip
     (1024000.0, 102400.0, 60000.0, 3.0, 5),   # examples/bandwidth_meter/main.rs:56: 10 : 1, L = 145
     (1024000.0, 384000.0, 200000.0, 3.0, 5),  # examples/simple_receiver.rs:28: 8 : 3, L = 34
@@ -418,6 +421,7 @@ FAST_CASES = [
     (700000.0, 300000.0, 100000.0, 3.5, 5),   # 7 : 3
     (2560000.0, 40000.0, 30000.0, 1.5, 5),    # 64 : 1, L = 768: tiles of 64 periods
     (45000.0, 40000.0, 30000.0, 1.0, 5),      # 9 : 8, the longest period served
+    (512000.0, 1000.0, 700.0, 2.0, 0),        # 512 : 1, L = 6827: beyond k_decim_poly's LDS -> k_fir, 8 outputs per workgroup, the taps in passes
     (48000.0, 44100.0, 30000.0, 2.0, 0),      # 160 : 147: period too long -> k_fir with the emission list
 ]
 
@@ -454,6 +458,22 @@ def test_downsampler_fast_path_can_be_switched_off(rr, oracle, monkeypatch):
     y = g.process_raw(200e6, x)
     assert g.last_kernel() == 0
     check(y, oracle.Downsampler(1000, 50e6, 40e6, flt=np.float64).process(200e6, x))
+
+
+@pytest.mark.parametrize("fin,fout,bw", [(200e6, 50e6, 30e6), (96000.0, 48000.0, 30000.0), (384000.0, 48000.0, 30000.0)])
+def test_downsampler_direct_form_on_request(rr, oracle, monkeypatch, fin, fout, bw):
+    """k_mix_fir_decim (the direct form, D = 2 / 4 / 8) is no default any more; RR_FUSED_KERNEL=direct keeps it reachable."""
+    monkeypatch.setenv("RR_FUSED_KERNEL", "direct")
+    g = rr.Downsampler.new(1000, fout, bw)
+    x = oracle.synth_iq(13, 0, 70000)
+    r = oracle.Downsampler(1000, fout, bw, flt=np.float64)
+    for a, b in ((0, 30000), (30000, 30007), (30007, 70000)):
+        y = g.process_raw(fin, x[a:b])
+        assert g.last_kernel() == (1 if b - a >= 4096 else 0)
+        want = r.process(fin, x[a:b])
+        assert len(y) == len(want)
+        if len(y) > 8:
+            check(y, want)
 
 
 def test_downsampler_output_chunks_and_events(rr, oracle):

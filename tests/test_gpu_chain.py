@@ -164,6 +164,9 @@ def test_chain_other_parameters(rr, oracle, allow_fused):
         (1024000.0, dict(shift=200e3, filter_len=128, freq_resp=lowpass(30e3), output_rate=102400.0, bandwidth=60e3, fft_len=1024), 4.0),
         (48000.0, dict(shift=700.0, filter_len=64, freq_resp=lowpass(8e3), output_rate=19200.0, bandwidth=12e3, fft_len=256), 2.0),
         (200e6, dict(shift=12.345e6, precision=1e3, filter_len=64, freq_resp=lowpass(20e6), output_rate=50e6, bandwidth=40e6, fft_len=512), 2.0),
+        # 8 : 1 (L = 288) and 2 : 1 (L = 144): k_ols_wave<8> / k_ols_wave<2> on the fused path
+        (384000.0, dict(shift=48e3, filter_len=64, freq_resp=lowpass(20e3), output_rate=48000.0, bandwidth=40000.0, fft_len=1024), 2.0),
+        (96000.0, dict(shift=12e3, filter_len=64, freq_resp=lowpass(20e3), output_rate=48000.0, bandwidth=44000.0, fft_len=2048), 2.0),
     ]
     for fs, params, nb in cases:
         n = 150000
