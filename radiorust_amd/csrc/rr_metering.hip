@@ -326,9 +326,115 @@ __global__ __launch_bounds__(256) void k_fmdemod(const CT *__restrict__ in, long
     }
 }
 
+// Complex<f32>, long calls: arg() as a polynomial instead of libm's atan2f (which made the kernel VALU-bound:
+// 0.221 ms per 2^26 samples).  a = min(|re|, |im|) / max(|re|, |im|) (v_rcp_f32 + one Newton step), atan(a) =
+// a P(a^2) with P of degree 8 (Chebyshev interpolation on [0, 1]: 1.0e-7 rad worst case in f32 arithmetic), then the
+// octant by subtractions from pi/2 and pi and the sign of im: within 4e-7 rad of the correctly rounded result
+// (the reference's Complex::arg is libm's atan2f, modulation.rs:117).  +-0 follow atan2's sign rules; infinities
+// do not (NaN).  A lane takes two neighbouring samples per trip (16-byte accesses), four trips in flight, the
+// workgroups of an XCD on a contiguous eighth of every grid stride (as k_freqshift).
+__device__ __forceinline__ float arg_poly(float im, float re) {
+    const float ax = __builtin_fabsf(re), ay = __builtin_fabsf(im);
+    const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
+    const float rc = __builtin_amdgcn_rcpf(mx);
+    float a = mn * rc;
+    a = __builtin_fmaf(__builtin_fmaf(-a, mx, mn), rc, a);
+    a = mx == 0.f ? 0.f : a;
+    const float q = a * a;
+    float p = 0x1.6a9512p-9f;
+    p = __builtin_fmaf(p, q, -0x1.01bda4p-6f);
+    p = __builtin_fmaf(p, q, 0x1.5931p-5f);
+    p = __builtin_fmaf(p, q, -0x1.316ecap-4f);
+    p = __builtin_fmaf(p, q, 0x1.b2edbp-4f);
+    p = __builtin_fmaf(p, q, -0x1.22c55ap-3f);
+    p = __builtin_fmaf(p, q, 0x1.996efcp-3f);
+    p = __builtin_fmaf(p, q, -0x1.55548ep-2f);
+    p = __builtin_fmaf(p, q, 1.0f);
+    float r = p * a;
+    r = ay > ax ? 0x1.921fb6p+0f - r : r;
+    r = __builtin_signbit(re) ? 0x1.921fb6p+1f - r : r;
+    return __builtin_copysignf(r, im);
+}
+
+__device__ __forceinline__ float fm_one(float2 cur, float2 pv, float factor) {
+    // sample * previous.conj() as num-complex multiplies (the products and sums rounded one by one, as above)
+    const float cr = pv.x, ci = -pv.y;
+    const float re = sub_rn(mul_rn(cur.x, cr), mul_rn(cur.y, ci));
+    const float im = add_rn(mul_rn(cur.x, ci), mul_rn(cur.y, cr));
+    return mul_rn(arg_poly(im, re), factor);
+}
+
+__global__ __launch_bounds__(256) void k_fmdemod_pairs(const float2 *__restrict__ in, long n, float2 *__restrict__ out,
+                                                       const float2 *__restrict__ st_in, float2 *__restrict__ st_out,
+                                                       int have_prev, float factor) {
+    typedef float f4s __attribute__((ext_vector_type(4)));
+    const long npair = n >> 1;  // whole pairs; an odd last sample is the last pair's owner's
+    const long stride = (long)gridDim.x * 256;
+    const long lb = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // grid: a multiple of 8
+    long i = lb * 256 + threadIdx.x;
+    auto finish = [&](long ip, f4s v, float2 pv) {
+        float2 o0, o1;
+        o0.y = 0.f;
+        o1.y = 0.f;
+        if (ip == 0 && !have_prev)
+            o0 = st_in[1];  // output_sample keeps its value (zero before the first pair)
+        else
+            o0.x = fm_one(float2{v.x, v.y}, pv, factor);
+        o1.x = fm_one(float2{v.z, v.w}, float2{v.x, v.y}, factor);
+        __builtin_nontemporal_store((f4s){o0.x, o0.y, o1.x, o1.y}, reinterpret_cast<f4s *>(out + 2 * ip));
+        if (2 * ip + 2 == n) {
+            st_out[0] = float2{v.z, v.w};
+            st_out[1] = o1;
+        } else if (2 * ip + 3 == n) {  // the odd last sample
+            const float2 cur = in[n - 1];
+            float2 o;
+            o.x = fm_one(cur, float2{v.z, v.w}, factor);
+            o.y = 0.f;
+            out[n - 1] = o;
+            st_out[0] = cur;
+            st_out[1] = o;
+        }
+    };
+    for (; i + 3 * stride < npair; i += 4 * stride) {
+        f4s v[4];
+        float2 pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f4s *>(in + 2 * (i + u * stride)));
+        // the sample in front of a lane's pair is its left neighbour's second one (a wave-wide shift by one lane);
+        // lane 0 reads it from memory
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long ip = i + u * stride;
+            pv[u].x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[u].z), 0x138, 0xf, 0xf, false));
+            pv[u].y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[u].w), 0x138, 0xf, 0xf, false));
+            if ((threadIdx.x & 63) == 0) pv[u] = ip ? in[2 * ip - 1] : st_in[0];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) finish(i + u * stride, v[u], pv[u]);
+    }
+    for (; i < npair; i += stride) {
+        const f4s v = *reinterpret_cast<const f4s *>(in + 2 * i);
+        finish(i, v, i ? in[2 * i - 1] : st_in[0]);
+    }
+}
+
 int launch_fmdemod(int dtype, hipStream_t s, const void *in, size_t n, void *out, const void *st_in, void *st_out,
                    int have_prev, double factor) {
     if (n == 0) return RR_OK;
+    static const bool generic = [] {
+        const char *e = std::getenv("RR_FMDEMOD_GENERIC");
+        return e && std::atoi(e) != 0;
+    }();
+    if (dtype == RR_F32 && n >= 4096 && !generic && reinterpret_cast<uintptr_t>(in) % 16 == 0 &&
+        reinterpret_cast<uintptr_t>(out) % 16 == 0) {
+        size_t blocks = (n / 2 + 255) / 256;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        blocks = (blocks + 7) / 8 * 8;
+        hipLaunchKernelGGL(k_fmdemod_pairs, dim3((unsigned)blocks), dim3(256), 0, s, (const float2 *)in, (long)n, (float2 *)out,
+                           (const float2 *)st_in, (float2 *)st_out, have_prev, (float)factor);
+        RR_HIP(hipGetLastError());
+        return RR_OK;
+    }
     const unsigned blocks = (unsigned)((n + 255) / 256);
     if (dtype == RR_F32)
         hipLaunchKernelGGL((k_fmdemod<float, float2>), dim3(blocks), dim3(256), 0, s, (const float2 *)in, (long)n,

@@ -101,6 +101,29 @@ def test_fmdemod_parity(rr, oracle, flt, tol_ulp):
     assert np.max(np.abs(y.real[-1000:] - msg[-1000:])) < 0.05  # and it demodulates
 
 
+def test_fmdemod_long_call_octants_and_zeros(rr, oracle):
+    """The long-call kernel computes arg() by a polynomial (k_fmdemod_pairs): every octant, the axes, zero samples
+    (atan2's signed-zero rules) and magnitudes from 1e-12 to 1e12, against the oracle's libm atan2f."""
+    rng = np.random.default_rng(5)
+    n = 3 * 4096 + 1
+    ang = rng.uniform(-np.pi, np.pi, n)
+    mag = 10.0 ** rng.uniform(-12, 12, n)
+    x = (mag * np.exp(1j * ang)).astype(np.complex64)
+    x[100:140] = (1, 1j, -1, -1j, 1 + 1j, -1 + 1j, -1 - 1j, 1 - 1j) * 5   # products on the axes and diagonals
+    x[200:204] = 0                                                       # 0 * conj(..) = +-0 +- 0j
+    x[300] = complex(-0.0, 0.0)
+    fs, dev = 48000.0, 2500.0
+    g, o = rr.FmDemod(dev), oracle.FmDemod(dev, flt=np.float32)
+    y, r = g.process_raw(fs, x), o.process(fs, x)
+    atol = 4 * np.finfo(np.float32).eps * np.pi * fs / dev / (2 * np.pi)
+    assert y.shape == r.shape and not np.any(y.imag)
+    assert np.max(np.abs(y.real - r.real)) <= atol
+    # ... and the short-call kernel (libm's atan2f on the device) agrees on the same stream
+    g2 = rr.FmDemod(dev)
+    y2 = np.concatenate([g2.process_raw(fs, x[a:a + 1000]) for a in range(0, n, 1000)])
+    assert np.max(np.abs(y2.real - y.real)) <= atol
+
+
 def test_fmdemod_interrupt_deviation_events(rr, oracle):
     fs = 48000.0
     x = oracle.synth_iq(15, 0, 96)
