@@ -866,6 +866,112 @@ __device__ __forceinline__ void fft4096_regs(f2 (&v)[16], f2 *lds, const float2 
 }
 
 // ---------------------------------------------------------------------------
+// Kernel 2r  k_stft4096<SH>: overlapping 4096-point frames at a hop of 256 SH samples (the Overlapper in front of
+// the Fourier block, chunks.rs:179-271, with P = 16 / SH chunks per span), a workgroup per RUN of neighbouring frames.
+// Lane j holds x[j + 256 k]: the next frame's samples are the current ones moved down SH registers plus SH new
+// loads, which are requested before the current frame's transform starts.  k_fft4096 at hop < 4096 reads every
+// sample 16 / SH times (from L2) and pays a full load latency per frame: it makes 16384 frames in 0.165 ms whatever
+// the hop, i.e. 51 % of the 8 + 32 B per input sample of the 1024 x 4 case.
+// ---------------------------------------------------------------------------
+constexpr unsigned kStftWin = 4;  // neighbouring runs per XCD (they share 4096 - hop samples)
+template <int SH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_stft4096(const float2 *__restrict__ head, long n_head,
+                                                  const float2 *__restrict__ in, float2 *__restrict__ out,
+                                                  const float *__restrict__ window, const float2 *__restrict__ tw,
+                                                  int center_dc, unsigned count, unsigned R, unsigned nruns) {
+    __shared__ f2 lds[4096 + 256];
+    const int j = threadIdx.x;
+    constexpr unsigned G = kStftWin;
+    const unsigned grp = blockIdx.x / (8 * G), rem = blockIdx.x % (8 * G);
+    const unsigned run = grp * 8 * G + (rem & 7) * G + (rem >> 3);
+    if (run >= nruns) return;
+    const unsigned f0 = run * R;
+    const unsigned nf = count - f0 < R ? count - f0 : R;
+    constexpr long hop = 256L * SH;
+    const long base0 = (long)f0 * hop - n_head;  // index into `in` of the run's first sample
+    auto ld = [&](long i) -> f2 {
+        const float2 *p = i >= 0 ? in + i : head + (n_head + i);
+        return *reinterpret_cast<const f2 *>(p);
+    };
+    float wv[16];
+    {
+        const float4 *wp = reinterpret_cast<const float4 *>(window + 4096) + 4 * j;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 w4 = wp[q];
+            wv[4 * q] = w4.x;
+            wv[4 * q + 1] = w4.y;
+            wv[4 * q + 2] = w4.z;
+            wv[4 * q + 3] = w4.w;
+        }
+    }
+    f2 xr[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) xr[k] = ld(base0 + j + 256 * k);
+    const int rot = center_dc ? 2048 : 0;
+#pragma unroll 1
+    for (unsigned i = 0; i < nf; ++i) {
+        f2 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = xr[k] * wv[k];
+        // the window moves on, and the next frame's new samples are requested before this frame's transform starts
+        // (the last frame of the run asks for its own last ones again: always valid)
+#pragma unroll
+        for (int k = 0; k + SH < 16; ++k) xr[k] = xr[k + SH];
+        const long nb = base0 + (long)(i + 1 < nf ? i + 1 : i) * hop;
+#pragma unroll
+        for (int q = 0; q < SH; ++q) xr[16 - SH + q] = ld(nb + j + 256 * (16 - SH + q));
+        if (i) __syncthreads();  // the previous frame's last pass has been read
+        fft4096_regs(v, lds, tw, j);
+        float2 *dst = out + (size_t)(f0 + i) * 4096;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) __builtin_nontemporal_store(v[k], reinterpret_cast<f2 *>(dst) + ((j + 256 * k + rot) & 4095));
+    }
+}
+
+// frames per run: as few rounds of the grid as possible at 3 workgroups per CU, and long runs within that
+static unsigned stft_run_length(size_t count) {
+    const size_t slots = 256 * 3;
+    size_t best = 1, best_cost = ~size_t(0);
+    for (size_t r = 1; r <= 16; ++r) {
+        const size_t runs = (count + r - 1) / r, rounds = (runs + slots - 1) / slots;
+        const size_t cost = rounds * (r + 2);  // a run costs its frames plus ~2 frames' worth of start-up
+        if (cost < best_cost || (cost == best_cost && r > best)) {
+            best = r;
+            best_cost = cost;
+        }
+    }
+    return (unsigned)best;
+}
+
+bool stft4096_supported(size_t hop) { return hop == 256 || hop == 512 || hop == 1024 || hop == 2048; }
+
+int launch_stft4096(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
+                    const void *window, const void *tw4096, bool center_dc, size_t hop) {
+    if (count == 0) return RR_OK;
+    if (count > 0x7fffff00ull) RR_FAIL(RR_ERR_BAD_ARG, "stft4096: too many frames");
+    const unsigned R = stft_run_length(count);
+    const unsigned nruns = (unsigned)((count + R - 1) / R);
+    const unsigned grid = (nruns + 8 * kStftWin - 1) / (8 * kStftWin) * (8 * kStftWin);
+#define RR_STFT_CASE(SH)                                                                                                   \
+    case 256 * SH:                                                                                                         \
+        hipLaunchKernelGGL(k_stft4096<SH>, dim3(grid), dim3(256), 0, s, (const float2 *)head, (long)n_head,               \
+                           (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw4096, (int)center_dc, \
+                           (unsigned)count, R, nruns);                                                                     \
+        break;
+    switch (hop) {
+        RR_STFT_CASE(1)
+        RR_STFT_CASE(2)
+        RR_STFT_CASE(4)
+        RR_STFT_CASE(8)
+    default: RR_FAIL(RR_ERR_BAD_ARG, "stft4096: hop %zu not instantiated", hop);
+    }
+#undef RR_STFT_CASE
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
 // Kernel 3  k_ols_decim4: the same mix + combined FIR + 4x decimation as
 // k_mix_fir_decim, computed by overlap-save fast convolution:
 //   block of 4096 mixed samples -> forward DFT (radix 16 x 3, as k_fft4096)

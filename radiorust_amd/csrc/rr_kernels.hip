@@ -772,9 +772,11 @@ int launch_fourier_overlapped(int dtype, hipStream_t s, const void *head, size_t
                               size_t n, size_t hop, size_t count, const void *window, const void *twiddle, bool center_dc) {
     if (count == 0) return RR_OK;
     RR_TRY(fourier_supported(dtype, n));
+    static const bool generic = [] { const char *e = std::getenv("RR_FOURIER_GENERIC"); return e && std::atoi(e) != 0; }();
+    if (dtype == RR_F32 && n == 4096 && stft4096_supported(hop) && count >= 64 && !generic)
+        return launch_stft4096(s, head, n_head, in, out, count, window, twiddle, center_dc, hop);
     if (dtype == RR_F32 && n == 4096)
         return launch_fft4096(s, head, n_head, in, out, count, window, twiddle, center_dc, hop);
-    static const bool generic = [] { const char *e = std::getenv("RR_FOURIER_GENERIC"); return e && std::atoi(e) != 0; }();
     if (dtype == RR_F32 && (n == 64 || n == 128) && hop == n && n_head == 0 && !generic)
         return launch_fft_small(s, in, out, n, count, window, twiddle, center_dc);
     if (dtype == RR_F32 && n == 8192 && !generic)

@@ -159,6 +159,10 @@ int launch_fft2048(hipStream_t s, const void *head, size_t n_head, const void *i
 int launch_fft1024(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
                    const void *window, const void *tw1024, bool center_dc, size_t hop);
 void append_wave1024_seeds(std::vector<float> &twb);
+// k_stft4096: runs of overlapping 4096-point frames (hop 256, 512, 1024 or 2048), the sliding window in registers
+bool stft4096_supported(size_t hop);
+int launch_stft4096(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
+                    const void *window, const void *tw4096, bool center_dc, size_t hop);
 int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
                    const void *window, const void *tw4096, bool center_dc, size_t hop = 4096,
                    hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);

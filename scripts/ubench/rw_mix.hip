@@ -75,6 +75,9 @@ int main() {
         run<4, 1, true>("4:1 read:write, nontemporal", blocks, rb);
         run<4, 4, true>("1:1 (copy), nontemporal", blocks, rb);
         run<8, 2, true>("4:1, 8 rows in flight, nt", blocks, rb);
+        run<1, 4, true>("1:4 read:write (Stft), nt", blocks, rb / 4);
+        run<1, 4, false>("1:4 read:write (Stft)", blocks, rb / 4);
+        run<1, 8, true>("1:8 read:write, nt", blocks, rb / 8);
     }
     return 0;
 }

@@ -172,6 +172,27 @@ def test_stft_parity(rr, oracle, M, P, center, dtype, tol):
         assert len(a.chunk) == M * P and rms_rel(a.chunk, b) <= tol
 
 
+@pytest.mark.parametrize("P,center", [(2, False), (4, True), (8, False), (16, True)])
+def test_stft_4096_point_spans_in_long_calls(rr, oracle, P, center):
+    """4096-point spans with 64 and more frames per call run k_stft4096 (a workgroup per run of frames, the
+    sliding window in registers); shorter calls k_fft4096 with a hop.  Both against the oracle composition,
+    with the history handed from call to call."""
+    M = 4096 // P
+    nchunks = 300 + P
+    x = oracle.synth_iq(26, 0, M * nchunks)
+    chunks = [x[i * M : (i + 1) * M] for i in range(nchunks)]
+    win = oracle.Kaiser.with_null_at_bin(2.0)
+    ref, _ = overlapped_spectra(oracle, chunks, P, win, center, np.float64)
+    g = rr.Stft(M, P, rr.Kaiser.with_null_at_bin(2.0), center_dc=center)
+    got = []
+    cuts = [0, 3, 100, 101, 180, 290, nchunks]   # calls of 3, 97, 1, 79, 110, 10 + P chunks
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        got += g.process(rr.Samples(1e6, x[a * M : b * M]))
+    assert len(got) == len(ref) == nchunks - (P - 1)
+    for a, b in zip(got, ref):
+        assert rms_rel(a.chunk, b) <= 1e-5
+
+
 def test_stft_event_resets_history(rr, oracle):
     M, P = 256, 4
     x = oracle.synth_iq(23, 0, M * 12)
