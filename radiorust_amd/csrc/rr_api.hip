@@ -812,10 +812,16 @@ int rr_fourier::prepare(size_t len) {
     window_f64.swap(vals);
     n = len;
     bs_M = 0;
+    bs_fused = false;
     big = use_big;
     if (use_bs) {
         size_t M = 64;
         while (M < 2 * len - 1) M *= 2;
+        // 513 .. 2048 points in f32: the whole algorithm in one kernel around two 4096-point transforms in LDS
+        // (RR_FOURIER_GENERIC=1 keeps the five launches)
+        static const bool generic = [] { const char *e = std::getenv("RR_FOURIER_GENERIC"); return e && std::atoi(e) != 0; }();
+        bs_fused = !generic && bluestein4096_supported(dtype, len);
+        if (bs_fused) M = 4096;
         // chirp w_m = e^{+j pi m^2 / n}, the phase reduced exactly (m^2 mod 2n) before it is evaluated
         std::vector<cd> w(len);
         for (size_t m = 0; m < len; ++m) {
@@ -880,6 +886,8 @@ int rr_fourier::transform_dev(const void *head, size_t n_head, const void *in, v
         return RR_OK;
     }
     if (!bs_M) return launch_fourier_overlapped(dtype, stream, head, n_head, in, out, n, hop, count, d_window.p, d_tw.p, center_dc);
+    if (bs_fused)
+        return launch_bluestein4096(stream, head, n_head, in, hop, n, d_bs_c.p, d_bs_B.p, d_bs_w.p, bs_fft->d_tw.p, out, center_dc, count);
     const size_t M = bs_M;
     // passes of at most 2^22 workspace elements per buffer (32 MiB each in f32)
     size_t per_pass = ((size_t)1 << 22) / M;

@@ -866,6 +866,86 @@ __device__ __forceinline__ void fft4096_regs(f2 (&v)[16], f2 *lds, const float2 
 }
 
 // ---------------------------------------------------------------------------
+// Kernel 2b  k_bluestein4096: the Fourier block for chunk lengths 513 .. 2048 that are not powers of two
+// (analysis.rs:82-115 accepts any length), Bluestein's algorithm in ONE kernel, a workgroup per chunk:
+//   v = x c (c = window conj(chirp), zero beyond n)  ->  DFT_4096  ->  * B (B = DFT_4096(chirp, wrapped) / 4096)
+//   ->  the inverse as a second forward DFT_4096 read at the reversed index  ->  * conj(chirp)  ->  n bins.
+// The five-launch form (k_bs_pre, k_fftM, k_bs_mul, k_fftM, k_bs_post through HBM) moves ~10 M 8 bytes per chunk
+// for 16 n algorithmic ones; here a chunk is read once and written once.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bluestein4096(const float2 *__restrict__ head, long n_head,
+                                                       const float2 *__restrict__ in, long hop, int n,
+                                                       const float2 *__restrict__ c, const float2 *__restrict__ B,
+                                                       const float2 *__restrict__ w, const float2 *__restrict__ tw,
+                                                       float2 *__restrict__ out, int center_dc, unsigned count) {
+    __shared__ f2 lds[4096 + 256];
+    const int j = threadIdx.x;
+    const unsigned fr = blockIdx.x;
+    if (fr >= count) return;
+    const long base = (long)fr * hop - n_head;
+    f2 v[16];
+    // every load is issued unconditionally at a clamped index and selected afterwards: under a condition each of
+    // them would be a round trip of its own (measured: 41 us per chunk instead of 11)
+    {
+        float2 xs[16], cs[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int m = j + 256 * k;
+            const int mc = m < n ? m : n - 1;
+            const long i = base + mc;
+            xs[k] = (i >= 0) ? in[i] : head[n_head + i];
+            cs[k] = c[mc];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const f2 p = cmul((f2){xs[k].x, xs[k].y}, (f2){cs[k].x, cs[k].y});
+            v[k] = (j + 256 * k < n) ? p : (f2){0.f, 0.f};
+        }
+    }
+    fft4096_regs(v, lds, tw, j);
+    {
+        float2 b[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) b[k] = B[j + 256 * k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = cmul(v[k], (f2){b[k].x, b[k].y});
+    }
+    __syncthreads();  // the first transform's last pass has been read
+    // (the chirp values of the bins this lane will store, requested ahead of the second transform)
+    float2 wt[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int t = (4096 - j - 256 * k) & 4095;
+        wt[k] = w[t < n ? t : 0];
+    }
+    fft4096_regs(v, lds, tw, j);
+    // v[k] = DFT(Z)[j + 256 k] = 4096 IDFT(Z)[t], t = (4096 - j - 256 k) mod 4096; bins t < n leave, times conj(chirp[t])
+    float2 *dst = out + (size_t)fr * n;
+    const int rot = center_dc ? n / 2 : 0;  // rotate_right(n / 2)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int t = (4096 - j - 256 * k) & 4095;
+        const f2 r = cmul_conj(v[k], (f2){wt[k].x, wt[k].y});
+        int o = t + rot;
+        if (o >= n) o -= n;
+        if (t < n) dst[o] = float2{r.x, r.y};
+    }
+}
+
+bool bluestein4096_supported(int dtype, size_t n) { return dtype == RR_F32 && n > 512 && n <= 2048 && (n & (n - 1)) != 0; }
+
+int launch_bluestein4096(hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n, const void *c,
+                         const void *B, const void *w, const void *tw4096, void *out, bool center_dc, size_t count) {
+    if (count == 0) return RR_OK;
+    if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: too many chunks in one call");
+    hipLaunchKernelGGL(k_bluestein4096, dim3((unsigned)count), dim3(256), 0, s, (const float2 *)head, (long)n_head,
+                       (const float2 *)in, (long)hop, (int)n, (const float2 *)c, (const float2 *)B, (const float2 *)w,
+                       (const float2 *)tw4096, (float2 *)out, (int)center_dc, (unsigned)count);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
 // Kernel 2r  k_stft4096<SH>: overlapping 4096-point frames at a hop of 256 SH samples (the Overlapper in front of
 // the Fourier block, chunks.rs:179-271, with P = 16 / SH chunks per span), a workgroup per RUN of neighbouring frames.
 // Lane j holds x[j + 256 k]: the next frame's samples are the current ones moved down SH registers plus SH new

@@ -159,6 +159,11 @@ int launch_fft2048(hipStream_t s, const void *head, size_t n_head, const void *i
 int launch_fft1024(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
                    const void *window, const void *tw1024, bool center_dc, size_t hop);
 void append_wave1024_seeds(std::vector<float> &twb);
+// k_bluestein4096: chunk lengths 513 .. 2048 that are not powers of two, one kernel per call (tables of rr_fourier::prepare
+// for M = 4096: c[n] = window conj(chirp), B[4096] = DFT(chirp) / 4096, w[n] = chirp; tw4096 as for k_fft4096)
+bool bluestein4096_supported(int dtype, size_t n);
+int launch_bluestein4096(hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n, const void *c,
+                         const void *B, const void *w, const void *tw4096, void *out, bool center_dc, size_t count);
 // k_stft4096: runs of overlapping 4096-point frames (hop 256, 512, 1024 or 2048), the sliding window in registers
 bool stft4096_supported(size_t hop);
 int launch_stft4096(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,

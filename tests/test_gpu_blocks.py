@@ -539,7 +539,8 @@ def test_fourier_reference_kat_on_gpu(rr):
 @pytest.mark.parametrize("n,center", [(4096, False), (4096, True), (8192, False), (8192, True), (256, True), (256, False), (1024, False),
                                       (1024, True), (2048, False), (2048, True), (2, False), (1, True), (1000, True), (7, True), (4095, False), (12000, False),
                                       (16384, True), (65536, False), (65536, True), (1 << 18, False),   # four-step through HBM
-                                      (20000, False), (20000, True), (5000, False), (31, True)])         # Bluestein beyond 4096 points; direct below 32
+                                      (20000, False), (20000, True), (5000, False), (31, True),          # Bluestein beyond 4096 points; direct below 32
+                                      (513, False), (1025, True), (1999, True), (2047, False)])          # 513 .. 2048: Bluestein in one kernel (k_bluestein4096)
 def test_fourier_parity(rr, oracle, n, center):
     x = oracle.synth_iq(12, 0, n)
     gw, ow = rr.Kaiser.with_null_at_bin(2.0), oracle.Kaiser.with_null_at_bin(2.0)
@@ -560,6 +561,29 @@ def test_fourier_f64_lengths(rr, oracle, n, center):
     (out,) = g.process(rr.Samples(1e6, x))
     ref = oracle.Fourier(oracle.Kaiser.with_null_at_bin(2.0), center, flt=np.float64).process(x)
     assert rms_rel(out.chunk, ref) < 1e-11
+
+
+def test_fourier_bluestein_one_kernel_many_chunks(rr, oracle, monkeypatch):
+    """n = 1000 and 1536: 40 chunks in one device call through k_bluestein4096, against the oracle and against the
+    five-launch form (RR_FOURIER_GENERIC=1)."""
+    import torch
+
+    for n, center in ((1000, False), (1536, True)):
+        x = oracle.synth_iq(14, 0, n * 40)
+        o = oracle.Fourier(oracle.Kaiser.with_null_at_bin(2.0), center, flt=np.float64)
+        ref = np.concatenate([o.process(x[i * n:(i + 1) * n]) for i in range(40)])
+        outs = []
+        for generic in ("0", "1"):
+            monkeypatch.setenv("RR_FOURIER_GENERIC", generic)
+            g = rr.Fourier(rr.Kaiser.with_null_at_bin(2.0), center)
+            d_in = torch.from_numpy(x).cuda()
+            d_out = torch.empty_like(d_in)
+            g.set_stream(torch.cuda.current_stream().cuda_stream)
+            assert g.process_dev(n, d_in.data_ptr(), n * 40, d_out.data_ptr(), n * 40) == n * 40
+            torch.cuda.synchronize()
+            outs.append(d_out.cpu().numpy())
+            check(outs[-1], ref)
+        assert rms_rel(outs[0], outs[1]) < 2e-6
 
 
 def test_fourier_custom_window_and_length_change(rr, oracle):
