@@ -2448,8 +2448,14 @@ __global__ __launch_bounds__(64) void k_channelizer256(const float2 *__restrict_
     for (int p = 0; p + 1 < P; ++p) load_chunk((long)f0 + p, xs[p]);
 
     f2 *const b_rd = lds + (l + 4 * g);  // B(l + 64 c) = b_rd + 80 c
+    // the chunk a frame adds is requested one frame ahead (the last frame of the run asks for its own once more)
+    // (cfg3: 0.217 -> 0.207 ms; two frames ahead no further gain; runs of 8 or 16 frames alike, 32 .. 128 slower: 0.226-0.236)
+    f2 nx[4];
+    load_chunk((long)f0 + (P - 1), nx);
     for (unsigned it = 0; it < cnt; ++it) {
-        load_chunk((long)f0 + it + (P - 1), xs[P - 1]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xs[P - 1][c] = nx[c];
+        load_chunk((long)f0 + (it + 1 < cnt ? it + 1 : it) + (P - 1), nx);
         // fold: y[c] = sum_p w[l + 64 c + 256 p] x[256 (f + p) + l + 64 c]
         f2 y[4];
 #pragma unroll

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Throughput of the paths round 2 added beside the headline ones (device-resident input, ms per call and GSamples/s):
+oversampled / any-bin channelizers, Filters beyond 2048 taps (partitions), Fourier beyond one LDS tile (four-step),
+Bluestein lengths, the f64 blocks."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import radiorust_amd as rr
+
+st = torch.cuda.current_stream().cuda_stream
+
+
+def timed(fn, k=5):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(k):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / k
+
+
+def line(name, n, dt, bps):
+    print(f"{name:58s} {dt*1e3:8.3f} ms  {n/dt/1e9:7.1f} GSamples/s  {100*bps*n/dt/8e12:5.1f} % of {bps:g} B/sample", flush=True)
+
+
+N = 1 << 26
+d_in = torch.empty(N, dtype=torch.complex64, device="cuda")
+rr.synth_iq_dev(0, st, 1, 0, N, d_in.data_ptr())
+d_out = torch.empty(2 * N, dtype=torch.complex64, device="cuda")
+
+for M, P, hop in ((256, 4, 256), (256, 4, 128), (256, 4, 64), (100, 4, 100), (1000, 2, 1000), (1024, 8, 1024)):
+    c = rr.Channelizer(M, P, hop=hop)
+    c.set_stream(st)
+    n = N // hop * hop
+    if hop < M:
+        n = (1 << 24) // hop * hop
+    outs = []
+    dt = timed(lambda: outs.append(c.process_dev(d_in.data_ptr(), n, d_out.data_ptr(), 2 * N)))
+    line(f"Channelizer {M} bins x {P} taps/branch, hop {hop}", n, dt, 8 + 8 * M / hop)
+
+lp = lambda cut: (lambda b, f: 1.0 if abs(f) <= cut else 0.0)
+for nt in (1024, 2048, 4096, 8192):
+    g = rr.Filter.new(lp(0.2e9))
+    g.set_stream(st)
+    n = N // nt * nt
+    dt = timed(lambda: g.process_dev(2e9, nt, d_in.data_ptr(), n, d_out.data_ptr(), n))
+    line(f"Filter n = {nt} (kernel {g.last_kernel()})", n, dt, 16)
+
+for nf in (8192, 16384, 65536, 1 << 20, 1000, 1536, 3000, 300, 20000):
+    g = rr.Fourier.with_window(rr.Kaiser.with_null_at_bin(2.0))
+    g.set_stream(st)
+    n = min(N, 1 << 24) // nf * nf
+    dt = timed(lambda: g.process_dev(nf, d_in.data_ptr(), n, d_out.data_ptr(), n))
+    line(f"Fourier n = {nf}", n, dt, 16)
+
+# f64
+N2 = 1 << 24
+d64 = torch.randn(N2, dtype=torch.complex128, device="cuda")
+o64 = torch.empty(N2, dtype=torch.complex128, device="cuda")
+g = rr.FreqShifter.with_shift(25e6, dtype=np.float64); g.set_stream(st)
+dt = timed(lambda: g.process_dev(200e6, d64.data_ptr(), N2, o64.data_ptr(), N2)); line("f64 FreqShifter", N2, dt, 32)
+g = rr.Filter.new(lp(20e6), dtype=np.float64); g.set_stream(st)
+dt = timed(lambda: g.process_dev(200e6, 64, d64.data_ptr(), N2, o64.data_ptr(), N2)); line("f64 Filter n = 64", N2, dt, 32)
+g = rr.Downsampler.new(4096, 50e6, 40e6, dtype=np.float64); g.set_stream(st)
+dt = timed(lambda: g.process_dev(200e6, d64.data_ptr(), N2, o64.data_ptr(), N2)); line("f64 Downsampler 4 : 1", N2, dt, 20)
+g = rr.Fourier.with_window(rr.Kaiser.with_null_at_bin(2.0), dtype=np.float64); g.set_stream(st)
+dt = timed(lambda: g.process_dev(4096, d64.data_ptr(), N2, o64.data_ptr(), N2)); line("f64 Fourier 4096", N2, dt, 32)
