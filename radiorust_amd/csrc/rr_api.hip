@@ -952,7 +952,7 @@ int rr_channelizer::process_dev(const void *d_in, size_t n_in, void *d_out, size
         const size_t first_complete = (have_chunks >= K - 1) ? 0 : (K - 1 - have_chunks);  // index of the chunk that ends frame 0
         const long base0 = ((long)first_complete - (long)(K - 1)) * (long)hop;
         if (!fo) {
-            RR_TRY(launch_channelizer(dtype, stream, hist[cur].p, H, d_in, base0, M, P, frames, d_window.p, d_tw.p, d_out));
+            RR_TRY(launch_channelizer(dtype, stream, hist[cur].p, H, d_in, base0, M, P, frames, d_window.p, d_tw.p, d_out, hop));
         } else {
             // general form: fold every frame into the workspace, then the M-point transforms (any M)
             const size_t esz = elem_size(dtype);
@@ -2487,8 +2487,7 @@ int rr_channelizer_create_ex(int dtype, size_t bins, size_t taps_per_branch, siz
                 bins * taps_per_branch);
     if (window->kind != RR_WIN_RECTANGULAR && window->kind != RR_WIN_KAISER)
         RR_FAIL(RR_ERR_BAD_ARG, "Channelizer: window must be a built-in window");
-    const bool pow2 = (bins & (bins - 1)) == 0;
-    const bool fast = hop == bins && pow2 && bins <= (dtype == RR_F32 ? 8192u : 4096u);  // one fused fold + FFT kernel
+    const bool fast = channelizer_fused_supported(dtype, bins, taps_per_branch, hop);  // one fused fold + FFT kernel
     auto *h = new rr_channelizer;
     int st = h->init_base(K_CHANNELIZER, dtype, device);
     if (st != RR_OK) {

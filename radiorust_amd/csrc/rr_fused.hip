@@ -2407,7 +2407,10 @@ int launch_filter_wave(hipStream_t s, const void *hist, size_t hist_len, const v
 // (4 P) and the three twiddle seeds stay in registers for the whole run.
 // ---------------------------------------------------------------------------
 #define RR_V_CHANWIN 4  // cfg3: one contiguous eighth of the runs per XCD 0.250 ms; windows of 1 .. 6 and 64 runs per XCD 0.222-0.226; 8: 0.232, 16: 0.265, 32: 0.233
-template <int P>
+// H = hop / 64: 4 is the critically sampled filterbank (one new chunk of 256 per frame); 2 and 1 are the filterbanks
+// oversampled 2 and 4 times (Rechunker(hop) -> Overlapper -> Fourier -> every P-th bin, hop 128 / 64): the window of
+// samples a lane keeps moves on by H pieces of 64 per frame.
+template <int P, int H>
 __global__ __launch_bounds__(64) void k_channelizer256(const float2 *__restrict__ hist, long hist_len,
                                                        const float2 *__restrict__ in, long base0,
                                                        const float *__restrict__ window,
@@ -2432,43 +2435,44 @@ __global__ __launch_bounds__(64) void k_channelizer256(const float2 *__restrict_
     const float2 s1 = tw[(l & 3) * 16], s2 = tw[q * 4], s3 = tw[l];
     const f2 seed[3] = {(f2){s1.x, s1.y}, (f2){s2.x, s2.y}, (f2){s3.x, s3.y}};
 
-    // chunk ci of the stream starts at base0 + 256 ci; base0 and hist_len are multiples of 256, so a
-    // chunk lies entirely in the history or entirely in the input
-    auto load_chunk = [&](long ci, f2(&dst)[4]) {
-        const long pos = base0 + 256 * ci;
+    // piece qi of the stream (64 samples) starts at base0 + 64 qi; base0 and hist_len are multiples of the hop (64 H),
+    // so a piece lies entirely in the history or entirely in the input.  Frame f covers the pieces H f .. H f + 4 P - 1.
+    auto load_piece = [&](long qi) -> f2 {
+        const long pos = base0 + 64 * qi;
         const float2 *src = pos >= 0 ? in + pos : hist + (hist_len + pos);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float2 v = src[l + 64 * c];
-            dst[c] = (f2){v.x, v.y};
-        }
+        const float2 v = src[l];
+        return (f2){v.x, v.y};
     };
-    f2 xs[P][4];
+    constexpr int NQ = 4 * P;
+    f2 xs[NQ];
 #pragma unroll
-    for (int p = 0; p + 1 < P; ++p) load_chunk((long)f0 + p, xs[p]);
+    for (int i = 0; i + H < NQ; ++i) xs[i] = load_piece((long)H * f0 + i);
 
     f2 *const b_rd = lds + (l + 4 * g);  // B(l + 64 c) = b_rd + 80 c
-    // the chunk a frame adds is requested one frame ahead (the last frame of the run asks for its own once more)
+    // the pieces a frame adds are requested one frame ahead (the last frame of the run asks for its own once more)
     // (cfg3: 0.217 -> 0.207 ms; two frames ahead no further gain; runs of 8 or 16 frames alike, 32 .. 128 slower: 0.226-0.236)
-    f2 nx[4];
-    load_chunk((long)f0 + (P - 1), nx);
+    f2 nx[H];
+#pragma unroll
+    for (int i = 0; i < H; ++i) nx[i] = load_piece((long)H * f0 + (NQ - H) + i);
     for (unsigned it = 0; it < cnt; ++it) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) xs[P - 1][c] = nx[c];
-        load_chunk((long)f0 + (it + 1 < cnt ? it + 1 : it) + (P - 1), nx);
-        // fold: y[c] = sum_p w[l + 64 c + 256 p] x[256 (f + p) + l + 64 c]
+        for (int i = 0; i < H; ++i) xs[NQ - H + i] = nx[i];
+        {
+            const long fn = (long)f0 + (it + 1 < cnt ? it + 1 : it);
+#pragma unroll
+            for (int i = 0; i < H; ++i) nx[i] = load_piece((long)H * fn + (NQ - H) + i);
+        }
+        // fold: y[c] = sum_p w[l + 64 c + 256 p] x[hop f + l + 64 c + 256 p]
         f2 y[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            f2 acc = xs[0][c] * wv[0][c];
+            f2 acc = xs[c] * wv[0][c];
 #pragma unroll
-            for (int p = 1; p < P; ++p) acc = __builtin_elementwise_fma(xs[p][c], (f2){wv[p][c], wv[p][c]}, acc);
+            for (int p = 1; p < P; ++p) acc = __builtin_elementwise_fma(xs[c + 4 * p], (f2){wv[p][c], wv[p][c]}, acc);
             y[c] = acc;
         }
 #pragma unroll
-        for (int p = 0; p + 1 < P; ++p)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) xs[p][c] = xs[p + 1][c];
+        for (int i = 0; i + H < NQ; ++i) xs[i] = xs[i + H];
         // forward DFT_256, Stockham radix 4 x 4: butterfly l reads in[l + 64 c]
         dft4(y[0], y[1], y[2], y[3]);  // pass 0 (Ns = 1): out 4 l + c
         wave_sync();                   // the previous frame's reads are done
@@ -2513,29 +2517,46 @@ __global__ __launch_bounds__(64) void k_channelizer256(const float2 *__restrict_
     }
 }
 
-bool channelizer256_supported(int dtype, size_t M, size_t P) {
-    return dtype == RR_F32 && M == 256 && (P == 1 || P == 2 || P == 3 || P == 4 || P == 6 || P == 8);
+bool channelizer256_supported(int dtype, size_t M, size_t P, size_t hop) {
+    if (dtype != RR_F32 || M != 256) return false;
+    if (hop == 256) return P == 1 || P == 2 || P == 3 || P == 4 || P == 6 || P == 8;
+    return (hop == 128 || hop == 64) && (P == 2 || P == 4 || P == 8);
 }
 
 int launch_channelizer256(hipStream_t s, const void *hist, size_t hist_len, const void *in, long base0, size_t P,
-                          size_t nframes, const void *window, const void *tw, void *out) {
+                          size_t nframes, const void *window, const void *tw, void *out, size_t hop) {
     if (nframes == 0) return RR_OK;
     if (nframes > 0x7ffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: too many frames in one call");
+    if (!channelizer256_supported(RR_F32, 256, P, hop))
+        RR_FAIL(RR_ERR_BAD_ARG, "channelizer256: %zu taps per branch at hop %zu not instantiated", P, hop);
 #define RR_V_CHANRUN 16
     const unsigned run = RR_V_CHANRUN;
     const unsigned grid = (unsigned)(((nframes + run - 1) / run + 8 * RR_V_CHANWIN - 1) / (8 * RR_V_CHANWIN) * (8 * RR_V_CHANWIN));
-#define RR_CHAN_LAUNCH(PP)                                                                                        \
-    hipLaunchKernelGGL(k_channelizer256<PP>, dim3(grid), dim3(64), 0, s, (const float2 *)hist, (long)hist_len,    \
-                       (const float2 *)in, base0, (const float *)window, (const float2 *)tw, (float2 *)out,      \
+#define RR_CHAN_LAUNCH(PP, HH)                                                                                       \
+    hipLaunchKernelGGL((k_channelizer256<PP, HH>), dim3(grid), dim3(64), 0, s, (const float2 *)hist, (long)hist_len, \
+                       (const float2 *)in, base0, (const float *)window, (const float2 *)tw, (float2 *)out,         \
                        (unsigned)nframes, run)
-    switch (P) {
-        case 1: RR_CHAN_LAUNCH(1); break;
-        case 2: RR_CHAN_LAUNCH(2); break;
-        case 3: RR_CHAN_LAUNCH(3); break;
-        case 4: RR_CHAN_LAUNCH(4); break;
-        case 6: RR_CHAN_LAUNCH(6); break;
-        case 8: RR_CHAN_LAUNCH(8); break;
-        default: RR_FAIL(RR_ERR_BAD_ARG, "channelizer256: %zu taps per branch not instantiated", P);
+    if (hop == 256) {
+        switch (P) {
+            case 1: RR_CHAN_LAUNCH(1, 4); break;
+            case 2: RR_CHAN_LAUNCH(2, 4); break;
+            case 3: RR_CHAN_LAUNCH(3, 4); break;
+            case 4: RR_CHAN_LAUNCH(4, 4); break;
+            case 6: RR_CHAN_LAUNCH(6, 4); break;
+            case 8: RR_CHAN_LAUNCH(8, 4); break;
+        }
+    } else if (hop == 128) {
+        switch (P) {
+            case 2: RR_CHAN_LAUNCH(2, 2); break;
+            case 4: RR_CHAN_LAUNCH(4, 2); break;
+            case 8: RR_CHAN_LAUNCH(8, 2); break;
+        }
+    } else {
+        switch (P) {
+            case 2: RR_CHAN_LAUNCH(2, 1); break;
+            case 4: RR_CHAN_LAUNCH(4, 1); break;
+            case 8: RR_CHAN_LAUNCH(8, 1); break;
+        }
     }
 #undef RR_CHAN_LAUNCH
     RR_HIP(hipGetLastError());

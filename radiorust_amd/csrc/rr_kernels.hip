@@ -891,12 +891,21 @@ __global__ __launch_bounds__(256) void k_channelizer(const v2<T> *__restrict__ h
     for (int i = threadIdx.x; i < M; i += blockDim.x) dst[i] = a[i];
 }
 
+// one fused fold + FFT kernel: hop = M for powers of two up to one LDS tile; hop < M through k_channelizer256
+bool channelizer_fused_supported(int dtype, size_t M, size_t P, size_t hop) {
+    const bool pow2 = (M & (M - 1)) == 0;
+    if (hop == M) return pow2 && M <= (dtype == RR_F32 ? 8192u : 4096u);
+    return channelizer256_supported(dtype, M, P, hop) && !std::getenv("RR_CHANNELIZER_GENERIC");
+}
+
 int launch_channelizer(int dtype, hipStream_t s, const void *hist, size_t hist_len, const void *in, long base0,
-                       size_t M, size_t P, size_t nframes, const void *window, const void *tw, void *out) {
+                       size_t M, size_t P, size_t nframes, const void *window, const void *tw, void *out, size_t hop) {
     if (nframes == 0) return RR_OK;
     if (nframes > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: too many frames in one call");
-    if (channelizer256_supported(dtype, M, P) && !std::getenv("RR_CHANNELIZER_GENERIC"))
-        return launch_channelizer256(s, hist, hist_len, in, base0, P, nframes, window, tw, out);
+    if (hop == 0) hop = M;
+    if (channelizer256_supported(dtype, M, P, hop) && !std::getenv("RR_CHANNELIZER_GENERIC"))
+        return launch_channelizer256(s, hist, hist_len, in, base0, P, nframes, window, tw, out, hop);
+    if (hop != M) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: hop %zu of %zu bins has no fused kernel", hop, M);
     const size_t lds = 2 * M * elem_size(dtype);
     int threads = (int)(M / 2);
     threads = threads > 256 ? 256 : (threads < 64 ? 64 : threads);

@@ -177,15 +177,17 @@ int launch_drop_tail(hipStream_t s, const void *oldh, void *newh, size_t H, size
 // over the virtual stream [ hist (hist_len samples, ends right before in[0]) | in ].
 // base0 = index (relative to in[0], may be negative) of the first sample of frame 0.
 int launch_channelizer(int dtype, hipStream_t s, const void *hist, size_t hist_len, const void *in, long base0,
-                       size_t M, size_t P, size_t nframes, const void *window, const void *tw, void *out);
+                       size_t M, size_t P, size_t nframes, const void *window, const void *tw, void *out, size_t hop = 0);
+// (hop = 0: M; hop < M only where channelizer_fused_supported says so)
+bool channelizer_fused_supported(int dtype, size_t M, size_t P, size_t hop);
 // the fold alone for any M and any hop (frames written to `out`, M values each); the transforms follow through rr_fourier
 int launch_chan_fold(int dtype, hipStream_t s, const void *hist, size_t hist_len, const void *in, long base0, size_t hop,
                      size_t M, size_t P, size_t frames, const void *window, void *out);
-// f32, M = 256, P in {1, 2, 3, 4, 6, 8}: one wave per run of frames, sliding window of chunks in
-// registers, radix-4 DFT_256 with wave-local exchanges (rr_fused.hip)
-bool channelizer256_supported(int dtype, size_t M, size_t P);
+// f32, M = 256, P in {1, 2, 3, 4, 6, 8} at hop 256 or P in {2, 4, 8} at hop 128 / 64 (the oversampled filterbanks): one wave
+// per run of frames, sliding window of samples in registers, radix-4 DFT_256 with wave-local exchanges (rr_fused.hip)
+bool channelizer256_supported(int dtype, size_t M, size_t P, size_t hop = 256);
 int launch_channelizer256(hipStream_t s, const void *hist, size_t hist_len, const void *in, long base0, size_t P,
-                          size_t nframes, const void *window, const void *tw, void *out);
+                          size_t nframes, const void *window, const void *tw, void *out, size_t hop = 256);
 
 // Upsampler (resampling.rs:237-267) as a gather: out[m] = sum over the inputs t with
 // 0 <= m - before[t] < L, ascending t, of x[t] * ir[m - before[t]], rounded like the reference's

@@ -62,6 +62,7 @@ def test_channelizer_parity(rr, oracle, M, P, dtype, tol):
 
 
 @pytest.mark.parametrize("M,P,hop,dtype,tol", [(256, 4, 128, np.float32, 1e-5), (256, 4, 64, np.float32, 1e-5),
+                                               (256, 8, 128, np.float32, 1e-5), (256, 2, 64, np.float32, 1e-5), (256, 3, 128, np.float32, 1e-5),
                                                (64, 3, 32, np.float64, 1e-12), (1024, 2, 512, np.float32, 1e-5),
                                                (100, 4, 100, np.float32, 1e-5), (100, 4, 50, np.float32, 1e-5),
                                                (1000, 2, 250, np.float64, 1e-11), (16384, 2, 8192, np.float32, 1e-5)])
