@@ -32,6 +32,11 @@ The JSON line also carries
   cpu_baseline — the CPU oracle (C restatement of the reference blocks, kind = "port")
                  timed on this host on a bounded sample: one thread per block (4 cores)
                  and single-threaded.
+  host_fed     — NOT `value`: after the timed region every rank feeds its chain from page-locked host
+                 buffers (rr_chain_enqueue + rr_wait), all ranks at once: the PCIe-inclusive rate of
+                 the boundary's host-pointer entry points (what N GPUs behind one host's
+                 links deliver together).  host_placement: each rank restricts itself to the CPUs of
+                 its GPU's NUMA node before it allocates anything (radiorust_amd/dist.py::pin_to_gpu_numa).
 """
 from __future__ import annotations
 
@@ -150,6 +155,8 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="rank logic rehearsal only: all ranks share cuda:0 and line up over gloo (RCCL refuses two ranks on one GPU)")
     ap.add_argument("--traffic-json", default=None, help="file holding measured HBM bytes per launch (PMC pass)")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the un-timed host-buffer (PCIe-inclusive) leg")
+    ap.add_argument("--no-numa-pin", action="store_true", help="leave the rank's CPU affinity alone")
     ap.add_argument("--profile", action="store_true",
                     help="profiler runs: only the chain's own launches (no block-by-block replay, no copy benchmark, no extra "
                          "timing steps, no CPU baseline), so that a rocprofv3 --kernel-trace --stats of this command averages "
@@ -186,6 +193,16 @@ def main():
     import radiorust_amd as rr
 
     rr._lib.lib()
+    # the feeder of a GPU (this rank) and its pinned buffers live on the GPU's NUMA node
+    host_info = {"pinned": False}
+    if not args.no_numa_pin:
+        import ctypes as C0
+
+        from radiorust_amd.dist import pin_to_gpu_numa
+
+        buf = C0.create_string_buffer(64)
+        if rr._lib.lib().rr_device_pci_bus_id(local_rank, buf, 64) == 0:
+            host_info = pin_to_gpu_numa(buf.value.decode())
     fs, n = 200e6, int(args.samples)
     stream = torch.cuda.current_stream().cuda_stream
     chain = rr.Chain(shift=25e6, filter_len=64, freq_resp=lowpass20, output_rate=50e6, bandwidth=40e6, fft_len=4096,
@@ -300,6 +317,53 @@ def main():
     stages = {}
     stages.update(timed_stages)
 
+    # Host-fed leg (never `value`; not part of the timed region): every rank feeds its chain from page-locked host
+    # buffers through rr_chain_enqueue + rr_wait, all ranks at the same time - the PCIe-inclusive rate of the
+    # boundary's host-pointer entry points, which is what N GPUs behind one host's links deliver together.
+    host_fed = None
+    if not args.profile and not args.no_host_fed:
+        hn = min(n, 1 << 24)
+        hcap = hn // 4 + 8192
+        p_in, p_out = C.c_void_p(), C.c_void_p()
+        rr._lib.check(lib.rr_host_alloc(hn * 8, C.byref(p_in)))
+        rr._lib.check(lib.rr_host_alloc(hcap * 8, C.byref(p_out)))
+        h_src = d_in[:hn].cpu().numpy()  # (kept alive across the copy)
+        C.memmove(p_in, h_src.ctypes.data, hn * 8)
+        del h_src
+        hchain = rr.Chain(shift=25e6, filter_len=64, freq_resp=lowpass20, output_rate=50e6, bandwidth=40e6, fft_len=4096,
+                          fft_window=rr.Kaiser.with_null_at_bin(2.0), device=local_rank)
+        hchain._ensure_design(fs)
+        cnt = C.c_size_t()
+        for _ in range(3):
+            rr._lib.check(lib.rr_chain_enqueue(hchain._h, fs, p_in, hn, p_out, hcap, C.byref(cnt)))
+        hchain.wait()
+        hk = 8
+        barrier()
+        th = time.perf_counter()
+        for _ in range(hk):
+            rr._lib.check(lib.rr_chain_enqueue(hchain._h, fs, p_in, hn, p_out, hcap, C.byref(cnt)))
+        hchain.wait()
+        h_el = time.perf_counter() - th
+        h_per_rank = ranks.gather_over_ranks(h_el)
+        h_max = ranks.max_over_ranks(h_el)
+        host_fed = {
+            "value": round(hn * hk * world / h_max / 1e6, 1),
+            "unit": "MSamples/s",
+            "per_rank_MSamples_s": [round(hn * hk / e / 1e6, 1) for e in h_per_rank],
+            "link_GB_s_per_rank": round((hn * 8 + cnt.value * 8) * hk / h_max / 1e9, 1),
+            "sample": f"{hk} calls of {hn} samples per rank from page-locked host buffers (rr_chain_enqueue + rr_wait), "
+                      "all ranks at once; PCIe-inclusive, never `value`",
+        }
+        del hchain
+        lib.rr_host_free(p_in)
+        lib.rr_host_free(p_out)
+    host_infos = [host_info] if world == 1 else None
+    if world > 1:
+        # (node per rank, in rank order)
+        nodes = ranks.gather_over_ranks(float(host_info.get("numa_node", -1)))
+        pins = ranks.gather_over_ranks(1.0 if host_info.get("pinned") else 0.0)
+        host_infos = [{"numa_node": int(a), "pinned": bool(b)} for a, b in zip(nodes, pins)]
+
     if rank == 0:
         value = whole_job_rate(n, args.steps, world, elapsed)
         dom = max(stages, key=lambda k: stages[k]["avg_ms"])
@@ -354,6 +418,8 @@ def main():
             "kernels": {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 5)} for k, v in stages.items()},
             "kernels_outside_timed_region": {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 5)}
                                              for k, v in other.items()},
+            "host_fed": host_fed,
+            "host_placement": host_infos,
             "parity_first_spectrum_rms": None,  # filled in by the cpu_baseline leg
             "parity_fused_vs_block_by_block_last_step_rms": fused_vs_blocks,
         }

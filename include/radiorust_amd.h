@@ -78,6 +78,9 @@ typedef struct rr_chain rr_chain;
 int rr_version(void);
 const char *rr_last_error_string(void);
 int rr_device_count(int *count);
+/* PCI address of a device ("0000:c1:00.0"): what a host layer needs to place its feeder thread and its pinned pool
+ * on the GPU's NUMA node; out_cap >= 16. */
+int rr_device_pci_bus_id(int device, char *out, size_t out_cap);
 
 /* Any handle may be passed as rr_block*.  stream = hipStream_t (NULL restores
  * the handle's own stream).  The handle never owns a caller's stream. */

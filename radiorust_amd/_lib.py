@@ -86,6 +86,7 @@ SIGNATURES = {
     "rr_version": (_i, []),
     "rr_last_error_string": (C.c_char_p, []),
     "rr_device_count": (_i, [C.POINTER(_i)]),
+    "rr_device_pci_bus_id": (_i, [_i, C.c_char_p, _sz]),
     "rr_set_stream": (_i, [_vp, _vp]),
     "rr_wait": (_i, [_vp]),
     "rr_query": (_i, [_vp]),

@@ -1599,6 +1599,16 @@ int rr_device_count(int *count) {
     return RR_OK;
 }
 
+int rr_device_pci_bus_id(int device, char *out, size_t out_cap) {
+    if (!out || out_cap < 16) RR_FAIL(RR_ERR_BAD_ARG, "rr_device_pci_bus_id: needs a buffer of at least 16 bytes");
+    out[0] = 0;
+    int count = 0;
+    RR_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) RR_FAIL(RR_ERR_BAD_ARG, "device %d out of range", device);
+    RR_HIP(hipDeviceGetPCIBusId(out, (int)out_cap, device));
+    return RR_OK;
+}
+
 int rr_set_stream(rr_block *h, void *hip_stream) {
     if (!h) RR_FAIL(RR_ERR_BAD_ARG, "null handle");
     h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;

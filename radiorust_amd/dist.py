@@ -77,6 +77,49 @@ class Ranks:
             self.dist = None
 
 
+def parse_cpulist(text: str) -> list:
+    """'0-31,64-95' -> [0..31, 64..95] (the format of /sys/devices/system/node/node*/cpulist)."""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.extend(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def numa_node_of_pci(bus_id: str, sysfs: str = "/sys") -> int:
+    """NUMA node of a PCI device ("0000:c1:00.0"), -1 when the platform does not say."""
+    try:
+        return int(open(os.path.join(sysfs, "bus/pci/devices", bus_id.lower(), "numa_node")).read().strip())
+    except (OSError, ValueError):
+        return -1
+
+
+def cpus_of_numa_node(node: int, sysfs: str = "/sys") -> list:
+    try:
+        return parse_cpulist(open(os.path.join(sysfs, "devices/system/node", f"node{node}", "cpulist")).read())
+    except (OSError, ValueError):
+        return []
+
+
+def pin_to_gpu_numa(bus_id: str, sysfs: str = "/sys") -> dict:
+    """the feeder of a GPU (here: the rank's own process, one per GPU) and the pinned pool it allocates
+    afterwards live on the GPU's NUMA node.  Restricts this process to the node's CPUs that it is allowed to use
+    (page-locked allocations follow the allocating thread's node) and says what it did; a platform without NUMA
+    information, or a node none of whose CPUs are allowed, leaves the affinity alone."""
+    info = {"pci_bus_id": bus_id, "numa_node": numa_node_of_pci(bus_id, sysfs), "pinned": False}
+    if info["numa_node"] < 0 or not hasattr(os, "sched_setaffinity"):
+        return info
+    allowed = os.sched_getaffinity(0)
+    want = set(cpus_of_numa_node(info["numa_node"], sysfs)) & allowed
+    if want:
+        os.sched_setaffinity(0, want)
+        info["pinned"] = True
+        info["cpus"] = len(want)
+    return info
+
+
 def whole_job_rate(samples_per_rank_per_step: int, steps: int, world: int, elapsed_max_s: float) -> float:
     """MSamples/s of the whole job: every rank processed its own channel."""
     return float(world) * samples_per_rank_per_step * steps / elapsed_max_s / 1e6

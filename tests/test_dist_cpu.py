@@ -128,3 +128,34 @@ def test_bench_spawns_before_touching_the_gpu():
     src = open(os.path.join(ROOT, "bench.py")).read()
     head = src[: src.index("spawn_ranks([sys.executable")]
     assert "import torch" not in head and "import radiorust_amd" not in head
+
+
+def test_numa_placement_helpers(tmp_path):
+    """a rank restricts itself to the CPUs of its GPU's NUMA node before it allocates pinned
+    buffers.  The sysfs walk is exercised on a fabricated tree; the affinity of this process is restored."""
+    import os
+
+    from radiorust_amd.dist import cpus_of_numa_node, numa_node_of_pci, parse_cpulist, pin_to_gpu_numa
+
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert parse_cpulist("") == []
+    dev = tmp_path / "bus/pci/devices/0000:c1:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    allowed = sorted(os.sched_getaffinity(0))
+    node = tmp_path / "devices/system/node/node1"
+    node.mkdir(parents=True)
+    (node / "cpulist").write_text(f"{allowed[0]},4000-4001\n")  # one CPU this process may use, two it does not have
+    sysfs = str(tmp_path)
+    assert numa_node_of_pci("0000:C1:00.0", sysfs) == 1 and numa_node_of_pci("0000:00:00.0", sysfs) == -1
+    assert cpus_of_numa_node(1, sysfs) == [allowed[0], 4000, 4001] and cpus_of_numa_node(7, sysfs) == []
+    try:
+        info = pin_to_gpu_numa("0000:c1:00.0", sysfs)
+        assert info == {"pci_bus_id": "0000:c1:00.0", "numa_node": 1, "pinned": True, "cpus": 1}
+        assert os.sched_getaffinity(0) == {allowed[0]}
+    finally:
+        os.sched_setaffinity(0, allowed)
+    # unknown device, or a node none of whose CPUs are allowed: nothing changes
+    assert pin_to_gpu_numa("0000:00:00.0", sysfs)["pinned"] is False
+    (node / "cpulist").write_text("4000-4001\n")
+    assert pin_to_gpu_numa("0000:c1:00.0", sysfs)["pinned"] is False and os.sched_getaffinity(0) == set(allowed)

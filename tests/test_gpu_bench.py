@@ -30,6 +30,8 @@ def test_bench_line_contract_small():
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
     assert d["config"]["path"] == "fused" and len(d["per_rank_MSamples_s"]) == 1
     assert d["parity_fused_vs_block_by_block_last_step_rms"] < 1e-5
+    # the un-timed host-fed leg (PCIe-inclusive) and the rank's NUMA placement ride along
+    assert d["host_fed"]["value"] > 0 and d["host_fed"]["value"] < d["value"] and len(d["host_placement"]) == 1
 
 
 def test_bench_spawns_its_own_ranks():
@@ -38,5 +40,6 @@ def test_bench_spawns_its_own_ranks():
                   "--settle-ms", "0", "--no-cpu-baseline")
     assert d["n_gpus"] == 2 and len(d["per_rank_MSamples_s"]) == 2
     assert "rehearsal" in d
+    assert len(d["host_fed"]["per_rank_MSamples_s"]) == 2 and len(d["host_placement"]) == 2
     # whole-job value = both ranks' samples over the slower rank's time
     assert d["value"] <= sum(d["per_rank_MSamples_s"]) * 1.001
