@@ -54,6 +54,10 @@ struct DecimArgs {
     // nco[(idx0 + pos) mod denom] as they are staged; `hist` and `hist_out` then hold MIXED samples.  denom = 0: no mixer
     const float2 *nco;
     unsigned denom, idx0;
+    // phase of the first sample of tile 0, (idx0 + p_ref) mod denom, the advance per tile (P TA) mod denom, 1 / denom:
+    // a tile's phase comes from three f64 operations (exact below 2^53) instead of a 64-bit integer division per lane
+    unsigned ph_ref, ph_tile_step;
+    double inv_denom;
 };
 
 // (T is a parameter of its own, const and restrict: only then does the compiler read the wave-uniform taps through
@@ -108,12 +112,26 @@ __global__ __launch_bounds__(256) void k_decim_poly(DecimArgs a, const uint2 *__
         };
         const bool interior = p_lo >= 0 && p_lo + nld <= a.n_in;
         // NCO phase of this lane's first sample and its step per 256 samples (interior tiles: every sample is in `in`)
-        unsigned ph = 0, dph = 0;
+        unsigned ph = 0, dph = 0, dph8 = 0;
+        f2 rot = {1.f, 0.f};
         if (a.denom) {
-            long r0 = ((long)a.idx0 + p_lo + t) % (long)a.denom;
-            if (r0 < 0) r0 += a.denom;
-            ph = (unsigned)r0;
+            const double dn = (double)a.denom;
+            const double prod = __builtin_fma((double)tile, (double)a.ph_tile_step, (double)a.ph_ref);
+            const double qd = __builtin_floor(prod * a.inv_denom);
+            double rd = __builtin_fma(-qd, dn, prod);
+            if (rd < 0.0) rd += dn;
+            if (rd >= dn) rd -= dn;
+            unsigned r0 = (unsigned)rd + (unsigned)t;  // < 2 denom where denom >= 256
+            if (a.denom >= 256u) {
+                if (r0 >= a.denom) r0 -= a.denom;
+            } else {
+                r0 %= a.denom;
+            }
+            ph = r0;
             dph = 256u % a.denom;
+            dph8 = 2048u % a.denom;
+            const float2 rt = a.nco[dph];
+            rot = (f2){rt.x, rt.y};
         }
         auto mix = [&](f2 v) {
             const float2 pp = a.nco[ph];
@@ -126,11 +144,31 @@ __global__ __launch_bounds__(256) void k_decim_poly(DecimArgs a, const uint2 *__
             int q = t;
             for (; q + 7 * 256 < nld; q += 8 * 256) {
                 f2 v[8];
+                // (the phasor first: loads complete in order, so asked for last it would make the first use wait for all
+                //  eight samples)
+                float2 p0 = {1.f, 0.f};
+                if (a.denom) p0 = a.nco[ph];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + q + 256 * u);
+                if (a.denom) {
+                    // the eight phasors are requested together with the samples (asked for one by one behind the
+                    // samples they were eight more round trips per batch: 0.212 ms for the meter's front end)
+                    // .. one table entry per batch, requested with the samples; the other seven by the rotation of 256
+                    // samples (the table is a geometric sequence: a last-bit difference from its own entries, as in
+                    // k_ols_wave's general-period path)
+                    ph += dph8;
+                    if (ph >= a.denom) ph -= a.denom;
+                    f2 pp = {p0.x, p0.y};
+                    v[0] = cmul(v[0], pp);
+#pragma unroll
+                    for (int u = 1; u < 8; ++u) {
+                        pp = cmul(pp, rot);
+                        v[u] = cmul(v[u], pp);
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    xs[row * S + col] = a.denom ? mix(v[u]) : v[u];
+                    xs[row * S + col] = v[u];
                     step();
                 }
             }
@@ -276,6 +314,8 @@ int launch_decim_poly(hipStream_t s, const void *hist, size_t hist_len, const vo
     a.nco = (const float2 *)nco;
     a.denom = nco ? denom : 0;
     a.idx0 = idx0;
+    a.ph_ref = a.ph_tile_step = 0;
+    a.inv_denom = 0.0;
     const int lds = decim_geometry(P, Q, (size_t)a.NC, &a.TA, &a.S);
     if (!lds) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: %llu : %llu with %d tap columns does not fit the LDS tile",
                       (unsigned long long)P, (unsigned long long)Q, a.NC);
@@ -283,6 +323,14 @@ int launch_decim_poly(hipStream_t s, const void *hist, size_t hist_len, const vo
     const size_t ntiles = (n_out + per_tile - 1) / per_tile;
     if (ntiles > 0x7ffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: too many tiles");
     a.ntiles = (unsigned)ntiles;
+    if (a.denom) {
+        const int64_t den = (int64_t)a.denom;
+        int64_t r = ((int64_t)a.idx0 + a.p_ref) % den;
+        if (r < 0) r += den;
+        a.ph_ref = (unsigned)r;
+        a.ph_tile_step = (unsigned)(((int64_t)P * a.TA) % den);
+        a.inv_denom = 1.0 / (double)den;
+    }
     const unsigned grid = (unsigned)((ntiles + 63) / 64 * 64);
     hipLaunchKernelGGL(k_decim_poly, dim3(grid), dim3(256), (size_t)lds, s, a, (const uint2 *)T);
     RR_HIP(hipGetLastError());

@@ -368,6 +368,19 @@ template <class T> class Sender {  // broadcast_bp::Sender (capacity 1, back-pre
         sh_->sndr_count -= 1;
         if (sh_->sndr_count == 0) sh_->notify_rcvr.notify_all();
     }
+    // Not in the reference: blocks until `n` receivers have subscribed (or `timeout_ms` have passed).  A value is
+    // delivered to the receivers subscribed at the time of the send (broadcast_bp.rs:273-291); under tokio's test
+    // runtime the reference's tests have every consumer task subscribed before their first send runs, with one OS
+    // thread per block that order has to be asked for where ONE sender feeds several blocks.
+    bool wait_for_receivers(size_t n, int timeout_ms = 10000) {
+        std::unique_lock<std::mutex> g(sh_->m);
+        const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
+        while (sh_->rcvr_count < n) {
+            if (std::chrono::steady_clock::now() >= until) return false;
+            sh_->notify_sndr.wait_for(g, std::chrono::milliseconds(1));
+        }
+        return true;
+    }
     // broadcast_bp.rs:230-291: waits until every receiver has seen the previous
     // value and at least one receiver exists; false = nobody can ever receive
     bool send(T msg, const std::atomic<bool> *stop = nullptr) {

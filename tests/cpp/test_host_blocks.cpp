@@ -109,6 +109,10 @@ static void test_fourier() {  // analysis.rs:139-209, verbatim structure and val
     fourier2->feed_from(sender_connector);
     fourier1->feed_into(*receiver1_connector);
     fourier2->feed_into(*receiver2_connector);
+    // both block threads must have subscribed before the first send: a value goes to the receivers that exist when it
+    // is sent (the second block subscribing a moment later would never see it, and receiver2.recv() below would wait
+    // for ever - seen twice on freshly started boxes)
+    CHECK(sender.wait_for_receivers(2));
     CHECK(sender.send(S::Samples(48000.0, chunk_of<double>({{1.0, 0.0}, {1.0, 0.0}, {1.0, 0.0}}))));
     auto o1 = receiver1.recv(), o2 = receiver2.recv();
     CHECK(o1 && o2 && !o1->is_event() && !o2->is_event());
