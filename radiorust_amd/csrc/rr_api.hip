@@ -812,7 +812,7 @@ int rr_fourier::prepare(size_t len) {
     window_f64.swap(vals);
     n = len;
     bs_M = 0;
-    bs_fused = false;
+    bs_fused = bs_wave = false;
     big = use_big;
     if (use_bs) {
         size_t M = 64;
@@ -822,6 +822,9 @@ int rr_fourier::prepare(size_t len) {
         static const bool generic = [] { const char *e = std::getenv("RR_FOURIER_GENERIC"); return e && std::atoi(e) != 0; }();
         bs_fused = !generic && bluestein4096_supported(dtype, len);
         if (bs_fused) M = 4096;
+        // 32 .. 512 points in f32: a wave per chunk around two 1024-point transforms (k_bluestein1024)
+        bs_wave = !generic && bluestein1024_supported(dtype, len);
+        if (bs_wave) M = 1024;
         // chirp w_m = e^{+j pi m^2 / n}, the phase reduced exactly (m^2 mod 2n) before it is evaluated
         std::vector<cd> w(len);
         for (size_t m = 0; m < len; ++m) {
@@ -833,7 +836,7 @@ int rr_fourier::prepare(size_t len) {
         bb[0] = w[0];
         for (size_t m = 1; m < len; ++m) bb[m] = bb[M - m] = w[m];
         fft_f64(bb, false);
-        std::vector<double> cf(2 * len), wf(2 * len), Bf(2 * M);
+        std::vector<double> cf(2 * (len + 1), 0.0), wf(2 * len), Bf(2 * M);  // (c: one zero entry behind an odd length)
         for (size_t m = 0; m < len; ++m) {
             const cd c = std::conj(w[m]) * window_f64[m];
             cf[2 * m] = c.real();
@@ -842,8 +845,14 @@ int rr_fourier::prepare(size_t len) {
             wf[2 * m + 1] = w[m].imag();
         }
         for (size_t m = 0; m < M; ++m) {
-            Bf[2 * m] = bb[m].real() / (double)M;
-            Bf[2 * m + 1] = bb[m].imag() / (double)M;
+            // k_bluestein1024 reads B pair-interleaved: [kp][l] = {B[l + 128 kp], B[l + 128 kp + 64]} (as k_filter_wave's H)
+            size_t dst = m;
+            if (bs_wave) {
+                const size_t l = m % 64, j = (m / 64) % 2, kp = m / 128;
+                dst = (kp * 64 + l) * 2 + j;
+            }
+            Bf[2 * dst] = bb[m].real() / (double)M;
+            Bf[2 * dst + 1] = bb[m].imag() / (double)M;
         }
         std::vector<unsigned char> cb, wwb, Bb;
         cast(cf, cb);
@@ -886,6 +895,8 @@ int rr_fourier::transform_dev(const void *head, size_t n_head, const void *in, v
         return RR_OK;
     }
     if (!bs_M) return launch_fourier_overlapped(dtype, stream, head, n_head, in, out, n, hop, count, d_window.p, d_tw.p, center_dc);
+    if (bs_wave)
+        return launch_bluestein1024(stream, head, n_head, in, hop, n, d_bs_c.p, d_bs_B.p, d_bs_w.p, bs_fft->d_tw.p, out, center_dc, count);
     if (bs_fused)
         return launch_bluestein4096(stream, head, n_head, in, hop, n, d_bs_c.p, d_bs_B.p, d_bs_w.p, bs_fft->d_tw.p, out, center_dc, count);
     const size_t M = bs_M;

@@ -176,6 +176,7 @@ struct rr_fourier : rr_block {
     // by a nested rectangular-window Fourier, tables c = window * conj(chirp), B = F(chirp) / M, w = chirp
     size_t bs_M = 0;
     bool bs_fused = false;  // f32, 513 .. 2048 points: k_bluestein4096 (one launch per call)
+    bool bs_wave = false;   // f32, 32 .. 512 points: k_bluestein1024 (a wave per chunk)
     rr_fourier *bs_fft = nullptr;
     rr::DevBuf d_bs_c, d_bs_B, d_bs_w, bs_ws[2];
     ~rr_fourier() override;

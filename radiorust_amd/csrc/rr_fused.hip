@@ -2292,6 +2292,110 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_FLTWOCC
 }
 
 // ---------------------------------------------------------------------------
+// Kernel 2c  k_bluestein1024: the Fourier block for chunk lengths 32 .. 512 that are not powers of two, Bluestein's
+// algorithm with ONE WAVE per chunk - k_filter_wave's two transforms around a table product:
+//   v = x c (c = window conj(chirp), zero beyond n) -> DFT_1024 -> * B (B = DFT_1024(chirp, wrapped) / 1024)
+//   -> IDFT_1024 (the same network run backwards on the conjugate) -> * conj(chirp) -> n bins.
+// c carries one more (zero) entry when n is odd, so that a lane's pair (2 l, 2 l + 1) is one 16-byte read; B is
+// pair-interleaved like k_filter_wave's response.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_FLTWOCC, RR_V_FLTWOCC))) void k_bluestein1024(
+    const float2 *__restrict__ head, long n_head, const float2 *__restrict__ in, long hop, int n,
+    const float2 *__restrict__ c, const float2 *__restrict__ B, const float2 *__restrict__ w,
+    const float2 *__restrict__ tw, float2 *__restrict__ out, int center_dc, unsigned count) {
+    __shared__ __attribute__((aligned(16))) f2 lds[kWaveLds];
+    const int l = threadIdx.x;
+    // chunks dealt to the XCDs in a moving window, 16 neighbouring chunks per XCD (as k_fft1024's frames)
+    const unsigned fr = blockIdx.x / 128 * 128 + (blockIdx.x % 128 & 7) * 16 + (blockIdx.x % 128 >> 3);
+    if (fr >= count) return;
+    const long base = (long)fr * hop - n_head;
+    // every load at a clamped index, selected afterwards (a load under a condition is a round trip of its own)
+    f2 v[16];
+    {
+        float2 xs[16];
+        float4 cs[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int m = 2 * l + 128 * k;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int mc = m + j < n ? m + j : n - 1;
+                const long i = base + mc;
+                xs[2 * k + j] = (i >= 0) ? in[i] : head[n_head + i];
+            }
+            cs[k] = *reinterpret_cast<const float4 *>(c + (m < n ? m : 0));
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int m = 2 * l + 128 * k;
+            const f2 p0 = cmul((f2){xs[2 * k].x, xs[2 * k].y}, (f2){cs[k].x, cs[k].y});
+            const f2 p1 = cmul((f2){xs[2 * k + 1].x, xs[2 * k + 1].y}, (f2){cs[k].z, cs[k].w});
+            v[2 * k] = m < n ? p0 : (f2){0.f, 0.f};
+            v[2 * k + 1] = m + 1 < n ? p1 : (f2){0.f, 0.f};
+        }
+    }
+    f2 t_p1, t_p2[2];
+    {
+        const float4 *tl = reinterpret_cast<const float4 *>(tw + 1024) + l;
+        const float4 s0 = tl[0], s1 = tl[64];
+        t_p1 = (f2){s0.x, s0.y};
+        t_p2[0] = (f2){s0.z, s0.w};
+        t_p2[1] = (f2){s1.x, s1.y};
+    }
+    float4 h4[8];
+    f2 X[16];
+    wave_dft1024(v, X, lds, l, t_p1, t_p2, [&] {
+#pragma unroll
+        for (int kp = 0; kp < 8; ++kp) h4[kp] = reinterpret_cast<const float4 *>(B)[l + 64 * kp];
+    });
+    // the chirp values of the bins this lane will store, requested ahead of the second transform
+    float2 wt[16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int t = 2 * l + j + 128 * k;
+            wt[2 * k + j] = w[t < n ? t : 0];
+        }
+#pragma unroll
+    for (int kp = 0; kp < 8; ++kp) {
+        const f2 p0 = cmul(X[2 * kp], (f2){h4[kp].x, h4[kp].y}), p1 = cmul(X[2 * kp + 1], (f2){h4[kp].z, h4[kp].w});
+        X[2 * kp] = (f2){p0.x, -p0.y};
+        X[2 * kp + 1] = (f2){p1.x, -p1.y};
+    }
+    wave_sync();  // the forward image has been read
+    wave_dft1024_t(X, v, lds, l, t_p1, t_p2);
+    // conj(v[2 k + j]) = IDFT(Z)[t], t = 2 l + j + 128 k; bins t < n leave, times conj(chirp[t])
+    float2 *dst = out + (size_t)fr * n;
+    const int rot = center_dc ? n / 2 : 0;  // rotate_right(n / 2)
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int t = 2 * l + j + 128 * k;
+            const f2 y = {v[2 * k + j].x, -v[2 * k + j].y};
+            const f2 r = cmul_conj(y, (f2){wt[2 * k + j].x, wt[2 * k + j].y});
+            int o = t + rot;
+            if (o >= n) o -= n;
+            if (t < n) dst[o] = float2{r.x, r.y};
+        }
+}
+
+bool bluestein1024_supported(int dtype, size_t n) { return dtype == RR_F32 && n >= 32 && n <= 512 && (n & (n - 1)) != 0; }
+
+int launch_bluestein1024(hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n, const void *c,
+                         const void *Bp, const void *w, const void *tw1024, void *out, bool center_dc, size_t count) {
+    if (count == 0) return RR_OK;
+    if (count > 0x7fffff00ull) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: too many chunks in one call");
+    const unsigned grid = (unsigned)((count + 127) / 128 * 128);
+    hipLaunchKernelGGL(k_bluestein1024, dim3(grid), dim3(64), 0, s, (const float2 *)head, (long)n_head, (const float2 *)in,
+                       (long)hop, (int)n, (const float2 *)c, (const float2 *)Bp, (const float2 *)w, (const float2 *)tw1024,
+                       (float2 *)out, (int)center_dc, (unsigned)count);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
 // Kernel 2w  k_fft1024: window * v -> 1024-point forward DFT with one wave per frame (analysis.rs:105-115
 // for chunks of 1024): the forward network of k_filter_wave on the windowed samples.  Frames come from
 // [ head | in ] at distance `hop` (the overlapped analysis of rr_stft), the twiddle table carries the lane

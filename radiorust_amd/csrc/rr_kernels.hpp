@@ -164,6 +164,11 @@ void append_wave1024_seeds(std::vector<float> &twb);
 bool bluestein4096_supported(int dtype, size_t n);
 int launch_bluestein4096(hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n, const void *c,
                          const void *B, const void *w, const void *tw4096, void *out, bool center_dc, size_t count);
+// k_bluestein1024: chunk lengths 32 .. 512 that are not powers of two, a wave per chunk (tables for M = 1024: c[n (+1)],
+// Bp[1024] pair-interleaved {B[l + 128 kp], B[l + 128 kp + 64]} at [kp][l], w[n]; tw1024 with the lane seeds)
+bool bluestein1024_supported(int dtype, size_t n);
+int launch_bluestein1024(hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n, const void *c,
+                         const void *Bp, const void *w, const void *tw1024, void *out, bool center_dc, size_t count);
 // k_stft4096: runs of overlapping 4096-point frames (hop 256, 512, 1024 or 2048), the sliding window in registers
 bool stft4096_supported(size_t hop);
 int launch_stft4096(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,

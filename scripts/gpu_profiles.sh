@@ -5,6 +5,7 @@
 #   pmc_{sq1,sq2,fetch,write}.summary.txt    separate --pmc passes of `bench.py --profile` (chain launches only)
 #   cfg5_kernel_stats.csv, cfg5_pmc_*.summary.txt   the same for BASELINE configs[4] (scripts/prof_cfg5.py)
 #   blocks.txt, cfg5.txt, cfg3.txt   scripts/bench_blocks.py, bench_cfg5.py, bench_cfg3.py
+#   extras.txt, decim_ab.txt, meter.txt, meter_kernel_stats.csv   bench_extras.py, bench_decim_ab.py, bench_meter.py, prof_meter.py
 # usage: scripts/gpu_profiles.sh TAG
 set -u -o pipefail
 TAG="${1:-prof}"
@@ -50,4 +51,10 @@ step blocks 400 python3 scripts/bench_blocks.py
 step fftsizes 300 python3 scripts/fft_sizes_probe.py
 step cfg5 300 python3 scripts/bench_cfg5.py
 step cfg3 300 python3 scripts/bench_cfg3.py
+step extras 400 python3 scripts/bench_extras.py
+step decim_ab 300 python3 scripts/bench_decim_ab.py
+step meter 200 python3 scripts/bench_meter.py
+step meterprof 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/meterprof" -- python3 scripts/prof_meter.py
+find "$OUT/meterprof" -name '*kernel_stats*.csv' | head -1 | xargs -r -I{} cp {} "$OUT/meter_kernel_stats.csv"
+step smoke 300 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
 echo "=== done"

@@ -540,7 +540,8 @@ def test_fourier_reference_kat_on_gpu(rr):
                                       (1024, True), (2048, False), (2048, True), (2, False), (1, True), (1000, True), (7, True), (4095, False), (12000, False),
                                       (16384, True), (65536, False), (65536, True), (1 << 18, False),   # four-step through HBM
                                       (20000, False), (20000, True), (5000, False), (31, True),          # Bluestein beyond 4096 points; direct below 32
-                                      (513, False), (1025, True), (1999, True), (2047, False)])          # 513 .. 2048: Bluestein in one kernel (k_bluestein4096)
+                                      (513, False), (1025, True), (1999, True), (2047, False),           # 513 .. 2048: Bluestein in one kernel (k_bluestein4096)
+                                      (33, False), (100, True), (255, False), (300, True), (511, True)])  # 32 .. 512: a wave per chunk (k_bluestein1024)
 def test_fourier_parity(rr, oracle, n, center):
     x = oracle.synth_iq(12, 0, n)
     gw, ow = rr.Kaiser.with_null_at_bin(2.0), oracle.Kaiser.with_null_at_bin(2.0)
@@ -564,11 +565,11 @@ def test_fourier_f64_lengths(rr, oracle, n, center):
 
 
 def test_fourier_bluestein_one_kernel_many_chunks(rr, oracle, monkeypatch):
-    """n = 1000 and 1536: 40 chunks in one device call through k_bluestein4096, against the oracle and against the
-    five-launch form (RR_FOURIER_GENERIC=1)."""
+    """n = 1000 and 1536 (k_bluestein4096), 300 and 97 (k_bluestein1024): 40 chunks in one device call, against the oracle
+    and against the five-launch form (RR_FOURIER_GENERIC=1)."""
     import torch
 
-    for n, center in ((1000, False), (1536, True)):
+    for n, center in ((1000, False), (1536, True), (300, True), (97, False)):
         x = oracle.synth_iq(14, 0, n * 40)
         o = oracle.Fourier(oracle.Kaiser.with_null_at_bin(2.0), center, flt=np.float64)
         ref = np.concatenate([o.process(x[i * n:(i + 1) * n]) for i in range(40)])
