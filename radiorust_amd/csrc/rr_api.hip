@@ -2528,7 +2528,19 @@ int rr_channelizer_create_ex(int dtype, size_t bins, size_t taps_per_branch, siz
         tw[2 * k + 1] = std::sin(ang);
     }
     std::vector<unsigned char> wb, tb;
-    if (dtype == RR_F32) {
+    if (dtype == RR_F32 && bins == 1024) {
+        // k_fft1024<FOLD>: all 1024 twiddles and the lane seeds of the wave-level transform behind them
+        cast_to<float>(vals.data(), n, wb);
+        std::vector<float> twb(2 * 1024);
+        for (size_t k = 0; k < 1024; ++k) {
+            const double ang = -2.0 * M_PI * (double)k / 1024.0;
+            twb[2 * k] = (float)std::cos(ang);
+            twb[2 * k + 1] = (float)std::sin(ang);
+        }
+        append_wave1024_seeds(twb);
+        tb.resize(twb.size() * sizeof(float));
+        std::memcpy(tb.data(), twb.data(), tb.size());
+    } else if (dtype == RR_F32) {
         cast_to<float>(vals.data(), n, wb);
         cast_to<float>(tw.data(), bins, tb);
     } else {

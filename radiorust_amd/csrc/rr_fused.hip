@@ -414,16 +414,59 @@ int launch_fused_fir(hipStream_t s, const FusedFirArgs &a) {
 // Downsampler's partly filled output chunk left over by the previous call.
 // (frames round robin over the XCDs: a contiguous eighth per XCD measured 0.181 against 0.176 ms per 2^26 samples, a
 //  moving window no gain)
+// FOLD: the polyphase channelizer with 4096 bins - the frame is the fold of `branches` windowed chunks,
+// v[i] = sum_p w[i + 4096 p] x[base + i + 4096 p] (window: 4096 branches plain values), then the same transform.
+template <bool FOLD>
 __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head, long n_head,
                                                  const float2 *__restrict__ in, float2 *__restrict__ out,
                                                  const float *__restrict__ window, const float2 *__restrict__ tw,
-                                                 int center_dc, long hop, unsigned count) {
+                                                 int center_dc, long hop, unsigned count, int branches) {
     __shared__ f2 lds[4096 + 256];
     const int j = threadIdx.x;
     const unsigned fr = blockIdx.x;
     const long base = (long)fr * hop - n_head;  // index into `in` of this frame's first sample
     float2 *dst = out + (size_t)fr * 4096;
     f2 v[16];
+    if constexpr (FOLD) {
+        const float2 s1 = tw[16 * (j & 15)], s2 = tw[j];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = (f2){0.f, 0.f};
+        for (int p = 0; p < branches; ++p) {
+            const long bp = base + 4096L * p + j;
+            float2 x[16];
+            float w[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const long i = bp + 256 * k;
+                x[k] = (i >= 0) ? in[i] : head[n_head + i];
+                w[k] = window[4096 * p + j + 256 * k];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = __builtin_elementwise_fma((f2){x[k].x, x[k].y}, (f2){w[k], w[k]}, v[k]);
+        }
+        dft16(v);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lds_st(lds + pad16(16 * j + k), v[k]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = lds_ld(lds + pad16(j + 256 * k));
+        apply_twiddle_powers(v, (f2){s1.x, s1.y});
+        dft16(v);
+        __syncthreads();
+        {
+            const int b2 = (j >> 4) * 256 + (j & 15);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) lds_st(lds + pad16(b2 + 16 * k), v[k]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = lds_ld(lds + pad16(j + 256 * k));
+        apply_twiddle_powers(v, (f2){s2.x, s2.y});
+        dft16(v);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) __builtin_nontemporal_store(v[k], reinterpret_cast<f2 *>(dst) + (j + 256 * k));
+        return;
+    }
     // the lane's 16 window values as 4 loads of 16 bytes (packed copy behind the table), its two twiddle
     // seeds up front, the frame's samples with the streaming hint when frames do not overlap
     float wv[16];
@@ -498,13 +541,25 @@ int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *i
     if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fft4096: too many frames");
     const unsigned grid = (unsigned)count;
     if (ev_start && ev_stop)
-        hipExtLaunchKernelGGL(k_fft4096, dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, (const float2 *)head,
+        hipExtLaunchKernelGGL(k_fft4096<false>, dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, (const float2 *)head,
                               (long)n_head, (const float2 *)in, (float2 *)out, (const float *)window,
-                              (const float2 *)tw4096, (int)center_dc, (long)hop, (unsigned)count);
+                              (const float2 *)tw4096, (int)center_dc, (long)hop, (unsigned)count, 1);
     else
-        hipLaunchKernelGGL(k_fft4096, dim3(grid), dim3(256), 0, s, (const float2 *)head, (long)n_head,
+        hipLaunchKernelGGL(k_fft4096<false>, dim3(grid), dim3(256), 0, s, (const float2 *)head, (long)n_head,
                            (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw4096,
-                           (int)center_dc, (long)hop, (unsigned)count);
+                           (int)center_dc, (long)hop, (unsigned)count, 1);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// the 4096-bin polyphase channelizer (see k_fft4096<true>)
+int launch_chan4096(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
+                    const void *window, const void *tw4096, size_t hop, size_t branches) {
+    if (count == 0) return RR_OK;
+    if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: too many frames");
+    hipLaunchKernelGGL(k_fft4096<true>, dim3((unsigned)count), dim3(256), 0, s, (const float2 *)head, (long)n_head,
+                       (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw4096, 0, (long)hop,
+                       (unsigned)count, (int)branches);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
@@ -2401,9 +2456,13 @@ int launch_bluestein1024(hipStream_t s, const void *head, size_t n_head, const v
 // [ head | in ] at distance `hop` (the overlapped analysis of rr_stft), the twiddle table carries the lane
 // seeds behind its 1024 entries (rr_fourier::prepare).
 // ---------------------------------------------------------------------------
+// FOLD: the polyphase channelizer with 1024 bins (BASELINE configs[2] at another size): the frame is the fold of
+// `branches` windowed chunks, v[i] = sum_p w[i + 1024 p] x[base + i + 1024 p], then the same transform.
+template <bool FOLD>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fft1024(
     const float2 *__restrict__ head, long n_head, const float2 *__restrict__ in, float2 *__restrict__ out,
-    const float *__restrict__ window, const float2 *__restrict__ tw, int center_dc, long hop, unsigned count) {
+    const float *__restrict__ window, const float2 *__restrict__ tw, int center_dc, long hop, unsigned count,
+    int branches) {
     __shared__ __attribute__((aligned(16))) f2 lds[kWaveLds];
     const int l = threadIdx.x;
     // frames dealt to the XCDs in a moving window, 16 neighbouring frames per XCD
@@ -2411,7 +2470,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     if (fr >= count) return;
     const long base = (long)fr * hop - n_head;
     f2 v[16];
-    if (base >= 0) {
+    if constexpr (FOLD) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = (f2){0.f, 0.f};
+        for (int p = 0; p < branches; ++p) {
+            const long bp = base + 1024L * p;
+            if (bp >= 0) {
+                const f4u *src = reinterpret_cast<const f4u *>(in + bp) + l;
+                f4u x[8];
+                float2 w[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    x[k] = *(src + 64 * k);
+                    w[k] = *reinterpret_cast<const float2 *>(window + 1024 * p + 2 * l + 128 * k);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v[2 * k] = __builtin_elementwise_fma((f2){x[k].x, x[k].y}, (f2){w[k].x, w[k].x}, v[2 * k]);
+                    v[2 * k + 1] = __builtin_elementwise_fma((f2){x[k].z, x[k].w}, (f2){w[k].y, w[k].y}, v[2 * k + 1]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const long i = bp + 2 * l + j + 128 * k;
+                        const float2 x = (i >= 0) ? in[i] : head[n_head + i];
+                        const float w = window[1024 * p + 2 * l + j + 128 * k];
+                        v[2 * k + j] = __builtin_elementwise_fma((f2){x.x, x.y}, (f2){w, w}, v[2 * k + j]);
+                    }
+            }
+        }
+    } else if (base >= 0) {
         const f4u *src = reinterpret_cast<const f4u *>(in + base) + l;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -2452,9 +2542,23 @@ int launch_fft1024(hipStream_t s, const void *head, size_t n_head, const void *i
     if (count == 0) return RR_OK;
     if (count > 0x7fffff00ull) RR_FAIL(RR_ERR_BAD_ARG, "fft1024: too many frames");
     const unsigned grid = (unsigned)((count + 127) / 128 * 128);
-    hipLaunchKernelGGL(k_fft1024, dim3(grid), dim3(64), 0, s, (const float2 *)head, (long)n_head, (const float2 *)in,
+    hipLaunchKernelGGL(k_fft1024<false>, dim3(grid), dim3(64), 0, s, (const float2 *)head, (long)n_head, (const float2 *)in,
                        (float2 *)out, (const float *)window, (const float2 *)tw1024, (int)center_dc, (long)hop,
-                       (unsigned)count);
+                       (unsigned)count, 1);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// the 1024-bin polyphase channelizer: frame f = DFT_1024 of the fold of `branches` windowed chunks starting hop f
+// samples behind the start of [ head | in ]; window: 1024 branches values; tw1024 with the lane seeds
+int launch_chan1024(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
+                    const void *window, const void *tw1024, size_t hop, size_t branches) {
+    if (count == 0) return RR_OK;
+    if (count > 0x7fffff00ull) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: too many frames");
+    const unsigned grid = (unsigned)((count + 127) / 128 * 128);
+    hipLaunchKernelGGL(k_fft1024<true>, dim3(grid), dim3(64), 0, s, (const float2 *)head, (long)n_head, (const float2 *)in,
+                       (float2 *)out, (const float *)window, (const float2 *)tw1024, 0, (long)hop, (unsigned)count,
+                       (int)branches);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
