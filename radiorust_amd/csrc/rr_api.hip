@@ -751,7 +751,7 @@ int rr_fourier::prepare(size_t len) {
     RR_TRY(fourier_design_window(len, rel.data(), vals.data()));
     const bool pow2 = is_pow2_sz(len);
     const bool generic = [] { const char *e = std::getenv("RR_FOURIER_GENERIC"); return e && std::atoi(e) != 0; }();
-    const bool use_big = pow2 && !fourier_pow2_path(dtype, len);
+    const bool use_big = pow2 && len >= 4 && !fourier_pow2_path(dtype, len);  // (a chunk of 1 sample is a power of two, too)
     const bool use_bs = !pow2 && len >= 32 && !(generic && len <= 16384);
     auto cast = [&](const std::vector<double> &src, std::vector<unsigned char> &dst) {
         if (dtype == RR_F32) cast_to<float>(src.data(), src.size(), dst);
@@ -759,7 +759,42 @@ int rr_fourier::prepare(size_t len) {
     };
     std::vector<unsigned char> wb, tb;
     cast(vals, wb);
-    if (use_big) {
+    big_t = false;
+    if (use_big && !generic) {
+        // four-step as row transforms between tiled transposes: nested transforms of N1 and N2 points and the
+        // twiddles W_len^e = tA[e >> h] tB[e & (2^h - 1)]
+        size_t N1, N2;
+        fft_big_split(len, &N1, &N2);
+        int lg = 0;
+        while (((size_t)1 << lg) < len) ++lg;
+        const int h = (lg + 1) / 2;
+        const size_t nB = (size_t)1 << h, nA = len >> h;
+        std::vector<double> tw(2 * (nA + nB));
+        for (size_t i = 0; i < nB; ++i) {
+            const double ang = -2.0 * M_PI * (double)i / (double)len;
+            tw[2 * i] = std::cos(ang);
+            tw[2 * i + 1] = std::sin(ang);
+        }
+        for (size_t i = 0; i < nA; ++i) {
+            const double ang = -2.0 * M_PI * (double)(i << h) / (double)len;
+            tw[2 * (nB + i)] = std::cos(ang);
+            tw[2 * (nB + i) + 1] = std::sin(ang);
+        }
+        cast(tw, tb);
+        RR_TRY(upload(d_window, wb.data(), wb.size(), stream));
+        RR_TRY(upload(d_tw, tb.data(), tb.size(), stream));
+        for (rr_fourier **sub : {&bigA, &bigB}) {
+            if (!*sub) {
+                *sub = new rr_fourier;
+                RR_TRY((*sub)->init_base(K_FOURIER, dtype, device));
+            }
+            (*sub)->stream = stream;
+        }
+        RR_TRY(bigA->prepare(N1));  // rectangular windows: all ones
+        RR_TRY(bigB->prepare(N2));
+        big_t = true;
+        big_h = h;
+    } else if (use_big) {
         // half tables e^{-j 2 pi k / N1}, e^{-j 2 pi k / N2} of the four-step split, one behind the other
         size_t N1, N2;
         fft_big_split(len, &N1, &N2);
@@ -872,7 +907,11 @@ int rr_fourier::prepare(size_t len) {
     return RR_OK;
 }
 
-rr_fourier::~rr_fourier() { delete bs_fft; }
+rr_fourier::~rr_fourier() {
+    delete bs_fft;
+    delete bigA;
+    delete bigB;
+}
 
 int rr_fourier::transform_dev(const void *head, size_t n_head, const void *in, void *out, size_t hop, size_t count) {
     const size_t esz = elem_size(dtype);
@@ -886,6 +925,23 @@ int rr_fourier::transform_dev(const void *head, size_t n_head, const void *in, v
         RR_TRY(big_ws.reserve(per_pass * n * esz));
         size_t N1, N2;
         fft_big_split(n, &N1, &N2);
+        if (big_t) {
+            RR_TRY(big_ws2.reserve(per_pass * n * esz));
+            bigA->stream = bigB->stream = stream;
+            const char *tB = d_tw.as<char>(), *tA = tB + ((size_t)1 << big_h) * esz;
+            for (size_t f0 = 0; f0 < count; f0 += per_pass) {
+                const size_t F = count - f0 < per_pass ? count - f0 : per_pass;
+                const char *src = static_cast<const char *>(in) + f0 * n * esz;
+                char *dst = static_cast<char *>(out) + f0 * n * esz;
+                RR_TRY(launch_transpose_mul(dtype, stream, src, big_ws.p, N1, N2, F, 1, d_window.p, nullptr, nullptr, 0, 0));
+                RR_TRY(bigA->transform_dev(nullptr, 0, big_ws.p, big_ws2.p, N1, F * N2));
+                RR_TRY(launch_transpose_mul(dtype, stream, big_ws2.p, big_ws.p, N2, N1, F, 2, nullptr, tB, tA, big_h, 0));
+                RR_TRY(bigB->transform_dev(nullptr, 0, big_ws.p, big_ws2.p, N2, F * N1));
+                RR_TRY(launch_transpose_mul(dtype, stream, big_ws2.p, dst, N1, N2, F, 0, nullptr, nullptr, nullptr, 0,
+                                            center_dc ? N2 / 2 : 0));
+            }
+            return RR_OK;
+        }
         const char *tw2 = d_tw.as<char>() + (N1 / 2) * esz;
         for (size_t f0 = 0; f0 < count; f0 += per_pass) {
             const size_t F = count - f0 < per_pass ? count - f0 : per_pass;

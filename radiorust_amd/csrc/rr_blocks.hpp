@@ -172,6 +172,12 @@ struct rr_fourier : rr_block {
     // powers of two beyond the LDS kernels (up to 2^24): four-step through a workspace in HBM
     bool big = false;
     rr::DevBuf big_ws;
+    // .. by default as row transforms between tiled transposes (launch_transpose_mul): nested rectangular-window
+    // transforms of N1 and N2 points, twiddle tables tB (2^big_h entries) | tA behind each other in d_tw
+    bool big_t = false;
+    int big_h = 0;
+    rr_fourier *bigA = nullptr, *bigB = nullptr;
+    rr::DevBuf big_ws2;
     // Bluestein for lengths that are not powers of two (n >= 32, either dtype): two transforms of bs_M points
     // by a nested rectangular-window Fourier, tables c = window * conj(chirp), B = F(chirp) / M, w = chirp
     size_t bs_M = 0;

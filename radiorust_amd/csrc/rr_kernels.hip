@@ -768,6 +768,74 @@ int launch_fft_big(int dtype, hipStream_t s, const void *in, void *out, void *ws
     return launch_fft_big_t<double>(s, in, out, ws, n, count, window, tw1, tw2, center_dc);
 }
 
+// ---------------------------------------------------------------------------
+// Four-step transform, second form (the default): the column transforms become ROW transforms between three tiled
+// transposes, so that both sets of sub-transforms run through the fast contiguous kernels (k_fft64 .. k_fft8192)
+// instead of the strided radix-2 kernel above:
+//   T1  y[n2][n1] = w[N2 n1 + n2] x[N2 n1 + n2]          rows of N1 -> DFT_N1 -> Y[n2][k1]
+//   T2  z[k1][n2] = Y[n2][k1] W_N^(n2 k1)                 rows of N2 -> DFT_N2 -> Z[k1][k2]
+//   T3  X[k1 + N1 k2] = Z[k1][k2]                          (rows rotated by N2 / 2 for center_dc)
+// W_N^e = tA[e >> h] tB[e & (2^h - 1)], two tables of about sqrt(N) entries computed in f64.
+// A 32 x 32 tile per workgroup through LDS (rows padded to 33), every global access 256 contiguous bytes.
+// ---------------------------------------------------------------------------
+template <class T, int MODE>
+__global__ __launch_bounds__(256) void k_transpose_mul(const v2<T> *__restrict__ in, v2<T> *__restrict__ out, int R, int C,
+                                                       const T *__restrict__ window, const v2<T> *__restrict__ tB,
+                                                       const v2<T> *__restrict__ tA, int h, int rot_rows) {
+    __shared__ v2<T> tile[32][33];
+    const size_t chunk = (size_t)blockIdx.z * R * C;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        v2<T> v = in[chunk + (size_t)r * C + c];
+        if (MODE == 1) {
+            const T w = window[(size_t)r * C + c];
+            v.x *= w;
+            v.y *= w;
+        } else if (MODE == 2) {
+            const unsigned e = ((unsigned)r * (unsigned)c) & ((unsigned)R * (unsigned)C - 1u);
+            const v2<T> w = cmul<T>(tA[e >> h], tB[e & ((1u << h) - 1u)]);
+            v = cmul<T>(v, w);
+        }
+        tile[ty + 8 * i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = c0 + ty + 8 * i;
+        const int r = r0 + tx;
+        const v2<T> v = tile[tx][ty + 8 * i];
+        c += rot_rows;
+        if (c >= C) c -= C;
+        out[chunk + (size_t)c * R + r] = v;
+    }
+}
+
+int launch_transpose_mul(int dtype, hipStream_t s, const void *in, void *out, size_t R, size_t C, size_t count, int mode,
+                         const void *window, const void *tB, const void *tA, int h, size_t rot_rows) {
+    if (count == 0) return RR_OK;
+    if (R % 32 || C % 32 || count > 65535 || R * C > ((size_t)1 << 24))
+        RR_FAIL(RR_ERR_BAD_ARG, "transpose: %zu x %zu x %zu is outside the tiled kernel's range", R, C, count);
+    const dim3 grid((unsigned)(C / 32), (unsigned)(R / 32), (unsigned)count);
+#define RR_TR(TT, VV, MM)                                                                                             \
+    hipLaunchKernelGGL((k_transpose_mul<TT, MM>), grid, dim3(256), 0, s, (const VV *)in, (VV *)out, (int)R, (int)C, \
+                       (const TT *)window, (const VV *)tB, (const VV *)tA, h, (int)rot_rows)
+    if (dtype == RR_F32) {
+        if (mode == 1) RR_TR(float, float2, 1);
+        else if (mode == 2) RR_TR(float, float2, 2);
+        else RR_TR(float, float2, 0);
+    } else {
+        if (mode == 1) RR_TR(double, double2, 1);
+        else if (mode == 2) RR_TR(double, double2, 2);
+        else RR_TR(double, double2, 0);
+    }
+#undef RR_TR
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
 int launch_fourier_overlapped(int dtype, hipStream_t s, const void *head, size_t n_head, const void *in, void *out,
                               size_t n, size_t hop, size_t count, const void *window, const void *twiddle, bool center_dc) {
     if (count == 0) return RR_OK;

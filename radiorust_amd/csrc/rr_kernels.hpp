@@ -139,6 +139,10 @@ int launch_bs_post(int dtype, hipStream_t s, const void *ws, const void *w, size
                    size_t frames);
 // power-of-two transforms beyond one LDS tile (up to 2^24 points): four-step through a workspace of count * n elements;
 // tw1 / tw2 = e^{-j 2 pi k / N1}, e^{-j 2 pi k / N2} (half tables) for the split of fft_big_split
+// tiled transpose of `count` R x C matrices with a factor on the way: mode 0 none (rows of the result rotated by rot_rows),
+// 1 window[r C + c] (real), 2 the four-step twiddle W_(R C)^(r c) = tA[e >> h] tB[e & (2^h - 1)]
+int launch_transpose_mul(int dtype, hipStream_t s, const void *in, void *out, size_t R, size_t C, size_t count, int mode,
+                         const void *window, const void *tB, const void *tA, int h, size_t rot_rows);
 bool fft_big_supported(size_t n);
 void fft_big_split(size_t n, size_t *N1, size_t *N2);
 int launch_fft_big(int dtype, hipStream_t s, const void *in, void *out, void *ws, size_t n, size_t count, const void *window,
