@@ -445,6 +445,7 @@ int rr_downsampler::process_dev(double input_rate, const void *d_in, size_t n_in
             f.H = f_H.p;
             f.tw4096 = f_tw.p;
             f.V = f_V;
+            f.poly = f_poly;
             next.advance(n_in, nullptr);
             if (fast_kind == rr_chain::FK_OLSW)
                 RR_TRY(launch_ols_wave(stream, f));
@@ -546,6 +547,7 @@ int rr_downsampler::ensure_fast() {
         RR_TRY(upload(f_H, t.H.data(), t.H.size() * sizeof(float), stream));
         RR_TRY(upload(f_tw, t.tw.data(), t.tw.size() * sizeof(float), stream));
         f_V = t.V;
+        f_poly = t.poly;
     }
     // NCO table of period 1: entry, wrap entry and the 8 rotations behind them (rr_freqshifter::prepare)
     float ones[2 * 10];
@@ -1298,6 +1300,7 @@ int rr_chain::pick_fused_kernel(uint64_t D, size_t lc, bool real_taps, size_t ff
 void build_fused_fir_tables(int kind, uint64_t D_, const std::vector<double> &c, const std::vector<cd> &cc, FusedFirTables &t) {
     const size_t lc = c.size();
     t.kind = kind;
+    t.poly = false;
     const bool wave = kind == rr_chain::FK_OLSW || kind == rr_chain::FK_OLSF;
     if (wave || kind == rr_chain::FK_OLS) {
         // H = DFT_N(c) / N (the inverse transform in the kernel is unnormalised)
@@ -1313,7 +1316,28 @@ void build_fused_fir_tables(int kind, uint64_t D_, const std::vector<double> &c,
             twb[2 * i] = (float)std::cos(ang);
             twb[2 * i + 1] = (float)std::sin(ang);
         }
-        if (wave) {  // k_ols_wave reads H as Hp[kp][l] = {H[l + 128 kp], H[l + 128 kp + 64]}, kp < 8, l < 64
+        static const bool no_poly = [] { const char *e = std::getenv("RR_OLSW_POLY"); return e && std::atoi(e) == 0; }();
+        if (kind == rr_chain::FK_OLSW && D_ == 4 && !no_poly) {
+            // k_ols_wave<4, POLY>: Y[k] = sum_p X_p[k] G_p[k] over the four phases x_p[m] = xs[4 m + p],
+            // G_p[k] = sum_q H[k + 256 q] W_1024^((k + 256 q) p), k < 256; the kernel reads {G_p[l + 128 h], G_p[l + 128 h + 64]}
+            // at [2 p + h][l]  (RR_OLSW_POLY=0 keeps the 1024-point forward transform: A/B runs)
+            std::vector<float> gp(2 * N);
+            for (size_t pp = 0; pp < 4; ++pp)
+                for (size_t k = 0; k < 256; ++k) {
+                    cd g(0, 0);
+                    for (size_t qq = 0; qq < 4; ++qq) {
+                        const size_t kk = k + 256 * qq;
+                        const double ang = -2.0 * M_PI * (double)((kk * pp) % 1024) / 1024.0;
+                        g += h[kk] / (double)N * cd(std::cos(ang), std::sin(ang));
+                    }
+                    const size_t l = k % 64, c = k / 64, dst = ((2 * pp + c / 2) * 64 + l) * 2 + (c & 1);
+                    gp[2 * dst] = (float)g.real();
+                    gp[2 * dst + 1] = (float)g.imag();
+                }
+            hb.swap(gp);
+            append_wave1024_seeds(twb);
+            t.poly = true;
+        } else if (wave) {  // k_ols_wave reads H as Hp[kp][l] = {H[l + 128 kp], H[l + 128 kp + 64]}, kp < 8, l < 64
             std::vector<float> hp(2 * N);
             for (size_t kp = 0; kp < 8; ++kp)
                 for (size_t l = 0; l < 64; ++l)
@@ -1365,6 +1389,7 @@ int rr_chain::ensure_ctaps() {
         RR_TRY(upload(d_olsH, t.H.data(), t.H.size() * sizeof(float), stream));
         RR_TRY(upload(d_tw4096, t.tw.data(), t.tw.size() * sizeof(float), stream));
         ols_V = t.V;
+        ols_poly = t.poly;
         ols_N = t.N;
     } else {
         RR_TRY(upload(d_ctaps, t.ctaps.data(), t.ctaps.size() * sizeof(float), stream));
@@ -1443,6 +1468,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
         a.H = d_olsH.p;
         a.tw4096 = d_tw4096.p;
         a.V = ols_V;
+        a.poly = ols_poly;
         const int tkf = timers.begin(ST_FUSED_FIR, stream);
         RR_TRY(launch_ols_frame(stream, a, pin, pending_len, pendbuf[po].p, d_out, fo->d_window.p, fo->d_tw.p,
                                 fo->center_dc));
@@ -1481,6 +1507,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     a.H = d_olsH.p;
     a.tw4096 = d_tw4096.p;
     a.V = ols_V;
+    a.poly = ols_poly;
     // k_ols_wave + k_fft4096: the launches record their own start / end (no marker packets, which
     // cost ~4 us of stream time each); the other kernels are bracketed by recorded events
     const bool ext = timers.on && use_ols && ols_N == 1024 && split && dec > 0;

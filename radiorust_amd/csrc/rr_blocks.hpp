@@ -57,6 +57,7 @@ struct FusedFirTables {
     int kind = 0;
     std::vector<float> ctaps, H, tw;
     int Gp = 0, V = 0, N = 0;
+    bool poly = false;  // H = the polyphase tables of k_ols_wave<4, POLY>
 };
 void build_fused_fir_tables(int kind, uint64_t D, const std::vector<double> &c, const std::vector<rr::cd> &cc, FusedFirTables &t);
 
@@ -78,6 +79,7 @@ struct rr_downsampler : rr_block {
     uint64_t fast_version = ~0ull;
     rr::DevBuf f_ctaps, f_H, f_tw, f_one;
     int f_Gp = 0, f_V = 0;
+    bool f_poly = false;
     // k_decim_poly (any integer ratio, short-period rational ratios): taps in f_ctaps, laid out for the schedule phase
     int f_NC = 0;
     uint64_t poly_version = ~0ull;
@@ -269,6 +271,7 @@ struct rr_chain : rr_block {
     // overlap-save variant of the fused FIR (k_ols_decim4)
     bool use_ols = false;
     int ols_V = 0;
+    bool ols_poly = false;
     int ols_N = 4096;  // 4096: k_ols_decim4 (workgroup per block), 1024: k_ols_wave (wave per block)
     rr::DevBuf d_olsH, d_tw4096;
     bool fused_candidate(double sample_rate) const;

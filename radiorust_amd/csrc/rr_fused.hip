@@ -1296,7 +1296,17 @@ constexpr unsigned kWaveWin = 64;  // blocks dealt to the XCDs in a moving windo
 // aliasing in frequency: Y[i] = sum_q X[i + (1024 / D) q] H[..]) and differ in the inverse only: 512 points as the
 // forward radix 8 x 8 x 8 routine of k_fft512 with the result index reversed (IDFT(Z)[t] = DFT(Z)[(N - t) mod N]),
 // 128 points as radix 2 x 4 x 4 x 4 on the lower half of the wave.
-template <int D>
+// POLY (D = 4 only): the forward transform in polyphase form.  With x_p[m] = xs[4 m + p], X[k + 256 q] =
+// sum_p W_1024^((k + 256 q) p) X_p[k] (X_p = DFT_256 x_p), so the folded spectrum is
+//   Y[k] = sum_p X_p[k] G_p[k],   G_p[k] = sum_q H[k + 256 q] W_1024^((k + 256 q) p)   (host, f64),
+// four 256-point transforms (radix 8 x 8 x 4) and the same 16 products instead of one 1024-point transform: the last
+// radix-4 stage of the long transform and a third of the twiddles are gone (-90 of 520 vector instructions per block,
+// k_ols_wave 0.1337 -> 0.129 ms by an instruction-count ablation before it was written).  A lane's 16 samples are two
+// phases p = 2 (l & 1) + j at m = (l >> 1) + 32 k', so the passes are: radix 8 over k' in the lane (as before),
+// twiddle W_256^(mu kappa1), exchange, radix 8 over mu2 (mu = mu1 + 4 mu2), exchange, twiddle W_32^(mu1 kappa2a),
+// radix 4 over mu1 for all four phases in lane kappa1 + 8 kappa2a - which leaves X_p[l + 64 c], the very layout the
+// product with G and the inverse DFT_256 want.  Both exchanges move (j = 0, 1) pairs as 16-byte accesses.
+template <int D, bool POLY>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ols_wave(
     const float2 *__restrict__ xh, int hx, const float2 *__restrict__ in, long n_in, const float2 *__restrict__ nco,
     unsigned denom, unsigned idx0, const float2 *__restrict__ H, const float2 *__restrict__ tw, int V,
@@ -1312,6 +1322,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const unsigned blk = grp * 8 * G + (rem & 7) * G + (rem >> 3);
     if (blk >= nblocks) return;
     static_assert(D == 2 || D == 4 || D == 8, "fold 2, 4 or 8");
+    static_assert(!POLY || D == 4, "the polyphase forward transform is written for the fold by 4");
     constexpr int ND = 16 / D;  // bins per lane behind the fold
     const int hop = 1024 - V, per_block = hop / D;
     const long b0 = e0 - V + (long)blk * hop;
@@ -1368,7 +1379,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         t_p1 = (f2){s0.x, s0.y};
         t_p2[0] = (f2){s0.z, s0.w};
         t_p2[1] = (f2){s1.x, s1.y};
-        if (D == 4) {
+        if (POLY) {  // tw[4 (l >> 1)], tw[32 (l >> 3)] and the three seeds of the inverse
+            const float4 s6 = tl[384], s7 = tl[448], s8 = tl[512];
+            t_p1 = (f2){s6.x, s6.y};
+            t_p2[0] = (f2){s6.z, s6.w};
+            t_inv[0] = (f2){s7.x, s7.y};
+            t_inv[1] = (f2){s7.z, s7.w};
+            t_inv[2] = (f2){s8.x, s8.y};
+        } else if (D == 4) {
             const float4 s2 = tl[128];
             t_inv[0] = (f2){s1.z, s1.w};
             t_inv[1] = (f2){s2.x, s2.y};
@@ -1454,6 +1472,84 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         hv[2 * kp + 1] = float2{h4.z, h4.w};
     }
     f2 y[ND];
+    if constexpr (POLY) {
+        // ---- four DFT_256 of the phases x_p[m] = xs[4 m + p]: radix 8 (k') x 8 (mu2) x 4 (mu1) --------------------
+        f2 e0[8], e1[8];  // phase j = 0 / 1 of this lane, over k'
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            e0[k] = v[2 * k];
+            e1[k] = v[2 * k + 1];
+        }
+        dft8(e0);
+        dft8(e1);
+        {   // * W_256^(mu kappa1), mu = l >> 1: powers of one seed
+            const f2 w1 = t_p1, w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+            const f2 w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+            e0[1] = cmul(e0[1], w1); e1[1] = cmul(e1[1], w1);
+            e0[2] = cmul(e0[2], w2); e1[2] = cmul(e1[2], w2);
+            e0[3] = cmul(e0[3], w3); e1[3] = cmul(e1[3], w3);
+            e0[4] = cmul(e0[4], w4); e1[4] = cmul(e1[4], w4);
+            e0[5] = cmul(e0[5], w5); e1[5] = cmul(e1[5], w5);
+            e0[6] = cmul(e0[6], w6); e1[6] = cmul(e1[6], w6);
+            e0[7] = cmul(e0[7], w7); e1[7] = cmul(e1[7], w7);
+        }
+        // exchange 1: element (a, j, kappa1, mu) at 2 (l + 72 kappa1) + j  (l = a + 2 mu); the reader - lane
+        // a + 2 mu1 + 8 kappa1 - takes mu = mu1 + 4 mu2: 2 ((l & 7) + 72 (l >> 3) + 8 mu2) + j
+        {
+            f2 *row = lds + 2 * l;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) *reinterpret_cast<float4 *>(row + 144 * k) = (float4){e0[k].x, e0[k].y, e1[k].x, e1[k].y};
+        }
+        wave_sync();
+        {
+            const f2 *col = lds + 2 * ((l & 7) + 72 * (l >> 3));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float4 r = *reinterpret_cast<const float4 *>(col + 16 * k);
+                e0[k] = (f2){r.x, r.y};
+                e1[k] = (f2){r.z, r.w};
+            }
+        }
+        dft8(e0);  // over mu2: out kappa2a
+        dft8(e1);
+        wave_sync();  // the first image has been read
+        // exchange 2: element (a, j, kappa1, mu1, kappa2a) at 2 (kappa1 + 8 kappa2a + 66 mu1 + 264 a) + j; the reader is lane
+        // kappa1 + 8 kappa2a
+        {
+            f2 *row = lds + 2 * ((l >> 3) + 66 * ((l >> 1) & 3) + 264 * (l & 1));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) *reinterpret_cast<float4 *>(row + 16 * k) = (float4){e0[k].x, e0[k].y, e1[k].x, e1[k].y};
+        }
+        wave_sync();
+        f2 d[4][4];  // [phase p][mu1]
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int m1 = 0; m1 < 4; ++m1) {
+                const float4 r = *reinterpret_cast<const float4 *>(lds + 2 * l + 132 * m1 + 528 * a);
+                d[2 * a][m1] = (f2){r.x, r.y};
+                d[2 * a + 1][m1] = (f2){r.z, r.w};
+            }
+        {   // * W_32^(mu1 kappa2a), kappa2a = l >> 3, then radix 4 over mu1: X_p[l + 64 c]
+            const f2 w1 = t_p2[0], w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                d[pp][1] = cmul(d[pp][1], w1);
+                d[pp][2] = cmul(d[pp][2], w2);
+                d[pp][3] = cmul(d[pp][3], w3);
+                dft4(d[pp][0], d[pp][1], d[pp][2], d[pp][3]);
+            }
+        }
+        // Y[l + 64 c] = sum_p X_p[l + 64 c] G_p[l + 64 c]; the table holds {G_p[l + 128 h], G_p[l + 128 h + 64]} at [2 p + h][l]
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f2 acc = cmul(d[0][c], (f2){hv[c].x, hv[c].y});
+            acc = cmac(acc, d[1][c], (f2){hv[4 + c].x, hv[4 + c].y});
+            acc = cmac(acc, d[2][c], (f2){hv[8 + c].x, hv[8 + c].y});
+            acc = cmac(acc, d[3][c], (f2){hv[12 + c].x, hv[12 + c].y});
+            y[c] = acc;
+        }
+    } else {
     // ---- forward DFT_1024 = radix 8 x 16 x 8 (Stockham) -------------------------------------------
     // pass 0 (Ns = 1): butterflies 2 l + j over x[2 l + j + 128 k']; out 8 (2 l + j) + r = 16 l + 8 j + r
     {
@@ -1522,6 +1618,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
         for (int q2 = 1; q2 < D; ++q2) acc = cmac(acc, X[m + ND * q2], (f2){hv[m + ND * q2].x, hv[m + ND * q2].y});
         y[m] = acc;
+    }
     }
     const int first = V / D;
     const long mb = (long)blk * per_block;
@@ -2095,7 +2192,7 @@ int ols_wave_overlap(size_t Lc) {  // V: multiple of 64 covering the Lc - 1 wrap
 
 bool ols_wave_supported(uint64_t D, size_t Lc) { return (D == 2 || D == 4 || D == 8) && Lc >= 1 && Lc - 1 <= 512; }
 
-template <int D>
+template <int D, bool POLY>
 static int launch_ols_wave_d(hipStream_t s, const FusedFirArgs &a) {
     const int per_block = (1024 - a.V) / D;
     const size_t nblocks = (a.n_out + per_block - 1) / per_block;
@@ -2106,13 +2203,13 @@ static int launch_ols_wave_d(hipStream_t s, const FusedFirArgs &a) {
     const unsigned hopm = (unsigned)((int64_t)(1024 - a.V) % den), kstep = (unsigned)(128 % den);
     const unsigned grid = (unsigned)((nblocks + 8 * kWaveWin - 1) / (8 * kWaveWin) * (8 * kWaveWin));
     if (a.ev_start && a.ev_stop)
-        hipExtLaunchKernelGGL(k_ols_wave<D>, dim3(grid), dim3(64), 0, s, a.ev_start, a.ev_stop, 0, (const float2 *)a.xh, (int)a.hx,
+        hipExtLaunchKernelGGL((k_ols_wave<D, POLY>), dim3(grid), dim3(64), 0, s, a.ev_start, a.ev_stop, 0, (const float2 *)a.xh, (int)a.hx,
                               (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0,
                               (const float2 *)a.H, (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out,
                               (long)a.e0, (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, kstep,
                               1.0 / (double)den);
     else
-        hipLaunchKernelGGL(k_ols_wave<D>, dim3(grid), dim3(64), 0, s, (const float2 *)a.xh, (int)a.hx,
+        hipLaunchKernelGGL((k_ols_wave<D, POLY>), dim3(grid), dim3(64), 0, s, (const float2 *)a.xh, (int)a.hx,
                            (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0,
                            (const float2 *)a.H, (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out, (long)a.e0,
                            (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, kstep, 1.0 / (double)den);
@@ -2123,9 +2220,9 @@ static int launch_ols_wave_d(hipStream_t s, const FusedFirArgs &a) {
 int launch_ols_wave(hipStream_t s, const FusedFirArgs &a) {
     if (a.n_out == 0) return RR_OK;
     switch (a.D) {
-    case 2: return launch_ols_wave_d<2>(s, a);
-    case 4: return launch_ols_wave_d<4>(s, a);
-    case 8: return launch_ols_wave_d<8>(s, a);
+    case 2: return launch_ols_wave_d<2, false>(s, a);
+    case 4: return a.poly ? launch_ols_wave_d<4, true>(s, a) : launch_ols_wave_d<4, false>(s, a);
+    case 8: return launch_ols_wave_d<8, false>(s, a);
     }
     RR_FAIL(RR_ERR_BAD_ARG, "fused OLS: decimation %u not instantiated", a.D);
 }
@@ -2571,10 +2668,10 @@ void append_wave1024_seeds(std::vector<float> &twb) {
         dst[0] = twb[2 * i];
         dst[1] = twb[2 * i + 1];
     };
-    twb.resize(2 * (N + 2 * 6 * 64));
+    twb.resize(2 * (N + 2 * 9 * 64));
     for (size_t l = 0; l < 64; ++l) {
         float *e0 = &twb[2 * N + 4 * l], *e1 = e0 + 4 * 64, *e2 = e1 + 4 * 64, *e3 = e2 + 4 * 64, *e4 = e3 + 4 * 64,
-              *e5 = e4 + 4 * 64;
+              *e5 = e4 + 4 * 64, *e6 = e5 + 4 * 64, *e7 = e6 + 4 * 64, *e8 = e7 + 4 * 64;
         twv(8 * (l & 7), e0);         // pass 1
         twv(l, e0 + 2);               // pass 2, m = 0
         twv(l + 64, e1);              // pass 2, m = 1
@@ -2587,6 +2684,12 @@ void append_wave1024_seeds(std::vector<float> &twb) {
         twv(16 * (l & 7), e4 + 2);    // k_ols_wave<2>: DFT_512, passes 1 and 2
         twv(2 * l, e5);
         e5[2] = e5[3] = 0.f;
+        twv(4 * (l >> 1), e6);        // k_ols_wave<4, POLY>: W_256^(l >> 1), W_32^(l >> 3), then the inverse's three
+        twv(32 * (l >> 3), e6 + 2);
+        twv(64 * (l & 3), e7);
+        twv(16 * (l & 15), e7 + 2);
+        twv(4 * l, e8);
+        e8[2] = e8[3] = 0.f;
     }
 }
 

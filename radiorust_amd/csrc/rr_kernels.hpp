@@ -104,6 +104,7 @@ struct FusedFirArgs {
     const void *H = nullptr;       // DFT_4096(c) / 4096, complex f32
     const void *tw4096 = nullptr;  // e^{-j 2 pi k / 4096}
     int V = 0;                     // overlap (samples), multiple of 256
+    bool poly = false;             // k_ols_wave<4>: H holds the polyphase tables G_p (build_fused_fir_tables)
     // optional: the launch itself records its start / end in these events (hipExtLaunchKernel):
     // kernel-only timing without marker packets on the stream
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
