@@ -1351,7 +1351,9 @@ void build_fused_fir_tables(int kind, uint64_t D_, const std::vector<double> &c,
         }
         t.H.swap(hb);
         t.tw.swap(twb);
-        t.V = wave ? ols_wave_overlap(lc) : ols_decim_overlap(lc);
+        // k_ols_wave: the overlap in steps of 16 samples - block starts stay on 128-byte lines (in steps of 8, cfg2's
+        // V = 184 instead of 192 measured 0.5-3 % SLOWER: every other block then starts in the middle of a line)
+        t.V = wave ? ols_wave_overlap(lc, kind == rr_chain::FK_OLSF ? 64 : 16) : ols_decim_overlap(lc);
         t.N = (int)N;
         return;
     }

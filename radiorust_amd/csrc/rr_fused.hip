@@ -1762,7 +1762,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 // fill) writes its samples to `pend_out` instead of transforming them, and leaves the mixed-sample
 // history for the next call.
 // ---------------------------------------------------------------------------
-int ols_wave_overlap(size_t Lc);
+int ols_wave_overlap(size_t Lc, size_t granule);
 #define RR_V_FRAMEWIN 1  // frames round robin over the XCDs: 0.1915 ms; a contiguous eighth per XCD (0): 0.1965
 #define RR_V_FRAMEWAVES 4  // measured (full-size images): 4 waves 0.233 ms, 5 waves 0.30 (one workgroup per CU), 8 waves 0.26, 10 waves 0.28
 constexpr int kFrameWaves = RR_V_FRAMEWAVES, kFrameBlocks = 20;
@@ -2141,7 +2141,7 @@ __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_e
 }
 
 bool ols_frame_supported(uint64_t D, size_t Lc, size_t fft_len) {
-    return D == 4 && fft_len == 4096 && Lc >= 1 && ols_wave_overlap(Lc) == 192;  // 208 outputs per block compiled in
+    return D == 4 && fft_len == 4096 && Lc >= 1 && ols_wave_overlap(Lc, 64) == 192;  // 208 outputs per block compiled in
 }
 
 int launch_ols_frame(hipStream_t s, const FusedFirArgs &a, const void *pend_in, size_t pl, void *pend_out, void *spectra,
@@ -2185,9 +2185,11 @@ int launch_ols_frame(hipStream_t s, const FusedFirArgs &a, const void *pend_in, 
     return RR_OK;
 }
 
-int ols_wave_overlap(size_t Lc) {  // V: multiple of 64 covering the Lc - 1 wrapped samples
-    const size_t v = (Lc - 1 + 63) / 64 * 64;
-    return v == 0 ? 64 : (int)v;
+// V: the Lc - 1 wrapped samples rounded up to a multiple of `granule` - 16 for k_ols_wave (V / D whole for D = 2, 4, 8,
+// block starts on 128-byte lines), 64 for k_ols_frame (208 outputs per block compiled in)
+int ols_wave_overlap(size_t Lc, size_t granule) {
+    const size_t v = (Lc - 1 + granule - 1) / granule * granule;
+    return v == 0 ? (int)granule : (int)v;
 }
 
 bool ols_wave_supported(uint64_t D, size_t Lc) { return (D == 2 || D == 4 || D == 8) && Lc >= 1 && Lc - 1 <= 512; }

@@ -119,7 +119,7 @@ bool filter_wave_supported(int dtype, size_t n);
 int launch_filter_wave(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *H,
                        const void *tw, int V, void *out, size_t n_out, long e0);
 bool ols_wave_supported(uint64_t D, size_t Lc);
-int ols_wave_overlap(size_t Lc);
+int ols_wave_overlap(size_t Lc, size_t granule = 16);
 int launch_ols_wave(hipStream_t s, const FusedFirArgs &a);
 // k_ols_frame: the same stage + the 4096-point Fourier stage in one kernel (a workgroup per frame of the
 // decimated stream; H / tw4096 fields as for launch_ols_wave).  pend_in: pl decimated samples pending from
