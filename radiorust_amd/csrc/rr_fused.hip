@@ -409,6 +409,9 @@ int launch_fused_fir(hipStream_t s, const FusedFirArgs &a) {
 
 // ---------------------------------------------------------------------------
 // 4096-point windowed FFT, radix 16 x 3
+#ifndef RR_V_FFT_LD_NT
+#define RR_V_FFT_LD_NT 1  // streaming hint on the frame loads when frames do not overlap
+#endif
 // ---------------------------------------------------------------------------
 // The input stream of frames is [ head (n_head samples) | in ]: the head is the
 // Downsampler's partly filled output chunk left over by the previous call.
@@ -485,7 +488,8 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
     if (base >= 0 && hop >= 4096) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const f2 x = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(in + base + j) + 256 * k);
+            const f2 x = RR_V_FFT_LD_NT ? __builtin_nontemporal_load(reinterpret_cast<const f2 *>(in + base + j) + 256 * k)
+                                        : *(reinterpret_cast<const f2 *>(in + base + j) + 256 * k);
             v[k] = x * wv[k];
         }
     } else {
@@ -1290,6 +1294,11 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));  // two compl
 // (the sample stream passes through once: with the streaming hint it does not displace the 16 KiB of H / twiddle
 //  tables from the CU's 32 KiB L1)
 __device__ __forceinline__ f4u ld_stream(const f4u *p) { return __builtin_nontemporal_load(p); }
+#ifndef RR_V_OLSW_ST_AUX
+#define RR_V_OLSW_ST_AUX 0  // cache policy of the decimated samples' stores: default.  With the streaming hint (2) the kernel
+                            // itself is as fast, but the Fourier stage behind it in the chain then reads its 134 MB from HBM
+                            // instead of (mostly) the memory-side cache: k_fft4096 0.048 -> 0.043 ms, chain step 0.1764 -> 0.173 ms
+#endif
 constexpr unsigned kWaveWin = 64;  // blocks dealt to the XCDs in a moving window, that many neighbouring blocks per XCD
                                    // (one contiguous eighth of the stream per XCD: 0.1375 -> 0.135 ms; 16 .. 1024 alike)
 // D = 4 is the benchmark's form.  D = 2 and D = 8 fold the spectrum into 2 resp. 8 parts instead of 4 (decimation =
@@ -1669,7 +1678,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         for (int c = 0; c < 4; ++c) {
             const int tau = l + 64 * c;
             const unsigned off = tau >= first ? (unsigned)(tau - first) * 8u : 0xffffffffu;
-            __builtin_amdgcn_raw_buffer_store_b64(y[c], rs, off, 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b64(y[c], rs, off, 0, RR_V_OLSW_ST_AUX);
         }
     } else if constexpr (D == 2) {
         // ---- inverse DFT_512 as the forward radix 8 x 8 x 8 (k_fft512's passes) with the result index reversed ----
