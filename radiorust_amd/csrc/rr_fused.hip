@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
                                                  int center_dc, long hop, unsigned count, int branches) {
     __shared__ f2 lds[4096 + 256];
     const int j = threadIdx.x;
-    const unsigned fr = blockIdx.x;
+    const unsigned fr = blockIdx.x;  // (frames in reverse order - the most recently written first - measured no different in the chain)
     const long base = (long)fr * hop - n_head;  // index into `in` of this frame's first sample
     float2 *dst = out + (size_t)fr * 4096;
     f2 v[16];
@@ -1084,6 +1084,8 @@ static unsigned stft_run_length(size_t count) {
 }
 
 bool stft4096_supported(size_t hop) { return hop == 256 || hop == 512 || hop == 1024 || hop == 2048; }
+// (hop 4096 = frames side by side, i.e. only the request one frame ahead at 3 workgroups per CU, measured slower than
+//  k_fft4096: 0.220 against 0.175 ms per 2^26 samples, chain step 0.182 against 0.174)
 
 int launch_stft4096(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
                     const void *window, const void *tw4096, bool center_dc, size_t hop) {
