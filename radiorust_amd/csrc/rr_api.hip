@@ -1317,20 +1317,22 @@ void build_fused_fir_tables(int kind, uint64_t D_, const std::vector<double> &c,
             twb[2 * i + 1] = (float)std::sin(ang);
         }
         static const bool no_poly = [] { const char *e = std::getenv("RR_OLSW_POLY"); return e && std::atoi(e) == 0; }();
-        if (kind == rr_chain::FK_OLSW && D_ == 4 && !no_poly) {
-            // k_ols_wave<4, POLY>: Y[k] = sum_p X_p[k] G_p[k] over the four phases x_p[m] = xs[4 m + p],
-            // G_p[k] = sum_q H[k + 256 q] W_1024^((k + 256 q) p), k < 256; the kernel reads {G_p[l + 128 h], G_p[l + 128 h + 64]}
-            // at [2 p + h][l]  (RR_OLSW_POLY=0 keeps the 1024-point forward transform: A/B runs)
+        if (kind == rr_chain::FK_OLSW && (D_ == 2 || D_ == 4 || D_ == 8) && !no_poly) {
+            // k_ols_wave<D, POLY>: Y[k] = sum_p X_p[k] G_p[k] over the D phases x_p[m] = xs[D m + p] (X_p = DFT_(1024/D) x_p),
+            // G_p[k] = sum_q H[k + (1024 / D) q] W_1024^((k + (1024 / D) q) p), k < 1024 / D; lane l = k mod 64 reads entry
+            // i = (16 / D) p + k / 64 as one half of the 16-byte piece [i >> 1][l]   (RR_OLSW_POLY=0 keeps the 1024-point
+            // forward transform: A/B runs)
+            const size_t D = (size_t)D_, NB = 1024 / D, ND = 16 / D;
             std::vector<float> gp(2 * N);
-            for (size_t pp = 0; pp < 4; ++pp)
-                for (size_t k = 0; k < 256; ++k) {
+            for (size_t pp = 0; pp < D; ++pp)
+                for (size_t k = 0; k < NB; ++k) {
                     cd g(0, 0);
-                    for (size_t qq = 0; qq < 4; ++qq) {
-                        const size_t kk = k + 256 * qq;
+                    for (size_t qq = 0; qq < D; ++qq) {
+                        const size_t kk = k + NB * qq;
                         const double ang = -2.0 * M_PI * (double)((kk * pp) % 1024) / 1024.0;
                         g += h[kk] / (double)N * cd(std::cos(ang), std::sin(ang));
                     }
-                    const size_t l = k % 64, c = k / 64, dst = ((2 * pp + c / 2) * 64 + l) * 2 + (c & 1);
+                    const size_t l = k % 64, c = k / 64, i = ND * pp + c, dst = ((i >> 1) * 64 + l) * 2 + (i & 1);
                     gp[2 * dst] = (float)g.real();
                     gp[2 * dst + 1] = (float)g.imag();
                 }

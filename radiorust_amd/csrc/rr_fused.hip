@@ -1317,13 +1317,16 @@ constexpr unsigned kWaveWin = 64;  // blocks dealt to the XCDs in a moving windo
 // twiddle W_256^(mu kappa1), exchange, radix 8 over mu2 (mu = mu1 + 4 mu2), exchange, twiddle W_32^(mu1 kappa2a),
 // radix 4 over mu1 for all four phases in lane kappa1 + 8 kappa2a - which leaves X_p[l + 64 c], the very layout the
 // product with G and the inverse DFT_256 want.  Both exchanges move (j = 0, 1) pairs as 16-byte accesses.
+#ifndef RR_V_OLSW_OCC
+#define RR_V_OLSW_OCC 4
+#endif
 template <int D, bool POLY>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ols_wave(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OCC, RR_V_OLSW_OCC))) void k_ols_wave(
     const float2 *__restrict__ xh, int hx, const float2 *__restrict__ in, long n_in, const float2 *__restrict__ nco,
     unsigned denom, unsigned idx0, const float2 *__restrict__ H, const float2 *__restrict__ tw, int V,
     float2 *__restrict__ out, long n_out, long e0, float2 *__restrict__ xh_out, int hx_out, unsigned nblocks,
     unsigned ph0, unsigned hopm, unsigned kstep, double inv_denom) {
-    __shared__ __attribute__((aligned(16))) f2 lds[kWaveLds];
+    __shared__ __attribute__((aligned(16))) f2 lds[POLY ? 1136 : kWaveLds];  // (POLY: 2 (63 + 72 * 7) + 2 elements)
     const int l = threadIdx.x;
     // Workgroups b, b+8, .. share an XCD.  Blocks are dealt so that neighbouring blocks run on one XCD - the V
     // samples two neighbours share come from HBM once -, and the XCDs work side by side in a moving window of
@@ -1333,7 +1336,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const unsigned blk = grp * 8 * G + (rem & 7) * G + (rem >> 3);
     if (blk >= nblocks) return;
     static_assert(D == 2 || D == 4 || D == 8, "fold 2, 4 or 8");
-    static_assert(!POLY || D == 4, "the polyphase forward transform is written for the fold by 4");
     constexpr int ND = 16 / D;  // bins per lane behind the fold
     const int hop = 1024 - V, per_block = hop / D;
     const long b0 = e0 - V + (long)blk * hop;
@@ -1390,13 +1392,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         t_p1 = (f2){s0.x, s0.y};
         t_p2[0] = (f2){s0.z, s0.w};
         t_p2[1] = (f2){s1.x, s1.y};
-        if (POLY) {  // tw[4 (l >> 1)], tw[32 (l >> 3)] and the three seeds of the inverse
+        if (POLY && D == 4) {  // tw[4 (l >> 1)], tw[32 (l >> 3)] and the three seeds of the inverse
             const float4 s6 = tl[384], s7 = tl[448], s8 = tl[512];
             t_p1 = (f2){s6.x, s6.y};
             t_p2[0] = (f2){s6.z, s6.w};
             t_inv[0] = (f2){s7.x, s7.y};
             t_inv[1] = (f2){s7.z, s7.w};
             t_inv[2] = (f2){s8.x, s8.y};
+        } else if (POLY && D == 8) {  // tw[8 (l >> 2)], tw[64 (l >> 3)]; the inverse's as below
+            const float4 s9 = tl[576], s3 = tl[192], s4 = tl[256];
+            t_p1 = (f2){s9.x, s9.y};
+            t_p2[0] = (f2){s9.z, s9.w};
+            t_inv[0] = (f2){s3.x, s3.y};
+            t_inv[1] = (f2){s3.z, s3.w};
+            t_inv[2] = (f2){s4.x, s4.y};
+        } else if (POLY) {  // D = 2: tw[2 l], tw[16 (l >> 3)]; the inverse's tw[16 (l mod 8)], tw[2 l]
+            const float4 s9 = tl[640], s4 = tl[256];
+            t_p1 = (f2){s9.x, s9.y};
+            t_p2[0] = (f2){s9.z, s9.w};
+            t_inv[0] = (f2){s4.z, s4.w};
+            t_inv[1] = t_p1;
+            t_inv[2] = t_p1;
         } else if (D == 4) {
             const float4 s2 = tl[128];
             t_inv[0] = (f2){s1.z, s1.w};
@@ -1484,8 +1500,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
     f2 y[ND];
     if constexpr (POLY) {
-        // ---- four DFT_256 of the phases x_p[m] = xs[4 m + p]: radix 8 (k') x 8 (mu2) x 4 (mu1) --------------------
-        f2 e0[8], e1[8];  // phase j = 0 / 1 of this lane, over k'
+        // ---- the D transforms of 1024 / D points of the phases x_p[m] = xs[D m + p]: radix 8 (k') x 8 (mu2) x RC (mu1) ----
+        // lane l = low3 + 8 mu2, low3 = a + (D / 2) mu1: phases p = 2 a + j, mu = mu1 + RC mu2, m = mu + (128 / D) k'
+        constexpr int RC = 16 / D;  // radix of the last pass = bins per lane (ND)
+        f2 e0[8], e1[8];            // phase j = 0 / 1 of this lane, over k'
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             e0[k] = v[2 * k];
@@ -1493,7 +1511,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         dft8(e0);
         dft8(e1);
-        {   // * W_256^(mu kappa1), mu = l >> 1: powers of one seed
+        {   // * W_(1024/D)^(mu kappa1): powers of one seed
             const f2 w1 = t_p1, w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
             const f2 w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
             e0[1] = cmul(e0[1], w1); e1[1] = cmul(e1[1], w1);
@@ -1504,8 +1522,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             e0[6] = cmul(e0[6], w6); e1[6] = cmul(e1[6], w6);
             e0[7] = cmul(e0[7], w7); e1[7] = cmul(e1[7], w7);
         }
-        // exchange 1: element (a, j, kappa1, mu) at 2 (l + 72 kappa1) + j  (l = a + 2 mu); the reader - lane
-        // a + 2 mu1 + 8 kappa1 - takes mu = mu1 + 4 mu2: 2 ((l & 7) + 72 (l >> 3) + 8 mu2) + j
+        // exchange 1: element (low3, mu2, j, kappa1) at 2 (l + 72 kappa1) + j; the reader - lane low3 + 8 kappa1 - takes
+        // mu2 = 0 .. 7: 2 ((l & 7) + 72 (l >> 3) + 8 mu2) + j
         {
             f2 *row = lds + 2 * l;
 #pragma unroll
@@ -1524,40 +1542,56 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         dft8(e0);  // over mu2: out kappa2a
         dft8(e1);
         wave_sync();  // the first image has been read
-        // exchange 2: element (a, j, kappa1, mu1, kappa2a) at 2 (kappa1 + 8 kappa2a + 66 mu1 + 264 a) + j; the reader is lane
-        // kappa1 + 8 kappa2a
+        // exchange 2: element (low3, kappa1, j, kappa2a) at 2 (kappa1 + 8 kappa2a + 66 low3) + j; the reader is lane kappa1 + 8 kappa2a
         {
-            f2 *row = lds + 2 * ((l >> 3) + 66 * ((l >> 1) & 3) + 264 * (l & 1));
+            f2 *row = lds + 2 * ((l >> 3) + 66 * (l & 7));
 #pragma unroll
             for (int k = 0; k < 8; ++k) *reinterpret_cast<float4 *>(row + 16 * k) = (float4){e0[k].x, e0[k].y, e1[k].x, e1[k].y};
         }
         wave_sync();
-        f2 d[4][4];  // [phase p][mu1]
+        f2 d[D][RC];  // [phase p][mu1]
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < D / 2; ++a)
 #pragma unroll
-            for (int m1 = 0; m1 < 4; ++m1) {
-                const float4 r = *reinterpret_cast<const float4 *>(lds + 2 * l + 132 * m1 + 528 * a);
+            for (int m1 = 0; m1 < RC; ++m1) {
+                const float4 r = *reinterpret_cast<const float4 *>(lds + 2 * l + 132 * (a + (D / 2) * m1));
                 d[2 * a][m1] = (f2){r.x, r.y};
                 d[2 * a + 1][m1] = (f2){r.z, r.w};
             }
-        {   // * W_32^(mu1 kappa2a), kappa2a = l >> 3, then radix 4 over mu1: X_p[l + 64 c]
-            const f2 w1 = t_p2[0], w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+        {   // * W_(8 RC)^(mu1 kappa2a), kappa2a = l >> 3, then radix RC over mu1: X_p[l + 64 c]
+            f2 w[RC];
+            w[1] = t_p2[0];
+            if constexpr (RC >= 4) {
+                w[2] = cmul(w[1], w[1]);
+                w[3] = cmul(w[2], w[1]);
+            }
+            if constexpr (RC == 8) {
+                w[4] = cmul(w[2], w[2]);
+                w[5] = cmul(w[4], w[1]);
+                w[6] = cmul(w[4], w[2]);
+                w[7] = cmul(w[4], w[3]);
+            }
 #pragma unroll
-            for (int pp = 0; pp < 4; ++pp) {
-                d[pp][1] = cmul(d[pp][1], w1);
-                d[pp][2] = cmul(d[pp][2], w2);
-                d[pp][3] = cmul(d[pp][3], w3);
-                dft4(d[pp][0], d[pp][1], d[pp][2], d[pp][3]);
+            for (int pp = 0; pp < D; ++pp) {
+#pragma unroll
+                for (int m1 = 1; m1 < RC; ++m1) d[pp][m1] = cmul(d[pp][m1], w[m1]);
+                if constexpr (RC == 2) {
+                    const f2 s0 = d[pp][0] + d[pp][1], s1 = d[pp][0] - d[pp][1];
+                    d[pp][0] = s0;
+                    d[pp][1] = s1;
+                } else if constexpr (RC == 4) {
+                    dft4(d[pp][0], d[pp][1], d[pp][2], d[pp][3]);
+                } else {
+                    dft8(d[pp]);
+                }
             }
         }
-        // Y[l + 64 c] = sum_p X_p[l + 64 c] G_p[l + 64 c]; the table holds {G_p[l + 128 h], G_p[l + 128 h + 64]} at [2 p + h][l]
+        // Y[l + 64 c] = sum_p X_p[l + 64 c] G_p[l + 64 c]; the table holds entry i = ND p + c as half of the 16-byte piece [i >> 1][l]
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < ND; ++c) {
             f2 acc = cmul(d[0][c], (f2){hv[c].x, hv[c].y});
-            acc = cmac(acc, d[1][c], (f2){hv[4 + c].x, hv[4 + c].y});
-            acc = cmac(acc, d[2][c], (f2){hv[8 + c].x, hv[8 + c].y});
-            acc = cmac(acc, d[3][c], (f2){hv[12 + c].x, hv[12 + c].y});
+#pragma unroll
+            for (int pp = 1; pp < D; ++pp) acc = cmac(acc, d[pp][c], (f2){hv[ND * pp + c].x, hv[ND * pp + c].y});
             y[c] = acc;
         }
     } else {
@@ -2233,9 +2267,9 @@ static int launch_ols_wave_d(hipStream_t s, const FusedFirArgs &a) {
 int launch_ols_wave(hipStream_t s, const FusedFirArgs &a) {
     if (a.n_out == 0) return RR_OK;
     switch (a.D) {
-    case 2: return launch_ols_wave_d<2, false>(s, a);
+    case 2: return a.poly ? launch_ols_wave_d<2, true>(s, a) : launch_ols_wave_d<2, false>(s, a);
     case 4: return a.poly ? launch_ols_wave_d<4, true>(s, a) : launch_ols_wave_d<4, false>(s, a);
-    case 8: return launch_ols_wave_d<8, false>(s, a);
+    case 8: return a.poly ? launch_ols_wave_d<8, true>(s, a) : launch_ols_wave_d<8, false>(s, a);
     }
     RR_FAIL(RR_ERR_BAD_ARG, "fused OLS: decimation %u not instantiated", a.D);
 }
@@ -2681,10 +2715,10 @@ void append_wave1024_seeds(std::vector<float> &twb) {
         dst[0] = twb[2 * i];
         dst[1] = twb[2 * i + 1];
     };
-    twb.resize(2 * (N + 2 * 9 * 64));
+    twb.resize(2 * (N + 2 * 11 * 64));
     for (size_t l = 0; l < 64; ++l) {
         float *e0 = &twb[2 * N + 4 * l], *e1 = e0 + 4 * 64, *e2 = e1 + 4 * 64, *e3 = e2 + 4 * 64, *e4 = e3 + 4 * 64,
-              *e5 = e4 + 4 * 64, *e6 = e5 + 4 * 64, *e7 = e6 + 4 * 64, *e8 = e7 + 4 * 64;
+              *e5 = e4 + 4 * 64, *e6 = e5 + 4 * 64, *e7 = e6 + 4 * 64, *e8 = e7 + 4 * 64, *e9 = e8 + 4 * 64, *e10 = e9 + 4 * 64;
         twv(8 * (l & 7), e0);         // pass 1
         twv(l, e0 + 2);               // pass 2, m = 0
         twv(l + 64, e1);              // pass 2, m = 1
@@ -2703,6 +2737,10 @@ void append_wave1024_seeds(std::vector<float> &twb) {
         twv(16 * (l & 15), e7 + 2);
         twv(4 * l, e8);
         e8[2] = e8[3] = 0.f;
+        twv(8 * (l >> 2), e9);        // k_ols_wave<8, POLY>: W_128^(l >> 2), W_16^(l >> 3)
+        twv(64 * (l >> 3), e9 + 2);
+        twv(2 * l, e10);              // k_ols_wave<2, POLY>: W_512^l, W_64^(l >> 3)
+        twv(16 * (l >> 3), e10 + 2);
     }
 }
 
