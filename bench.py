@@ -10,7 +10,7 @@ Fourier 4096-pt, Kaiser null-at-bin 2.  A step = one pass of the chain over one
 batch of 2^26 synthetic complex samples already resident in HBM (the stream
 continues from step to step, so every step is steady state).
 
-  python bench.py --gpus N --steps K --warmup W      (defaults: N = 1, K = 200, W = 20; ~1 s of GPU time)
+  python bench.py --gpus N --steps K --warmup W      (defaults: N = 1, K = 400, W = 20; ~1 s of GPU time)
 
 Before the W warm-up steps the chain runs for --settle-ms (100 ms) so that the GPU's power management
 has reached its steady state: measured on MI355X, the first ~10 steps after an idle gap run at 0.201
@@ -145,7 +145,7 @@ def cpu_baseline(budget_s: float = 6.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--samples", type=int, default=1 << 26, help="complex samples per step per GPU")
     ap.add_argument("--settle-ms", type=float, default=100.0, help="GPU load before the warm-up steps, for steady clocks")
