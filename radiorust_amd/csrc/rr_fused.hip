@@ -572,10 +572,12 @@ int launch_chan4096(hipStream_t s, const void *head, size_t n_head, const void *
 // Kernel 2s  k_fft512: window * v -> 512-point forward DFT, radix 8 x 8 x 8, one wave per frame (8 values per
 // lane, wave-local exchanges through a padded 4.5 KiB image).
 // ---------------------------------------------------------------------------
+// (FOLD: the 512-bin polyphase channelizer - the frame is the fold of `branches` windowed chunks)
+template <bool FOLD>
 __global__ __launch_bounds__(64) void k_fft512(const float2 *__restrict__ head, long n_head,
                                                const float2 *__restrict__ in, float2 *__restrict__ out,
                                                const float *__restrict__ window, const float2 *__restrict__ tw,
-                                               int center_dc, long hop, unsigned count) {
+                                               int center_dc, long hop, unsigned count, int branches) {
     __shared__ f2 lds[512 + 64];
     const int l = threadIdx.x;
     // frames dealt to the XCDs in a moving window, 16 neighbouring frames per XCD
@@ -583,12 +585,29 @@ __global__ __launch_bounds__(64) void k_fft512(const float2 *__restrict__ head, 
     if (fr >= count) return;
     const long base = (long)fr * hop - n_head;
     f2 a[8];
+    if constexpr (FOLD) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const long i = base + l + 64 * k;
-        const float2 x = (i >= 0) ? in[i] : head[n_head + i];
-        const float w = window[l + 64 * k];
-        a[k] = (f2){x.x * w, x.y * w};
+        for (int k = 0; k < 8; ++k) a[k] = (f2){0.f, 0.f};
+        for (int p = 0; p < branches; ++p) {
+            float2 x[8];
+            float w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const long i = base + 512L * p + l + 64 * k;
+                x[k] = (i >= 0) ? in[i] : head[n_head + i];
+                w[k] = window[512 * p + l + 64 * k];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = __builtin_elementwise_fma((f2){x[k].x, x[k].y}, (f2){w[k], w[k]}, a[k]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const long i = base + l + 64 * k;
+            const float2 x = (i >= 0) ? in[i] : head[n_head + i];
+            const float w = window[l + 64 * k];
+            a[k] = (f2){x.x * w, x.y * w};
+        }
     }
     const float2 s1 = tw[8 * (l & 7)], s2 = tw[l];  // tw[k] = e^{-j 2 pi k / 512}
     dft8(a);  // pass 0 (Ns = 1): out 8 l + k
@@ -621,9 +640,21 @@ int launch_fft512(hipStream_t s, const void *head, size_t n_head, const void *in
     if (count == 0) return RR_OK;
     if (count > 0x7fffff00ull) RR_FAIL(RR_ERR_BAD_ARG, "fft512: too many frames");
     const unsigned grid = (unsigned)((count + 127) / 128 * 128);
-    hipLaunchKernelGGL(k_fft512, dim3(grid), dim3(64), 0, s, (const float2 *)head, (long)n_head, (const float2 *)in,
+    hipLaunchKernelGGL(k_fft512<false>, dim3(grid), dim3(64), 0, s, (const float2 *)head, (long)n_head, (const float2 *)in,
                        (float2 *)out, (const float *)window, (const float2 *)tw512, (int)center_dc, (long)hop,
-                       (unsigned)count);
+                       (unsigned)count, 1);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+int launch_chan512(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
+                   const void *window, const void *tw512, size_t hop, size_t branches) {
+    if (count == 0) return RR_OK;
+    if (count > 0x7fffff00ull) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: too many frames");
+    const unsigned grid = (unsigned)((count + 127) / 128 * 128);
+    hipLaunchKernelGGL(k_fft512<true>, dim3(grid), dim3(64), 0, s, (const float2 *)head, (long)n_head, (const float2 *)in,
+                       (float2 *)out, (const float *)window, (const float2 *)tw512, 0, (long)hop, (unsigned)count,
+                       (int)branches);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
@@ -711,15 +742,33 @@ int launch_fft_small(hipStream_t s, const void *in, void *out, size_t n, size_t 
 // k_fft4096 (analysis.rs:105-115; rr_stft with 2048-sample spans).  The window table carries a packed copy
 // behind its 2048 entries (wp[16 t + k] = w[t + 128 k], rr_fourier::prepare).
 // ---------------------------------------------------------------------------
+// (FOLD: the 2048-bin polyphase channelizer - the frame is the fold of `branches` windowed chunks, window: plain values)
+template <bool FOLD>
 __global__ __launch_bounds__(128) void k_fft2048(const float2 *__restrict__ head, long n_head,
                                                  const float2 *__restrict__ in, float2 *__restrict__ out,
                                                  const float *__restrict__ window, const float2 *__restrict__ tw,
-                                                 int center_dc, long hop) {
+                                                 int center_dc, long hop, int branches) {
     __shared__ f2 lds[2048 + 128];
     const int t = threadIdx.x;
     const long base = (long)blockIdx.x * hop - n_head;
     f2 v[16];
-    {
+    if constexpr (FOLD) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = (f2){0.f, 0.f};
+        for (int p = 0; p < branches; ++p) {
+            const long bp = base + 2048L * p + t;
+            float2 x[16];
+            float w[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const long i = bp + 128 * k;
+                x[k] = (i >= 0) ? in[i] : head[n_head + i];
+                w[k] = window[2048 * p + t + 128 * k];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = __builtin_elementwise_fma((f2){x[k].x, x[k].y}, (f2){w[k], w[k]}, v[k]);
+        }
+    } else {
         float wv[16];
         const float4 *wp = reinterpret_cast<const float4 *>(window + 2048) + 4 * t;
 #pragma unroll
@@ -790,9 +839,20 @@ int launch_fft2048(hipStream_t s, const void *head, size_t n_head, const void *i
                    const void *window, const void *tw2048, bool center_dc, size_t hop) {
     if (count == 0) return RR_OK;
     if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fft2048: too many frames");
-    hipLaunchKernelGGL(k_fft2048, dim3((unsigned)count), dim3(128), 0, s, (const float2 *)head, (long)n_head,
+    hipLaunchKernelGGL(k_fft2048<false>, dim3((unsigned)count), dim3(128), 0, s, (const float2 *)head, (long)n_head,
                        (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw2048, (int)center_dc,
-                       (long)hop);
+                       (long)hop, 1);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+int launch_chan2048(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
+                    const void *window, const void *tw2048, size_t hop, size_t branches) {
+    if (count == 0) return RR_OK;
+    if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: too many frames");
+    hipLaunchKernelGGL(k_fft2048<true>, dim3((unsigned)count), dim3(128), 0, s, (const float2 *)head, (long)n_head,
+                       (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw2048, 0, (long)hop,
+                       (int)branches);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }

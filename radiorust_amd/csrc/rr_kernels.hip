@@ -974,12 +974,14 @@ int launch_channelizer(int dtype, hipStream_t s, const void *hist, size_t hist_l
     if (channelizer256_supported(dtype, M, P, hop) && !std::getenv("RR_CHANNELIZER_GENERIC"))
         return launch_channelizer256(s, hist, hist_len, in, base0, P, nframes, window, tw, out, hop);
     if (hop != M) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: hop %zu of %zu bins has no fused kernel", hop, M);
-    if (dtype == RR_F32 && (M == 1024 || M == 4096) && !std::getenv("RR_CHANNELIZER_GENERIC")) {
+    if (dtype == RR_F32 && (M == 512 || M == 1024 || M == 2048 || M == 4096) && !std::getenv("RR_CHANNELIZER_GENERIC")) {
         // frame 0 starts at base0 (<= 0) relative to in[0]: the last -base0 samples of the history are its head
         const size_t nh = base0 < 0 ? (size_t)(-base0) : 0;
         if (base0 <= 0 && nh <= hist_len) {
             const char *hd = static_cast<const char *>(hist) + (hist_len - nh) * sizeof(float2);
+            if (M == 512) return launch_chan512(s, hd, nh, in, out, nframes, window, tw, hop, P);
             if (M == 1024) return launch_chan1024(s, hd, nh, in, out, nframes, window, tw, hop, P);
+            if (M == 2048) return launch_chan2048(s, hd, nh, in, out, nframes, window, tw, hop, P);
             return launch_chan4096(s, hd, nh, in, out, nframes, window, tw, hop, P);
         }
     }

@@ -174,10 +174,14 @@ int launch_bluestein4096(hipStream_t s, const void *head, size_t n_head, const v
 bool bluestein1024_supported(int dtype, size_t n);
 int launch_bluestein1024(hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n, const void *c,
                          const void *Bp, const void *w, const void *tw1024, void *out, bool center_dc, size_t count);
-// polyphase channelizers with 1024 / 4096 bins: the Fourier kernels with the fold of `branches` windowed chunks at the load
+// polyphase channelizers with 512 / 1024 / 2048 / 4096 bins: the Fourier kernels with the fold of `branches` windowed chunks at the load
 // (window: bins * branches plain values; tw1024 with the lane seeds / tw4096: at least 256 entries)
 int launch_chan1024(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
                     const void *window, const void *tw1024, size_t hop, size_t branches);
+int launch_chan512(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
+                   const void *window, const void *tw512, size_t hop, size_t branches);
+int launch_chan2048(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
+                    const void *window, const void *tw2048, size_t hop, size_t branches);
 int launch_chan4096(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
                     const void *window, const void *tw4096, size_t hop, size_t branches);
 // k_stft4096: runs of overlapping 4096-point frames (hop 256, 512, 1024 or 2048), the sliding window in registers

@@ -31,7 +31,7 @@ d_in = torch.empty(N, dtype=torch.complex64, device="cuda")
 rr.synth_iq_dev(0, st, 1, 0, N, d_in.data_ptr())
 d_out = torch.empty(2 * N, dtype=torch.complex64, device="cuda")
 
-for M, P, hop in ((256, 4, 256), (256, 4, 128), (256, 4, 64), (100, 4, 100), (1000, 2, 1000), (1024, 8, 1024)):
+for M, P, hop in ((256, 4, 256), (256, 4, 128), (256, 4, 64), (100, 4, 100), (1000, 2, 1000), (1024, 8, 1024), (512, 4, 512), (2048, 4, 2048), (4096, 4, 4096)):
     c = rr.Channelizer(M, P, hop=hop)
     c.set_stream(st)
     n = N // hop * hop

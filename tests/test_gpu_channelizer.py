@@ -42,9 +42,10 @@ def reference_frames(oracle, chunks, M, P, flt, history=None):
                                            (128, 4, np.float64, 1e-12), (256, 2, np.float32, 1e-5), (256, 3, np.float32, 1e-5),
                                            (256, 6, np.float32, 1e-5), (256, 8, np.float32, 1e-5), (256, 5, np.float32, 1e-5),
                                            (256, 4, np.float64, 1e-12),
-                                           # 1024 / 4096 bins: the Fourier kernels with the fold at the load (k_fft1024<true>, k_fft4096<true>)
+                                           # 512 / 1024 / 2048 / 4096 bins: the Fourier kernels with the fold at the load (k_fft512<true> .. k_fft4096<true>)
                                            (1024, 8, np.float32, 1e-5), (1024, 3, np.float32, 1e-5), (1024, 1, np.float32, 1e-5),
-                                           (4096, 2, np.float32, 1e-5), (4096, 5, np.float32, 1e-5), (512, 4, np.float32, 1e-5)])
+                                           (4096, 2, np.float32, 1e-5), (4096, 5, np.float32, 1e-5), (512, 4, np.float32, 1e-5), (512, 1, np.float32, 1e-5),
+                                           (2048, 3, np.float32, 1e-5), (2048, 8, np.float32, 1e-5)])
 def test_channelizer_parity(rr, oracle, M, P, dtype, tol):
     nchunks = 37
     x = oracle.synth_iq(21, 0, M * nchunks)
