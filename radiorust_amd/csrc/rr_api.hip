@@ -295,6 +295,13 @@ int rr_filter::process_dev(double sample_rate, const void *d_in, size_t n_in, vo
         last_kernel = 2;
         // out[m] = sum_p sum_{k < 2048} g[2048 p + k] x[e0 + m - 2048 p - k]: partition p is the 2048-tap kernel run on
         // the stream delayed by 2048 p; the last launch also leaves the next call's history
+        static const bool per_launch = [] { const char *e = std::getenv("RR_FILTER_PARTS"); return e && !std::strcmp(e, "acc"); }();
+        if (!per_launch) {
+            // one launch: the workgroup of a block transforms the stream at every partition's delay and sums the products
+            // before ONE inverse (npart + 1 transforms per block; RR_FILTER_PARTS=acc keeps a launch per partition)
+            RR_TRY(launch_filter_blk4096(stream, hist[cur].p, hist_valid ? n : 0, d_in, n_in, d_G4096.p, d_tw4096.p, 2048, d_out,
+                                         produce, hist_valid ? 0 : (long)n, false, false, hist[cur ^ 1].p, n, false, npart));
+        } else
         for (size_t pt = 0; pt < npart; ++pt)
             RR_TRY(launch_filter_blk4096(stream, hist[cur].p, hist_valid ? n : 0, d_in, n_in,
                                          static_cast<const char *>(d_G4096.p) + pt * 2 * 4096 * sizeof(float), d_tw4096.p, 2048,

@@ -87,12 +87,17 @@ struct Blk4096Args {
     unsigned blk_lo, blk_hi;  // the blocks that lie entirely inside the input
     float2 *hist_out;         // receives the last hist_out_len samples of [ hist | in ] (may be null)
     int hist_out_len;
+    int nparts;               // PARTS: partitions of 2048 taps, G holds their tables one behind the other
 };
 
 // ACC: the block's results are added to what `out` holds (responses longer than 2048 taps run as partitions of 2048,
 // one launch each, the later ones delayed by 2048 p samples and accumulating).
-template <bool OUT16, bool G16, bool ACC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_filter_blk4096(Blk4096Args a) {
+// PARTS: responses beyond 2048 taps in ONE launch.  g = sum_p delay(g_p, 2048 p) with partitions g_p of 2048 taps, so
+// y_block = IDFT( sum_p DFT(x_block delayed by 2048 p) G_p ): the workgroup transforms its block of the stream at the
+// nparts delays, sums the products in registers and runs ONE inverse - nparts + 1 transforms per block where a launch per
+// partition (the first form, kept as ACC) takes 2 nparts and reads and rewrites the output nparts - 1 times.
+template <bool OUT16, bool G16, bool ACC, bool PARTS = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PARTS ? 3 : 4, PARTS ? 3 : 4))) void k_filter_blk4096(Blk4096Args a) {
     __shared__ __attribute__((aligned(16))) f2 img[kImg];
     __shared__ __attribute__((aligned(16))) f2 tab[kTab];
     const int j = threadIdx.x;
@@ -107,28 +112,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (blk >= a.nblocks) return;
     const long b0 = a.e0 - a.V + (long)blk * hop;
 
-    // the block's samples: v[k] = x[b0 + j + 256 k]
+    // the block's samples: v[k] = x[b0 - delay + j + 256 k]
     f2 v[16];
-    if (blk >= a.blk_lo && blk < a.blk_hi) {
-        const __amdgpu_buffer_rsrc_t rs = rsrc_of(a.in + b0, 32768);
+    auto load_block = [&](long delay) {
+        const long bs = b0 - delay;
+        if (blk >= a.blk_lo && blk < a.blk_hi && bs >= 0) {
+            const __amdgpu_buffer_rsrc_t rs = rsrc_of(a.in + bs, 32768);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = buf_ld_f2<2>(rs, 8u * j, 2048u * k);
-    } else {
-        // edges: the previous chunk in front (none after a reset), nothing behind the input
+            for (int k = 0; k < 16; ++k) v[k] = buf_ld_f2<2>(rs, 8u * j, 2048u * k);
+        } else {
+            // edges: the previous chunk in front (none after a reset), nothing behind the input
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const long pos = b0 + j + 256 * k;
-            float2 xv;
-            xv.x = 0.f;
-            xv.y = 0.f;
-            if (pos >= 0) {
-                if (pos < a.n_in) xv = a.in[pos];
-            } else if (pos >= -(long)a.hist_len) {
-                xv = a.hist[a.hist_len + pos];
+            for (int k = 0; k < 16; ++k) {
+                const long pos = bs + j + 256 * k;
+                float2 xv;
+                xv.x = 0.f;
+                xv.y = 0.f;
+                if (pos >= 0) {
+                    if (pos < a.n_in) xv = a.in[pos];
+                } else if (pos >= -(long)a.hist_len) {
+                    xv = a.hist[a.hist_len + pos];
+                }
+                v[k] = (f2){xv.x, xv.y};
             }
-            v[k] = (f2){xv.x, xv.y};
         }
-    }
+    };
+    load_block(0);
     // twiddles: pass 1 e^{-j 2 pi (j mod 16) k / 256} = tw[16 (j mod 16) k] from the LDS table (filled below, read
     // after the first exchange's barrier); pass 2 tw[j]^k by a product tree
     f2 s2;
@@ -169,7 +178,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     f2 *const w0 = img + 17 * j;                              // pad16(16 j + k)  = w0 + k
     f2 *const w1 = img + ((j >> 4) * 272 + (j & 15));         // pad16((j / 16) 256 + j % 16 + 16 k) = w1 + 17 k
     [[maybe_unused]] const f2 *const trow = tab + 15 * (j & 15) - 1;  // W_256^((j mod 16) k) = trow[k]
-    const __amdgpu_buffer_rsrc_t rsG = rsrc_of(a.G, G16 ? 16384 : 32768);
+    const __amdgpu_buffer_rsrc_t rsG = rsrc_of(a.G, PARTS ? 32768u * (unsigned)a.nparts : (G16 ? 16384u : 32768u));
 
     // forward DFT_4096: in v[k] = x[j + 256 k], out v[k] = X[j + 256 k]; `late` runs in front of the last
     // butterflies, where few registers are live (the place to request G)
@@ -201,32 +210,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
     // the lane's 16 G values: 8 reads of 16 (8) bytes, requested in front of the forward transform's last butterflies
     float4 g4[8];
-    transform(false, [&] {
+    auto forward_times_g = [&](bool pre_barrier, unsigned gofs) {
+        transform(pre_barrier, [&] {
+#pragma unroll
+            for (int kp = 0; kp < 8; ++kp) {
+                if constexpr (G16) {
+                    const f2 raw = buf_ld_f2<0>(rsG, 8u * j, 2048u * kp);
+                    g4[kp] = float4{raw.x, raw.y, 0.f, 0.f};
+                } else {
+                    g4[kp] = buf_ld_f4<0>(rsG, 16u * j + gofs, 4096u * kp);
+                }
+            }
+        });
 #pragma unroll
         for (int kp = 0; kp < 8; ++kp) {
+            f2 ga, gb;
             if constexpr (G16) {
-                const f2 raw = buf_ld_f2<0>(rsG, 8u * j, 2048u * kp);
-                g4[kp] = float4{raw.x, raw.y, 0.f, 0.f};
+                const unsigned ra = __float_as_uint(g4[kp].x), rb = __float_as_uint(g4[kp].y);
+                const float2 fa = __half22float2(*reinterpret_cast<const __half2 *>(&ra));
+                const float2 fb = __half22float2(*reinterpret_cast<const __half2 *>(&rb));
+                ga = (f2){fa.x, fa.y};
+                gb = (f2){fb.x, fb.y};
             } else {
-                g4[kp] = buf_ld_f4<0>(rsG, 16u * j, 4096u * kp);
+                ga = (f2){g4[kp].x, g4[kp].y};
+                gb = (f2){g4[kp].z, g4[kp].w};
             }
+            v[2 * kp] = cmul(v[2 * kp], ga);
+            v[2 * kp + 1] = cmul(v[2 * kp + 1], gb);
         }
-    });
+    };
+    if constexpr (PARTS) {
+        f2 acc[16];
+        forward_times_g(false, 0u);
 #pragma unroll
-    for (int kp = 0; kp < 8; ++kp) {
-        f2 ga, gb;
-        if constexpr (G16) {
-            const unsigned ra = __float_as_uint(g4[kp].x), rb = __float_as_uint(g4[kp].y);
-            const float2 fa = __half22float2(*reinterpret_cast<const __half2 *>(&ra));
-            const float2 fb = __half22float2(*reinterpret_cast<const __half2 *>(&rb));
-            ga = (f2){fa.x, fa.y};
-            gb = (f2){fb.x, fb.y};
-        } else {
-            ga = (f2){g4[kp].x, g4[kp].y};
-            gb = (f2){g4[kp].z, g4[kp].w};
+        for (int k = 0; k < 16; ++k) acc[k] = v[k];
+        for (int pt = 1; pt < a.nparts; ++pt) {
+            load_block(2048L * pt);
+            forward_times_g(true, 32768u * (unsigned)pt);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[k] += v[k];
         }
-        v[2 * kp] = cmul(v[2 * kp], ga);
-        v[2 * kp + 1] = cmul(v[2 * kp + 1], gb);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = acc[k];
+    } else {
+        forward_times_g(false, 0u);
     }
     transform(true, [] {});
 
@@ -262,8 +289,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 int launch_filter_blk4096(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *G,
                           const void *tw4096, size_t n, void *out, size_t n_out, long e0, bool out_f16, bool g_f16,
-                          void *hist_out, size_t hist_out_len, bool accumulate) {
+                          void *hist_out, size_t hist_out_len, bool accumulate, size_t nparts) {
     if (n_out == 0) return RR_OK;
+    if (nparts > 1 && (out_f16 || g_f16 || accumulate)) RR_FAIL(RR_ERR_BAD_ARG, "Filter: the partitioned form is f32 only");
     if (accumulate && (out_f16 || g_f16)) RR_FAIL(RR_ERR_BAD_ARG, "Filter: partitions accumulate in f32");
     Blk4096Args a;
     a.hist = (const float2 *)hist;
@@ -278,6 +306,7 @@ int launch_filter_blk4096(hipStream_t s, const void *hist, size_t hist_len, cons
     a.e0 = e0;
     a.hist_out = (float2 *)hist_out;
     a.hist_out_len = (int)hist_out_len;
+    a.nparts = (int)(nparts ? nparts : 1);
     const size_t hop = 4096 - a.V;
     const size_t nblocks = (n_out + hop - 1) / hop;
     if (nblocks > 0x7ffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "Filter: too many blocks");
@@ -293,7 +322,9 @@ int launch_filter_blk4096(hipStream_t s, const void *hist, size_t hist_len, cons
         a.blk_hi = (unsigned)hi;
     }
     const unsigned grid = (unsigned)((nblocks + 127) / 128 * 128);
-    if (accumulate) {
+    if (nparts > 1) {
+        hipLaunchKernelGGL((k_filter_blk4096<false, false, false, true>), dim3(grid), dim3(256), 0, s, a);
+    } else if (accumulate) {
         hipLaunchKernelGGL((k_filter_blk4096<false, false, true>), dim3(grid), dim3(256), 0, s, a);
     } else if (out_f16) {
         if (g_f16) hipLaunchKernelGGL((k_filter_blk4096<true, true, false>), dim3(grid), dim3(256), 0, s, a);

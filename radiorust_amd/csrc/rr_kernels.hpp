@@ -51,7 +51,7 @@ int launch_filter_ols(int dtype, hipStream_t s, const void *hist, const void *in
 bool filter_ols4096_supported(int dtype, size_t n);
 int launch_filter_blk4096(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *G,
                           const void *tw4096, size_t n, void *out, size_t n_out, long e0, bool out_f16, bool g_f16,
-                          void *hist_out, size_t hist_out_len, bool accumulate = false);
+                          void *hist_out, size_t hist_out_len, bool accumulate = false, size_t nparts = 1);
 
 // Downsampler for any integer ratio P : 1 and rational ratios P : Q with Q <= 8 (rr_decim.hip), Complex<f32>:
 // out[Q a + b] = sum_j ir[j] x[e_first[b] + P a - (L - 1) + j] over [ hist | in ]; T = build_decim_poly_taps' table.
