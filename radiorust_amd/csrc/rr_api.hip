@@ -423,7 +423,7 @@ int rr_downsampler::process_dev(double input_rate, const void *d_in, size_t n_in
             RR_TRY(ensure_poly_taps(e_first));
             next.advance(n_in, nullptr);
             RR_TRY(launch_decim_poly(stream, hist[cur].p, L, d_in, n_in, f_ctaps.p, sched.P, sched.Q, f_NC, L, e_first[0],
-                                     d_out, produce, hist[cur ^ 1].p, L, nco, nco_denom, nco_idx0));
+                                     d_out, produce, hist[cur ^ 1].p, L, nco, nco_denom, nco_idx0, dtype));
             sched = next;
             cur ^= 1;
             last_kernel = fast_kind;
@@ -509,7 +509,7 @@ int rr_downsampler::ensure_poly_taps(const int64_t *e_first) {
     if (poly_version == design_version && delta == poly_delta) return RR_OK;
     std::vector<uint32_t> T;
     int lp = 0;
-    build_decim_poly_taps(ir_f64, sched.P, sched.Q, e_first, T, &lp);
+    build_decim_poly_taps(ir_f64, sched.P, sched.Q, e_first, T, &lp, dtype);
     RR_TRY(upload(f_ctaps, T.data(), T.size() * sizeof(uint32_t), stream));
     f_NC = lp;
     poly_delta.swap(delta);
@@ -523,8 +523,9 @@ int rr_downsampler::ensure_fast() {
     fast_version = design_version;
     fast_kind = rr_chain::FK_NONE;
     const char *e = std::getenv("RR_DOWNSAMPLER_GENERIC");
-    if (dtype != RR_F32 || !sched.periodic || (e && std::atoi(e) != 0)) return RR_OK;
-    int kind = sched.integer_ratio ? rr_chain::pick_fused_kernel(sched.D, L, true, 0) : rr_chain::FK_NONE;
+    if (!sched.periodic || (e && std::atoi(e) != 0)) return RR_OK;
+    // (f64: no fused overlap-save kernels, the polyphase kernel for every periodic ratio it fits)
+    int kind = (dtype == RR_F32 && sched.integer_ratio) ? rr_chain::pick_fused_kernel(sched.D, L, true, 0) : rr_chain::FK_NONE;
     if (kind == rr_chain::FK_OLSF) kind = rr_chain::FK_OLSW;
     {
         // RR_DOWNSAMPLER_POLY=1: k_decim_poly also where a fused kernel applies (A/B runs)

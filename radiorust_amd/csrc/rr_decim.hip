@@ -242,6 +242,102 @@ __global__ __launch_bounds__(256) void k_decim_poly(DecimArgs a, const uint2 *__
     }
 }
 
+// Complex<f64>: the same polyphase staging and tap list, without the mixer (the f64 FreqShifter stays its own block)
+// and without the f32 kernel's tuning - 16-byte LDS elements, taps as { f64 value, byte offset } entries of 16 bytes.
+typedef double d2 __attribute__((ext_vector_type(2)));
+struct DecimArgs64 {
+    const double2 *hist;
+    int hist_len;
+    const double2 *in;
+    long n_in;
+    int P, Q, NC, Lp;
+    long p_ref;
+    double2 *out;
+    long n_out;
+    int TA, S;
+    unsigned ntiles;
+    double2 *hist_out;
+    int hist_out_len;
+};
+struct Tap64 {
+    double tap;
+    unsigned off, pad;
+};
+__global__ __launch_bounds__(256) void k_decim_poly_f64(DecimArgs64 a, const Tap64 *__restrict__ T) {
+    extern __shared__ __attribute__((aligned(16))) char decim_smem[];
+    d2 *const xs = reinterpret_cast<d2 *>(decim_smem);
+    d2 *const ost = xs + (size_t)a.P * a.S;
+    const int t = threadIdx.x;
+    constexpr unsigned G = 8;
+    const unsigned grp = blockIdx.x / (8 * G), rem = blockIdx.x % (8 * G);
+    const unsigned tile = grp * 8 * G + (rem & 7) * G + (rem >> 3);
+    if (tile >= a.ntiles) return;
+    const int P = a.P, Q = a.Q, TA = a.TA, S = a.S;
+    const long a0 = (long)tile * TA;
+    const long p_lo = a.p_ref + (long)P * a0;
+    const int nld = P * (TA + a.NC);
+    auto fetch = [&](long pos) -> double2 {
+        double2 h;
+        h.x = 0.0;
+        h.y = 0.0;
+        if (pos >= 0) {
+            if (pos < a.n_in) h = a.in[pos];
+        } else if (pos >= -(long)a.hist_len) {
+            h = a.hist[a.hist_len + pos];
+        }
+        return h;
+    };
+    if (a.hist_out && tile == a.ntiles - 1)
+        for (int i = t; i < a.hist_out_len; i += 256) a.hist_out[i] = fetch(a.n_in - a.hist_out_len + i);
+    {
+        int row = t % P, col = t / P;
+        const int dr = 256 % P, dc = 256 / P;
+        const bool interior = p_lo >= 0 && p_lo + nld <= a.n_in;
+        for (int q = t; q < nld; q += 256) {
+            const double2 xv = interior ? a.in[p_lo + q] : fetch(p_lo + q);
+            xs[row * S + col] = (d2){xv.x, xv.y};
+            row += dr;
+            col += dc;
+            if (row >= P) {
+                row -= P;
+                ++col;
+            }
+        }
+    }
+    __syncthreads();
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    const int segs = TA >> 6, ntask = Q * segs;
+    for (int task = w; task < ntask; task += 4) {
+        const int b = task / segs, seg = task - b * segs;
+        const int al = seg * 64 + lane;
+        const char *base = reinterpret_cast<const char *>(xs + al);
+        const Tap64 *tl = T + (size_t)b * a.Lp;
+        d2 acc0 = {0.0, 0.0}, acc1 = {0.0, 0.0};
+        for (int i = 0; i < a.Lp; i += 2) {
+            const Tap64 e0 = tl[i], e1 = tl[i + 1];  // uniform addresses: scalar reads
+            const d2 x0 = *reinterpret_cast<const d2 *>(base + e0.off);
+            const d2 x1 = *reinterpret_cast<const d2 *>(base + e1.off);
+            acc0 = __builtin_elementwise_fma(x0, (d2){e0.tap, e0.tap}, acc0);
+            acc1 = __builtin_elementwise_fma(x1, (d2){e1.tap, e1.tap}, acc1);
+        }
+        const d2 acc = acc0 + acc1;
+        if (Q == 1) {
+            const long m = a0 + al;
+            if (m < a.n_out) reinterpret_cast<d2 *>(a.out)[m] = acc;
+        } else {
+            ost[Q * al + b] = acc;
+        }
+    }
+    if (Q > 1) {
+        __syncthreads();
+        const long m0 = (long)Q * a0;
+        for (int i = t; i < TA * Q; i += 256) {
+            const long m = m0 + i;
+            if (m < a.n_out) reinterpret_cast<d2 *>(a.out)[m] = ost[i];
+        }
+    }
+}
+
 }  // namespace
 
 // LDS per workgroup: tiles of about 24 KiB (6 workgroups per CU) where the period allows, never more than 64 KiB
@@ -249,12 +345,12 @@ static constexpr size_t kDecimLdsTarget = 24 * 1024, kDecimLdsMax = 64 * 1024;
 
 static size_t decim_nc(uint64_t P, size_t L) { return (P - 1 + L + P - 1) / P; }  // tap columns for any phase offset
 
-static int decim_geometry(size_t P, size_t Q, size_t NC, int *TA, int *S) {
+static int decim_geometry(size_t P, size_t Q, size_t NC, int *TA, int *S, size_t esz = 8) {
     int best = 0;
     for (int ta : {1024, 512, 256, 128, 64}) {
         int s = ta + (int)NC;
         if (!(s & 1)) ++s;  // odd row stride: the staging writes of neighbouring rows fall on different banks
-        const size_t bytes = (P * (size_t)s + (Q > 1 ? (size_t)ta * Q : 0)) * 8;
+        const size_t bytes = (P * (size_t)s + (Q > 1 ? (size_t)ta * Q : 0)) * esz;
         if (bytes <= kDecimLdsTarget || (ta == 64 && bytes <= kDecimLdsMax)) {
             *TA = ta;
             *S = s;
@@ -266,28 +362,35 @@ static int decim_geometry(size_t P, size_t Q, size_t NC, int *TA, int *S) {
 }
 
 bool decim_poly_supported(int dtype, uint64_t P, uint64_t Q, size_t L) {
-    if (dtype != RR_F32 || P < 2 || P > 512 || Q < 1 || Q > 8 || Q >= P || L < 1) return false;
+    if ((dtype != RR_F32 && dtype != RR_F64) || P < 2 || P > 512 || Q < 1 || Q > 8 || Q >= P || L < 1) return false;
     int ta, s;
-    return decim_geometry(P, Q, decim_nc(P, L), &ta, &s) != 0;
+    return decim_geometry(P, Q, decim_nc(P, L), &ta, &s, dtype == RR_F64 ? 16 : 8) != 0;
 }
 
 // taps in the kernel's order: T[b][j] = { ir[j], byte offset of tap j's (row, column) }, (delta_b + j) = P column + row,
 // delta_b = e[b] - e[0]; padded to a multiple of 8 taps per phase with { 0, 0 }
 void build_decim_poly_taps(const std::vector<double> &ir, uint64_t P, uint64_t Q, const int64_t *e_first, std::vector<uint32_t> &T,
-                           int *Lp_out) {
+                           int *Lp_out, int dtype) {
     const size_t L = ir.size(), Lp = (L + 7) / 8 * 8;
     int ta = 0, S = 0;
-    decim_geometry(P, Q, decim_nc(P, L), &ta, &S);
-    T.assign((size_t)Q * Lp * 2, 0u);
+    const bool f64 = dtype == RR_F64;
+    decim_geometry(P, Q, decim_nc(P, L), &ta, &S, f64 ? 16 : 8);
+    T.assign((size_t)Q * Lp * (f64 ? 4 : 2), 0u);
     for (uint64_t b = 0; b < Q; ++b) {
         const size_t d = (size_t)(e_first[b] - e_first[0]);
         for (size_t j = 0; j < L; ++j) {
             const size_t idx = d + j, r = idx % P, c = idx / P;
-            const float tap = (float)ir[j];
-            uint32_t bits;
-            std::memcpy(&bits, &tap, 4);
-            T[((size_t)b * Lp + j) * 2] = bits;
-            T[((size_t)b * Lp + j) * 2 + 1] = (uint32_t)((r * (size_t)S + c) * 8);
+            if (f64) {  // { f64 tap, byte offset, pad }
+                uint32_t *e = &T[((size_t)b * Lp + j) * 4];
+                std::memcpy(e, &ir[j], 8);
+                e[2] = (uint32_t)((r * (size_t)S + c) * 16);
+            } else {
+                const float tap = (float)ir[j];
+                uint32_t bits;
+                std::memcpy(&bits, &tap, 4);
+                T[((size_t)b * Lp + j) * 2] = bits;
+                T[((size_t)b * Lp + j) * 2 + 1] = (uint32_t)((r * (size_t)S + c) * 8);
+            }
         }
     }
     *Lp_out = (int)Lp;
@@ -295,8 +398,36 @@ void build_decim_poly_taps(const std::vector<double> &ir, uint64_t P, uint64_t Q
 
 int launch_decim_poly(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *T,
                       uint64_t P, uint64_t Q, int Lp, size_t L, int64_t e_first0, void *out, size_t n_out, void *hist_out,
-                      size_t hist_out_len, const void *nco, uint32_t denom, uint32_t idx0) {
+                      size_t hist_out_len, const void *nco, uint32_t denom, uint32_t idx0, int dtype) {
     if (n_out == 0) return RR_OK;
+    if (dtype == RR_F64) {
+        if (nco) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: the fused mixer is f32 only");
+        DecimArgs64 a;
+        a.hist = (const double2 *)hist;
+        a.hist_len = (int)hist_len;
+        a.in = (const double2 *)in;
+        a.n_in = (long)n_in;
+        a.P = (int)P;
+        a.Q = (int)Q;
+        a.NC = (int)decim_nc(P, L);
+        a.Lp = Lp;
+        a.p_ref = (long)e_first0 - (long)(L - 1);
+        a.out = (double2 *)out;
+        a.n_out = (long)n_out;
+        a.hist_out = (double2 *)hist_out;
+        a.hist_out_len = (int)hist_out_len;
+        const int lds = decim_geometry(P, Q, (size_t)a.NC, &a.TA, &a.S, 16);
+        if (!lds) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: %llu : %llu with %d tap columns does not fit the LDS tile",
+                          (unsigned long long)P, (unsigned long long)Q, a.NC);
+        const size_t per_tile = (size_t)a.TA * Q;
+        const size_t ntiles = (n_out + per_tile - 1) / per_tile;
+        if (ntiles > 0x7ffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: too many tiles");
+        a.ntiles = (unsigned)ntiles;
+        const unsigned grid = (unsigned)((ntiles + 63) / 64 * 64);
+        hipLaunchKernelGGL(k_decim_poly_f64, dim3(grid), dim3(256), (size_t)lds, s, a, (const Tap64 *)T);
+        RR_HIP(hipGetLastError());
+        return RR_OK;
+    }
     DecimArgs a;
     a.hist = (const float2 *)hist;
     a.hist_len = (int)hist_len;

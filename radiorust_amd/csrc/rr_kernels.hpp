@@ -59,10 +59,10 @@ int launch_filter_blk4096(hipStream_t s, const void *hist, size_t hist_len, cons
 // front - in[pos] * nco[(idx0 + pos) mod denom] -, hist / hist_out then hold mixed samples.
 bool decim_poly_supported(int dtype, uint64_t P, uint64_t Q, size_t L);
 void build_decim_poly_taps(const std::vector<double> &ir, uint64_t P, uint64_t Q, const int64_t *e_first, std::vector<uint32_t> &T,
-                           int *Lp_out);
+                           int *Lp_out, int dtype = RR_F32);
 int launch_decim_poly(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *T,
                       uint64_t P, uint64_t Q, int Lp, size_t L, int64_t e_first0, void *out, size_t n_out, void *hist_out,
-                      size_t hist_out_len, const void *nco = nullptr, uint32_t denom = 0, uint32_t idx0 = 0);
+                      size_t hist_out_len, const void *nco = nullptr, uint32_t denom = 0, uint32_t idx0 = 0, int dtype = RR_F32);
 
 // new_hist (H samples) = last H samples of [ zeros | old_hist (H) | in (n_in) ]
 int launch_update_hist(int dtype, hipStream_t s, const void *old_hist, void *new_hist, size_t H, const void *in,

@@ -451,6 +451,26 @@ def test_downsampler_fast_paths(rr, oracle, fin, fout, bw, q, kernel):
             check(y, r)
 
 
+@pytest.mark.parametrize("fin,fout,bw,q", [(200e6, 50e6, 40e6, 3.0), (1024000.0, 102400.0, 60000.0, 3.0), (1024000.0, 384000.0, 200000.0, 3.0),
+                                          (48000.0, 32000.0, 20000.0, 2.0)])
+def test_downsampler_f64_polyphase_kernel(rr, oracle, fin, fout, bw, q):
+    """Complex<f64>: every periodic ratio the LDS tile fits runs k_decim_poly_f64 in long calls (kernel 5), k_fir in short
+    ones; the history is handed over between them."""
+    n = 90000
+    x = oracle.synth_iq(17, 0, n).astype(np.complex128)
+    g = rr.Downsampler.with_quality(1000, fout, bw, q, dtype=np.float64)
+    o = oracle.Downsampler(1000, fout, bw, q, flt=np.float64)
+    cuts = [0, 5000, 5003, 40000, 40001, n]
+    kernels = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        y, r = g.process_raw(fin, x[a:b]), o.process(fin, x[a:b])
+        kernels.append(g.last_kernel())
+        assert len(y) == len(r)
+        if len(y) > 8:
+            assert rms_rel(y, r) <= 1e-12
+    assert kernels == [5, 0, 5, 0, 5], kernels
+
+
 def test_downsampler_fast_path_can_be_switched_off(rr, oracle, monkeypatch):
     monkeypatch.setenv("RR_DOWNSAMPLER_GENERIC", "1")
     g = rr.Downsampler.new(1000, 50e6, 40e6)
