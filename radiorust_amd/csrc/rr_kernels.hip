@@ -421,7 +421,7 @@ int launch_update_hist(int dtype, hipStream_t s, const void *old_hist, void *new
 template <class T>
 // Frames are cut from the stream [ head (n_head samples) | in ] every `hop` samples (hop = n: the
 // plain chunk-by-chunk Fourier; hop < n: the Overlapper's overlapping chunks, chunks.rs:194-242).
-__global__ __launch_bounds__(256) void k_fft_pow2(const v2<T> *__restrict__ head, long n_head,
+__global__ __launch_bounds__(1024) void k_fft_pow2(const v2<T> *__restrict__ head, long n_head,
                                                   const v2<T> *__restrict__ in, v2<T> *__restrict__ out, int n,
                                                   long hop, const T *__restrict__ window,
                                                   const v2<T> *__restrict__ tw, int center_dc) {
@@ -441,7 +441,33 @@ __global__ __launch_bounds__(256) void k_fft_pow2(const v2<T> *__restrict__ head
     }
     __syncthreads();
     const int half = n >> 1;
-    for (int ns = 1; ns < n; ns <<= 1) {
+    int ns = 1;
+    // radix-4 passes while they fit (half the exchanges and barriers of radix 2; the table holds all n twiddles)
+    for (; ns * 4 <= n; ns <<= 2) {
+        const int quarter = n >> 2, tstride4 = quarter / ns;  // e^{-j 2 pi k c / (4 ns)} = tw[k c n / (4 ns)]
+        for (int j = threadIdx.x; j < quarter; j += blockDim.x) {
+            const int k = j & (ns - 1);
+            const v2<T> x0 = a[j];
+            const v2<T> x1 = cmul<T>(a[j + quarter], tw[k * tstride4]);
+            const v2<T> x2 = cmul<T>(a[j + 2 * quarter], tw[2 * k * tstride4]);
+            const v2<T> x3 = cmul<T>(a[j + 3 * quarter], tw[3 * k * tstride4]);
+            v2<T> t0, t1, t2, t3, y;
+            t0.x = x0.x + x2.x; t0.y = x0.y + x2.y;
+            t1.x = x0.x - x2.x; t1.y = x0.y - x2.y;
+            t2.x = x1.x + x3.x; t2.y = x1.y + x3.y;
+            t3.x = x1.y - x3.y; t3.y = x3.x - x1.x;  // -j (x1 - x3)
+            const int j0 = ((j - k) << 2) + k;
+            y.x = t0.x + t2.x; y.y = t0.y + t2.y; b[j0] = y;
+            y.x = t1.x + t3.x; y.y = t1.y + t3.y; b[j0 + ns] = y;
+            y.x = t0.x - t2.x; y.y = t0.y - t2.y; b[j0 + 2 * ns] = y;
+            y.x = t1.x - t3.x; y.y = t1.y - t3.y; b[j0 + 3 * ns] = y;
+        }
+        __syncthreads();
+        v2<T> *t = a;
+        a = b;
+        b = t;
+    }
+    for (; ns < n; ns <<= 1) {
         const int tstride = half / ns;  // tw index step: e^{-j 2 pi k / (2 ns)} = tw[k * n / (2 ns)]
         for (int j = threadIdx.x; j < half; j += blockDim.x) {
             const int k = j & (ns - 1);
@@ -535,8 +561,10 @@ static int launch_fourier_t(hipStream_t s, const void *head, size_t n_head, cons
         const size_t lds = 2 * n * sizeof(v2<T>);
         auto fn = k_fft_pow2<T>;
         RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));
-        int threads = (int)(n / 2);
-        if (threads > 256) threads = 256;
+        // a workgroup per chunk, a lane per radix-4 butterfly: large chunks fill the CU with ONE workgroup (the two
+        // Stockham images of 4096 f64 points are 128 KiB), so it gets up to 16 waves
+        int threads = (int)(n / 4);
+        if (threads > 1024) threads = 1024;
         if (threads < 64) threads = 64;
         hipLaunchKernelGGL(fn, dim3((unsigned)count), dim3(threads), lds, s, (const v2<T> *)head, (long)n_head,
                            (const v2<T> *)in, (v2<T> *)out, (int)n, (long)hop, (const T *)window, (const v2<T> *)twiddle,
