@@ -1271,8 +1271,8 @@ int rr_chain::ensure_xh() {
 //   ols     k_ols_decim4     overlap-save, workgroup per 4096-block, D = 4, any taps       0.21 ms
 //   olsw    k_ols_wave<D>    overlap-save, wave per 1024-block, D in {2, 4, 8}, any taps, Lc <= 513   0.132 ms
 //   olsf    k_ols_frame      olsw's blocks + the 4096-point Fourier stage in one kernel (a workgroup
-//                            per frame), D = 4, 129 <= Lc <= 193, fft_len = 4096; 0.233 ms for BOTH
-//                            stages against olsw + k_fft4096 = 0.207: on request only
+//                            per frame), D = 4, 129 <= Lc <= 193, fft_len = 4096; 0.160 ms for BOTH
+//                            stages against olsw + k_fft4096 = 0.170: the default where it applies
 // Unforced: olsw wherever it applies (D in {2, 4, 8}, Lc <= 513), ols beyond an overlap of 384 at D = 4, the direct
 // form for what is left.  RR_FUSED_KERNEL = direct | ols | olsw | olsf forces one of them where it applies (A/B
 // runs and tests).
@@ -1292,6 +1292,9 @@ int rr_chain::pick_fused_kernel(uint64_t D, size_t lc, bool real_taps, size_t ff
     // 2 : 1 L = 32 0.149 against 0.173, 4 : 1 L = 60 0.121 against 0.144, 8 : 1 L = 83 0.117 against 0.129).  Beyond an
     // overlap of 384 of the 1024 samples (Lc > 385) the 4096-blocks are ahead at 4 : 1 (measured: Lc = 455: 0.252
     // against 0.259 ms per step; Lc = 375: 0.250 against 0.222).
+    // the whole chain in one kernel where its shape is compiled in (4 : 1, 4096-point Fourier stage, 129 <= Lc <= 193 - cfg2):
+    // since its second form (time-shared LDS, polyphase blocks) 0.160 ms per 2^26 samples against 0.126 + 0.044
+    if (can_frame) return FK_OLSF;
     if (can_wave && (ols_wave_overlap(lc) <= 384 || !can_ols)) return FK_OLSW;
     if (can_ols) return FK_OLS;
     if (can_direct) return FK_DIRECT;
@@ -1325,7 +1328,8 @@ void build_fused_fir_tables(int kind, uint64_t D_, const std::vector<double> &c,
             twb[2 * i + 1] = (float)std::sin(ang);
         }
         static const bool no_poly = [] { const char *e = std::getenv("RR_OLSW_POLY"); return e && std::atoi(e) == 0; }();
-        if (kind == rr_chain::FK_OLSW && (D_ == 2 || D_ == 4 || D_ == 8) && !no_poly) {
+        // (the frame kernel exists in the polyphase form only)
+        if ((kind == rr_chain::FK_OLSW && (D_ == 2 || D_ == 4 || D_ == 8) && !no_poly) || (kind == rr_chain::FK_OLSF && D_ == 4)) {
             // k_ols_wave<D, POLY>: Y[k] = sum_p X_p[k] G_p[k] over the D phases x_p[m] = xs[D m + p] (X_p = DFT_(1024/D) x_p),
             // G_p[k] = sum_q H[k + (1024 / D) q] W_1024^((k + (1024 / D) q) p), k < 1024 / D; lane l = k mod 64 reads entry
             // i = (16 / D) p + k / 64 as one half of the 16-byte piece [i >> 1][l]   (RR_OLSW_POLY=0 keeps the 1024-point
@@ -1468,7 +1472,11 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     a.e0 = (int64_t)ds->sched.first_emit() - (int64_t)carry_len;
     a.D = (uint32_t)ds->sched.D;
     a.xh_out = xh[xh_cur ^ 1].p;  // written by the kernel's last workgroup
-    if (use_frame && n_in >= 1024) {  // (shorter calls: k_ols_wave + k_fft4096 below)
+    // (calls below 2^23 samples: k_ols_wave + k_fft4096 below - a workgroup of the frame kernel runs five blocks per wave in a
+    //  row, 25 us even for one frame, where the two kernels take 12; from 2^24 samples on the frame kernel is ahead)
+    const char *fke = std::getenv("RR_FUSED_KERNEL");  // (tests force the frame kernel on short streams)
+    const bool frame_forced = fke && !std::strcmp(fke, "olsf");
+    if (use_frame && n_in >= (frame_forced ? (size_t)1024 : (size_t)1 << 23)) {
         // one kernel: FIR stage + Fourier; the decimated samples stay on chip, only the unfinished
         // frame goes to a small pending buffer
         if (nfr * LF > cap) RR_FAIL(RR_ERR_CAPACITY, "Chain: out_cap %zu < %zu", cap, nfr * LF);

@@ -1872,125 +1872,102 @@ int ols_wave_overlap(size_t Lc, size_t granule);
 #define RR_V_FRAMEWAVES 4  // measured (full-size images): 4 waves 0.233 ms, 5 waves 0.30 (one workgroup per CU), 8 waves 0.26, 10 waves 0.28
 constexpr int kFrameWaves = RR_V_FRAMEWAVES, kFrameBlocks = 20;
 
-// the transforms of one 1024-sample block: v = mixed samples in the pair layout of k_ols_wave;
-// y[c] = result[l + 64 c] of the 256-point inverse (see k_ols_wave for the passes)
-// HALF: the forward exchanges go through an image of 512 elements in two rounds (lanes 0-31 write,
-// everyone reads the lower half of what it needs, then lanes 32-63 and the upper half): 4.6 KiB of LDS
-// per wave instead of 9.2, two more wave-local round trips per block.
-constexpr int kWaveLdsHalf = 584;  // A(511) + 1 = 582, rounded up to a multiple of 8
-template <bool HALF>
-__device__ __forceinline__ void wave_block_transform(f2 (&v)[16], f2 (&y)[4], f2 *lds, int l, f2 t_p1,
-                                                     const f2 (&t_p2)[2], const f2 (&t_inv)[3],
-                                                     const float2 (&hv)[16]) {
+// One 1024-sample block of k_ols_wave<4, POLY> as a function (the fused frame kernel's waves run five of them in a
+// row): v = mixed samples in the pair layout, hv = the lane's 16 entries of the polyphase tables G_p; y[c] =
+// result[l + 64 c] of the 256-point inverse.  See k_ols_wave for the passes and the two exchange images.
+constexpr int kPolyLds = 1136;  // 2 (63 + 72 * 7) + 2 elements
+__device__ __forceinline__ void poly4_block(f2 (&v)[16], f2 (&y)[4], f2 *lds, int l, f2 t_p1, f2 t_p2, const f2 (&t_inv)[3],
+                                            const float2 *__restrict__ G) {
     const int g = l >> 4, q = l & 15;
-    f2 *const a_rd = lds + (l + 2 * g);
-    f2 *const b_rd = lds + (l + 4 * g);
+    f2 e0[8], e1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        e0[k] = v[2 * k];
+        e1[k] = v[2 * k + 1];
+    }
+    dft8(e0);
+    dft8(e1);
     {
-        f2 e0[8], e1[8];
+        const f2 w1 = t_p1, w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+        const f2 w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+        e0[1] = cmul(e0[1], w1); e1[1] = cmul(e1[1], w1);
+        e0[2] = cmul(e0[2], w2); e1[2] = cmul(e1[2], w2);
+        e0[3] = cmul(e0[3], w3); e1[3] = cmul(e1[3], w3);
+        e0[4] = cmul(e0[4], w4); e1[4] = cmul(e1[4], w4);
+        e0[5] = cmul(e0[5], w5); e1[5] = cmul(e1[5], w5);
+        e0[6] = cmul(e0[6], w6); e1[6] = cmul(e1[6], w6);
+        e0[7] = cmul(e0[7], w7); e1[7] = cmul(e1[7], w7);
+    }
+    wave_sync();  // the previous block's last reads are done
+    {
+        f2 *row = lds + 2 * l;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) *reinterpret_cast<float4 *>(row + 144 * k) = (float4){e0[k].x, e0[k].y, e1[k].x, e1[k].y};
+    }
+    wave_sync();
+    {
+        const f2 *col = lds + 2 * ((l & 7) + 72 * (l >> 3));
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            e0[k] = v[2 * k];
-            e1[k] = v[2 * k + 1];
-        }
-        dft8(e0);
-        dft8(e1);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            v[k] = e0[k];
-            v[8 + k] = e1[k];
+            const float4 r = *reinterpret_cast<const float4 *>(col + 16 * k);
+            e0[k] = (f2){r.x, r.y};
+            e1[k] = (f2){r.z, r.w};
         }
     }
-    wave_sync();  // the previous block's last reads of image B are done
-    if constexpr (!HALF) {
-        f2 *row = lds + (18 * l + 8 * g);
+    dft8(e0);
+    dft8(e1);
+    wave_sync();
+    {
+        f2 *row = lds + 2 * ((l >> 3) + 66 * (l & 7));
 #pragma unroll
-        for (int k = 0; k < 16; k += 2)
-            *reinterpret_cast<float4 *>(row + k) = (float4){v[k].x, v[k].y, v[k + 1].x, v[k + 1].y};
-        wave_sync();
+        for (int k = 0; k < 8; ++k) *reinterpret_cast<float4 *>(row + 16 * k) = (float4){e0[k].x, e0[k].y, e1[k].x, e1[k].y};
+    }
+    wave_sync();
+    // the lane's 16 entries of G_p are requested HERE, in two halves (phases 0, 1 / 2, 3), not in front of the transform as
+    // k_ols_wave does: kept through the passes they are 32 registers the frame kernel does not have
+    float4 ga[4], gb[4];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = lds_ld(a_rd + (72 * (k & 3) + 296 * (k >> 2)));
-    } else {
-        // rows 0..31 (elements < 512) belong to lanes 0..31; a reader's k < 8 are its elements < 512
-        f2 w[16];
+    for (int kp = 0; kp < 4; ++kp) ga[kp] = reinterpret_cast<const float4 *>(G)[l + 64 * kp];
+    f2 d[4][4];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) w[k] = v[k];
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if ((l >> 5) == h) {
-                f2 *row = lds + (18 * (l & 31) + 8 * ((l & 31) >> 4));
+        for (int m1 = 0; m1 < 4; ++m1) {
+            const float4 r = *reinterpret_cast<const float4 *>(lds + 2 * l + 132 * (a + 2 * m1));
+            d[2 * a][m1] = (f2){r.x, r.y};
+            d[2 * a + 1][m1] = (f2){r.z, r.w};
+        }
+    {
+        const f2 w1 = t_p2, w2 = cmul(w1, w1), w3 = cmul(w2, w1);
 #pragma unroll
-                for (int k = 0; k < 16; k += 2)
-                    *reinterpret_cast<float4 *>(row + k) = (float4){w[k].x, w[k].y, w[k + 1].x, w[k + 1].y};
-            }
-            wave_sync();
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[8 * h + k] = lds_ld(a_rd + (72 * (k & 3) + 296 * (k >> 2)));  // in[l + 64 (8 h + k)] - 512 h
-            wave_sync();
+        for (int pp = 0; pp < 4; ++pp) {
+            d[pp][1] = cmul(d[pp][1], w1);
+            d[pp][2] = cmul(d[pp][2], w2);
+            d[pp][3] = cmul(d[pp][3], w3);
+            dft4(d[pp][0], d[pp][1], d[pp][2], d[pp][3]);
         }
     }
-    twiddle16(v, t_p1);
-    dft16(v);
-    f2 ain[2][8];
-    if constexpr (!HALF) {
-        wave_sync();
-        {
-            f2 *col = lds + (144 * (l >> 3) + 8 * (l >> 4) + (l & 7));
+    // entry i = 4 p + c is half (i & 1) of piece i >> 1: phase 0 = pieces 0, 1; phase 1 = 2, 3; ..
+    y[0] = cmul(d[0][0], (f2){ga[0].x, ga[0].y});
+    y[1] = cmul(d[0][1], (f2){ga[0].z, ga[0].w});
+    y[2] = cmul(d[0][2], (f2){ga[1].x, ga[1].y});
+    y[3] = cmul(d[0][3], (f2){ga[1].z, ga[1].w});
 #pragma unroll
-            for (int k = 0; k < 16; ++k) lds_st(col + (8 * k + 2 * (k >> 1)), v[k]);
-        }
-        wave_sync();
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int c = 0; c < 8; ++c) ain[m][c] = lds_ld(a_rd + (72 * m + 144 * c + 8 * (c >> 1)));
-    } else {
-        // elements 128 h' + p + 8 k with h' = l / 8 < 4 (lanes 0..31) are the lower 512; a reader's c < 4 too
-        if constexpr (true) wave_sync();
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if ((l >> 5) == h) {
-                const int ll = l & 31;
-                f2 *col = lds + (144 * (ll >> 3) + 8 * (ll >> 4) + (ll & 7));
-#pragma unroll
-                for (int k = 0; k < 16; ++k) lds_st(col + (8 * k + 2 * (k >> 1)), v[k]);
-            }
-            wave_sync();
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) ain[m][4 * h + c] = lds_ld(a_rd + (72 * m + 144 * c + 8 * (c >> 1)));
-            wave_sync();
-        }
-    }
-    f2 X[16];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        f2 a[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) a[c] = ain[m][c];
-        const f2 w1 = t_p2[m];
-        const f2 w2 = cmul(w1, w1);
-        const f2 w3 = cmul(w2, w1);
-        const f2 w4 = cmul(w2, w2);
-        a[1] = cmul(a[1], w1);
-        a[2] = cmul(a[2], w2);
-        a[3] = cmul(a[3], w3);
-        a[4] = cmul(a[4], w4);
-        a[5] = cmul(a[5], cmul(w4, w1));
-        a[6] = cmul(a[6], cmul(w4, w2));
-        a[7] = cmul(a[7], cmul(w4, w3));
-        dft8(a);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) X[m + 2 * c] = a[c];
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        f2 acc = cmul(X[m], (f2){hv[m].x, hv[m].y});
-        acc = cmac(acc, X[m + 4], (f2){hv[m + 4].x, hv[m + 4].y});
-        acc = cmac(acc, X[m + 8], (f2){hv[m + 8].x, hv[m + 8].y});
-        acc = cmac(acc, X[m + 12], (f2){hv[m + 12].x, hv[m + 12].y});
-        y[m] = acc;
-    }
+    for (int kp = 0; kp < 4; ++kp) gb[kp] = reinterpret_cast<const float4 *>(G)[l + 64 * (4 + kp)];
+    y[0] = cmac(y[0], d[1][0], (f2){ga[2].x, ga[2].y});
+    y[1] = cmac(y[1], d[1][1], (f2){ga[2].z, ga[2].w});
+    y[2] = cmac(y[2], d[1][2], (f2){ga[3].x, ga[3].y});
+    y[3] = cmac(y[3], d[1][3], (f2){ga[3].z, ga[3].w});
+    y[0] = cmac(y[0], d[2][0], (f2){gb[0].x, gb[0].y});
+    y[1] = cmac(y[1], d[2][1], (f2){gb[0].z, gb[0].w});
+    y[2] = cmac(y[2], d[2][2], (f2){gb[1].x, gb[1].y});
+    y[3] = cmac(y[3], d[2][3], (f2){gb[1].z, gb[1].w});
+    y[0] = cmac(y[0], d[3][0], (f2){gb[2].x, gb[2].y});
+    y[1] = cmac(y[1], d[3][1], (f2){gb[2].z, gb[2].w});
+    y[2] = cmac(y[2], d[3][2], (f2){gb[3].x, gb[3].y});
+    y[3] = cmac(y[3], d[3][3], (f2){gb[3].z, gb[3].w});
+    // inverse DFT_256 (radix 4 x 4 x 4 x 4, as k_ols_wave<4>)
+    f2 *const b_rd = lds + (l + 4 * g);
     idft4(y[0], y[1], y[2], y[3]);
     wave_sync();
     {
@@ -2051,22 +2028,18 @@ struct FrameArgs {
     unsigned nfr;           // full frames
 };
 
-#define RR_V_FRAMEOCC 4
-#define RR_V_FRAMEOCCMIN 3  // 12 waves per CU need <= 168 VGPRs
-__global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_eu(RR_V_FRAMEOCCMIN, RR_V_FRAMEOCC))) void k_ols_frame(FrameArgs a_) {
-    // The fields used once per workgroup (pending buffers, spectra, window ..) are re-read from the
-    // kernel-argument segment where they are needed: held in SGPRs through the block loop they push
-    // the kernel one VGPR (of spilled SGPRs) over the 128 that two 5-wave workgroups per CU need.
+// The fused frame kernel, second form (round 2).  What made the first one slower than the two kernels it replaces was
+// its LDS: the 34 KiB frame buffer NEXT TO the wave images left room for 12 waves per CU (with half-size images).  Here
+// the two share the same LDS in time: the four waves keep the results of their five blocks in registers (20 values per
+// lane), and only when all of them are done do they drop them into what were their exchange images - now the frame, and then
+// the exchange image of the DFT_4096.  37 KiB per workgroup = 4 workgroups = 16 waves per CU, as k_ols_wave has; the
+// polyphase block transform leaves the registers for it (92 + 32 kept while the fifth block runs).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ols_frame(FrameArgs a_) {
     const FrameArgs &a = a_;
     const FrameArgs *ka = (const FrameArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-#define RR_V_FRAMEHALF 1  // half-size wave images: 3 workgroups per CU instead of 2
-    constexpr int kImg = RR_V_FRAMEHALF ? kWaveLdsHalf : kWaveLds;
-    // the frame (+ the surplus of block 19); once every lane holds its 16 frame samples it becomes the
-    // padded exchange image of the DFT_4096
-    __shared__ __attribute__((aligned(16))) f2 fr[4096 + 256];
-    __shared__ __attribute__((aligned(16))) f2 img[kFrameWaves * kImg];  // wave images
+    __shared__ __attribute__((aligned(16))) f2 smem[4 * kPolyLds];  // 4544 elements >= the 4352 of the padded frame image
+    f2 *const fr = smem;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    // frames dealt so that an XCD owns a contiguous range (grid: multiple of 8)
     // frames dealt to the XCDs in a moving window, RR_V_FRAMEWIN neighbouring frames per XCD
     const unsigned f = blockIdx.x / (8 * RR_V_FRAMEWIN) * (8 * RR_V_FRAMEWIN) + (blockIdx.x % (8 * RR_V_FRAMEWIN) & 7) * RR_V_FRAMEWIN +
                        (blockIdx.x % (8 * RR_V_FRAMEWIN) >> 3);
@@ -2077,7 +2050,7 @@ __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_e
 
     if (tail && ka->xh_out) {  // mixed-sample history for the next call
         const int hxe = ka->hx;
-        for (int i = tid; i < hxe; i += 64 * kFrameWaves) {
+        for (int i = tid; i < hxe; i += 256) {
             const long pos = a.n_in - hxe + i;
             float2 v;
             if (pos >= 0) {
@@ -2091,42 +2064,25 @@ __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_e
             ka->xh_out[i] = v;
         }
     }
-    // the part of frame 0 that was pending
-    if (f == 0)
-        for (int i = tid; i < a.pl; i += 64 * kFrameWaves) {
-            const float2 p = ka->pend_in[i];
-            fr[i] = (f2){p.x, p.y};
-        }
 
-    // lane constants (as in k_ols_wave)
-    f2 t_p1, t_p2[2], t_inv[3];
+    // lane constants of the polyphase block transform: tw[4 (l >> 1)], tw[32 (l >> 3)], the inverse's three
+    f2 t_p1, t_p2, t_inv[3];
     {
         const float4 *tl = reinterpret_cast<const float4 *>(a.tw + 1024) + l;
-        const float4 s0 = tl[0], s1 = tl[64], s2 = tl[128];
-        t_p1 = (f2){s0.x, s0.y};
-        t_p2[0] = (f2){s0.z, s0.w};
-        t_p2[1] = (f2){s1.x, s1.y};
-        t_inv[0] = (f2){s1.z, s1.w};
-        t_inv[1] = (f2){s2.x, s2.y};
-        t_inv[2] = (f2){s2.z, s2.w};
+        const float4 s6 = tl[384], s7 = tl[448], s8 = tl[512];
+        t_p1 = (f2){s6.x, s6.y};
+        t_p2 = (f2){s6.z, s6.w};
+        t_inv[0] = (f2){s7.x, s7.y};
+        t_inv[1] = (f2){s7.z, s7.w};
+        t_inv[2] = (f2){s8.x, s8.y};
     }
-    f2 *const lds = img + w * kImg;
-    size_t zoff = 0;
-
-    // The next block's samples are requested while the current block is transformed (a block alone
-    // is 14 k cycles of which 7 k wait for its samples, and a CU holds only 10 of these waves).  The
-    // request is unconditional - a conditional one would turn every later wait for an H value into a
-    // wait for it (see k_ols_wave) - so the last of a wave's four blocks asks for its own samples
-    // again (an L2 hit), and blocks outside the call's range run on clamped addresses with their
-    // results masked.
+    f2 *const lds = smem + w * kPolyLds;
     const long n_clamp = a.n_in - 1024;  // the launcher guarantees n_in >= 1024
-    auto block_b0 = [&](int jb) { return a.e0 - a.V + 4 * (F0 + (long)per_block * jb); };
-    [[maybe_unused]] auto clampb = [&](long b) { return b < 0 ? 0 : (b > n_clamp ? n_clamp : b); };
-    f4u x[8];
-    for (int jb = w; jb < kFrameBlocks; jb += kFrameWaves) {
-        asm volatile("" : "+v"(t_p1), "+v"(t_p2[0]), "+v"(t_p2[1]), "+v"(t_inv[0]), "+v"(t_inv[1]), "+v"(t_inv[2]));
-        asm volatile("" : "+s"(zoff));
-        const long b0 = block_b0(jb);
+    f2 keep[kFrameBlocks / 4][4];
+#pragma unroll
+    for (int kb = 0; kb < kFrameBlocks / 4; ++kb) {
+        const int jb = w + 4 * kb;
+        const long b0 = a.e0 - a.V + 4 * (F0 + (long)per_block * jb);
         // phase of the lane's first sample: (idx0 + b0 + 2 l) mod denom, b0 = const + 4 (4096 f + 208 jb)
         unsigned r;
         {
@@ -2147,6 +2103,7 @@ __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_e
         }
         f2 v[16];
         if (b0 >= 0 && b0 <= n_clamp) {
+            f4u x[8];
             {
                 const f4u *src = reinterpret_cast<const f4u *>(a.in + b0) + l;
 #pragma unroll
@@ -2160,13 +2117,19 @@ __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_e
                     v[2 * k + 1] = cmul((f2){x[k].z, x[k].w}, (f2){pp.z, pp.w});
                 }
             } else {
+                // general period: the lane's pair at the block start from the table, the seven 128-sample steps by the
+                // rotations kept behind the table (as k_ols_wave; a table walk - 8 pair reads per block - cost 0.19 / 0.25 ms
+                // per step for the 40 000- and the 10^8-entry tables)
+                const f4u pp = *reinterpret_cast<const f4u *>(a.nco + r);
+                const f2 p0 = {pp.x, pp.y}, p1 = {pp.z, pp.w};
+                v[0] = cmul((f2){x[0].x, x[0].y}, p0);
+                v[1] = cmul((f2){x[0].z, x[0].w}, p1);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const f4u pp = *reinterpret_cast<const f4u *>(a.nco + r);
-                    v[2 * k] = cmul((f2){x[k].x, x[k].y}, (f2){pp.x, pp.y});
-                    v[2 * k + 1] = cmul((f2){x[k].z, x[k].w}, (f2){pp.z, pp.w});
-                    r += a.kstep;
-                    if (r >= a.denom) r -= a.denom;
+                for (int k = 1; k < 8; ++k) {
+                    const float2 rt = a.nco[a.denom + 1 + k];  // uniform address: a scalar read
+                    const f2 rot = {rt.x, rt.y};
+                    v[2 * k] = cmul((f2){x[k].x, x[k].y}, cmul(p0, rot));
+                    v[2 * k + 1] = cmul((f2){x[k].z, x[k].w}, cmul(p1, rot));
                 }
             }
         } else {
@@ -2190,29 +2153,33 @@ __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_e
                 if (r >= a.denom) r -= a.denom;
             }
         }
-        float2 hv[16];
-#pragma unroll
-        for (int kp = 0; kp < 8; ++kp) {
-            const float4 h4 = reinterpret_cast<const float4 *>(a.H + zoff)[l + 64 * kp];
-            hv[2 * kp] = float2{h4.x, h4.y};
-            hv[2 * kp + 1] = float2{h4.z, h4.w};
+        poly4_block(v, keep[kb], lds, l, t_p1, t_p2, t_inv, a.H);
+        // (one block at a time: without this the five unrolled blocks' loads are all hoisted to the front)
+        asm volatile("" : "+v"(keep[kb][0]), "+v"(keep[kb][1]), "+v"(keep[kb][2]), "+v"(keep[kb][3]));
+    }
+    __syncthreads();  // every wave is done with its exchange images: they become the frame
+    // the part of frame 0 that was pending
+    if (f == 0)
+        for (int i = tid; i < a.pl; i += 256) {
+            const float2 p = ka->pend_in[i];
+            fr[i] = (f2){p.x, p.y};
         }
-        f2 y[4];
-        wave_block_transform<RR_V_FRAMEHALF != 0>(v, y, lds, l, t_p1, t_p2, t_inv, hv);
-        // valid results tau = l + 64 c >= first; frame-relative index i = per_block * jb + tau - first
+    // valid results tau = l + 64 c >= first; frame-relative index i = per_block * jb + tau - first
+#pragma unroll
+    for (int kb = 0; kb < kFrameBlocks / 4; ++kb) {
+        const int jb = w + 4 * kb;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int tau = l + 64 * c;
             const int i = per_block * jb + tau - first;
             const long m = F0 + i;
-            if (tau >= first && m >= 0 && m < a.n_dec) fr[i] = y[c];
+            if (tau >= first && m >= 0 && m < a.n_dec) fr[i] = keep[kb][c];
         }
     }
     __syncthreads();
-    asm volatile("" : "+s"(ka));  // not earlier
     if (tail) {
         const long have = a.pl + a.n_dec - 4096l * a.nfr;  // samples of the unfinished frame
-        for (int i = tid; i < have; i += 64 * kFrameWaves) {
+        for (int i = tid; i < have; i += 256) {
             float2 o;
             o.x = fr[i].x;
             o.y = fr[i].y;
@@ -2220,7 +2187,6 @@ __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_e
         }
         return;
     }
-    if (tid >= 256) return;  // (kFrameWaves >= 4)
     // ---- Fourier: window, DFT_4096 (radix 16 x 3 as k_fft4096), optional DC centring ---------------
     f2 v[16];
 #pragma unroll
@@ -2229,20 +2195,12 @@ __global__ __launch_bounds__(64 * kFrameWaves) __attribute__((amdgpu_waves_per_e
         const f2 s = fr[tid + 256 * k];
         v[k] = (f2){s.x * wv, s.y * wv};
     }
-    // all four waves must have read the frame before it is overwritten (named barrier of the 256 lanes
-    // left: the fifth.. waves of larger workgroups have returned, so a workgroup barrier would hang)
-    static_assert(kFrameWaves == 4 || !RR_V_FRAMEHALF, "the in-place DFT image needs a barrier of exactly the four transforming waves");
-    __syncthreads();
+    __syncthreads();  // the frame has been read: it becomes the padded exchange image
     fft4096_regs(v, fr, ka->tw4096, tid);
     float2 *dst = ka->spectra + (size_t)f * 4096;
     const int rot = ka->center_dc ? 2048 : 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        float2 o;
-        o.x = v[k].x;
-        o.y = v[k].y;
-        dst[(tid + 256 * k + rot) & 4095] = o;
-    }
+    for (int k = 0; k < 16; ++k) __builtin_nontemporal_store(v[k], reinterpret_cast<f2 *>(dst) + ((tid + 256 * k + rot) & 4095));
 }
 
 bool ols_frame_supported(uint64_t D, size_t Lc, size_t fft_len) {
@@ -2285,7 +2243,7 @@ int launch_ols_frame(hipStream_t s, const FusedFirArgs &a, const void *pend_in, 
     f.inv_denom = 1.0 / (double)den;
     f.nfr = (unsigned)nfr;
     const unsigned grid = (unsigned)((nfr + 1 + 8 * RR_V_FRAMEWIN - 1) / (8 * RR_V_FRAMEWIN) * (8 * RR_V_FRAMEWIN));
-    hipLaunchKernelGGL(k_ols_frame, dim3(grid), dim3(64 * kFrameWaves), 0, s, f);
+    hipLaunchKernelGGL(k_ols_frame, dim3(grid), dim3(256), 0, s, f);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
