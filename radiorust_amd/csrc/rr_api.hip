@@ -1489,10 +1489,10 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
         a.tw4096 = d_tw4096.p;
         a.V = ols_V;
         a.poly = ols_poly;
-        const int tkf = timers.begin(ST_FUSED_FIR, stream);
+        // (the launch records its own start / end: marker packets would cost ~4 us of stream time each)
+        if (timers.on) timers.begin_ext(ST_FUSED_FIR, &a.ev_start, &a.ev_stop);
         RR_TRY(launch_ols_frame(stream, a, pin, pending_len, pendbuf[po].p, d_out, fo->d_window.p, fo->d_tw.p,
                                 fo->center_dc));
-        timers.end(tkf, stream);
         xh_cur ^= 1;
         if (left) RR_HIP(hipMemcpyAsync(carry.p, xh[xh_cur].as<char>() + (HX - left) * esz, left * esz, hipMemcpyDeviceToDevice, stream));
         const uint64_t den0 = (uint64_t)fs->denom;

@@ -2040,10 +2040,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __shared__ __attribute__((aligned(16))) f2 smem[4 * kPolyLds];  // 4544 elements >= the 4352 of the padded frame image
     f2 *const fr = smem;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    // frames dealt to the XCDs in a moving window, RR_V_FRAMEWIN neighbouring frames per XCD
-    const unsigned f = blockIdx.x / (8 * RR_V_FRAMEWIN) * (8 * RR_V_FRAMEWIN) + (blockIdx.x % (8 * RR_V_FRAMEWIN) & 7) * RR_V_FRAMEWIN +
-                       (blockIdx.x % (8 * RR_V_FRAMEWIN) >> 3);
-    if (f > a.nfr) return;
+    // The frame that does not fill (its samples go to pend_out) is workgroup 0: dispatched first it runs beside the first
+    // round of frames; as the LAST workgroup it ran alone behind the four full rounds of a 2^26-sample call.
+    // The others: frames dealt to the XCDs in a moving window, RR_V_FRAMEWIN neighbouring frames per XCD.
+    unsigned f;
+    if (blockIdx.x == 0) {
+        f = a.nfr;
+    } else {
+        const unsigned bx = blockIdx.x - 1;
+        f = bx / (8 * RR_V_FRAMEWIN) * (8 * RR_V_FRAMEWIN) + (bx % (8 * RR_V_FRAMEWIN) & 7) * RR_V_FRAMEWIN + (bx % (8 * RR_V_FRAMEWIN) >> 3);
+        if (f >= a.nfr) return;
+    }
     const bool tail = f == a.nfr;  // the frame that does not fill: goes to pend_out
     const long F0 = 4096l * f - a.pl;  // decimated index (of this call) of the frame's first sample
     const int hop = 1024 - a.V, per_block = hop >> 2, first = a.V >> 2;
@@ -2189,11 +2196,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     // ---- Fourier: window, DFT_4096 (radix 16 x 3 as k_fft4096), optional DC centring ---------------
     f2 v[16];
+    {
+        // the lane's 16 window values as 4 loads of 16 bytes (the packed copy behind the table, as k_fft4096)
+        const float4 *wp = reinterpret_cast<const float4 *>(ka->window + 4096) + 4 * tid;
+        float wv[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const float wv = ka->window[tid + 256 * k];
-        const f2 s = fr[tid + 256 * k];
-        v[k] = (f2){s.x * wv, s.y * wv};
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const float4 w4 = wp[q4];
+            wv[4 * q4] = w4.x;
+            wv[4 * q4 + 1] = w4.y;
+            wv[4 * q4 + 2] = w4.z;
+            wv[4 * q4 + 3] = w4.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = fr[tid + 256 * k] * wv[k];
     }
     __syncthreads();  // the frame has been read: it becomes the padded exchange image
     fft4096_regs(v, fr, ka->tw4096, tid);
@@ -2242,8 +2258,11 @@ int launch_ols_frame(hipStream_t s, const FusedFirArgs &a, const void *pend_in, 
     f.kstep = (unsigned)(128 % den);
     f.inv_denom = 1.0 / (double)den;
     f.nfr = (unsigned)nfr;
-    const unsigned grid = (unsigned)((nfr + 1 + 8 * RR_V_FRAMEWIN - 1) / (8 * RR_V_FRAMEWIN) * (8 * RR_V_FRAMEWIN));
-    hipLaunchKernelGGL(k_ols_frame, dim3(grid), dim3(256), 0, s, f);
+    const unsigned grid = 1u + (unsigned)((nfr + 8 * RR_V_FRAMEWIN - 1) / (8 * RR_V_FRAMEWIN) * (8 * RR_V_FRAMEWIN));
+    if (a.ev_start && a.ev_stop)
+        hipExtLaunchKernelGGL(k_ols_frame, dim3(grid), dim3(256), 0, s, a.ev_start, a.ev_stop, 0, f);
+    else
+        hipLaunchKernelGGL(k_ols_frame, dim3(grid), dim3(256), 0, s, f);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
