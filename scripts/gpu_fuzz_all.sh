@@ -6,7 +6,7 @@ TAG="${1:-fuzz}"; ROUNDS="${2:-3}"
 OUT="$GRAFT_REPO_ROOT/gpurun_out/$TAG"
 mkdir -p "$OUT"; cd "$GRAFT_REPO_ROOT"
 for r in $(seq 1 "$ROUNDS"); do
-  for f in fuzz_r2 fuzz_fast fuzz_blocks fuzz_chain; do
+  for f in fuzz_r2 fuzz_fast fuzz_blocks fuzz_chain fuzz_frame; do
     seed=$((100 * r + 7))
     echo "=== $f seed $seed"
     timeout -k 10 280 python3 scripts/$f.py 25 $seed > "$OUT/${f}_$seed.log" 2>&1
