@@ -444,6 +444,71 @@ def test_chain_one_call_of_2_pow_28_samples(rr, oracle):
     assert err <= 2e-6, err
 
 
+def test_chain_frame_kernel_and_two_kernel_calls_in_one_stream(rr, oracle):
+    """Calls of 2^23 samples and more run the fused frame kernel (k_ols_frame: FIR and Fourier stage in one kernel, the
+    unfinished frame in a pending buffer), shorter ones k_ols_wave + k_fft4096 with the same tables; the pending samples,
+    the mixed-sample history and the NCO phase have to pass from one to the other - also across a retune and an
+    interrupt.  Every call's spectra against the same stream fed through a chain that never takes the frame kernel
+    (compared on the device), the first ones of every section against the C oracle."""
+    import torch
+
+    fs = 200e6
+    # (the first call of a stream, and the first after an interrupt, runs block by block: the fused kernels need the
+    #  Filter's previous chunk and a filled Downsampler window)
+    sizes = [50000, (1 << 23) + 12345, 70000, 1 << 23, 1000, 30000, (1 << 23) + 64, 300000]
+    n = sum(sizes)
+    st = torch.cuda.current_stream().cuda_stream
+    d_in = torch.empty(n, dtype=torch.complex64, device="cuda")
+    rr.synth_iq_dev(0, st, 5, 0, n, d_in.data_ptr())
+    torch.cuda.synchronize()
+
+    def run(env_kernel):
+        if env_kernel:
+            os.environ["RR_FUSED_KERNEL"] = env_kernel
+        else:
+            os.environ.pop("RR_FUSED_KERNEL", None)
+        g = make(rr, oracle, CFG2, True)
+        g.set_stream(st)
+        outs, kernels, off = [], [], 0
+        for i, m in enumerate(sizes):
+            if i == 3:
+                g.set_shift(-12.5e6)  # retune between calls (transform.rs:318-340)
+            if i == 5:
+                g.interrupt()         # the Filter's history and the carry go (filters.rs:262-265)
+            cap = (m // 4 // 4096 + 2) * 4096
+            d_out = torch.empty(cap, dtype=torch.complex64, device="cuda")
+            w = g.process_dev(fs, d_in.data_ptr() + 8 * off, m, d_out.data_ptr(), cap)
+            torch.cuda.synchronize()
+            outs.append(d_out[:w].clone())
+            kernels.append(g.last_path_kernel())
+            off += m
+        return outs, kernels
+
+    import os
+    try:
+        got, kernels = run(None)
+        ref, kref = run("olsw")
+    finally:
+        os.environ.pop("RR_FUSED_KERNEL", None)
+    assert kernels == ["", "k_ols_frame", "k_ols_wave", "k_ols_frame", "k_ols_wave", "", "k_ols_frame", "k_ols_wave"], kernels
+    assert "k_ols_frame" not in kref
+    for a, b in zip(got, ref):
+        assert a.numel() == b.numel()
+        if a.numel():
+            fa, fb = a.view(-1, 4096), b.view(-1, 4096)
+            err = (torch.linalg.vector_norm(fa - fb, dim=1) / torch.linalg.vector_norm(fb, dim=1)).max().item()
+            assert err <= 2e-6, err
+    # and the first 32 spectra of the stream against the C oracle
+    K = 32
+    x = d_in[: (K + 2) * 16384].cpu().numpy()
+    want = oracle.run_chain_c(x, fs, shift=25e6, filter_len=64, freq_resp=lowpass(20e6), output_rate=50e6, bandwidth=40e6,
+                              fft_len=4096, fft_window=oracle.Kaiser.with_null_at_bin(2.0), flt=np.float64, threads=4,
+                              max_frames=K + 1)[0][:K]
+    y = torch.cat([got[0], got[1]])[: K * 4096].cpu().numpy().reshape(K, 4096)
+    for a, b in zip(y, want):
+        assert rms_rel(a, b) <= 1e-5
+
+
 @pytest.mark.parametrize("dtype,tol", [(np.float32, 1e-5), (np.float64, 1e-11)])
 def test_meter_is_the_bandwidth_meter_example(rr, oracle, dtype, tol):
     """rr_meter_*: the reference's own pipeline in its own order (examples/bandwidth_meter/main.rs:53-69) -
