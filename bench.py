@@ -27,8 +27,9 @@ the max-over-ranks of the elapsed time.  scaling = weak.
 The JSON line also carries
   roofline     — dominant kernel: algorithmic bytes (10 B per input sample:
                  8 B read + 8 B / 4 written) / its average
-                 duration from hipEvents recorded by the library around each
-                 launch on the stream it runs on, against the 8 TB/s HBM peak.
+                 duration from hipEvents recorded by the library around its
+                 launches on the stream it runs on (inside the timed region, one
+                 launch in --time-every = 4), against the 8 TB/s HBM peak.
   cpu_baseline — the CPU oracle (C restatement of the reference blocks, kind = "port")
                  timed on this host on a bounded sample: one thread per block (4 cores)
                  and single-threaded.
@@ -152,6 +153,9 @@ def main():
     ap.add_argument("--no-fused", action="store_true", help="force the block-by-block kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--time-all", action="store_true", help="time every kernel inside the timed region, not only the dominant one")
+    ap.add_argument("--time-every", type=int, default=4,
+                    help="inside the timed region one launch in this many of the dominant kernel records its start / end "
+                         "(a timed launch cannot overlap its neighbours' head and tail: timing all of them costs 2-3 %% of `value`)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="rank logic rehearsal only: all ranks share cuda:0 and line up over gloo (RCCL refuses two ranks on one GPU)")
     ap.add_argument("--traffic-json", default=None, help="file holding measured HBM bytes per launch (PMC pass)")
@@ -239,6 +243,7 @@ def main():
     # inside the timed region only the dominant kernel is timed (a timed launch costs ~5 us of stream
     # time); the other kernels' averages come from a few extra steps after the timed region
     lib.rr_chain_timing_enable(chain._h, 2 if not (args.no_fused or args.time_all) else 1)
+    lib.rr_chain_timing_every(chain._h, max(1, args.time_every) if not (args.no_fused or args.time_all) else 1)
     lib.rr_chain_timing_reset(chain._h)
 
     barrier = ranks.barrier
@@ -309,6 +314,7 @@ def main():
     other = {}
     if not args.no_fused and not args.profile:  # the remaining kernels, outside the timed region
         lib.rr_chain_timing_enable(chain._h, 1)
+        lib.rr_chain_timing_every(chain._h, 1)
         lib.rr_chain_timing_reset(chain._h)
         for _ in range(20):
             step()
@@ -415,7 +421,9 @@ def main():
                 "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
                 "frac_of_measured_copy": round(achieved / copy_gbs, 5) if copy_gbs else None,
             },
+            # (launches = the launches that recorded their start / end: one in --time-every inside the timed region)
             "kernels": {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 5)} for k, v in stages.items()},
+            "timed_launch_every": max(1, args.time_every) if not (args.no_fused or args.time_all) else 1,
             "kernels_outside_timed_region": {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 5)}
                                              for k, v in other.items()},
             "host_fed": host_fed,

@@ -319,6 +319,10 @@ int rr_chain_destroy(rr_chain *h);
  * stage (a timed launch costs about 5 us of stream time; the benchmark times only
  * its dominant kernel inside the timed region); on = 0: off. */
 int rr_chain_timing_enable(rr_chain *h, int on);
+/* With on = 2, time one launch in `every` (default 1 = all of them): a launch that records its own start and end
+ * neither overlaps its predecessor's tail nor lets its successor start early, so timing every launch of a back-to-back
+ * stream costs it 2-3 % of its rate; the benchmark samples every 4th. */
+int rr_chain_timing_every(rr_chain *h, unsigned every);
 int rr_chain_timing_reset(rr_chain *h);
 int rr_chain_timing_read(rr_chain *h, int stage, double *total_ms, uint64_t *launches);
 const char *rr_chain_timing_stage_name(int stage); /* NULL past the last stage */

@@ -154,6 +154,7 @@ SIGNATURES = {
     "rr_chain_last_path": (_i, [_vp, C.POINTER(_i)]),
     "rr_chain_destroy": (_i, [_vp]),
     "rr_chain_timing_enable": (_i, [_vp, _i]),
+    "rr_chain_timing_every": (_i, [_vp, C.c_uint]),
     "rr_chain_timing_reset": (_i, [_vp]),
     "rr_chain_timing_read": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(C.c_uint64)]),
     "rr_chain_timing_stage_name": (C.c_char_p, [_i]),

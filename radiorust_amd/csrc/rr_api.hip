@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 
 using namespace rr;
 
@@ -790,18 +791,34 @@ int rr_fourier::prepare(size_t len) {
             tw[2 * (nB + i)] = std::cos(ang);
             tw[2 * (nB + i) + 1] = std::sin(ang);
         }
+        // 2^13 / 2^14 .. 2^18 points: two passes over HBM (k_fft_tile) with the sub-transforms' own tables behind tB | tA;
+        // RR_FOURIER_BIG=transpose keeps the five launches (transposes around the fast row kernels)
+        const bool force_tr = [] { const char *e = std::getenv("RR_FOURIER_BIG"); return e && std::string(e) == "transpose"; }();
+        big_tile = !force_tr && fft_tile_supported(dtype, N1, N2);
+        if (big_tile) {
+            big_tw1_off = nA + nB;
+            big_tw2_off = big_tw1_off + N1;
+            for (size_t Nx : {N1, N2})
+                for (size_t i = 0; i < Nx; ++i) {
+                    const double ang = -2.0 * M_PI * (double)i / (double)Nx;
+                    tw.push_back(std::cos(ang));
+                    tw.push_back(std::sin(ang));
+                }
+        }
         cast(tw, tb);
         RR_TRY(upload(d_window, wb.data(), wb.size(), stream));
         RR_TRY(upload(d_tw, tb.data(), tb.size(), stream));
-        for (rr_fourier **sub : {&bigA, &bigB}) {
-            if (!*sub) {
-                *sub = new rr_fourier;
-                RR_TRY((*sub)->init_base(K_FOURIER, dtype, device));
+        if (!big_tile) {
+            for (rr_fourier **sub : {&bigA, &bigB}) {
+                if (!*sub) {
+                    *sub = new rr_fourier;
+                    RR_TRY((*sub)->init_base(K_FOURIER, dtype, device));
+                }
+                (*sub)->stream = stream;
             }
-            (*sub)->stream = stream;
+            RR_TRY(bigA->prepare(N1));  // rectangular windows: all ones
+            RR_TRY(bigB->prepare(N2));
         }
-        RR_TRY(bigA->prepare(N1));  // rectangular windows: all ones
-        RR_TRY(bigB->prepare(N2));
         big_t = true;
         big_h = h;
     } else if (use_big) {
@@ -935,6 +952,19 @@ int rr_fourier::transform_dev(const void *head, size_t n_head, const void *in, v
         RR_TRY(big_ws.reserve(per_pass * n * esz));
         size_t N1, N2;
         fft_big_split(n, &N1, &N2);
+        if (big_t && big_tile) {
+            const char *tB = d_tw.as<char>(), *tA = tB + ((size_t)1 << big_h) * esz;
+            const char *tw1 = tB + big_tw1_off * esz, *tw2 = tB + big_tw2_off * esz;
+            for (size_t f0 = 0; f0 < count; f0 += per_pass) {
+                const size_t F = count - f0 < per_pass ? count - f0 : per_pass;
+                const char *src = static_cast<const char *>(in) + f0 * n * esz;
+                char *dst = static_cast<char *>(out) + f0 * n * esz;
+                RR_TRY(launch_fft_tile(dtype, stream, 0, src, big_ws.p, N1, N2, F, d_window.p, tw1, tB, tA, big_h, 0));
+                RR_TRY(launch_fft_tile(dtype, stream, 1, big_ws.p, dst, N1, N2, F, nullptr, tw2, nullptr, nullptr, 0,
+                                       center_dc ? N2 / 2 : 0));
+            }
+            return RR_OK;
+        }
         if (big_t) {
             RR_TRY(big_ws2.reserve(per_pass * n * esz));
             bigA->stream = bigB->stream = stream;
@@ -1161,6 +1191,7 @@ void StageTimers::end(int idx, hipStream_t s) {
 bool StageTimers::begin_ext(int stage, hipEvent_t *a, hipEvent_t *b) {
     *a = *b = nullptr;
     if (!on || (only_stage >= 0 && stage != only_stage)) return false;
+    if (every > 1 && (seen++ % every) != 0) return false;
     if (pending.size() >= 8192 && drain() != RR_OK) return false;
     hipEvent_t e[2] = {nullptr, nullptr};
     for (hipEvent_t &x : e) {
@@ -2571,9 +2602,16 @@ int rr_chain_timing_enable(rr_chain *h, int on) {
     h->timers.only_stage = on == 2 ? ST_FUSED_FIR : -1;
     return RR_OK;
 }
+int rr_chain_timing_every(rr_chain *h, unsigned every) {
+    RR_CHECK_HANDLE(h, K_CHAIN);
+    h->timers.every = every ? every : 1;
+    h->timers.seen = 0;
+    return RR_OK;
+}
 int rr_chain_timing_reset(rr_chain *h) {
     RR_CHECK_HANDLE(h, K_CHAIN);
     RR_TRY(h->select());
+    h->timers.seen = 0;
     h->timers.reset();
     return RR_OK;
 }

@@ -178,6 +178,9 @@ struct rr_fourier : rr_block {
     // transforms of N1 and N2 points, twiddle tables tB (2^big_h entries) | tA behind each other in d_tw
     bool big_t = false;
     int big_h = 0;
+    // two passes (k_fft_tile) instead of five launches: e^{-j 2 pi k / N1} and e^{-j 2 pi k / N2} follow tB | tA in d_tw
+    bool big_tile = false;
+    size_t big_tw1_off = 0, big_tw2_off = 0;  // element offsets into d_tw
     rr_fourier *bigA = nullptr, *bigB = nullptr;
     rr::DevBuf big_ws2;
     // Bluestein for lengths that are not powers of two (n >= 32, either dtype): two transforms of bs_M points
@@ -220,6 +223,7 @@ enum Stage { ST_FREQSHIFT = 0, ST_FILTER, ST_DECIM, ST_FOURIER, ST_FUSED_FIR, ST
 struct StageTimers {
     bool on = false;
     int only_stage = -1;  // >= 0: only this stage is timed (each timed launch costs ~5 us of stream time)
+    unsigned every = 1, seen = 0;  // begin_ext: one launch in `every` records its start / end
     struct Pair { hipEvent_t a, b; int stage; bool a_shared; };  // a_shared: `a` is the previous pair's `b`
     std::vector<Pair> pending;
     std::vector<hipEvent_t> pool;

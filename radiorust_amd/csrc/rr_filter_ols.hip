@@ -174,9 +174,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PARTS ? 3 :
     }
 
     // lane terms of the four access patterns; everything else is an immediate offset
+    // First exchange: rows of 16 padded to 17 (pad16) - its stores, 16 elements apart from lane to lane, need that; its reads pay
+    // a second cycle per half-wave for the pad inside their 32 elements.  Second exchange: NO padding - its stores go in groups of
+    // 16 lanes = 16 neighbouring elements whatever the layout, and its reads then find their 32 elements in one piece.
     const f2 *const rd = img + (j + (j >> 4));               // pad16(j + 256 k) = rd + 272 k
     f2 *const w0 = img + 17 * j;                              // pad16(16 j + k)  = w0 + k
-    f2 *const w1 = img + ((j >> 4) * 272 + (j & 15));         // pad16((j / 16) 256 + j % 16 + 16 k) = w1 + 17 k
+    f2 *const w1 = img + ((j >> 4) * 256 + (j & 15));         // (j / 16) 256 + j % 16 + 16 k = w1 + 16 k
+    const f2 *const rd1 = img + j;                            // j + 256 k = rd1 + 256 k
     [[maybe_unused]] const f2 *const trow = tab + 15 * (j & 15) - 1;  // W_256^((j mod 16) k) = trow[k]
     const __amdgpu_buffer_rsrc_t rsG = rsrc_of(a.G, PARTS ? 32768u * (unsigned)a.nparts : (G16 ? 16384u : 32768u));
 
@@ -199,10 +203,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PARTS ? 3 :
         dft16(v);
         lds_bar();
 #pragma unroll
-        for (int k = 0; k < 16; ++k) img_st(w1 + 17 * k, v[k]);
+        for (int k = 0; k < 16; ++k) img_st(w1 + 16 * k, v[k]);
         lds_bar();
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = img_ld(rd + 272 * k);
+        for (int k = 0; k < 16; ++k) v[k] = img_ld(rd1 + 256 * k);
         twiddle16(v, s2);
         late();
         dft16(v);

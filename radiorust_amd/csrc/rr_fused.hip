@@ -459,11 +459,11 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
         {
             const int b2 = (j >> 4) * 256 + (j & 15);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) lds_st(lds + pad16(b2 + 16 * k), v[k]);
+            for (int k = 0; k < 16; ++k) lds_st(lds + (b2 + 16 * k), v[k]);  // (second exchange: no padding, see below)
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = lds_ld(lds + pad16(j + 256 * k));
+        for (int k = 0; k < 16; ++k) v[k] = lds_ld(lds + (j + 256 * k));
         apply_twiddle_powers(v, (f2){s2.x, s2.y});
         dft16(v);
 #pragma unroll
@@ -517,14 +517,18 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
     dft16(v);
     __syncthreads();
     {
+        // The second exchange uses the image WITHOUT padding: its stores go in groups of 16 lanes = 16 neighbouring elements
+        // (conflict-free under any layout), and the reads - halves of 32 lanes over 64 banks - want their 32 neighbouring
+        // elements in one piece; the padded rows of the first exchange (needed by ITS stores, 16 elements apart per lane)
+        // cost every read of a half-wave a second cycle.
         const int base = (j >> 4) * 256 + (j & 15);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) lds_st(lds + pad16(base + 16 * k), v[k]);
+        for (int k = 0; k < 16; ++k) lds_st(lds + (base + 16 * k), v[k]);
     }
     __syncthreads();
     // pass 2 (Ns = 256): twiddle e^{-j 2 pi k j / 4096}; out j + 256 k
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = lds_ld(lds + pad16(j + 256 * k));
+    for (int k = 0; k < 16; ++k) v[k] = lds_ld(lds + (j + 256 * k));
     {
         const float2 t = s2;
         apply_twiddle_powers(v, (f2){t.x, t.y});
@@ -970,13 +974,13 @@ __device__ __forceinline__ void fft4096_regs(f2 (&v)[16], f2 *lds, const float2 
     dft16(v);
     __syncthreads();
     {
-        const int base = (j >> 4) * 256 + (j & 15);
+        const int base = (j >> 4) * 256 + (j & 15);  // (second exchange: no padding, as k_fft4096)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) lds_st(lds + pad16(base + 16 * k), v[k]);
+        for (int k = 0; k < 16; ++k) lds_st(lds + (base + 16 * k), v[k]);
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = lds_ld(lds + pad16(j + 256 * k));
+    for (int k = 0; k < 16; ++k) v[k] = lds_ld(lds + (j + 256 * k));
     {
         const float2 t = tw[j];
         apply_twiddle_powers(v, (f2){t.x, t.y});
@@ -1380,6 +1384,17 @@ constexpr unsigned kWaveWin = 64;  // blocks dealt to the XCDs in a moving windo
 #ifndef RR_V_OLSW_OCC
 #define RR_V_OLSW_OCC 4
 #endif
+// Read side of the three exchanges of the wave-local inverse DFT_256 (butterfly l takes in[l + 64 c], c < 4, at rd + st c):
+//   pass 1  the image of pass 0 (element i at 2 (i >> 2) + (i & 1) + 144 ((i >> 1) & 1)), st = 32
+//   pass 2  element i at i + 4 (i >> 4), st = 80 (its stores - 20 (l >> 2) + (l & 3) + 4 c - are conflict-free, these reads
+//           2-way: groups of 16 lanes on the store side and halves of 32 on the read side cannot both be served by a padding)
+//   pass 3  element i at i + 16 (i >> 6), st = 80 (stores 80 g + q + 16 c)
+__device__ __forceinline__ const f2 *inv256_rd(const f2 *lds, int l, int pass) {
+    if (pass == 1) return lds + (2 * (l >> 2) + (l & 1) + 144 * ((l >> 1) & 1));
+    if (pass == 2) return lds + (l + 4 * (l >> 4));
+    return lds + l;
+}
+
 template <int D, bool POLY>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OCC, RR_V_OLSW_OCC))) void k_ols_wave(
     const float2 *__restrict__ xh, int hx, const float2 *__restrict__ in, long n_in, const float2 *__restrict__ nco,
@@ -1490,8 +1505,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OC
             t_inv[2] = t_inv[1];
         }
     }
-    f2 *const a_rd = lds + (l + 2 * g);  // A(l + 64 m + 256 c) = a_rd + 72 m + 296 c
-    f2 *const b_rd = lds + (l + 4 * g);  // B(l + 64 c) = b_rd + 80 c
+    [[maybe_unused]] f2 *const a_rd = lds + (l + 2 * g);  // A(l + 64 m + 256 c) = a_rd + 72 m + 296 c
     // ---- phase of the lane's first sample (2 l into the block): (base + 2 l) mod denom -----------
     unsigned r = base + 2u * (unsigned)l;
     if (denom >= 128u) {
@@ -1602,9 +1616,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OC
         dft8(e0);  // over mu2: out kappa2a
         dft8(e1);
         wave_sync();  // the first image has been read
-        // exchange 2: element (low3, kappa1, j, kappa2a) at 2 (kappa1 + 8 kappa2a + 66 low3) + j; the reader is lane kappa1 + 8 kappa2a
+        // exchange 2: element (low3, kappa1, j, kappa2a) at 2 (kappa1 + 8 kappa2a + 65 low3) + j; the reader is lane kappa1 + 8 kappa2a.
+        // (A 16-byte store is served in groups of 8 neighbouring lanes over 32 banks: the planes of the eight low3 values must
+        // start 4 banks apart - 130 elements = 260 dwords = 4 mod 32; a pitch of 132 elements put lanes t and t + 4 on the same
+        // banks, 2-way conflicts on every store of this exchange.)
         {
-            f2 *row = lds + 2 * ((l >> 3) + 66 * (l & 7));
+            f2 *row = lds + 2 * ((l >> 3) + 65 * (l & 7));
 #pragma unroll
             for (int k = 0; k < 8; ++k) *reinterpret_cast<float4 *>(row + 16 * k) = (float4){e0[k].x, e0[k].y, e1[k].x, e1[k].y};
         }
@@ -1614,7 +1631,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OC
         for (int a = 0; a < D / 2; ++a)
 #pragma unroll
             for (int m1 = 0; m1 < RC; ++m1) {
-                const float4 r = *reinterpret_cast<const float4 *>(lds + 2 * l + 132 * (a + (D / 2) * m1));
+                const float4 r = *reinterpret_cast<const float4 *>(lds + 2 * l + 130 * (a + (D / 2) * m1));
                 d[2 * a][m1] = (f2){r.x, r.y};
                 d[2 * a + 1][m1] = (f2){r.z, r.w};
             }
@@ -1732,19 +1749,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OC
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + mb, 0, recs, 0x00020000);
     if constexpr (D == 4) {
         // ---- inverse DFT_256, Stockham radix 4 x 4: butterfly l reads in[l + 64 c] ------------------
-        // pass 0 (Ns = 1): no twiddle; out 4 l + c: B = 4 l + 4 (l >> 2) + c
+        // Each of the three exchanges has its own image layout (inv256_rd): the LDS serves 8-byte reads in halves of 32 lanes
+        // over 64 banks, 8-byte stores in groups of 16 lanes and 16-byte stores in groups of 8 lanes over 32 banks, and one
+        // padding for all three (4 elements per 16, the first form) left 2-way conflicts on the first exchange's stores and on
+        // the reads of the first and the last.
+        // pass 0 (Ns = 1): no twiddle; out 4 l + c, element i at 2 (i >> 2) + (i & 1) + 144 ((i >> 1) & 1): the lane's pairs
+        // {y0, y1} at 2 l and {y2, y3} at 144 + 2 l - neighbouring lanes store neighbouring 16-byte pieces, and the 32
+        // elements a half-wave reads are two runs of 16, 32 banks apart
         idft4(y[0], y[1], y[2], y[3]);
         wave_sync();  // the forward image has been read
         {
-            f2 *row = lds + (4 * l + 4 * (l >> 2));
+            f2 *row = lds + 2 * l;
             *reinterpret_cast<float4 *>(row) = (float4){y[0].x, y[0].y, y[1].x, y[1].y};
-            *reinterpret_cast<float4 *>(row + 2) = (float4){y[2].x, y[2].y, y[3].x, y[3].y};
+            *reinterpret_cast<float4 *>(row + 144) = (float4){y[2].x, y[2].y, y[3].x, y[3].y};
         }
         wave_sync();
 #pragma unroll
         for (int pass = 1; pass < 4; ++pass) {
+            const f2 *const rd = inv256_rd(lds, l, pass);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) y[c] = lds_ld(b_rd + (80 * c));
+            for (int c = 0; c < 4; ++c) y[c] = lds_ld(rd + ((pass == 1 ? 32 : 80) * c));
             // twiddles e^{+j 2 pi c (l mod ns) / (4 ns)} = conj(tw[(l mod ns) 256 / ns])^c, ns = 4^pass
             const f2 w1 = t_inv[pass - 1];
             const f2 w2 = cmul(w1, w1);
@@ -1755,14 +1779,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OC
             idft4(y[0], y[1], y[2], y[3]);
             if (pass == 3) break;  // natural order: y[c] = result[l + 64 c]
             wave_sync();
-            if (pass == 1) {  // out 16 (l >> 2) + (l & 3) + 4 c: B = 20 (l >> 2) + (l & 3) + 4 c
+            if (pass == 1) {  // out 16 (l >> 2) + (l & 3) + 4 c, element i at i + 4 (i >> 4): 20 (l >> 2) + (l & 3) + 4 c
                 f2 *col = lds + (20 * (l >> 2) + (l & 3));
 #pragma unroll
                 for (int c = 0; c < 4; ++c) lds_st(col + (4 * c), y[c]);
-            } else {  // out 64 g + q + 16 c: B = 80 g + q + 20 c
+            } else {  // out 64 g + q + 16 c, element i at i + 16 (i >> 6): 80 g + q + 16 c
                 f2 *col = lds + (80 * g + q);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) lds_st(col + (20 * c), y[c]);
+                for (int c = 0; c < 4; ++c) lds_st(col + (16 * c), y[c]);
             }
             wave_sync();
         }
@@ -1918,7 +1942,7 @@ __device__ __forceinline__ void poly4_block(f2 (&v)[16], f2 (&y)[4], f2 *lds, in
     dft8(e1);
     wave_sync();
     {
-        f2 *row = lds + 2 * ((l >> 3) + 66 * (l & 7));
+        f2 *row = lds + 2 * ((l >> 3) + 65 * (l & 7));  // (planes 130 elements apart: k_ols_wave's exchange 2)
 #pragma unroll
         for (int k = 0; k < 8; ++k) *reinterpret_cast<float4 *>(row + 16 * k) = (float4){e0[k].x, e0[k].y, e1[k].x, e1[k].y};
     }
@@ -1933,7 +1957,7 @@ __device__ __forceinline__ void poly4_block(f2 (&v)[16], f2 (&y)[4], f2 *lds, in
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int m1 = 0; m1 < 4; ++m1) {
-            const float4 r = *reinterpret_cast<const float4 *>(lds + 2 * l + 132 * (a + 2 * m1));
+            const float4 r = *reinterpret_cast<const float4 *>(lds + 2 * l + 130 * (a + 2 * m1));
             d[2 * a][m1] = (f2){r.x, r.y};
             d[2 * a + 1][m1] = (f2){r.z, r.w};
         }
@@ -1966,20 +1990,20 @@ __device__ __forceinline__ void poly4_block(f2 (&v)[16], f2 (&y)[4], f2 *lds, in
     y[1] = cmac(y[1], d[3][1], (f2){gb[2].z, gb[2].w});
     y[2] = cmac(y[2], d[3][2], (f2){gb[3].x, gb[3].y});
     y[3] = cmac(y[3], d[3][3], (f2){gb[3].z, gb[3].w});
-    // inverse DFT_256 (radix 4 x 4 x 4 x 4, as k_ols_wave<4>)
-    f2 *const b_rd = lds + (l + 4 * g);
+    // inverse DFT_256 (radix 4 x 4 x 4 x 4, as k_ols_wave<4>: one image layout per exchange, inv256_rd)
     idft4(y[0], y[1], y[2], y[3]);
     wave_sync();
     {
-        f2 *row = lds + (4 * l + 4 * (l >> 2));
+        f2 *row = lds + 2 * l;
         *reinterpret_cast<float4 *>(row) = (float4){y[0].x, y[0].y, y[1].x, y[1].y};
-        *reinterpret_cast<float4 *>(row + 2) = (float4){y[2].x, y[2].y, y[3].x, y[3].y};
+        *reinterpret_cast<float4 *>(row + 144) = (float4){y[2].x, y[2].y, y[3].x, y[3].y};
     }
     wave_sync();
 #pragma unroll
     for (int pass = 1; pass < 4; ++pass) {
+        const f2 *const rd = inv256_rd(lds, l, pass);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) y[c] = lds_ld(b_rd + (80 * c));
+        for (int c = 0; c < 4; ++c) y[c] = lds_ld(rd + ((pass == 1 ? 32 : 80) * c));
         const f2 w1 = t_inv[pass - 1];
         const f2 w2 = cmul(w1, w1);
         const f2 w3 = cmul(w2, w1);
@@ -1996,7 +2020,7 @@ __device__ __forceinline__ void poly4_block(f2 (&v)[16], f2 (&y)[4], f2 *lds, in
         } else {
             f2 *col = lds + (80 * g + q);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) lds_st(col + (20 * c), y[c]);
+            for (int c = 0; c < 4; ++c) lds_st(col + (16 * c), y[c]);
         }
         wave_sync();
     }

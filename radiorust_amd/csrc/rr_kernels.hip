@@ -864,6 +864,170 @@ int launch_transpose_mul(int dtype, hipStream_t s, const void *in, void *out, si
     return RR_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Four-step transform, third form (the default for 2^13 / 2^14 .. 2^18 points): TWO passes over HBM instead of five.
+//   pass A  a workgroup takes a bundle of C neighbouring columns n2 (C x 8 or 16 bytes = one 128-byte line per row n1),
+//           multiplies by the window, transforms the C columns over n1 (N1 points) in LDS, multiplies by W_N^(n2 k1) and
+//           writes Y[k1][n2] back in the same [row][column] shape
+//   pass B  a workgroup takes C neighbouring rows k1 of Y (contiguous), transforms them over n2 (N2 points) in LDS and
+//           writes X[k1 + N1 k2]: for every k2 its C results are neighbours in memory (a 128-byte line)
+// Both passes are the same kernel: a tile of Np x C elements in LDS (element (n, c) at n SN + c SC), in-place radix-4
+// decimation-in-frequency passes with a lane per butterfly (one radix-2 pass at the end when log2 Np is odd), the result
+// in digit-reversed order, which the store undoes in its address.  Twiddles W_Np^k from an LDS copy of the sub-transform's
+// table.  The tile is Np x 128 bytes; used for Np <= 512 (N <= 2^18), beyond that the five-launch form takes over.
+// ---------------------------------------------------------------------------
+template <class T, int MODE>
+__global__ __launch_bounds__(1024) void k_fft_tile(const v2<T> *__restrict__ in, v2<T> *__restrict__ out, int Np, int lgNp, int No,
+                                                   const T *__restrict__ window, const v2<T> *__restrict__ twNp,
+                                                   const v2<T> *__restrict__ tB, const v2<T> *__restrict__ tA, int h, int rot) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
+    constexpr int C = 128 / (int)sizeof(v2<T>);
+    v2<T> *const tile = reinterpret_cast<v2<T> *>(tile_raw);
+    // MODE 0: lanes run along the columns (element (n, c) at n C + c); MODE 1: along a row (element (n, c) at c (Np + 1) + n)
+    const int SN = MODE == 0 ? C : 1, SC = MODE == 0 ? 1 : Np + 1;
+    v2<T> *const tw = tile + (MODE == 0 ? Np * C : C * (Np + 1));
+    const int nt = blockDim.x, t = threadIdx.x;
+    const size_t chunk = (size_t)blockIdx.y * (size_t)Np * (size_t)No;
+    const int g0 = blockIdx.x * C;
+    for (int i = t; i < Np; i += nt) tw[i] = twNp[i];
+    if (MODE == 0) {
+        for (int idx = t; idx < Np * C; idx += nt) {
+            const int n = idx / C, c = idx % C;
+            const size_t e = (size_t)n * No + g0 + c;
+            v2<T> v = in[chunk + e];
+            const T w = window[e];
+            v.x *= w;
+            v.y *= w;
+            tile[n * C + c] = v;
+        }
+    } else {
+        for (int idx = t; idx < Np * C; idx += nt) {
+            const int c = idx >> lgNp, n = idx & (Np - 1);
+            tile[c * (Np + 1) + n] = in[chunk + (size_t)(g0 + c) * Np + n];
+        }
+    }
+    __syncthreads();
+    int L = Np, lgL = lgNp;
+    for (; L >= 4; L >>= 2, lgL -= 2) {
+        const int q = L >> 2, lgq = lgL - 2, step = Np >> lgL;
+        for (int b = t; b < (Np >> 2) * C; b += nt) {
+            int jj, c;
+            if (MODE == 0) {
+                c = b % C;
+                jj = b / C;
+            } else {
+                jj = b & ((Np >> 2) - 1);
+                c = b >> (lgNp - 2);
+            }
+            const int blk = jj >> lgq, j = jj & (q - 1);
+            v2<T> *p = tile + ((blk << lgL) + j) * SN + c * SC;
+            const v2<T> a0 = p[0], a1 = p[q * SN], a2 = p[2 * q * SN], a3 = p[3 * q * SN];
+            const v2<T> s02 = {a0.x + a2.x, a0.y + a2.y}, d02 = {a0.x - a2.x, a0.y - a2.y};
+            const v2<T> s13 = {a1.x + a3.x, a1.y + a3.y}, d13 = {a1.x - a3.x, a1.y - a3.y};
+            // W_4 = -j: y1 = d02 - j d13, y3 = d02 + j d13
+            const v2<T> y0 = {s02.x + s13.x, s02.y + s13.y}, y2 = {s02.x - s13.x, s02.y - s13.y};
+            const v2<T> y1 = {d02.x + d13.y, d02.y - d13.x}, y3 = {d02.x - d13.y, d02.y + d13.x};
+            p[0] = y0;
+            if (j == 0) {
+                p[q * SN] = y1;
+                p[2 * q * SN] = y2;
+                p[3 * q * SN] = y3;
+            } else {
+                const int k1 = j * step;
+                p[q * SN] = cmul<T>(y1, tw[k1]);
+                p[2 * q * SN] = cmul<T>(y2, tw[2 * k1]);
+                p[3 * q * SN] = cmul<T>(y3, tw[3 * k1]);
+            }
+        }
+        __syncthreads();
+    }
+    if (L == 2) {
+        for (int b = t; b < (Np >> 1) * C; b += nt) {
+            int jj, c;
+            if (MODE == 0) {
+                c = b % C;
+                jj = b / C;
+            } else {
+                jj = b & ((Np >> 1) - 1);
+                c = b >> (lgNp - 1);
+            }
+            v2<T> *p = tile + (2 * jj) * SN + c * SC;
+            const v2<T> a0 = p[0], a1 = p[SN];
+            p[0] = v2<T>{a0.x + a1.x, a0.y + a1.y};
+            p[SN] = v2<T>{a0.x - a1.x, a0.y - a1.y};
+        }
+        __syncthreads();
+    }
+    // position p holds frequency k = d1 + 4 d2 + 16 d3 + .. of p = d1 Np / 4 + d2 Np / 16 + .. (the radix-2 digit last)
+    for (int idx = t; idx < Np * C; idx += nt) {
+        const int p = idx / C, c = idx % C;
+        int k = 0, sh = 0, rem = p, lgs = lgNp;
+        while (lgs >= 2) {
+            lgs -= 2;
+            const int d = rem >> lgs;
+            rem -= d << lgs;
+            k += d << sh;
+            sh += 2;
+        }
+        if (lgs == 1) k += rem << sh;
+        v2<T> v = tile[p * SN + c * SC];
+        if (MODE == 0) {
+            const unsigned e = (unsigned)k * (unsigned)(g0 + c);  // < N1 N2 <= 2^20
+            v = cmul<T>(v, cmul<T>(tA[e >> h], tB[e & ((1u << h) - 1u)]));
+            out[chunk + (size_t)k * No + g0 + c] = v;
+        } else {
+            int kk = k + rot;
+            if (kk >= Np) kk -= Np;
+            out[chunk + (size_t)kk * No + g0 + c] = v;
+        }
+    }
+}
+
+bool fft_tile_supported(int dtype, size_t N1, size_t N2) {
+    const size_t C = dtype == RR_F32 ? 16 : 8;
+    // (the kernel itself takes Np = 1024, a 136 KiB tile and one workgroup per CU: measured 0.225 / 0.252 ms per 2^24 samples at
+    // 2^19 / 2^20 points against 0.225 / 0.223 for the five launches, so those stay with the transposes)
+    auto ok = [&](size_t n) { return n >= 64 && n <= 512 && is_pow2_n(n); };
+    return ok(N1) && ok(N2) && N1 >= C && N2 >= C;
+}
+
+// pass 0: in = `count` chunks of N1 x N2 (row n1, column n2), out = the same shape holding Y[k1][n2] W_N^(n2 k1);
+// pass 1: in = Y, out = X[k1 + N1 k2] (rows k2 rotated by rot for center_dc)
+template <class T>
+static int launch_fft_tile_t(hipStream_t s, int pass, const void *in, void *out, size_t N1, size_t N2, size_t count,
+                             const void *window, const void *twNp, const void *tB, const void *tA, int h, size_t rot) {
+    constexpr size_t C = 128 / sizeof(v2<T>);
+    const size_t Np = pass == 0 ? N1 : N2, No = pass == 0 ? N2 : N1;
+    int lg = 0;
+    while (((size_t)1 << lg) < Np) ++lg;
+    const size_t lds = (pass == 0 ? Np * C : C * (Np + 1)) * sizeof(v2<T>) + Np * sizeof(v2<T>);
+    size_t nt = Np * C / 4;  // a lane per radix-4 butterfly
+    if (nt > 1024) nt = 1024;
+    if (nt < 256) nt = 256;
+    const dim3 grid((unsigned)(No / C), (unsigned)count);
+    if (pass == 0) {
+        auto fn = k_fft_tile<T, 0>;
+        RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));
+        hipLaunchKernelGGL(fn, grid, dim3((unsigned)nt), lds, s, (const v2<T> *)in, (v2<T> *)out, (int)Np, lg, (int)No,
+                           (const T *)window, (const v2<T> *)twNp, (const v2<T> *)tB, (const v2<T> *)tA, h, 0);
+    } else {
+        auto fn = k_fft_tile<T, 1>;
+        RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));
+        hipLaunchKernelGGL(fn, grid, dim3((unsigned)nt), lds, s, (const v2<T> *)in, (v2<T> *)out, (int)Np, lg, (int)No,
+                           (const T *)nullptr, (const v2<T> *)twNp, (const v2<T> *)nullptr, (const v2<T> *)nullptr, 0, (int)rot);
+    }
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+int launch_fft_tile(int dtype, hipStream_t s, int pass, const void *in, void *out, size_t N1, size_t N2, size_t count,
+                    const void *window, const void *twNp, const void *tB, const void *tA, int h, size_t rot) {
+    if (count == 0) return RR_OK;
+    if (!fft_tile_supported(dtype, N1, N2) || count > 65535)
+        RR_FAIL(RR_ERR_BAD_ARG, "tile transform: %zu x %zu x %zu is outside the kernel's range", N1, N2, count);
+    if (dtype == RR_F32) return launch_fft_tile_t<float>(s, pass, in, out, N1, N2, count, window, twNp, tB, tA, h, rot);
+    return launch_fft_tile_t<double>(s, pass, in, out, N1, N2, count, window, twNp, tB, tA, h, rot);
+}
+
 int launch_fourier_overlapped(int dtype, hipStream_t s, const void *head, size_t n_head, const void *in, void *out,
                               size_t n, size_t hop, size_t count, const void *window, const void *twiddle, bool center_dc) {
     if (count == 0) return RR_OK;

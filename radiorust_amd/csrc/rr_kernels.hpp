@@ -144,6 +144,11 @@ int launch_bs_post(int dtype, hipStream_t s, const void *ws, const void *w, size
 // 1 window[r C + c] (real), 2 the four-step twiddle W_(R C)^(r c) = tA[e >> h] tB[e & (2^h - 1)]
 int launch_transpose_mul(int dtype, hipStream_t s, const void *in, void *out, size_t R, size_t C, size_t count, int mode,
                          const void *window, const void *tB, const void *tA, int h, size_t rot_rows);
+// two-pass four-step (k_fft_tile): pass 0 = window, column transforms over n1, twiddle; pass 1 = row transforms over n2 with
+// the transposed store; twNp = e^{-j 2 pi k / Np} (Np entries) of the pass's sub-transform
+bool fft_tile_supported(int dtype, size_t N1, size_t N2);
+int launch_fft_tile(int dtype, hipStream_t s, int pass, const void *in, void *out, size_t N1, size_t N2, size_t count,
+                    const void *window, const void *twNp, const void *tB, const void *tA, int h, size_t rot);
 bool fft_big_supported(size_t n);
 void fft_big_split(size_t n, size_t *N1, size_t *N2);
 int launch_fft_big(int dtype, hipStream_t s, const void *in, void *out, void *ws, size_t n, size_t count, const void *window,

@@ -559,6 +559,8 @@ def test_fourier_reference_kat_on_gpu(rr):
 @pytest.mark.parametrize("n,center", [(4096, False), (4096, True), (8192, False), (8192, True), (256, True), (256, False), (1024, False),
                                       (1024, True), (2048, False), (2048, True), (2, False), (1, True), (1000, True), (7, True), (4095, False), (12000, False),
                                       (16384, True), (65536, False), (65536, True), (1 << 18, False),   # four-step through HBM
+                                      (1 << 15, False), (1 << 17, True), (1 << 19, False), (1 << 20, True),  # (two passes, k_fft_tile, up to 512 x 512; the transposes beyond)
+                                      (1 << 21, False),                                                  # (beyond the tile kernel: transposes around the row kernels)
                                       (20000, False), (20000, True), (5000, False), (31, True),          # Bluestein beyond 4096 points; direct below 32
                                       (513, False), (1025, True), (1999, True), (2047, False),           # 513 .. 2048: Bluestein in one kernel (k_bluestein4096)
                                       (33, False), (100, True), (255, False), (300, True), (511, True)])  # 32 .. 512: a wave per chunk (k_bluestein1024)
@@ -572,7 +574,8 @@ def test_fourier_parity(rr, oracle, n, center):
     check(out.chunk, t64, t32)
 
 
-@pytest.mark.parametrize("n,center", [(1000, True), (20000, False), (8192, False), (32768, True), (65536, False), (33, False)])
+@pytest.mark.parametrize("n,center", [(1000, True), (20000, False), (8192, False), (32768, True), (65536, False), (33, False),
+                                      (1 << 14, True), (1 << 17, False), (1 << 20, True)])
 def test_fourier_f64_lengths(rr, oracle, n, center):
     """Complex<f64>: powers of two beyond the LDS kernel (4096) by the four-step transform, every other length >= 32 by
     Bluestein over f64 power-of-two transforms (the twiddles of the four-step split are evaluated in f64 with the
@@ -582,6 +585,30 @@ def test_fourier_f64_lengths(rr, oracle, n, center):
     (out,) = g.process(rr.Samples(1e6, x))
     ref = oracle.Fourier(oracle.Kaiser.with_null_at_bin(2.0), center, flt=np.float64).process(x)
     assert rms_rel(out.chunk, ref) < 1e-11
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fourier_big_two_pass_against_the_transposes(rr, oracle, monkeypatch, dtype):
+    """Powers of two beyond one LDS tile, several chunks per device call: the two-pass form (k_fft_tile, the default up to
+    2^18 points) against the five-launch form (RR_FOURIER_BIG=transpose) and the oracle."""
+    import torch
+
+    for n, chunks, center in ((1 << 14, 5, False), (1 << 15, 3, True), (1 << 16, 3, True)):
+        x = oracle.synth_iq(21, 0, n * chunks).astype(np.complex128 if dtype == np.float64 else np.complex64)
+        o = oracle.Fourier(oracle.Kaiser.with_null_at_bin(2.0), center, flt=np.float64)
+        ref = np.concatenate([o.process(x[i * n:(i + 1) * n]) for i in range(chunks)])
+        outs = []
+        for form in ("", "transpose"):
+            monkeypatch.setenv("RR_FOURIER_BIG", form)
+            g = rr.Fourier(rr.Kaiser.with_null_at_bin(2.0), center, dtype=dtype)
+            d_in = torch.from_numpy(x).cuda()
+            d_out = torch.empty_like(d_in)
+            assert g.process_dev(n, d_in.data_ptr(), n * chunks, d_out.data_ptr(), n * chunks) == n * chunks
+            torch.cuda.synchronize()
+            outs.append(d_out.cpu().numpy())
+        tol = 1e-11 if dtype == np.float64 else 2e-6
+        assert rms_rel(outs[0], ref) < tol and rms_rel(outs[1], ref) < tol
+        assert rms_rel(outs[0], outs[1]) < tol
 
 
 def test_fourier_bluestein_one_kernel_many_chunks(rr, oracle, monkeypatch):
