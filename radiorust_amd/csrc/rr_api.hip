@@ -763,7 +763,12 @@ int rr_fourier::prepare(size_t len) {
     const bool pow2 = is_pow2_sz(len);
     const bool generic = [] { const char *e = std::getenv("RR_FOURIER_GENERIC"); return e && std::atoi(e) != 0; }();
     const bool use_big = pow2 && len >= 4 && !fourier_pow2_path(dtype, len);  // (a chunk of 1 sample is a power of two, too)
-    const bool use_bs = !pow2 && len >= 32 && !(generic && len <= 16384);
+    // lengths 2^a 3^b 5^c <= 4096 that are not powers of two: mixed-radix passes in one LDS image instead of Bluestein's two
+    // padded power-of-two transforms, where measured faster (fft_mixed_preferred; RR_FOURIER_MIXED=0 keeps Bluestein, 2 takes it wherever it applies)
+    const int mixed_env = [] { const char *e = std::getenv("RR_FOURIER_MIXED"); return e ? std::atoi(e) : 1; }();  // 0 never, 2 wherever it applies
+    const bool use_mixed = !pow2 && !generic && mixed_env != 0 && fft_mixed_supported(dtype, len) &&
+                           (mixed_env == 2 || fft_mixed_preferred(dtype, len));
+    const bool use_bs = !pow2 && len >= 32 && !(generic && len <= 16384) && !use_mixed;
     auto cast = [&](const std::vector<double> &src, std::vector<unsigned char> &dst) {
         if (dtype == RR_F32) cast_to<float>(src.data(), src.size(), dst);
         else cast_to<double>(src.data(), src.size(), dst);
@@ -873,6 +878,7 @@ int rr_fourier::prepare(size_t len) {
     }
     window_f64.swap(vals);
     n = len;
+    mixed = use_mixed;
     bs_M = 0;
     bs_fused = bs_wave = false;
     big = use_big;
@@ -990,6 +996,7 @@ int rr_fourier::transform_dev(const void *head, size_t n_head, const void *in, v
         }
         return RR_OK;
     }
+    if (mixed) return launch_fft_mixed(dtype, stream, head, n_head, in, hop, n, d_window.p, d_tw.p, out, center_dc, count);
     if (!bs_M) return launch_fourier_overlapped(dtype, stream, head, n_head, in, out, n, hop, count, d_window.p, d_tw.p, center_dc);
     if (bs_wave)
         return launch_bluestein1024(stream, head, n_head, in, hop, n, d_bs_c.p, d_bs_B.p, d_bs_w.p, bs_fft->d_tw.p, out, center_dc, count);

@@ -1028,6 +1028,185 @@ int launch_fft_tile(int dtype, hipStream_t s, int pass, const void *in, void *ou
     return launch_fft_tile_t<double>(s, pass, in, out, N1, N2, count, window, twNp, tB, tA, h, rot);
 }
 
+// ---------------------------------------------------------------------------
+// Mixed-radix transform: chunk lengths n = 2^a 3^b 5^c that are not powers of two (1000, 3000, 4800 / 5 ..; analysis.rs:82-115
+// accepts any length), one workgroup per chunk, the whole transform in ONE LDS image of n elements: in-place decimation-in-
+// frequency passes of radix 5, 4, 3, 2 with a lane per butterfly, the result in mixed-radix digit-reversed order which the store
+// undoes in its address.  Bluestein's algorithm needs two power-of-two transforms of M >= 2 n - 1 points for the same chunk
+// (n = 3000: M = 8192 and five launches; n = 1000: two 4096-point transforms in one kernel); here the work is n log n.
+//   pass with block length L and radix r, q = L / r: inputs a_s = x[blk L + j + s q], outputs
+//   x[blk L + j + m q] = W_L^(j m) sum_s a_s W_r^(s m); position p = d_1 n / r_1 + d_2 n / (r_1 r_2) + .. ends as frequency
+//   k = d_1 + r_1 (d_2 + r_2 (..)).
+// Frames come from [ head | in ] at any hop (Fourier: hop = n; Stft: overlapping spans).
+// ---------------------------------------------------------------------------
+struct MixedPlan {
+    int nrad;
+    unsigned char radix[12];
+    unsigned short q[12];   // butterflies per block of the pass = L / r
+    float rq[12];           // 1 / q: b / q = (int)((b + 0.5) rq) exactly for b, q <= 4096 (the product's error, (b / q) 1.2e-7, stays
+                            // below the 0.5 / q the half moves it away from a whole number) - an integer division by a run-time
+                            // value costs ~35 instructions, and the passes are index arithmetic more than anything else
+};
+__device__ __forceinline__ int div_small(int b, float rq) { return (int)(((float)b + 0.5f) * rq); }
+
+template <class T>
+__global__ __launch_bounds__(256) void k_fft_mixed(const v2<T> *__restrict__ head, long n_head, const v2<T> *__restrict__ in,
+                                                   long hop, int n, MixedPlan plan, const T *__restrict__ window,
+                                                   const v2<T> *__restrict__ tw, v2<T> *__restrict__ out, int center_dc,
+                                                   unsigned count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mixed_raw[];
+    v2<T> *const x = reinterpret_cast<v2<T> *>(mixed_raw);
+    const int nt = blockDim.x, t = threadIdx.x;
+    const unsigned fr = blockIdx.x;
+    if (fr >= count) return;
+    const long base = (long)fr * hop - n_head;
+    for (int i = t; i < n; i += nt) {
+        const long g = base + i;
+        v2<T> v = g >= 0 ? in[g] : head[n_head + g];
+        const T w = window[i];
+        v.x *= w;
+        v.y *= w;
+        x[i] = v;
+    }
+    __syncthreads();
+    int L = n;
+    for (int ps = 0; ps < plan.nrad; ++ps) {
+        const int r = plan.radix[ps], q = plan.q[ps], step = n / L, nb = n / r;
+        const float rq = plan.rq[ps];
+        for (int b = t; b < nb; b += nt) {
+            const int blk = div_small(b, rq), j = b - blk * q;
+            v2<T> *p = x + blk * L + j;
+            const int k1 = j * step;  // W_L^j = tw[j n / L]
+            if (r == 4) {
+                const v2<T> a0 = p[0], a1 = p[q], a2 = p[2 * q], a3 = p[3 * q];
+                const v2<T> s02 = {a0.x + a2.x, a0.y + a2.y}, d02 = {a0.x - a2.x, a0.y - a2.y};
+                const v2<T> s13 = {a1.x + a3.x, a1.y + a3.y}, d13 = {a1.x - a3.x, a1.y - a3.y};
+                p[0] = v2<T>{s02.x + s13.x, s02.y + s13.y};
+                const v2<T> y1 = {d02.x + d13.y, d02.y - d13.x}, y2 = {s02.x - s13.x, s02.y - s13.y};
+                const v2<T> y3 = {d02.x - d13.y, d02.y + d13.x};
+                p[q] = cmul<T>(y1, tw[k1]);
+                p[2 * q] = cmul<T>(y2, tw[2 * k1]);
+                p[3 * q] = cmul<T>(y3, tw[3 * k1]);
+            } else if (r == 2) {
+                const v2<T> a0 = p[0], a1 = p[q];
+                p[0] = v2<T>{a0.x + a1.x, a0.y + a1.y};
+                p[q] = cmul<T>(v2<T>{a0.x - a1.x, a0.y - a1.y}, tw[k1]);
+            } else if (r == 3) {
+                // W_3 = -1/2 - j sqrt(3)/2
+                const T h = (T)0.86602540378443864676;
+                const v2<T> a0 = p[0], a1 = p[q], a2 = p[2 * q];
+                const v2<T> s = {a1.x + a2.x, a1.y + a2.y}, d = {a1.x - a2.x, a1.y - a2.y};
+                p[0] = v2<T>{a0.x + s.x, a0.y + s.y};
+                const v2<T> m = {a0.x - (T)0.5 * s.x, a0.y - (T)0.5 * s.y};
+                // -j h d = (h d.y, -h d.x)
+                const v2<T> y1 = {m.x + h * d.y, m.y - h * d.x}, y2 = {m.x - h * d.y, m.y + h * d.x};
+                p[q] = cmul<T>(y1, tw[k1]);
+                p[2 * q] = cmul<T>(y2, tw[2 * k1]);
+            } else {  // r == 5
+                const T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410;  // cos(2 pi / 5), cos(4 pi / 5)
+                const T s1 = (T)0.95105651629515357212, s2 = (T)0.58778525229247312917;   // sin(2 pi / 5), sin(4 pi / 5)
+                const v2<T> a0 = p[0], a1 = p[q], a2 = p[2 * q], a3 = p[3 * q], a4 = p[4 * q];
+                const v2<T> s14 = {a1.x + a4.x, a1.y + a4.y}, d14 = {a1.x - a4.x, a1.y - a4.y};
+                const v2<T> s23 = {a2.x + a3.x, a2.y + a3.y}, d23 = {a2.x - a3.x, a2.y - a3.y};
+                p[0] = v2<T>{a0.x + s14.x + s23.x, a0.y + s14.y + s23.y};
+                const v2<T> m1 = {a0.x + c1 * s14.x + c2 * s23.x, a0.y + c1 * s14.y + c2 * s23.y};
+                const v2<T> m2 = {a0.x + c2 * s14.x + c1 * s23.x, a0.y + c2 * s14.y + c1 * s23.y};
+                // forward kernel e^{-j ..}: y_1 = m1 - j (s1 d14 + s2 d23), y_4 = m1 + j (..); y_2 = m2 - j (s2 d14 - s1 d23), y_3 = m2 + j (..)
+                const v2<T> u1 = {s1 * d14.x + s2 * d23.x, s1 * d14.y + s2 * d23.y};
+                const v2<T> u2 = {s2 * d14.x - s1 * d23.x, s2 * d14.y - s1 * d23.y};
+                const v2<T> y1 = {m1.x + u1.y, m1.y - u1.x}, y4 = {m1.x - u1.y, m1.y + u1.x};
+                const v2<T> y2 = {m2.x + u2.y, m2.y - u2.x}, y3 = {m2.x - u2.y, m2.y + u2.x};
+                p[q] = cmul<T>(y1, tw[k1]);
+                p[2 * q] = cmul<T>(y2, tw[2 * k1]);
+                p[3 * q] = cmul<T>(y3, tw[3 * k1]);
+                p[4 * q] = cmul<T>(y4, tw[4 * k1]);
+            }
+        }
+        __syncthreads();
+        L = q;
+    }
+    v2<T> *dst = out + (size_t)fr * n;
+    const int rot = center_dc ? n / 2 : 0;  // rotate_right(n / 2)
+    for (int i = t; i < n; i += nt) {
+        int k = 0, mul = 1, rem = i;
+        for (int ps = 0; ps < plan.nrad; ++ps) {  // span of digit ps = the pass's q
+            const int d = div_small(rem, plan.rq[ps]);
+            rem -= d * plan.q[ps];
+            k += d * mul;
+            mul *= plan.radix[ps];
+        }
+        int o = k + rot;
+        if (o >= n) o -= n;
+        dst[o] = x[i];
+    }
+}
+
+// n = 2^a 3^b 5^c, not a power of two, at most 4096 points: the radices, largest first (5s, 4s, 3s, at most one 2)
+static bool mixed_plan(size_t n, MixedPlan *pl) {
+    if (n < 6 || n > 4096 || is_pow2_n(n)) return false;
+    size_t m = n;
+    int a = 0, b = 0, c = 0;
+    while (m % 2 == 0) m /= 2, ++a;
+    while (m % 3 == 0) m /= 3, ++b;
+    while (m % 5 == 0) m /= 5, ++c;
+    if (m != 1) return false;
+    int k = 0;
+    for (int i = 0; i < c; ++i) pl->radix[k++] = 5;
+    for (int i = 0; i < a / 2; ++i) pl->radix[k++] = 4;
+    for (int i = 0; i < b; ++i) pl->radix[k++] = 3;
+    if (a & 1) pl->radix[k++] = 2;
+    if (k > 12) return false;
+    pl->nrad = k;
+    size_t L = n;
+    for (int i = 0; i < k; ++i) {
+        L /= pl->radix[i];
+        pl->q[i] = (unsigned short)L;
+        pl->rq[i] = 1.0f / (float)L;
+    }
+    return true;
+}
+bool fft_mixed_supported(int dtype, size_t n) {
+    (void)dtype;
+    MixedPlan pl;
+    return mixed_plan(n, &pl);
+}
+// Where k_fft_mixed is ahead of the Bluestein kernels (ms per 2^24 samples, one session: mixed 96 / 300 / 500 / 1000 / 1200 / 1536 /
+// 2000 / 3000 / 4000 points 0.185 / 0.141 / 0.128 / 0.148 / 0.149 / 0.185 / 0.166 / 0.203 / 0.231; k_bluestein1024 41 / n, k_bluestein4096
+// 222 / n - their cost per chunk does not depend on n -, the five launches beyond 2048 points 0.80 / 0.62 at 3000 / 4000).  Below 32
+// points the direct kernel stays.  Complex<f64> has no one-kernel Bluestein: mixed wherever it applies.
+bool fft_mixed_preferred(int dtype, size_t n) {
+    if (n < 32) return false;
+    if (dtype != RR_F32) return true;
+    return n < 288 || (n > 512 && n <= 1280) || n > 2048;
+}
+int launch_fft_mixed(int dtype, hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n,
+                     const void *window, const void *tw, void *out, bool center_dc, size_t count) {
+    if (count == 0) return RR_OK;
+    MixedPlan pl;
+    if (!mixed_plan(n, &pl)) RR_FAIL(RR_ERR_BAD_ARG, "mixed-radix transform: %zu points", n);
+    if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: too many chunks in one call");
+    // a lane per butterfly of the widest pass, whole waves
+    unsigned nt = (unsigned)((n / 4 + 63) / 64 * 64);
+    if (nt > 256) nt = 256;
+    if (nt < 64) nt = 64;
+    if (dtype == RR_F32) {
+        auto fn = k_fft_mixed<float>;
+        const size_t lds = n * sizeof(float2);
+        hipLaunchKernelGGL(fn, dim3((unsigned)count), dim3(nt), lds, s, (const float2 *)head, (long)n_head, (const float2 *)in,
+                           (long)hop, (int)n, pl, (const float *)window, (const float2 *)tw, (float2 *)out, (int)center_dc,
+                           (unsigned)count);
+    } else {
+        auto fn = k_fft_mixed<double>;
+        const size_t lds = n * sizeof(double2);
+        RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));
+        hipLaunchKernelGGL(fn, dim3((unsigned)count), dim3(nt), lds, s, (const double2 *)head, (long)n_head, (const double2 *)in,
+                           (long)hop, (int)n, pl, (const double *)window, (const double2 *)tw, (double2 *)out, (int)center_dc,
+                           (unsigned)count);
+    }
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
 int launch_fourier_overlapped(int dtype, hipStream_t s, const void *head, size_t n_head, const void *in, void *out,
                               size_t n, size_t hop, size_t count, const void *window, const void *twiddle, bool center_dc) {
     if (count == 0) return RR_OK;

@@ -144,6 +144,12 @@ int launch_bs_post(int dtype, hipStream_t s, const void *ws, const void *w, size
 // 1 window[r C + c] (real), 2 the four-step twiddle W_(R C)^(r c) = tA[e >> h] tB[e & (2^h - 1)]
 int launch_transpose_mul(int dtype, hipStream_t s, const void *in, void *out, size_t R, size_t C, size_t count, int mode,
                          const void *window, const void *tB, const void *tA, int h, size_t rot_rows);
+// chunk lengths 2^a 3^b 5^c <= 4096 that are not powers of two: mixed-radix passes in one LDS image (k_fft_mixed); window = n reals,
+// tw = e^{-j 2 pi k / n} (n entries); frames from [ head | in ] at any hop
+bool fft_mixed_supported(int dtype, size_t n);
+bool fft_mixed_preferred(int dtype, size_t n);  // measured crossover against the Bluestein kernels
+int launch_fft_mixed(int dtype, hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n,
+                     const void *window, const void *tw, void *out, bool center_dc, size_t count);
 // two-pass four-step (k_fft_tile): pass 0 = window, column transforms over n1, twiddle; pass 1 = row transforms over n2 with
 // the transposed store; twNp = e^{-j 2 pi k / Np} (Np entries) of the pass's sub-transform
 bool fft_tile_supported(int dtype, size_t N1, size_t N2);

@@ -587,6 +587,33 @@ def test_fourier_f64_lengths(rr, oracle, n, center):
     assert rms_rel(out.chunk, ref) < 1e-11
 
 
+@pytest.mark.parametrize("n,center", [(6, False), (12, True), (60, False), (96, True), (360, False), (1536, True), (2000, False), (3000, True),
+                                      (3072, False), (3125, True), (3840, False), (4000, True), (4050, False), (4095, True)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fourier_mixed_radix_lengths(rr, oracle, monkeypatch, n, center, dtype):
+    """Chunk lengths 2^a 3^b 5^c that are not powers of two run k_fft_mixed (radix 5 / 4 / 3 / 2 passes in one LDS image); every
+    other length keeps Bluestein (4095 = 3^2 5 7 13 here).  Several chunks per call, against the oracle and against the Bluestein
+    form of the same handle type (RR_FOURIER_MIXED=0)."""
+    import torch
+
+    chunks = 7
+    x = oracle.synth_iq(23, 0, n * chunks).astype(np.complex128 if dtype == np.float64 else np.complex64)
+    o = oracle.Fourier(oracle.Kaiser.with_null_at_bin(2.0), center, flt=np.float64)
+    ref = np.concatenate([o.process(x[i * n:(i + 1) * n]) for i in range(chunks)])
+    outs = []
+    for mixed in ("2", "0"):  # 2: wherever it applies (by default only where it was measured faster than Bluestein's kernels)
+        monkeypatch.setenv("RR_FOURIER_MIXED", mixed)
+        g = rr.Fourier(rr.Kaiser.with_null_at_bin(2.0), center, dtype=dtype)
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.empty_like(d_in)
+        assert g.process_dev(n, d_in.data_ptr(), n * chunks, d_out.data_ptr(), n * chunks) == n * chunks
+        torch.cuda.synchronize()
+        outs.append(d_out.cpu().numpy())
+    tol = 1e-11 if dtype == np.float64 else 2e-6
+    assert rms_rel(outs[0], ref) < tol, rms_rel(outs[0], ref)
+    assert rms_rel(outs[1], ref) < tol, rms_rel(outs[1], ref)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_fourier_big_two_pass_against_the_transposes(rr, oracle, monkeypatch, dtype):
     """Powers of two beyond one LDS tile, several chunks per device call: the two-pass form (k_fft_tile, the default up to
