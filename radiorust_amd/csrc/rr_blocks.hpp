@@ -185,7 +185,7 @@ struct rr_fourier : rr_block {
     rr::DevBuf big_ws2;
     // Bluestein for lengths that are not powers of two (n >= 32, either dtype): two transforms of bs_M points
     // by a nested rectangular-window Fourier, tables c = window * conj(chirp), B = F(chirp) / M, w = chirp
-    bool mixed = false;     // 2^a 3^b 5^c <= 4096 points, not a power of two: k_fft_mixed (one launch, n log n work)
+    bool mixed = false;     // 2^a 3^b 5^c points (<= 8192 in f32, <= 4096 in f64), not a power of two: k_fft_mixed (one launch, n log n work)
     size_t bs_M = 0;
     bool bs_fused = false;  // f32, 513 .. 2048 points: k_bluestein4096 (one launch per call)
     bool bs_wave = false;   // f32, 32 .. 512 points: k_bluestein1024 (a wave per chunk)

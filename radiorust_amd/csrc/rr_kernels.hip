@@ -1029,7 +1029,7 @@ int launch_fft_tile(int dtype, hipStream_t s, int pass, const void *in, void *ou
 }
 
 // ---------------------------------------------------------------------------
-// Mixed-radix transform: chunk lengths n = 2^a 3^b 5^c that are not powers of two (1000, 3000, 4800 / 5 ..; analysis.rs:82-115
+// Mixed-radix transform: chunk lengths n = 2^a 3^b 5^c (up to 8192 in f32, 4096 in f64) that are not powers of two (1000, 3000, 4800 ..; analysis.rs:82-115
 // accepts any length), one workgroup per chunk, the whole transform in ONE LDS image of n elements: in-place decimation-in-
 // frequency passes of radix 5, 4, 3, 2 with a lane per butterfly, the result in mixed-radix digit-reversed order which the store
 // undoes in its address.  Bluestein's algorithm needs two power-of-two transforms of M >= 2 n - 1 points for the same chunk
@@ -1045,7 +1045,7 @@ struct MixedPlan {
     unsigned short q[12];   // butterflies per block of the pass = L / r
     float rq[12];           // 1 / q: b / q = (int)((b + 0.5) rq) exactly for b, q <= 4096 (the product's error, (b / q) 1.2e-7, stays
                             // below the 0.5 / q the half moves it away from a whole number) - an integer division by a run-time
-                            // value costs ~35 instructions, and the passes are index arithmetic more than anything else
+                            // value costs ~35 instructions; checked for every b <= 8192, q <= 4096, and the passes are index arithmetic more than anything else
 };
 __device__ __forceinline__ int div_small(int b, float rq) { return (int)(((float)b + 0.5f) * rq); }
 
@@ -1141,9 +1141,9 @@ __global__ __launch_bounds__(256) void k_fft_mixed(const v2<T> *__restrict__ hea
     }
 }
 
-// n = 2^a 3^b 5^c, not a power of two, at most 4096 points: the radices, largest first (5s, 4s, 3s, at most one 2)
-static bool mixed_plan(size_t n, MixedPlan *pl) {
-    if (n < 6 || n > 4096 || is_pow2_n(n)) return false;
+// n = 2^a 3^b 5^c, not a power of two, at most nmax points: the radices, largest first (5s, 4s, 3s, at most one 2)
+static bool mixed_plan(size_t n, size_t nmax, MixedPlan *pl) {
+    if (n < 6 || n > nmax || is_pow2_n(n)) return false;
     size_t m = n;
     int a = 0, b = 0, c = 0;
     while (m % 2 == 0) m /= 2, ++a;
@@ -1165,10 +1165,11 @@ static bool mixed_plan(size_t n, MixedPlan *pl) {
     }
     return true;
 }
+// one LDS image of at most 64 KiB: 8192 points in f32, 4096 in f64
+static size_t mixed_max(int dtype) { return dtype == RR_F32 ? 8192 : 4096; }
 bool fft_mixed_supported(int dtype, size_t n) {
-    (void)dtype;
     MixedPlan pl;
-    return mixed_plan(n, &pl);
+    return mixed_plan(n, mixed_max(dtype), &pl);
 }
 // Where k_fft_mixed is ahead of the Bluestein kernels (ms per 2^24 samples, one session: mixed 96 / 300 / 500 / 1000 / 1200 / 1536 /
 // 2000 / 3000 / 4000 points 0.185 / 0.141 / 0.128 / 0.148 / 0.149 / 0.185 / 0.166 / 0.203 / 0.231; k_bluestein1024 41 / n, k_bluestein4096
@@ -1183,7 +1184,7 @@ int launch_fft_mixed(int dtype, hipStream_t s, const void *head, size_t n_head, 
                      const void *window, const void *tw, void *out, bool center_dc, size_t count) {
     if (count == 0) return RR_OK;
     MixedPlan pl;
-    if (!mixed_plan(n, &pl)) RR_FAIL(RR_ERR_BAD_ARG, "mixed-radix transform: %zu points", n);
+    if (!mixed_plan(n, mixed_max(dtype), &pl)) RR_FAIL(RR_ERR_BAD_ARG, "mixed-radix transform: %zu points", n);
     if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: too many chunks in one call");
     // a lane per butterfly of the widest pass, whole waves
     unsigned nt = (unsigned)((n / 4 + 63) / 64 * 64);

@@ -144,7 +144,7 @@ int launch_bs_post(int dtype, hipStream_t s, const void *ws, const void *w, size
 // 1 window[r C + c] (real), 2 the four-step twiddle W_(R C)^(r c) = tA[e >> h] tB[e & (2^h - 1)]
 int launch_transpose_mul(int dtype, hipStream_t s, const void *in, void *out, size_t R, size_t C, size_t count, int mode,
                          const void *window, const void *tB, const void *tA, int h, size_t rot_rows);
-// chunk lengths 2^a 3^b 5^c <= 4096 that are not powers of two: mixed-radix passes in one LDS image (k_fft_mixed); window = n reals,
+// chunk lengths 2^a 3^b 5^c (<= 8192 in f32, <= 4096 in f64) that are not powers of two: mixed-radix passes in one LDS image (k_fft_mixed); window = n reals,
 // tw = e^{-j 2 pi k / n} (n entries); frames from [ head | in ] at any hop
 bool fft_mixed_supported(int dtype, size_t n);
 bool fft_mixed_preferred(int dtype, size_t n);  // measured crossover against the Bluestein kernels

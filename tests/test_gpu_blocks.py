@@ -588,7 +588,8 @@ def test_fourier_f64_lengths(rr, oracle, n, center):
 
 
 @pytest.mark.parametrize("n,center", [(6, False), (12, True), (60, False), (96, True), (360, False), (1536, True), (2000, False), (3000, True),
-                                      (3072, False), (3125, True), (3840, False), (4000, True), (4050, False), (4095, True)])
+                                      (3072, False), (3125, True), (3840, False), (4000, True), (4050, False), (4095, True),
+                                      (4800, False), (6000, True), (7776, False), (8000, True)])   # (beyond 4096: f32 only, Bluestein in f64)
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_fourier_mixed_radix_lengths(rr, oracle, monkeypatch, n, center, dtype):
     """Chunk lengths 2^a 3^b 5^c that are not powers of two run k_fft_mixed (radix 5 / 4 / 3 / 2 passes in one LDS image); every
