@@ -768,7 +768,10 @@ int rr_fourier::prepare(size_t len) {
     const int mixed_env = [] { const char *e = std::getenv("RR_FOURIER_MIXED"); return e ? std::atoi(e) : 1; }();  // 0 never, 2 wherever it applies
     const bool use_mixed = !pow2 && !generic && mixed_env != 0 && fft_mixed_supported(dtype, len) &&
                            (mixed_env == 2 || fft_mixed_preferred(dtype, len));
-    const bool use_bs = !pow2 && len >= 32 && !(generic && len <= 16384) && !use_mixed;
+    size_t tmN1 = 0, tmN2 = 0;
+    const bool use_tilem = !pow2 && !generic && mixed_env != 0 && !fft_mixed_supported(dtype, len) &&
+                           fft_tilem_split(dtype, len, &tmN1, &tmN2);
+    const bool use_bs = !pow2 && len >= 32 && !(generic && len <= 16384) && !use_mixed && !use_tilem;
     auto cast = [&](const std::vector<double> &src, std::vector<unsigned char> &dst) {
         if (dtype == RR_F32) cast_to<float>(src.data(), src.size(), dst);
         else cast_to<double>(src.data(), src.size(), dst);
@@ -844,6 +847,27 @@ int rr_fourier::prepare(size_t len) {
         cast(tw, tb);
         RR_TRY(upload(d_window, wb.data(), wb.size(), stream));
         RR_TRY(upload(d_tw, tb.data(), tb.size(), stream));
+    } else if (use_tilem) {
+        // e^{-j 2 pi k / N1} | e^{-j 2 pi k / N2} | T1[i] = W_N^(C i), i < N1 ceil(N2 / C) | T2[i] = W_N^i, i < N1 C
+        const size_t Cc = dtype == RR_F32 ? 16 : 8, nbx = (tmN2 + Cc - 1) / Cc;
+        std::vector<double> tw;
+        tw.reserve(2 * (tmN1 + tmN2 + tmN1 * nbx + tmN1 * Cc));
+        auto push = [&](size_t num, size_t den) {  // e^{-j 2 pi num / den}, the phase reduced exactly
+            const double ang = -2.0 * M_PI * (double)(num % den) / (double)den;
+            tw.push_back(std::cos(ang));
+            tw.push_back(std::sin(ang));
+        };
+        for (size_t i = 0; i < tmN1; ++i) push(i, tmN1);
+        for (size_t i = 0; i < tmN2; ++i) push(i, tmN2);
+        for (size_t i = 0; i < tmN1 * nbx; ++i) push(Cc * i, len);
+        for (size_t i = 0; i < tmN1 * Cc; ++i) push(i, len);
+        cast(tw, tb);
+        RR_TRY(upload(d_window, wb.data(), wb.size(), stream));
+        RR_TRY(upload(d_tw, tb.data(), tb.size(), stream));
+        tm_N1 = tmN1;
+        tm_N2 = tmN2;
+        tm_T1 = tmN1 + tmN2;
+        tm_T2 = tm_T1 + tmN1 * nbx;
     } else if (use_bs) {
         RR_TRY(upload(d_window, wb.data(), wb.size(), stream));  // (kept for symmetry; Bluestein folds the window into c)
     } else {
@@ -879,6 +903,7 @@ int rr_fourier::prepare(size_t len) {
     window_f64.swap(vals);
     n = len;
     mixed = use_mixed;
+    tilem = use_tilem;
     bs_M = 0;
     bs_fused = bs_wave = false;
     big = use_big;
@@ -997,6 +1022,32 @@ int rr_fourier::transform_dev(const void *head, size_t n_head, const void *in, v
         return RR_OK;
     }
     if (mixed) return launch_fft_mixed(dtype, stream, head, n_head, in, hop, n, d_window.p, d_tw.p, out, center_dc, count);
+    if (tilem) {
+        // passes of at most 2^24 workspace elements; frame f0's first sample sits f0 * hop behind the start of [head | in]
+        size_t per_pass = ((size_t)1 << 24) / n;
+        if (per_pass < 1) per_pass = 1;
+        if (per_pass > 65535) per_pass = 65535;
+        if (per_pass > count) per_pass = count;
+        RR_TRY(big_ws.reserve(per_pass * n * esz));
+        const char *tw1 = d_tw.as<char>(), *tw2 = tw1 + tm_N1 * esz, *T1 = tw1 + tm_T1 * esz, *T2 = tw1 + tm_T2 * esz;
+        for (size_t f0 = 0; f0 < count; f0 += per_pass) {
+            const size_t F = count - f0 < per_pass ? count - f0 : per_pass;
+            const size_t skip = f0 * hop;
+            const char *hd = static_cast<const char *>(head), *src = static_cast<const char *>(in);
+            size_t nh = n_head;
+            if (skip >= n_head) {
+                src += (skip - n_head) * esz;
+                nh = 0;
+            } else {
+                hd += skip * esz;
+                nh = n_head - skip;
+            }
+            RR_TRY(launch_fft_tilem(dtype, stream, 0, hd, nh, src, hop, big_ws.p, tm_N1, tm_N2, F, d_window.p, tw1, T1, T2, 0));
+            RR_TRY(launch_fft_tilem(dtype, stream, 1, nullptr, 0, big_ws.p, 0, static_cast<char *>(out) + f0 * n * esz, tm_N1,
+                                    tm_N2, F, nullptr, tw2, nullptr, nullptr, center_dc ? n / 2 : 0));
+        }
+        return RR_OK;
+    }
     if (!bs_M) return launch_fourier_overlapped(dtype, stream, head, n_head, in, out, n, hop, count, d_window.p, d_tw.p, center_dc);
     if (bs_wave)
         return launch_bluestein1024(stream, head, n_head, in, hop, n, d_bs_c.p, d_bs_B.p, d_bs_w.p, bs_fft->d_tw.p, out, center_dc, count);

@@ -186,6 +186,9 @@ struct rr_fourier : rr_block {
     // Bluestein for lengths that are not powers of two (n >= 32, either dtype): two transforms of bs_M points
     // by a nested rectangular-window Fourier, tables c = window * conj(chirp), B = F(chirp) / M, w = chirp
     bool mixed = false;     // 2^a 3^b 5^c points (<= 8192 in f32, <= 4096 in f64), not a power of two: k_fft_mixed (one launch, n log n work)
+    // 2^a 3^b 5^c points beyond one LDS image (up to 512 x 512): two passes, k_fft_tilem; d_tw = twN1 | twN2 | T1 | T2
+    bool tilem = false;
+    size_t tm_N1 = 0, tm_N2 = 0, tm_T1 = 0, tm_T2 = 0;  // (T1 / T2: element offsets into d_tw)
     size_t bs_M = 0;
     bool bs_fused = false;  // f32, 513 .. 2048 points: k_bluestein4096 (one launch per call)
     bool bs_wave = false;   // f32, 32 .. 512 points: k_bluestein1024 (a wave per chunk)

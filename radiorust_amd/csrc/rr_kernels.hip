@@ -1049,6 +1049,56 @@ struct MixedPlan {
 };
 __device__ __forceinline__ int div_small(int b, float rq) { return (int)(((float)b + 0.5f) * rq); }
 
+// one radix-r butterfly (r = 2, 3, 4, 5) of a decimation-in-frequency pass, in place: inputs p[s q], outputs p[m q] =
+// W^(m k1) sum_s a_s W_r^(s m) with W^k = tw[k]
+template <class T>
+__device__ __forceinline__ void mixed_bfly(v2<T> *p, int q, int r, const v2<T> *__restrict__ tw, int k1) {
+    if (r == 4) {
+        const v2<T> a0 = p[0], a1 = p[q], a2 = p[2 * q], a3 = p[3 * q];
+        const v2<T> s02 = {a0.x + a2.x, a0.y + a2.y}, d02 = {a0.x - a2.x, a0.y - a2.y};
+        const v2<T> s13 = {a1.x + a3.x, a1.y + a3.y}, d13 = {a1.x - a3.x, a1.y - a3.y};
+        p[0] = v2<T>{s02.x + s13.x, s02.y + s13.y};
+        const v2<T> y1 = {d02.x + d13.y, d02.y - d13.x}, y2 = {s02.x - s13.x, s02.y - s13.y};
+        const v2<T> y3 = {d02.x - d13.y, d02.y + d13.x};
+        p[q] = cmul<T>(y1, tw[k1]);
+        p[2 * q] = cmul<T>(y2, tw[2 * k1]);
+        p[3 * q] = cmul<T>(y3, tw[3 * k1]);
+    } else if (r == 2) {
+        const v2<T> a0 = p[0], a1 = p[q];
+        p[0] = v2<T>{a0.x + a1.x, a0.y + a1.y};
+        p[q] = cmul<T>(v2<T>{a0.x - a1.x, a0.y - a1.y}, tw[k1]);
+    } else if (r == 3) {
+        // W_3 = -1/2 - j sqrt(3)/2
+        const T h = (T)0.86602540378443864676;
+        const v2<T> a0 = p[0], a1 = p[q], a2 = p[2 * q];
+        const v2<T> s = {a1.x + a2.x, a1.y + a2.y}, d = {a1.x - a2.x, a1.y - a2.y};
+        p[0] = v2<T>{a0.x + s.x, a0.y + s.y};
+        const v2<T> m = {a0.x - (T)0.5 * s.x, a0.y - (T)0.5 * s.y};
+        // -j h d = (h d.y, -h d.x)
+        const v2<T> y1 = {m.x + h * d.y, m.y - h * d.x}, y2 = {m.x - h * d.y, m.y + h * d.x};
+        p[q] = cmul<T>(y1, tw[k1]);
+        p[2 * q] = cmul<T>(y2, tw[2 * k1]);
+    } else {  // r == 5
+        const T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410;  // cos(2 pi / 5), cos(4 pi / 5)
+        const T s1 = (T)0.95105651629515357212, s2 = (T)0.58778525229247312917;   // sin(2 pi / 5), sin(4 pi / 5)
+        const v2<T> a0 = p[0], a1 = p[q], a2 = p[2 * q], a3 = p[3 * q], a4 = p[4 * q];
+        const v2<T> s14 = {a1.x + a4.x, a1.y + a4.y}, d14 = {a1.x - a4.x, a1.y - a4.y};
+        const v2<T> s23 = {a2.x + a3.x, a2.y + a3.y}, d23 = {a2.x - a3.x, a2.y - a3.y};
+        p[0] = v2<T>{a0.x + s14.x + s23.x, a0.y + s14.y + s23.y};
+        const v2<T> m1 = {a0.x + c1 * s14.x + c2 * s23.x, a0.y + c1 * s14.y + c2 * s23.y};
+        const v2<T> m2 = {a0.x + c2 * s14.x + c1 * s23.x, a0.y + c2 * s14.y + c1 * s23.y};
+        // forward kernel e^{-j ..}: y_1 = m1 - j (s1 d14 + s2 d23), y_4 = m1 + j (..); y_2 = m2 - j (s2 d14 - s1 d23), y_3 = m2 + j (..)
+        const v2<T> u1 = {s1 * d14.x + s2 * d23.x, s1 * d14.y + s2 * d23.y};
+        const v2<T> u2 = {s2 * d14.x - s1 * d23.x, s2 * d14.y - s1 * d23.y};
+        const v2<T> y1 = {m1.x + u1.y, m1.y - u1.x}, y4 = {m1.x - u1.y, m1.y + u1.x};
+        const v2<T> y2 = {m2.x + u2.y, m2.y - u2.x}, y3 = {m2.x - u2.y, m2.y + u2.x};
+        p[q] = cmul<T>(y1, tw[k1]);
+        p[2 * q] = cmul<T>(y2, tw[2 * k1]);
+        p[3 * q] = cmul<T>(y3, tw[3 * k1]);
+        p[4 * q] = cmul<T>(y4, tw[4 * k1]);
+    }
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void k_fft_mixed(const v2<T> *__restrict__ head, long n_head, const v2<T> *__restrict__ in,
                                                    long hop, int n, MixedPlan plan, const T *__restrict__ window,
@@ -1077,50 +1127,7 @@ __global__ __launch_bounds__(256) void k_fft_mixed(const v2<T> *__restrict__ hea
             const int blk = div_small(b, rq), j = b - blk * q;
             v2<T> *p = x + blk * L + j;
             const int k1 = j * step;  // W_L^j = tw[j n / L]
-            if (r == 4) {
-                const v2<T> a0 = p[0], a1 = p[q], a2 = p[2 * q], a3 = p[3 * q];
-                const v2<T> s02 = {a0.x + a2.x, a0.y + a2.y}, d02 = {a0.x - a2.x, a0.y - a2.y};
-                const v2<T> s13 = {a1.x + a3.x, a1.y + a3.y}, d13 = {a1.x - a3.x, a1.y - a3.y};
-                p[0] = v2<T>{s02.x + s13.x, s02.y + s13.y};
-                const v2<T> y1 = {d02.x + d13.y, d02.y - d13.x}, y2 = {s02.x - s13.x, s02.y - s13.y};
-                const v2<T> y3 = {d02.x - d13.y, d02.y + d13.x};
-                p[q] = cmul<T>(y1, tw[k1]);
-                p[2 * q] = cmul<T>(y2, tw[2 * k1]);
-                p[3 * q] = cmul<T>(y3, tw[3 * k1]);
-            } else if (r == 2) {
-                const v2<T> a0 = p[0], a1 = p[q];
-                p[0] = v2<T>{a0.x + a1.x, a0.y + a1.y};
-                p[q] = cmul<T>(v2<T>{a0.x - a1.x, a0.y - a1.y}, tw[k1]);
-            } else if (r == 3) {
-                // W_3 = -1/2 - j sqrt(3)/2
-                const T h = (T)0.86602540378443864676;
-                const v2<T> a0 = p[0], a1 = p[q], a2 = p[2 * q];
-                const v2<T> s = {a1.x + a2.x, a1.y + a2.y}, d = {a1.x - a2.x, a1.y - a2.y};
-                p[0] = v2<T>{a0.x + s.x, a0.y + s.y};
-                const v2<T> m = {a0.x - (T)0.5 * s.x, a0.y - (T)0.5 * s.y};
-                // -j h d = (h d.y, -h d.x)
-                const v2<T> y1 = {m.x + h * d.y, m.y - h * d.x}, y2 = {m.x - h * d.y, m.y + h * d.x};
-                p[q] = cmul<T>(y1, tw[k1]);
-                p[2 * q] = cmul<T>(y2, tw[2 * k1]);
-            } else {  // r == 5
-                const T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410;  // cos(2 pi / 5), cos(4 pi / 5)
-                const T s1 = (T)0.95105651629515357212, s2 = (T)0.58778525229247312917;   // sin(2 pi / 5), sin(4 pi / 5)
-                const v2<T> a0 = p[0], a1 = p[q], a2 = p[2 * q], a3 = p[3 * q], a4 = p[4 * q];
-                const v2<T> s14 = {a1.x + a4.x, a1.y + a4.y}, d14 = {a1.x - a4.x, a1.y - a4.y};
-                const v2<T> s23 = {a2.x + a3.x, a2.y + a3.y}, d23 = {a2.x - a3.x, a2.y - a3.y};
-                p[0] = v2<T>{a0.x + s14.x + s23.x, a0.y + s14.y + s23.y};
-                const v2<T> m1 = {a0.x + c1 * s14.x + c2 * s23.x, a0.y + c1 * s14.y + c2 * s23.y};
-                const v2<T> m2 = {a0.x + c2 * s14.x + c1 * s23.x, a0.y + c2 * s14.y + c1 * s23.y};
-                // forward kernel e^{-j ..}: y_1 = m1 - j (s1 d14 + s2 d23), y_4 = m1 + j (..); y_2 = m2 - j (s2 d14 - s1 d23), y_3 = m2 + j (..)
-                const v2<T> u1 = {s1 * d14.x + s2 * d23.x, s1 * d14.y + s2 * d23.y};
-                const v2<T> u2 = {s2 * d14.x - s1 * d23.x, s2 * d14.y - s1 * d23.y};
-                const v2<T> y1 = {m1.x + u1.y, m1.y - u1.x}, y4 = {m1.x - u1.y, m1.y + u1.x};
-                const v2<T> y2 = {m2.x + u2.y, m2.y - u2.x}, y3 = {m2.x - u2.y, m2.y + u2.x};
-                p[q] = cmul<T>(y1, tw[k1]);
-                p[2 * q] = cmul<T>(y2, tw[2 * k1]);
-                p[3 * q] = cmul<T>(y3, tw[3 * k1]);
-                p[4 * q] = cmul<T>(y4, tw[4 * k1]);
-            }
+            mixed_bfly<T>(p, q, r, tw, k1);
         }
         __syncthreads();
         L = q;
@@ -1142,8 +1149,8 @@ __global__ __launch_bounds__(256) void k_fft_mixed(const v2<T> *__restrict__ hea
 }
 
 // n = 2^a 3^b 5^c, not a power of two, at most nmax points: the radices, largest first (5s, 4s, 3s, at most one 2)
-static bool mixed_plan(size_t n, size_t nmax, MixedPlan *pl) {
-    if (n < 6 || n > nmax || is_pow2_n(n)) return false;
+static bool mixed_plan_impl(size_t n, size_t nmax, MixedPlan *pl, bool pow2_too) {
+    if (n < 2 || n > nmax || (!pow2_too && (n < 6 || is_pow2_n(n)))) return false;
     size_t m = n;
     int a = 0, b = 0, c = 0;
     while (m % 2 == 0) m /= 2, ++a;
@@ -1167,10 +1174,171 @@ static bool mixed_plan(size_t n, size_t nmax, MixedPlan *pl) {
 }
 // one LDS image of at most 64 KiB: 8192 points in f32, 4096 in f64
 static size_t mixed_max(int dtype) { return dtype == RR_F32 ? 8192 : 4096; }
+static bool mixed_plan(size_t n, size_t nmax, MixedPlan *pl) { return mixed_plan_impl(n, nmax, pl, false); }
+static bool mixed_plan_any(size_t n, size_t nmax, MixedPlan *pl) { return mixed_plan_impl(n, nmax, pl, true); }
 bool fft_mixed_supported(int dtype, size_t n) {
     MixedPlan pl;
     return mixed_plan(n, mixed_max(dtype), &pl);
 }
+// ---------------------------------------------------------------------------
+// Lengths 2^a 3^b 5^c beyond one LDS image (20000, 48000, 100000 ..; up to 512 x 512): the four-step split N = N1 N2 in two
+// passes over HBM like k_fft_tile, with mixed-radix sub-transforms (k_fft_mixed's butterflies on a tile of Np x C elements).
+//   pass A  bundles of C neighbouring columns n2: window, transforms over n1, times W_N^(n2 k1), Y[k1][n2] in the same shape
+//   pass B  bundles of C neighbouring rows k1: transforms over n2, X[k1 + N1 k2] (C neighbours per k2)
+// N1 and N2 need not be multiples of C: the last bundle is partly empty.  W_N^(k1 n2) with n2 = C bx + c is the product of
+// T1[k1 bx] = W_N^(C k1 bx) and T2[k1 c] = W_N^(k1 c): two exact table indices, no division by a run-time length.
+// Frames come from [ head | in ] at any hop.
+// ---------------------------------------------------------------------------
+template <class T, int MODE>
+__global__ __launch_bounds__(1024) void k_fft_tilem(const v2<T> *__restrict__ head, long n_head, const v2<T> *__restrict__ in,
+                                                    long hop, v2<T> *__restrict__ out, int Np, int No, MixedPlan plan,
+                                                    const T *__restrict__ window, const v2<T> *__restrict__ twNp,
+                                                    const v2<T> *__restrict__ T1, const v2<T> *__restrict__ T2, int rot) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tilem_raw[];
+    constexpr int C = 128 / (int)sizeof(v2<T>);
+    v2<T> *const tile = reinterpret_cast<v2<T> *>(tilem_raw);
+    const int SN = MODE == 0 ? C : 1, SC = MODE == 0 ? 1 : Np + 1;
+    v2<T> *const tw = tile + (MODE == 0 ? Np * C : C * (Np + 1));
+    const int nt = blockDim.x, t = threadIdx.x;
+    const size_t N = (size_t)Np * (size_t)No;
+    const int g0 = blockIdx.x * C;
+    const int cv = No - g0 < C ? No - g0 : C;  // columns (rows) of this bundle that exist
+    for (int i = t; i < Np; i += nt) tw[i] = twNp[i];
+    if (MODE == 0) {
+        const long base = (long)blockIdx.y * hop - n_head;  // frames from [ head | in ]
+        for (int idx = t; idx < Np * C; idx += nt) {
+            const int n = idx / C, c = idx % C;
+            v2<T> v = {(T)0, (T)0};
+            if (c < cv) {
+                const size_t e = (size_t)n * No + g0 + c;
+                const long g = base + (long)e;
+                v = g >= 0 ? in[g] : head[n_head + g];
+                const T w = window[e];
+                v.x *= w;
+                v.y *= w;
+            }
+            tile[n * C + c] = v;
+        }
+    } else {
+        const float rNp = 1.0f / (float)Np;
+        const size_t chunk = (size_t)blockIdx.y * N;
+        for (int idx = t; idx < Np * C; idx += nt) {
+            const int c = div_small(idx, rNp), n = idx - c * Np;
+            tile[c * (Np + 1) + n] = c < cv ? in[chunk + (size_t)(g0 + c) * Np + n] : v2<T>{(T)0, (T)0};
+        }
+    }
+    __syncthreads();
+    int L = Np, step = 1;
+    for (int ps = 0; ps < plan.nrad; ++ps) {
+        const int r = plan.radix[ps], q = plan.q[ps], nb = step * q;  // nb = Np / r butterflies per column
+        const float rq = plan.rq[ps], rnb = 1.0f / (float)nb;
+        for (int b = t; b < nb * C; b += nt) {
+            int jj, c;
+            if (MODE == 0) {
+                c = b % C;
+                jj = b / C;
+            } else {
+                c = div_small(b, rnb);
+                jj = b - c * nb;
+            }
+            const int blk = div_small(jj, rq), j = jj - blk * q;
+            mixed_bfly<T>(tile + (blk * L + j) * SN + c * SC, q * SN, r, tw, j * step);
+        }
+        __syncthreads();
+        L = q;
+        step *= r;
+    }
+    const size_t ochunk = (size_t)blockIdx.y * N;
+    for (int idx = t; idx < Np * C; idx += nt) {
+        const int p = idx / C, c = idx % C;
+        if (c >= cv) continue;
+        int k = 0, mul = 1, rem = p;
+        for (int ps = 0; ps < plan.nrad; ++ps) {
+            const int d = div_small(rem, plan.rq[ps]);
+            rem -= d * plan.q[ps];
+            k += d * mul;
+            mul *= plan.radix[ps];
+        }
+        v2<T> v = tile[p * SN + c * SC];
+        if (MODE == 0) {
+            v = cmul<T>(v, cmul<T>(T1[(size_t)k * blockIdx.x], T2[k * c]));
+            out[ochunk + (size_t)k * No + g0 + c] = v;
+        } else {
+            size_t o = (size_t)k * No + g0 + c + (size_t)rot;  // X[k1 + N1 k2], rotated right by rot = n / 2 ELEMENTS for center_dc
+            if (o >= N) o -= N;
+            out[ochunk + o] = v;
+        }
+    }
+}
+
+static bool mixed_plan_any(size_t n, size_t nmax, MixedPlan *pl);  // (powers of two too)
+
+// the split of a length 2^a 3^b 5^c into two factors of C .. 512 points each, as balanced as possible
+bool fft_tilem_split(int dtype, size_t n, size_t *N1, size_t *N2) {
+    const size_t C = dtype == RR_F32 ? 16 : 8;
+    if (n > 512 * 512 || n < C * C) return false;
+    {
+        size_t m = n;
+        while (m % 2 == 0) m /= 2;
+        while (m % 3 == 0) m /= 3;
+        while (m % 5 == 0) m /= 5;
+        if (m != 1) return false;
+    }
+    size_t best = 0;
+    for (size_t d = C; d <= 512; ++d) {
+        if (n % d) continue;
+        const size_t e = n / d;
+        if (e < C || e > 512) continue;
+        const size_t lo = d < e ? d : e;
+        // the more balanced pair; among equals the one whose row length N2 is a whole number of 128-byte lines
+        if (lo > best || (lo == best && e % C == 0 && *N2 % C != 0)) {
+            best = lo;
+            *N1 = d;
+            *N2 = e;
+        }
+    }
+    return best != 0;
+}
+
+template <class T>
+static int launch_fft_tilem_t(hipStream_t s, int pass, const void *head, size_t n_head, const void *in, size_t hop, void *out,
+                              size_t N1, size_t N2, size_t count, const void *window, const void *twNp, const void *T1,
+                              const void *T2, size_t rot) {
+    constexpr size_t C = 128 / sizeof(v2<T>);
+    const size_t Np = pass == 0 ? N1 : N2, No = pass == 0 ? N2 : N1;
+    MixedPlan pl;
+    if (!mixed_plan_any(Np, 512, &pl)) RR_FAIL(RR_ERR_BAD_ARG, "tile transform: %zu points", Np);
+    const size_t lds = (pass == 0 ? Np * C : C * (Np + 1)) * sizeof(v2<T>) + Np * sizeof(v2<T>);
+    size_t nt = (Np * C / 4 + 63) / 64 * 64;
+    if (nt > 1024) nt = 1024;
+    if (nt < 256) nt = 256;
+    const dim3 grid((unsigned)((No + C - 1) / C), (unsigned)count);
+    if (pass == 0) {
+        auto fn = k_fft_tilem<T, 0>;
+        RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));
+        hipLaunchKernelGGL(fn, grid, dim3((unsigned)nt), lds, s, (const v2<T> *)head, (long)n_head, (const v2<T> *)in, (long)hop,
+                           (v2<T> *)out, (int)Np, (int)No, pl, (const T *)window, (const v2<T> *)twNp, (const v2<T> *)T1,
+                           (const v2<T> *)T2, 0);
+    } else {
+        auto fn = k_fft_tilem<T, 1>;
+        RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));
+        hipLaunchKernelGGL(fn, grid, dim3((unsigned)nt), lds, s, (const v2<T> *)nullptr, 0L, (const v2<T> *)in, 0L, (v2<T> *)out,
+                           (int)Np, (int)No, pl, (const T *)nullptr, (const v2<T> *)twNp, (const v2<T> *)nullptr,
+                           (const v2<T> *)nullptr, (int)rot);
+    }
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+int launch_fft_tilem(int dtype, hipStream_t s, int pass, const void *head, size_t n_head, const void *in, size_t hop, void *out,
+                     size_t N1, size_t N2, size_t count, const void *window, const void *twNp, const void *T1, const void *T2,
+                     size_t rot) {
+    if (count == 0) return RR_OK;
+    if (count > 65535) RR_FAIL(RR_ERR_BAD_ARG, "tile transform: too many chunks in one launch");
+    if (dtype == RR_F32)
+        return launch_fft_tilem_t<float>(s, pass, head, n_head, in, hop, out, N1, N2, count, window, twNp, T1, T2, rot);
+    return launch_fft_tilem_t<double>(s, pass, head, n_head, in, hop, out, N1, N2, count, window, twNp, T1, T2, rot);
+}
+
 // Where k_fft_mixed is ahead of the Bluestein kernels (ms per 2^24 samples, one session: mixed 96 / 300 / 500 / 1000 / 1200 / 1536 /
 // 2000 / 3000 / 4000 points 0.185 / 0.141 / 0.128 / 0.148 / 0.149 / 0.185 / 0.166 / 0.203 / 0.231; k_bluestein1024 41 / n, k_bluestein4096
 // 222 / n - their cost per chunk does not depend on n -, the five launches beyond 2048 points 0.80 / 0.62 at 3000 / 4000).  Below 32

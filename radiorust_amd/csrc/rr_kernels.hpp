@@ -150,6 +150,12 @@ bool fft_mixed_supported(int dtype, size_t n);
 bool fft_mixed_preferred(int dtype, size_t n);  // measured crossover against the Bluestein kernels
 int launch_fft_mixed(int dtype, hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n,
                      const void *window, const void *tw, void *out, bool center_dc, size_t count);
+// lengths 2^a 3^b 5^c beyond one LDS image, up to 512 x 512: two passes (k_fft_tilem).  twNp = the pass's sub-transform table;
+// T1[i] = W_N^(C i) (N1 ceil(N2 / C) entries), T2[i] = W_N^i (N1 C entries), C = 16 (f32) / 8 (f64) columns per bundle
+bool fft_tilem_split(int dtype, size_t n, size_t *N1, size_t *N2);
+int launch_fft_tilem(int dtype, hipStream_t s, int pass, const void *head, size_t n_head, const void *in, size_t hop, void *out,
+                     size_t N1, size_t N2, size_t count, const void *window, const void *twNp, const void *T1, const void *T2,
+                     size_t rot);
 // two-pass four-step (k_fft_tile): pass 0 = window, column transforms over n1, twiddle; pass 1 = row transforms over n2 with
 // the transposed store; twNp = e^{-j 2 pi k / Np} (Np entries) of the pass's sub-transform
 bool fft_tile_supported(int dtype, size_t N1, size_t N2);

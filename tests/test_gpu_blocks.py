@@ -615,6 +615,39 @@ def test_fourier_mixed_radix_lengths(rr, oracle, monkeypatch, n, center, dtype):
     assert rms_rel(outs[1], ref) < tol, rms_rel(outs[1], ref)
 
 
+@pytest.mark.parametrize("n,center", [(20000, True), (48000, False), (10000, True), (30375, True), (12000, False), (100000, True),
+                                      (8640, False), (262144 // 2 * 2 - 12144, False), (5000, True)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fourier_mixed_radix_two_pass(rr, oracle, monkeypatch, n, center, dtype):
+    """Lengths 2^a 3^b 5^c beyond one LDS image (8192 points in f32, 4096 in f64) up to 512 x 512: two passes, k_fft_tilem - bundles
+    that are partly empty (N1 or N2 not a multiple of 16 / 8), odd lengths (30375 = 3^5 5^3: center_dc rotates by n // 2), several
+    chunks per call; against the oracle and against Bluestein (RR_FOURIER_MIXED=0)."""
+    import torch
+
+    from oracle import oracle_np as onp
+
+    chunks = 3
+    x = oracle.synth_iq(29, 0, n * chunks).astype(np.complex128 if dtype == np.float64 else np.complex64)
+    # the C oracle's transform of a length that is not a power of two is the O(n^2) sum: the reference here is its window
+    # (analysis.rs:88-101, oracle's own Kaiser) and numpy's f64 transform - the formulation tests/test_oracle_crosscheck.py
+    # checks the oracle against
+    win = oracle.Kaiser.with_null_at_bin(2.0)
+    w = onp.fourier_window(n, np.array([win.relative_value_at(p) for p in onp.window_positions(n)]))
+    ref = np.concatenate([onp.fourier(x[i * n:(i + 1) * n], w, center) for i in range(chunks)])
+    outs = []
+    for mixed in ("1", "0"):
+        monkeypatch.setenv("RR_FOURIER_MIXED", mixed)
+        g = rr.Fourier(rr.Kaiser.with_null_at_bin(2.0), center, dtype=dtype)
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.empty_like(d_in)
+        assert g.process_dev(n, d_in.data_ptr(), n * chunks, d_out.data_ptr(), n * chunks) == n * chunks
+        torch.cuda.synchronize()
+        outs.append(d_out.cpu().numpy())
+    tol = 1e-11 if dtype == np.float64 else 2e-6
+    assert rms_rel(outs[0], ref) < tol, rms_rel(outs[0], ref)
+    assert rms_rel(outs[1], ref) < tol, rms_rel(outs[1], ref)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_fourier_big_two_pass_against_the_transposes(rr, oracle, monkeypatch, dtype):
     """Powers of two beyond one LDS tile, several chunks per device call: the two-pass form (k_fft_tile, the default up to
