@@ -767,7 +767,7 @@ int rr_fourier::prepare(size_t len) {
     // padded power-of-two transforms, where measured faster (fft_mixed_preferred; RR_FOURIER_MIXED=0 keeps Bluestein, 2 takes it wherever it applies)
     const int mixed_env = [] { const char *e = std::getenv("RR_FOURIER_MIXED"); return e ? std::atoi(e) : 1; }();  // 0 never, 2 wherever it applies
     const bool use_mixed = !pow2 && !generic && mixed_env != 0 && fft_mixed_supported(dtype, len) &&
-                           (mixed_env == 2 || fft_mixed_preferred(dtype, len));
+                           (mixed_env == 2 || force_mixed || fft_mixed_preferred(dtype, len));
     size_t tmN1 = 0, tmN2 = 0;
     const bool use_tilem = !pow2 && !generic && mixed_env != 0 && !fft_mixed_supported(dtype, len) &&
                            fft_tilem_split(dtype, len, &tmN1, &tmN2);
@@ -1127,8 +1127,15 @@ int rr_channelizer::process_dev(const void *d_in, size_t n_in, void *d_out, size
             if (per_pass > frames) per_pass = frames;
             RR_TRY(fold_ws.reserve(per_pass * M * esz));
             fo->stream = stream;
+            fo->force_mixed = true;
             RR_TRY(fo->prepare(M));
-            for (size_t f0 = 0; f0 < frames; f0 += per_pass) {
+            if (fo->mixed) {
+                // bin counts 2^a 3^b 5^c: fold and transform in one kernel (k_fft_mixed with the fold at its load), no workspace
+                RR_TRY(launch_fft_mixed_fold(dtype, stream, hist[cur].p, H, d_in, base0, hop, M, P, d_window.p, fo->d_tw.p, d_out,
+                                             false, frames));
+                per_pass = 0;
+            }
+            for (size_t f0 = 0; per_pass && f0 < frames; f0 += per_pass) {
                 const size_t F = frames - f0 < per_pass ? frames - f0 : per_pass;
                 RR_TRY(launch_chan_fold(dtype, stream, hist[cur].p, H, d_in, base0 + (long)(f0 * hop), hop, M, P, F, d_window.p,
                                         fold_ws.p));

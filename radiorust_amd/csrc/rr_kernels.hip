@@ -1101,22 +1101,28 @@ __device__ __forceinline__ void mixed_bfly(v2<T> *p, int q, int r, const v2<T> *
 
 template <class T>
 __global__ __launch_bounds__(256) void k_fft_mixed(const v2<T> *__restrict__ head, long n_head, const v2<T> *__restrict__ in,
-                                                   long hop, int n, MixedPlan plan, const T *__restrict__ window,
-                                                   const v2<T> *__restrict__ tw, v2<T> *__restrict__ out, int center_dc,
-                                                   unsigned count) {
+                                                   long base0, long hop, int n, int branches, MixedPlan plan,
+                                                   const T *__restrict__ window, const v2<T> *__restrict__ tw,
+                                                   v2<T> *__restrict__ out, int center_dc, unsigned count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mixed_raw[];
     v2<T> *const x = reinterpret_cast<v2<T> *>(mixed_raw);
     const int nt = blockDim.x, t = threadIdx.x;
     const unsigned fr = blockIdx.x;
     if (fr >= count) return;
-    const long base = (long)fr * hop - n_head;
+    // frame fr starts base0 + fr hop samples into `in` (negative: inside head, which ends where `in` begins); with
+    // branches > 1 the frame is the fold of that many windowed chunks of n samples (the polyphase channelizer's front end,
+    // chunks.rs:194-242 + analysis.rs:105-112 with every branches-th bin kept: v[i] = sum_p w[i + n p] x[base + i + n p])
+    const long base = base0 + (long)fr * hop;
     for (int i = t; i < n; i += nt) {
-        const long g = base + i;
-        v2<T> v = g >= 0 ? in[g] : head[n_head + g];
-        const T w = window[i];
-        v.x *= w;
-        v.y *= w;
-        x[i] = v;
+        v2<T> acc = {(T)0, (T)0};
+        for (int pb = 0; pb < branches; ++pb) {
+            const long g = base + i + (long)pb * n;
+            const v2<T> v = g >= 0 ? in[g] : head[n_head + g];
+            const T w = window[i + pb * n];
+            acc.x += v.x * w;
+            acc.y += v.y * w;
+        }
+        x[i] = acc;
     }
     __syncthreads();
     int L = n;
@@ -1350,7 +1356,12 @@ bool fft_mixed_preferred(int dtype, size_t n) {
 }
 int launch_fft_mixed(int dtype, hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n,
                      const void *window, const void *tw, void *out, bool center_dc, size_t count) {
+    return launch_fft_mixed_fold(dtype, s, head, n_head, in, -(long)n_head, hop, n, 1, window, tw, out, center_dc, count);
+}
+int launch_fft_mixed_fold(int dtype, hipStream_t s, const void *head, size_t n_head, const void *in, long base0, size_t hop,
+                          size_t n, size_t branches, const void *window, const void *tw, void *out, bool center_dc, size_t count) {
     if (count == 0) return RR_OK;
+    if (branches < 1 || base0 < -(long)n_head) RR_FAIL(RR_ERR_BAD_ARG, "mixed-radix transform: frame 0 starts in front of the history");
     MixedPlan pl;
     if (!mixed_plan(n, mixed_max(dtype), &pl)) RR_FAIL(RR_ERR_BAD_ARG, "mixed-radix transform: %zu points", n);
     if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: too many chunks in one call");
@@ -1362,15 +1373,15 @@ int launch_fft_mixed(int dtype, hipStream_t s, const void *head, size_t n_head, 
         auto fn = k_fft_mixed<float>;
         const size_t lds = n * sizeof(float2);
         hipLaunchKernelGGL(fn, dim3((unsigned)count), dim3(nt), lds, s, (const float2 *)head, (long)n_head, (const float2 *)in,
-                           (long)hop, (int)n, pl, (const float *)window, (const float2 *)tw, (float2 *)out, (int)center_dc,
-                           (unsigned)count);
+                           base0, (long)hop, (int)n, (int)branches, pl, (const float *)window, (const float2 *)tw, (float2 *)out,
+                           (int)center_dc, (unsigned)count);
     } else {
         auto fn = k_fft_mixed<double>;
         const size_t lds = n * sizeof(double2);
         RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));
         hipLaunchKernelGGL(fn, dim3((unsigned)count), dim3(nt), lds, s, (const double2 *)head, (long)n_head, (const double2 *)in,
-                           (long)hop, (int)n, pl, (const double *)window, (const double2 *)tw, (double2 *)out, (int)center_dc,
-                           (unsigned)count);
+                           base0, (long)hop, (int)n, (int)branches, pl, (const double *)window, (const double2 *)tw, (double2 *)out,
+                           (int)center_dc, (unsigned)count);
     }
     RR_HIP(hipGetLastError());
     return RR_OK;

@@ -69,7 +69,11 @@ def test_channelizer_parity(rr, oracle, M, P, dtype, tol):
                                                (256, 8, 128, np.float32, 1e-5), (256, 2, 64, np.float32, 1e-5), (256, 3, 128, np.float32, 1e-5),
                                                (64, 3, 32, np.float64, 1e-12), (1024, 2, 512, np.float32, 1e-5),
                                                (100, 4, 100, np.float32, 1e-5), (100, 4, 50, np.float32, 1e-5),
-                                               (1000, 2, 250, np.float64, 1e-11), (16384, 2, 8192, np.float32, 1e-5)])
+                                               (1000, 2, 250, np.float64, 1e-11), (16384, 2, 8192, np.float32, 1e-5),
+                                               # bin counts 2^a 3^b 5^c: fold + mixed-radix transform in one kernel (k_fft_mixed)
+                                               (300, 3, 100, np.float32, 1e-5), (1500, 2, 1500, np.float32, 1e-5),
+                                               (3000, 2, 1000, np.float64, 1e-11), (6000, 2, 3000, np.float32, 1e-5),
+                                               (77, 2, 77, np.float32, 1e-5)])   # (7 x 11: the fold to a workspace + Bluestein)
 def test_channelizer_oversampled_and_any_bins(rr, oracle, M, P, hop, dtype, tol):
     """The general form (rr_channelizer_create_ex): `hop` < bins samples between frames - the oversampled
     filterbank - and bin counts that are not powers of two, against the composition it is defined by:
