@@ -1099,16 +1099,24 @@ __device__ __forceinline__ void mixed_bfly(v2<T> *p, int q, int r, const v2<T> *
     }
 }
 
-template <class T>
-__global__ __launch_bounds__(256) void k_fft_mixed(const v2<T> *__restrict__ head, long n_head, const v2<T> *__restrict__ in,
+// TWLDS: the twiddle table W_n^k is copied into LDS behind the image (2 n elements per workgroup; lengths up to half the
+// largest image) - a pass then waits for LDS reads instead of L2 hits between its butterflies' loads and stores
+template <class T, bool TWLDS>
+__global__ __launch_bounds__(1024) void k_fft_mixed(const v2<T> *__restrict__ head, long n_head, const v2<T> *__restrict__ in,
                                                    long base0, long hop, int n, int branches, MixedPlan plan,
-                                                   const T *__restrict__ window, const v2<T> *__restrict__ tw,
+                                                   const T *__restrict__ window, const v2<T> *__restrict__ tw_g,
                                                    v2<T> *__restrict__ out, int center_dc, unsigned count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mixed_raw[];
     v2<T> *const x = reinterpret_cast<v2<T> *>(mixed_raw);
     const int nt = blockDim.x, t = threadIdx.x;
     const unsigned fr = blockIdx.x;
     if (fr >= count) return;
+    const v2<T> *tw = tw_g;
+    if constexpr (TWLDS) {
+        v2<T> *twl = x + n;
+        for (int i = t; i < n; i += nt) twl[i] = tw_g[i];
+        tw = twl;  // (visible after the barrier behind the load of the samples)
+    }
     // frame fr starts base0 + fr hop samples into `in` (negative: inside head, which ends where `in` begins); with
     // branches > 1 the frame is the fold of that many windowed chunks of n samples (the polyphase channelizer's front end,
     // chunks.rs:194-242 + analysis.rs:105-112 with every branches-th bin kept: v[i] = sum_p w[i + n p] x[base + i + n p])
@@ -1366,23 +1374,36 @@ int launch_fft_mixed_fold(int dtype, hipStream_t s, const void *head, size_t n_h
     if (!mixed_plan(n, mixed_max(dtype), &pl)) RR_FAIL(RR_ERR_BAD_ARG, "mixed-radix transform: %zu points", n);
     if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: too many chunks in one call");
     // a lane per butterfly of the widest pass, whole waves
+    // a lane per butterfly of the radix-4 passes, at most 512 lanes (1024 beyond 4096 points): measured per 2^24 samples with
+    // at most 256 / 512 / 1024 lanes - 3000 points 0.205 / 0.166 / 0.195 ms, 4000 0.237 / 0.174 / 0.186, 4800 0.268 / 0.197 / 0.184,
+    // 8000 0.347 / 0.248 / 0.207 (RR_FOURIER_MIXED_NT overrides the limit)
+    static const unsigned nt_env = [] { const char *e = std::getenv("RR_FOURIER_MIXED_NT"); return e ? (unsigned)std::atoi(e) : 0u; }();
+    const unsigned nt_max = nt_env ? nt_env : (n > 4096 ? 1024u : 512u);
     unsigned nt = (unsigned)((n / 4 + 63) / 64 * 64);
-    if (nt > 256) nt = 256;
+    if (nt > nt_max) nt = nt_max;
     if (nt < 64) nt = 64;
+    // twiddles in LDS while image + table stay within 32 KiB per workgroup (at least four workgroups per CU)
+    static const int twlds_env = [] { const char *e = std::getenv("RR_FOURIER_MIXED_TWLDS"); return e ? std::atoi(e) : 1; }();
+    const size_t esz = dtype == RR_F32 ? sizeof(float2) : sizeof(double2);
+    const size_t twcap = twlds_env > 1 ? (size_t)twlds_env : 32768;
+    const bool twlds = twlds_env != 0 && 2 * n * esz <= twcap;
+    const size_t lds = (twlds ? 2 : 1) * n * esz;
+#define RR_MIXED(TT, VV, TL)                                                                                              \
+    do {                                                                                                                  \
+        auto fn = k_fft_mixed<TT, TL>;                                                                                    \
+        RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));                                                     \
+        hipLaunchKernelGGL(fn, dim3((unsigned)count), dim3(nt), lds, s, (const VV *)head, (long)n_head, (const VV *)in,  \
+                           base0, (long)hop, (int)n, (int)branches, pl, (const TT *)window, (const VV *)tw, (VV *)out,    \
+                           (int)center_dc, (unsigned)count);                                                              \
+    } while (0)
     if (dtype == RR_F32) {
-        auto fn = k_fft_mixed<float>;
-        const size_t lds = n * sizeof(float2);
-        hipLaunchKernelGGL(fn, dim3((unsigned)count), dim3(nt), lds, s, (const float2 *)head, (long)n_head, (const float2 *)in,
-                           base0, (long)hop, (int)n, (int)branches, pl, (const float *)window, (const float2 *)tw, (float2 *)out,
-                           (int)center_dc, (unsigned)count);
+        if (twlds) RR_MIXED(float, float2, true);
+        else RR_MIXED(float, float2, false);
     } else {
-        auto fn = k_fft_mixed<double>;
-        const size_t lds = n * sizeof(double2);
-        RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));
-        hipLaunchKernelGGL(fn, dim3((unsigned)count), dim3(nt), lds, s, (const double2 *)head, (long)n_head, (const double2 *)in,
-                           base0, (long)hop, (int)n, (int)branches, pl, (const double *)window, (const double2 *)tw, (double2 *)out,
-                           (int)center_dc, (unsigned)count);
+        if (twlds) RR_MIXED(double, double2, true);
+        else RR_MIXED(double, double2, false);
     }
+#undef RR_MIXED
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
