@@ -1371,7 +1371,7 @@ int launch_fft_mixed_fold(int dtype, hipStream_t s, const void *head, size_t n_h
     if (count == 0) return RR_OK;
     if (branches < 1 || base0 < -(long)n_head) RR_FAIL(RR_ERR_BAD_ARG, "mixed-radix transform: frame 0 starts in front of the history");
     MixedPlan pl;
-    if (!mixed_plan(n, mixed_max(dtype), &pl)) RR_FAIL(RR_ERR_BAD_ARG, "mixed-radix transform: %zu points", n);
+    if (!mixed_plan_any(n, mixed_max(dtype), &pl)) RR_FAIL(RR_ERR_BAD_ARG, "mixed-radix transform: %zu points", n);
     if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: too many chunks in one call");
     // a lane per butterfly of the widest pass, whole waves
     // a lane per butterfly of the radix-4 passes, at most 512 lanes (1024 beyond 4096 points): measured per 2^24 samples with
