@@ -1029,7 +1029,7 @@ int launch_fft_tile(int dtype, hipStream_t s, int pass, const void *in, void *ou
 }
 
 // ---------------------------------------------------------------------------
-// Mixed-radix transform: chunk lengths n = 2^a 3^b 5^c (up to 8192 in f32, 4096 in f64) that are not powers of two (1000, 3000, 4800 ..; analysis.rs:82-115
+// Mixed-radix transform: chunk lengths n = 2^a 3^b 5^c 7^d 11^e 13^f (up to 8192 in f32, 4096 in f64) that are not powers of two (1000, 3000, 4800, 1001 ..; analysis.rs:82-115
 // accepts any length), one workgroup per chunk, the whole transform in ONE LDS image of n elements: in-place decimation-in-
 // frequency passes of radix 5, 4, 3, 2 with a lane per butterfly, the result in mixed-radix digit-reversed order which the store
 // undoes in its address.  Bluestein's algorithm needs two power-of-two transforms of M >= 2 n - 1 points for the same chunk
@@ -1049,11 +1049,45 @@ struct MixedPlan {
 };
 __device__ __forceinline__ int div_small(int b, float rq) { return (int)(((float)b + 0.5f) * rq); }
 
-// one radix-r butterfly (r = 2, 3, 4, 5) of a decimation-in-frequency pass, in place: inputs p[s q], outputs p[m q] =
-// W^(m k1) sum_s a_s W_r^(s m) with W^k = tw[k]
-template <class T>
-__device__ __forceinline__ void mixed_bfly(v2<T> *p, int q, int r, const v2<T> *__restrict__ tw, int k1) {
-    if (r == 4) {
+// radix 7, 11, 13 (lengths with those prime factors, at most a pass or two each): the R x R sum itself, W_R^k = tw[k ws]
+template <class T, int R>
+__device__ __forceinline__ void odd_bfly(v2<T> *p, int q, const v2<T> *__restrict__ tw, int k1, int ws) {
+    v2<T> a[R];
+#pragma unroll
+    for (int s = 0; s < R; ++s) a[s] = p[s * q];
+    v2<T> y0 = a[0];
+#pragma unroll
+    for (int s = 1; s < R; ++s) {
+        y0.x += a[s].x;
+        y0.y += a[s].y;
+    }
+    p[0] = y0;
+#pragma unroll
+    for (int m = 1; m < R; ++m) {
+        v2<T> acc = a[0];
+#pragma unroll
+        for (int s = 1; s < R; ++s) {
+            const v2<T> w = tw[((s * m) % R) * ws];
+            acc.x += a[s].x * w.x - a[s].y * w.y;
+            acc.y += a[s].x * w.y + a[s].y * w.x;
+        }
+        p[m * q] = cmul<T>(acc, tw[m * k1]);
+    }
+}
+
+// one radix-r butterfly (r = 2, 3, 4, 5; 7, 11, 13) of a decimation-in-frequency pass, in place: inputs p[s q], outputs p[m q] =
+// W^(m k1) sum_s a_s W_r^(s m) with W^k = tw[k] (a table of ntab entries)
+// ODD: the kernel instance that also carries the radix-7 / 11 / 13 butterflies (their 13 live inputs cost the other lengths
+// a third of their residency when they shared one instance: 1000 points 0.139 -> 0.225 ms per 2^24 samples)
+template <class T, bool ODD>
+__device__ __forceinline__ void mixed_bfly(v2<T> *p, int q, int r, const v2<T> *__restrict__ tw, int k1, int ntab) {
+    if (ODD && r > 5) {
+        if constexpr (ODD) {
+            if (r == 7) odd_bfly<T, 7>(p, q, tw, k1, ntab / 7);
+            else if (r == 11) odd_bfly<T, 11>(p, q, tw, k1, ntab / 11);
+            else odd_bfly<T, 13>(p, q, tw, k1, ntab / 13);
+        }
+    } else if (r == 4) {
         const v2<T> a0 = p[0], a1 = p[q], a2 = p[2 * q], a3 = p[3 * q];
         const v2<T> s02 = {a0.x + a2.x, a0.y + a2.y}, d02 = {a0.x - a2.x, a0.y - a2.y};
         const v2<T> s13 = {a1.x + a3.x, a1.y + a3.y}, d13 = {a1.x - a3.x, a1.y - a3.y};
@@ -1101,7 +1135,7 @@ __device__ __forceinline__ void mixed_bfly(v2<T> *p, int q, int r, const v2<T> *
 
 // TWLDS: the twiddle table W_n^k is copied into LDS behind the image (2 n elements per workgroup; lengths up to half the
 // largest image) - a pass then waits for LDS reads instead of L2 hits between its butterflies' loads and stores
-template <class T, bool TWLDS>
+template <class T, bool TWLDS, bool ODD>
 __global__ __launch_bounds__(1024) void k_fft_mixed(const v2<T> *__restrict__ head, long n_head, const v2<T> *__restrict__ in,
                                                    long base0, long hop, int n, int branches, MixedPlan plan,
                                                    const T *__restrict__ window, const v2<T> *__restrict__ tw_g,
@@ -1141,7 +1175,7 @@ __global__ __launch_bounds__(1024) void k_fft_mixed(const v2<T> *__restrict__ he
             const int blk = div_small(b, rq), j = b - blk * q;
             v2<T> *p = x + blk * L + j;
             const int k1 = j * step;  // W_L^j = tw[j n / L]
-            mixed_bfly<T>(p, q, r, tw, k1);
+            mixed_bfly<T, ODD>(p, q, r, tw, k1, n);
         }
         __syncthreads();
         L = q;
@@ -1175,7 +1209,8 @@ __global__ __launch_bounds__(1024) void k_fft_mixed(const v2<T> *__restrict__ he
         int p = 0;
         for (int ps = 0; ps < plan.nrad; ++ps) {
             const int r = plan.radix[ps];
-            const int hi = div_small(rem, r == 2 ? 0.5f : r == 3 ? (1.0f / 3.0f) : r == 4 ? 0.25f : 0.2f);
+            const int hi = div_small(rem, r == 2 ? 0.5f : r == 3 ? (1.0f / 3.0f) : r == 4 ? 0.25f : r == 5 ? 0.2f
+                                          : r == 7 ? (1.0f / 7.0f) : r == 11 ? (1.0f / 11.0f) : (1.0f / 13.0f));
             p += (rem - hi * r) * plan.q[ps];
             rem = hi;
         }
@@ -1187,12 +1222,18 @@ __global__ __launch_bounds__(1024) void k_fft_mixed(const v2<T> *__restrict__ he
 static bool mixed_plan_impl(size_t n, size_t nmax, MixedPlan *pl, bool pow2_too) {
     if (n < 2 || n > nmax || (!pow2_too && (n < 6 || is_pow2_n(n)))) return false;
     size_t m = n;
-    int a = 0, b = 0, c = 0;
+    int a = 0, b = 0, c = 0, k = 0;
     while (m % 2 == 0) m /= 2, ++a;
     while (m % 3 == 0) m /= 3, ++b;
     while (m % 5 == 0) m /= 5, ++c;
+    for (size_t pr : {13, 11, 7})
+        while (m % pr == 0) {
+            m /= pr;
+            if (k >= 12) return false;
+            pl->radix[k++] = (unsigned char)pr;
+        }
     if (m != 1) return false;
-    int k = 0;
+    if (k + c + a / 2 + b + (a & 1) > 12) return false;
     for (int i = 0; i < c; ++i) pl->radix[k++] = 5;
     for (int i = 0; i < a / 2; ++i) pl->radix[k++] = 4;
     for (int i = 0; i < b; ++i) pl->radix[k++] = 3;
@@ -1224,7 +1265,7 @@ bool fft_mixed_supported(int dtype, size_t n) {
 // T1[k1 bx] = W_N^(C k1 bx) and T2[k1 c] = W_N^(k1 c): two exact table indices, no division by a run-time length.
 // Frames come from [ head | in ] at any hop.
 // ---------------------------------------------------------------------------
-template <class T, int MODE>
+template <class T, int MODE, bool ODD>
 __global__ __launch_bounds__(1024) void k_fft_tilem(const v2<T> *__restrict__ head, long n_head, const v2<T> *__restrict__ in,
                                                     long hop, v2<T> *__restrict__ out, int Np, int No, MixedPlan plan,
                                                     const T *__restrict__ window, const v2<T> *__restrict__ twNp,
@@ -1277,7 +1318,7 @@ __global__ __launch_bounds__(1024) void k_fft_tilem(const v2<T> *__restrict__ he
                 jj = b - c * nb;
             }
             const int blk = div_small(jj, rq), j = jj - blk * q;
-            mixed_bfly<T>(tile + (blk * L + j) * SN + c * SC, q * SN, r, tw, j * step);
+            mixed_bfly<T, ODD>(tile + (blk * L + j) * SN + c * SC, q * SN, r, tw, j * step, Np);
         }
         __syncthreads();
         L = q;
@@ -1314,9 +1355,8 @@ bool fft_tilem_split(int dtype, size_t n, size_t *N1, size_t *N2) {
     if (n > 512 * 512 || n < C * C) return false;
     {
         size_t m = n;
-        while (m % 2 == 0) m /= 2;
-        while (m % 3 == 0) m /= 3;
-        while (m % 5 == 0) m /= 5;
+        for (size_t pr : {2, 3, 5, 7, 11, 13})
+            while (m % pr == 0) m /= pr;
         if (m != 1) return false;
     }
     size_t best = 0;
@@ -1348,19 +1388,28 @@ static int launch_fft_tilem_t(hipStream_t s, int pass, const void *head, size_t 
     if (nt > 1024) nt = 1024;
     if (nt < 256) nt = 256;
     const dim3 grid((unsigned)((No + C - 1) / C), (unsigned)count);
+    const bool odd = pl.radix[0] > 5;  // (the primes beyond 5 come first in the plan)
+#define RR_TILEM(MM, OO)                                                                                                        \
+    do {                                                                                                                        \
+        auto fn = k_fft_tilem<T, MM, OO>;                                                                                       \
+        RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));                                                           \
+        if (MM == 0)                                                                                                            \
+            hipLaunchKernelGGL(fn, grid, dim3((unsigned)nt), lds, s, (const v2<T> *)head, (long)n_head, (const v2<T> *)in,     \
+                               (long)hop, (v2<T> *)out, (int)Np, (int)No, pl, (const T *)window, (const v2<T> *)twNp,          \
+                               (const v2<T> *)T1, (const v2<T> *)T2, 0);                                                        \
+        else                                                                                                                    \
+            hipLaunchKernelGGL(fn, grid, dim3((unsigned)nt), lds, s, (const v2<T> *)nullptr, 0L, (const v2<T> *)in, 0L,        \
+                               (v2<T> *)out, (int)Np, (int)No, pl, (const T *)nullptr, (const v2<T> *)twNp,                     \
+                               (const v2<T> *)nullptr, (const v2<T> *)nullptr, (int)rot);                                       \
+    } while (0)
     if (pass == 0) {
-        auto fn = k_fft_tilem<T, 0>;
-        RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));
-        hipLaunchKernelGGL(fn, grid, dim3((unsigned)nt), lds, s, (const v2<T> *)head, (long)n_head, (const v2<T> *)in, (long)hop,
-                           (v2<T> *)out, (int)Np, (int)No, pl, (const T *)window, (const v2<T> *)twNp, (const v2<T> *)T1,
-                           (const v2<T> *)T2, 0);
+        if (odd) RR_TILEM(0, true);
+        else RR_TILEM(0, false);
     } else {
-        auto fn = k_fft_tilem<T, 1>;
-        RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));
-        hipLaunchKernelGGL(fn, grid, dim3((unsigned)nt), lds, s, (const v2<T> *)nullptr, 0L, (const v2<T> *)in, 0L, (v2<T> *)out,
-                           (int)Np, (int)No, pl, (const T *)nullptr, (const v2<T> *)twNp, (const v2<T> *)nullptr,
-                           (const v2<T> *)nullptr, (int)rot);
+        if (odd) RR_TILEM(1, true);
+        else RR_TILEM(1, false);
     }
+#undef RR_TILEM
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
@@ -1381,6 +1430,9 @@ int launch_fft_tilem(int dtype, hipStream_t s, int pass, const void *head, size_
 bool fft_mixed_preferred(int dtype, size_t n) {
     if (n < 32) return false;
     if (dtype != RR_F32) return true;
+    // lengths with a factor 7, 11 or 13 (the R x R butterflies): 1001 points 0.301 ms against k_bluestein4096's 0.219; beyond 2048
+    // points, where Bluestein takes five launches, 4004 points 0.225 against 0.635
+    if (n % 7 == 0 || n % 11 == 0 || n % 13 == 0) return n > 2048;
     return n < 288 || (n > 512 && n <= 1280) || n > 2048;
 }
 int launch_fft_mixed(int dtype, hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n,
@@ -1409,9 +1461,15 @@ int launch_fft_mixed_fold(int dtype, hipStream_t s, const void *head, size_t n_h
     const size_t twcap = twlds_env > 1 ? (size_t)twlds_env : 32768;
     const bool twlds = twlds_env != 0 && 2 * n * esz <= twcap;
     const size_t lds = (twlds ? 2 : 1) * n * esz;
+    const bool odd = pl.radix[0] > 5;  // (the primes beyond 5 come first in the plan)
 #define RR_MIXED(TT, VV, TL)                                                                                              \
     do {                                                                                                                  \
-        auto fn = k_fft_mixed<TT, TL>;                                                                                    \
+        if (odd) RR_MIXED2(TT, VV, TL, true);                                                                             \
+        else RR_MIXED2(TT, VV, TL, false);                                                                                \
+    } while (0)
+#define RR_MIXED2(TT, VV, TL, OO)                                                                                         \
+    do {                                                                                                                  \
+        auto fn = k_fft_mixed<TT, TL, OO>;                                                                                \
         RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));                                                     \
         hipLaunchKernelGGL(fn, dim3((unsigned)count), dim3(nt), lds, s, (const VV *)head, (long)n_head, (const VV *)in,  \
                            base0, (long)hop, (int)n, (int)branches, pl, (const TT *)window, (const VV *)tw, (VV *)out,    \
@@ -1425,6 +1483,7 @@ int launch_fft_mixed_fold(int dtype, hipStream_t s, const void *head, size_t n_h
         else RR_MIXED(double, double2, false);
     }
 #undef RR_MIXED
+#undef RR_MIXED2
     RR_HIP(hipGetLastError());
     return RR_OK;
 }

@@ -589,7 +589,9 @@ def test_fourier_f64_lengths(rr, oracle, n, center):
 
 @pytest.mark.parametrize("n,center", [(6, False), (12, True), (60, False), (96, True), (360, False), (1536, True), (2000, False), (3000, True),
                                       (3072, False), (3125, True), (3840, False), (4000, True), (4050, False), (4095, True),
-                                      (4800, False), (6000, True), (7776, False), (8000, True)])   # (beyond 4096: f32 only, Bluestein in f64)
+                                      (4800, False), (6000, True), (7776, False), (8000, True),   # (beyond 4096: f32 only, Bluestein in f64)
+                                      (77, False), (343, True), (1001, False), (1331, True), (2002, False), (2401, True), (4004, False),
+                                      (6006, True), (8008, False)])   # radix 7 / 11 / 13 passes
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_fourier_mixed_radix_lengths(rr, oracle, monkeypatch, n, center, dtype):
     """Chunk lengths 2^a 3^b 5^c that are not powers of two run k_fft_mixed (radix 5 / 4 / 3 / 2 passes in one LDS image); every
@@ -616,7 +618,8 @@ def test_fourier_mixed_radix_lengths(rr, oracle, monkeypatch, n, center, dtype):
 
 
 @pytest.mark.parametrize("n,center", [(20000, True), (48000, False), (10000, True), (30375, True), (12000, False), (100000, True),
-                                      (8640, False), (262144 // 2 * 2 - 12144, False), (5000, True)])
+                                      (8640, False), (262144 // 2 * 2 - 12144, False), (5000, True),
+                                      (77000, True), (91091, False)])   # 275 x 280 with radix 7 / 11 passes; 7^2 11 13^2 has no split up to 512: Bluestein
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_fourier_mixed_radix_two_pass(rr, oracle, monkeypatch, n, center, dtype):
     """Lengths 2^a 3^b 5^c beyond one LDS image (8192 points in f32, 4096 in f64) up to 512 x 512: two passes, k_fft_tilem - bundles
