@@ -160,7 +160,9 @@ def overlapped_spectra(oracle, chunks, P, window, center_dc, flt, history=None):
                                                   (64, 8, False, np.float64, 1e-12), (512, 16, False, np.float32, 1e-5),
                                                   (512, 2, False, np.float32, 1e-5), (256, 1, False, np.float32, 1e-5),
                                                   (1024, 1, True, np.float32, 1e-5), (1024, 2, False, np.float32, 1e-5), (512, 4, True, np.float32, 1e-5), (128, 4, True, np.float32, 1e-5), (256, 2, False, np.float32, 1e-5), (2048, 4, True, np.float32, 1e-5), (250, 4, True, np.float32, 1e-5), (100, 3, False, np.float32, 1e-5),
-                                                  (100, 3, True, np.float64, 1e-11), (1500, 4, False, np.float32, 1e-5)])
+                                                  (100, 3, True, np.float64, 1e-11), (1500, 4, False, np.float32, 1e-5),
+                                                  # spans 2^a 3^b 5^c (7 ..): overlapping frames through k_fft_mixed / the two passes of k_fft_tilem
+                                                  (3000, 4, True, np.float32, 1e-5), (2500, 2, False, np.float64, 1e-11), (1001, 4, False, np.float32, 1e-5)])
 def test_stft_parity(rr, oracle, M, P, center, dtype, tol):
     """rr_stft_*: Rechunker -> Overlapper -> Fourier on the device (4096-point spans run k_fft4096
     with a hop, the others the generic power-of-two kernel) against the oracle composition."""
