@@ -1893,8 +1893,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OC
 // ---------------------------------------------------------------------------
 int ols_wave_overlap(size_t Lc, size_t granule);
 #define RR_V_FRAMEWIN 1  // frames round robin over the XCDs: 0.1915 ms; a contiguous eighth per XCD (0): 0.1965
-#define RR_V_FRAMEWAVES 4  // measured (full-size images): 4 waves 0.233 ms, 5 waves 0.30 (one workgroup per CU), 8 waves 0.26, 10 waves 0.28
-constexpr int kFrameWaves = RR_V_FRAMEWAVES, kFrameBlocks = 20;
+// (waves per frame, first form with full-size images: 4 waves 0.233 ms, 5 waves 0.30 (one workgroup per CU), 8 waves 0.26, 10 waves 0.28)
+constexpr int kFrameBlocks = 20;
 
 // One 1024-sample block of k_ols_wave<4, POLY> as a function (the fused frame kernel's waves run five of them in a
 // row): v = mixed samples in the pair layout, hv = the lane's 16 entries of the polyphase tables G_p; y[c] =

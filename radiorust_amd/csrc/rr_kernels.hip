@@ -540,7 +540,6 @@ __global__ __launch_bounds__(256) void k_dft_direct(const v2<T> *__restrict__ in
 
 static bool is_pow2(size_t n) { return n && (n & (n - 1)) == 0; }
 static size_t pow2_limit(int dtype) { return dtype == RR_F32 ? 8192 : 4096; }  // 2 LDS buffers <= 128 KiB
-constexpr size_t kDirectLimit = 16384;
 
 bool fourier_pow2_path(int dtype, size_t n) { return is_pow2(n) && n >= 2 && n <= pow2_limit(dtype); }
 
