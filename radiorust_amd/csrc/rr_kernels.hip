@@ -889,20 +889,39 @@ __global__ __launch_bounds__(1024) void k_fft_tile(const v2<T> *__restrict__ in,
     const size_t chunk = (size_t)blockIdx.y * (size_t)Np * (size_t)No;
     const int g0 = blockIdx.x * C;
     for (int i = t; i < Np; i += nt) tw[i] = twNp[i];
+    // (four loads in flight per lane: left as one loop the compiler keeps a single load between a wait and the LDS store)
     if (MODE == 0) {
-        for (int idx = t; idx < Np * C; idx += nt) {
-            const int n = idx / C, c = idx % C;
-            const size_t e = (size_t)n * No + g0 + c;
-            v2<T> v = in[chunk + e];
-            const T w = window[e];
-            v.x *= w;
-            v.y *= w;
-            tile[n * C + c] = v;
+        for (int idx0 = t; idx0 < Np * C; idx0 += 4 * nt) {
+            v2<T> v[4];
+            T w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + u * nt;
+                if (idx < Np * C) {
+                    const size_t e = (size_t)(idx / C) * No + g0 + idx % C;
+                    v[u] = in[chunk + e];
+                    w[u] = window[e];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + u * nt;
+                if (idx < Np * C) tile[idx] = v2<T>{v[u].x * w[u], v[u].y * w[u]};  // (n C + c = idx)
+            }
         }
     } else {
-        for (int idx = t; idx < Np * C; idx += nt) {
-            const int c = idx >> lgNp, n = idx & (Np - 1);
-            tile[c * (Np + 1) + n] = in[chunk + (size_t)(g0 + c) * Np + n];
+        for (int idx0 = t; idx0 < Np * C; idx0 += 4 * nt) {
+            v2<T> v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + u * nt;
+                if (idx < Np * C) v[u] = in[chunk + (size_t)(g0 + (idx >> lgNp)) * Np + (idx & (Np - 1))];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + u * nt;
+                if (idx < Np * C) tile[(idx >> lgNp) * (Np + 1) + (idx & (Np - 1))] = v[u];
+            }
         }
     }
     __syncthreads();
@@ -1154,16 +1173,38 @@ __global__ __launch_bounds__(1024) void k_fft_mixed(const v2<T> *__restrict__ he
     // branches > 1 the frame is the fold of that many windowed chunks of n samples (the polyphase channelizer's front end,
     // chunks.rs:194-242 + analysis.rs:105-112 with every branches-th bin kept: v[i] = sum_p w[i + n p] x[base + i + n p])
     const long base = base0 + (long)fr * hop;
-    for (int i = t; i < n; i += nt) {
-        v2<T> acc = {(T)0, (T)0};
-        for (int pb = 0; pb < branches; ++pb) {
-            const long g = base + i + (long)pb * n;
-            const v2<T> v = g >= 0 ? in[g] : head[n_head + g];
-            const T w = window[i + pb * n];
-            acc.x += v.x * w;
-            acc.y += v.y * w;
+    if (branches == 1) {
+        // (four loads in flight per lane: left as one loop the compiler keeps a single load between a wait and the LDS store)
+        for (int i0 = t; i0 < n; i0 += 4 * nt) {
+            v2<T> v[4];
+            T w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * nt;
+                if (i < n) {
+                    const long g = base + i;
+                    v[u] = g >= 0 ? in[g] : head[n_head + g];
+                    w[u] = window[i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * nt;
+                if (i < n) x[i] = v2<T>{v[u].x * w[u], v[u].y * w[u]};
+            }
         }
-        x[i] = acc;
+    } else {
+        for (int i = t; i < n; i += nt) {
+            v2<T> acc = {(T)0, (T)0};
+            for (int pb = 0; pb < branches; ++pb) {
+                const long g = base + i + (long)pb * n;
+                const v2<T> v = g >= 0 ? in[g] : head[n_head + g];
+                const T w = window[i + pb * n];
+                acc.x += v.x * w;
+                acc.y += v.y * w;
+            }
+            x[i] = acc;
+        }
     }
     __syncthreads();
     int L = n;
@@ -1281,25 +1322,48 @@ __global__ __launch_bounds__(1024) void k_fft_tilem(const v2<T> *__restrict__ he
     for (int i = t; i < Np; i += nt) tw[i] = twNp[i];
     if (MODE == 0) {
         const long base = (long)blockIdx.y * hop - n_head;  // frames from [ head | in ]
-        for (int idx = t; idx < Np * C; idx += nt) {
-            const int n = idx / C, c = idx % C;
-            v2<T> v = {(T)0, (T)0};
-            if (c < cv) {
-                const size_t e = (size_t)n * No + g0 + c;
-                const long g = base + (long)e;
-                v = g >= 0 ? in[g] : head[n_head + g];
-                const T w = window[e];
-                v.x *= w;
-                v.y *= w;
+        // (four loads in flight per lane, as k_fft_tile)
+        for (int idx0 = t; idx0 < Np * C; idx0 += 4 * nt) {
+            v2<T> v[4];
+            T w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + u * nt;
+                v[u] = v2<T>{(T)0, (T)0};
+                w[u] = (T)0;
+                if (idx < Np * C && idx % C < cv) {
+                    const size_t e = (size_t)(idx / C) * No + g0 + idx % C;
+                    const long g = base + (long)e;
+                    v[u] = g >= 0 ? in[g] : head[n_head + g];
+                    w[u] = window[e];
+                }
             }
-            tile[n * C + c] = v;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + u * nt;
+                if (idx < Np * C) tile[idx] = v2<T>{v[u].x * w[u], v[u].y * w[u]};  // (n C + c = idx)
+            }
         }
     } else {
         const float rNp = 1.0f / (float)Np;
         const size_t chunk = (size_t)blockIdx.y * N;
-        for (int idx = t; idx < Np * C; idx += nt) {
-            const int c = div_small(idx, rNp), n = idx - c * Np;
-            tile[c * (Np + 1) + n] = c < cv ? in[chunk + (size_t)(g0 + c) * Np + n] : v2<T>{(T)0, (T)0};
+        for (int idx0 = t; idx0 < Np * C; idx0 += 4 * nt) {
+            v2<T> v[4];
+            int at[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + u * nt;
+                v[u] = v2<T>{(T)0, (T)0};
+                at[u] = -1;
+                if (idx < Np * C) {
+                    const int c = div_small(idx, rNp), n = idx - c * Np;
+                    at[u] = c * (Np + 1) + n;
+                    if (c < cv) v[u] = in[chunk + (size_t)(g0 + c) * Np + n];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (at[u] >= 0) tile[at[u]] = v[u];
         }
     }
     __syncthreads();
