@@ -431,13 +431,24 @@ __global__ __launch_bounds__(1024) void k_fft_pow2(const v2<T> *__restrict__ hea
     const size_t chunk = blockIdx.x;
     const long base = (long)chunk * hop - n_head;
     v2<T> *dst = out + chunk * (size_t)n;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const long pos = base + i;
-        v2<T> v = pos >= 0 ? in[pos] : head[n_head + pos];
-        const T w = window[i];
-        v.x *= w;
-        v.y *= w;
-        a[i] = v;
+    // (four loads in flight per lane: as one loop there is a single load between a wait and the LDS store)
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * blockDim.x) {
+        v2<T> v[4];
+        T w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * (int)blockDim.x;
+            if (i < n) {
+                const long pos = base + i;
+                v[u] = pos >= 0 ? in[pos] : head[n_head + pos];
+                w[u] = window[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * (int)blockDim.x;
+            if (i < n) a[i] = v2<T>{v[u].x * w[u], v[u].y * w[u]};
+        }
     }
     __syncthreads();
     const int half = n >> 1;
