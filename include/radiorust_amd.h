@@ -142,6 +142,11 @@ int rr_downsampler_schedule(double input_rate, double output_rate, size_t n_in,
 
 /* Fourier window, analysis.rs:88-101: values[i] = rel[i] * sqrt(n / sum rel^2). */
 int rr_fourier_design_window(size_t n, const double *window_rel, double *values);
+/* Which kernels transform a chunk of n samples (host only, no device needed; the same decision rr_fourier_process takes):
+ * writes a short description into buf - "pow2", "pow2 two passes 128 x 256", "pow2 five launches 1024 x 1024",
+ * "mixed 5 5 5 4 2" (the radices of the passes), "mixed two passes 125 x 160", "bluestein wave M=1024",
+ * "bluestein one kernel M=4096", "bluestein five launches M=65536", "direct".  analysis.rs:82-115 accepts any length. */
+int rr_fourier_route(int dtype, size_t n, char *buf, size_t cap);
 
 /* ------------------------------------------------------------------------ */
 /* FreqShifter — src/blocks/transform.rs:266-391                            */

@@ -107,6 +107,7 @@ SIGNATURES = {
     "rr_downsampler_design": (_i, [_d, _d, _d, _d, _psz, _vp, _sz]),
     "rr_downsampler_schedule": (_i, [_d, _d, _sz, C.POINTER(_d), _vp, _sz, _psz]),
     "rr_fourier_design_window": (_i, [_sz, _vp, _vp]),
+    "rr_fourier_route": (_i, [_i, _sz, C.c_char_p, _sz]),
     "rr_freqshifter_create": (_i, [_i, _d, _d, _i, C.POINTER(_vp)]),
     "rr_freqshifter_set_shift": (_i, [_vp, _d]),
     "rr_freqshifter_shift": (_i, [_vp, C.POINTER(_d)]),

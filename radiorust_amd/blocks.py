@@ -134,6 +134,13 @@ def deemphasis_factor(tau: float, frequency: float) -> complex:
     return complex(out[0], out[1])
 
 
+def fourier_route(n: int, dtype=np.float32) -> str:
+    """Which kernels transform a chunk of n samples (rr_fourier_route: host only, the decision rr_fourier_process takes)."""
+    buf = C.create_string_buffer(128)
+    _lib.check(_lib.lib().rr_fourier_route(0 if np.dtype(dtype) == np.float32 else 1, int(n), buf, 128))
+    return buf.value.decode()
+
+
 def sample_freq_resp(freq_resp, n: int, sample_rate: float) -> np.ndarray:
     """Evaluates the user's closure exactly where the reference does
     (filters.rs:188-199): bins 0..=(n-1)/2 and their negatives; for even n the

@@ -4,6 +4,7 @@
 #include "rr_blocks.hpp"
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -747,6 +748,67 @@ int rr_fmdemod::process_dev(double sample_rate, const void *d_in, size_t n_in, v
 //   direct   other lengths below 32: the O(n^2) kernel
 static bool is_pow2_sz(size_t n) { return n && (n & (n - 1)) == 0; }
 
+// Which kernels transform a chunk of `len` points - ONE decision, used by prepare() and by rr_fourier_route() (host only).
+struct FourierRoute {
+    enum Kind { DIRECT, POW2, BIG_TILE, BIG_TRANSPOSE, BIG_GENERIC, MIXED, TILEM, BS_WAVE, BS_FUSED, BS_LAUNCHES } kind = DIRECT;
+    size_t N1 = 0, N2 = 0;  // the four-step / two-pass split
+    size_t M = 0;           // Bluestein's power-of-two length
+};
+static FourierRoute fourier_route(int dtype, size_t len, bool force_mixed) {
+    FourierRoute r;
+    const bool pow2 = is_pow2_sz(len);
+    const bool generic = [] { const char *e = std::getenv("RR_FOURIER_GENERIC"); return e && std::atoi(e) != 0; }();
+    const int mixed_env = [] { const char *e = std::getenv("RR_FOURIER_MIXED"); return e ? std::atoi(e) : 1; }();  // 0 never, 2 wherever it applies
+    if (pow2) {
+        if (len < 4 || fourier_pow2_path(dtype, len)) {  // (a chunk of 1 sample is a power of two, too)
+            r.kind = FourierRoute::POW2;
+            return r;
+        }
+        fft_big_split(len, &r.N1, &r.N2);
+        if (generic) {
+            r.kind = FourierRoute::BIG_GENERIC;
+            return r;
+        }
+        // 2^13 / 2^14 .. 2^18 points: two passes over HBM (k_fft_tile); RR_FOURIER_BIG=transpose keeps the five launches
+        const bool force_tr = [] { const char *e = std::getenv("RR_FOURIER_BIG"); return e && std::string(e) == "transpose"; }();
+        r.kind = (!force_tr && fft_tile_supported(dtype, r.N1, r.N2)) ? FourierRoute::BIG_TILE : FourierRoute::BIG_TRANSPOSE;
+        return r;
+    }
+    // lengths 2^a 3^b 5^c (7^d 11^e 13^f): mixed-radix passes in one LDS image instead of Bluestein's two padded power-of-two
+    // transforms, where measured faster (fft_mixed_preferred; RR_FOURIER_MIXED=0 keeps Bluestein, 2 takes it wherever it applies);
+    // beyond one image the two passes of k_fft_tilem.  (Complex<f64> powers of two through the same in-place kernel were measured
+    // SLOWER than k_fft_pow2's Stockham passes: 4096 points 0.355 against 0.241 ms per 2^24 samples, 256 points 0.237 against 0.133.)
+    if (!generic && mixed_env != 0) {
+        if (fft_mixed_supported(dtype, len)) {
+            if (mixed_env == 2 || force_mixed || fft_mixed_preferred(dtype, len)) {
+                r.kind = FourierRoute::MIXED;
+                return r;
+            }
+        } else if (fft_tilem_split(dtype, len, &r.N1, &r.N2)) {
+            r.kind = FourierRoute::TILEM;
+            return r;
+        }
+    }
+    if (len >= 32 && !(generic && len <= 16384)) {
+        size_t M = 64;
+        while (M < 2 * len - 1) M *= 2;
+        r.kind = FourierRoute::BS_LAUNCHES;
+        // 513 .. 2048 points in f32: the whole algorithm in one kernel around two 4096-point transforms in LDS; 32 .. 512 points
+        // in f32: a wave per chunk around two 1024-point transforms (RR_FOURIER_GENERIC=1 keeps the five launches)
+        if (!generic && bluestein4096_supported(dtype, len)) {
+            r.kind = FourierRoute::BS_FUSED;
+            M = 4096;
+        } else if (!generic && bluestein1024_supported(dtype, len)) {
+            r.kind = FourierRoute::BS_WAVE;
+            M = 1024;
+        }
+        r.M = M;
+        return r;
+    }
+    r.kind = FourierRoute::DIRECT;  // (also: RR_FOURIER_GENERIC=1 up to 16384 points)
+    return r;
+}
+
 int rr_fourier::prepare(size_t len) {
     if (len == n) return RR_OK;
     RR_TRY(fourier_supported(dtype, len));
@@ -760,20 +822,13 @@ int rr_fourier::prepare(size_t len) {
     }
     std::vector<double> vals(len);
     RR_TRY(fourier_design_window(len, rel.data(), vals.data()));
-    const bool pow2 = is_pow2_sz(len);
-    const bool generic = [] { const char *e = std::getenv("RR_FOURIER_GENERIC"); return e && std::atoi(e) != 0; }();
-    const bool use_big = pow2 && len >= 4 && !fourier_pow2_path(dtype, len);  // (a chunk of 1 sample is a power of two, too)
-    // lengths 2^a 3^b 5^c <= 4096 that are not powers of two: mixed-radix passes in one LDS image instead of Bluestein's two
-    // padded power-of-two transforms, where measured faster (fft_mixed_preferred; RR_FOURIER_MIXED=0 keeps Bluestein, 2 takes it wherever it applies)
-    const int mixed_env = [] { const char *e = std::getenv("RR_FOURIER_MIXED"); return e ? std::atoi(e) : 1; }();  // 0 never, 2 wherever it applies
-    // (Complex<f64> powers of two through the same in-place kernel were measured SLOWER than k_fft_pow2's Stockham passes:
-    // 4096 points 0.355 against 0.241 ms per 2^24 samples, 256 points 0.237 against 0.133)
-    const bool use_mixed = !pow2 && !generic && mixed_env != 0 && fft_mixed_supported(dtype, len) &&
-                           (mixed_env == 2 || force_mixed || fft_mixed_preferred(dtype, len));
-    size_t tmN1 = 0, tmN2 = 0;
-    const bool use_tilem = !pow2 && !generic && mixed_env != 0 && !fft_mixed_supported(dtype, len) &&
-                           fft_tilem_split(dtype, len, &tmN1, &tmN2);
-    const bool use_bs = !pow2 && len >= 32 && !(generic && len <= 16384) && !use_mixed && !use_tilem;
+    const FourierRoute route = fourier_route(dtype, len, force_mixed);
+    using FR = FourierRoute;
+    const bool use_big = route.kind == FR::BIG_TILE || route.kind == FR::BIG_TRANSPOSE || route.kind == FR::BIG_GENERIC;
+    const bool generic = route.kind == FR::BIG_GENERIC;  // (only consulted on the `big` branches below)
+    const bool use_mixed = route.kind == FR::MIXED, use_tilem = route.kind == FR::TILEM;
+    const size_t tmN1 = route.N1, tmN2 = route.N2;
+    const bool use_bs = route.kind == FR::BS_WAVE || route.kind == FR::BS_FUSED || route.kind == FR::BS_LAUNCHES;
     auto cast = [&](const std::vector<double> &src, std::vector<unsigned char> &dst) {
         if (dtype == RR_F32) cast_to<float>(src.data(), src.size(), dst);
         else cast_to<double>(src.data(), src.size(), dst);
@@ -801,10 +856,9 @@ int rr_fourier::prepare(size_t len) {
             tw[2 * (nB + i)] = std::cos(ang);
             tw[2 * (nB + i) + 1] = std::sin(ang);
         }
-        // 2^13 / 2^14 .. 2^18 points: two passes over HBM (k_fft_tile) with the sub-transforms' own tables behind tB | tA;
-        // RR_FOURIER_BIG=transpose keeps the five launches (transposes around the fast row kernels)
-        const bool force_tr = [] { const char *e = std::getenv("RR_FOURIER_BIG"); return e && std::string(e) == "transpose"; }();
-        big_tile = !force_tr && fft_tile_supported(dtype, N1, N2);
+        // two passes over HBM (k_fft_tile) with the sub-transforms' own tables behind tB | tA, or the five launches
+        // (transposes around the fast row kernels): fourier_route
+        big_tile = route.kind == FR::BIG_TILE;
         if (big_tile) {
             big_tw1_off = nA + nB;
             big_tw2_off = big_tw1_off + N1;
@@ -910,16 +964,9 @@ int rr_fourier::prepare(size_t len) {
     bs_fused = bs_wave = false;
     big = use_big;
     if (use_bs) {
-        size_t M = 64;
-        while (M < 2 * len - 1) M *= 2;
-        // 513 .. 2048 points in f32: the whole algorithm in one kernel around two 4096-point transforms in LDS
-        // (RR_FOURIER_GENERIC=1 keeps the five launches)
-        static const bool generic = [] { const char *e = std::getenv("RR_FOURIER_GENERIC"); return e && std::atoi(e) != 0; }();
-        bs_fused = !generic && bluestein4096_supported(dtype, len);
-        if (bs_fused) M = 4096;
-        // 32 .. 512 points in f32: a wave per chunk around two 1024-point transforms (k_bluestein1024)
-        bs_wave = !generic && bluestein1024_supported(dtype, len);
-        if (bs_wave) M = 1024;
+        const size_t M = route.M;
+        bs_fused = route.kind == FR::BS_FUSED;  // k_bluestein4096
+        bs_wave = route.kind == FR::BS_WAVE;    // k_bluestein1024
         // chirp w_m = e^{+j pi m^2 / n}, the phase reduced exactly (m^2 mod 2n) before it is evaluated
         std::vector<cd> w(len);
         for (size_t m = 0; m < len; ++m) {
@@ -2441,6 +2488,34 @@ int rr_fmdemod_destroy(rr_fmdemod *h) {
 }
 
 // ---- Fourier --------------------------------------------------------------------------
+int rr_fourier_route(int dtype, size_t n, char *buf, size_t cap) {
+    if (!buf || cap == 0) RR_FAIL(RR_ERR_BAD_ARG, "rr_fourier_route: no buffer");
+    if (dtype != RR_F32 && dtype != RR_F64) RR_FAIL(RR_ERR_BAD_ARG, "rr_fourier_route: dtype");
+    buf[0] = 0;
+    RR_TRY(fourier_supported(dtype, n));
+    const FourierRoute r = fourier_route(dtype, n, false);
+    using FR = FourierRoute;
+    switch (r.kind) {
+        case FR::DIRECT: std::snprintf(buf, cap, "direct"); break;
+        case FR::POW2: std::snprintf(buf, cap, "pow2"); break;
+        case FR::BIG_TILE: std::snprintf(buf, cap, "pow2 two passes %zu x %zu", r.N1, r.N2); break;
+        case FR::BIG_TRANSPOSE: std::snprintf(buf, cap, "pow2 five launches %zu x %zu", r.N1, r.N2); break;
+        case FR::BIG_GENERIC: std::snprintf(buf, cap, "pow2 strided %zu x %zu", r.N1, r.N2); break;
+        case FR::MIXED: {
+            unsigned char rad[16];
+            const int k = fft_mixed_radices(dtype, n, rad, 16);
+            int pos = std::snprintf(buf, cap, "mixed");
+            for (int i = 0; i < k && pos > 0 && (size_t)pos < cap; ++i) pos += std::snprintf(buf + pos, cap - pos, " %d", (int)rad[i]);
+            break;
+        }
+        case FR::TILEM: std::snprintf(buf, cap, "mixed two passes %zu x %zu", r.N1, r.N2); break;
+        case FR::BS_WAVE: std::snprintf(buf, cap, "bluestein wave M=%zu", r.M); break;
+        case FR::BS_FUSED: std::snprintf(buf, cap, "bluestein one kernel M=%zu", r.M); break;
+        case FR::BS_LAUNCHES: std::snprintf(buf, cap, "bluestein five launches M=%zu", r.M); break;
+    }
+    return RR_OK;
+}
+
 int rr_fourier_create(int dtype, const rr_window *window, int center_dc, int device, rr_fourier **out) {
     RR_GUARD_BEGIN
     if (!out || !window) RR_FAIL(RR_ERR_BAD_ARG, "null");

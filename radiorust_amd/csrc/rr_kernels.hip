@@ -1303,6 +1303,13 @@ static bool mixed_plan_impl(size_t n, size_t nmax, MixedPlan *pl, bool pow2_too)
 static size_t mixed_max(int dtype) { return dtype == RR_F32 ? 8192 : 4096; }
 static bool mixed_plan(size_t n, size_t nmax, MixedPlan *pl) { return mixed_plan_impl(n, nmax, pl, false); }
 static bool mixed_plan_any(size_t n, size_t nmax, MixedPlan *pl) { return mixed_plan_impl(n, nmax, pl, true); }
+// the radices of k_fft_mixed's passes for a length it serves (for rr_fourier_route)
+int fft_mixed_radices(int dtype, size_t n, unsigned char *radices, int cap) {
+    MixedPlan pl;
+    if (!mixed_plan(n, mixed_max(dtype), &pl)) return 0;
+    for (int i = 0; i < pl.nrad && i < cap; ++i) radices[i] = pl.radix[i];
+    return pl.nrad;
+}
 bool fft_mixed_supported(int dtype, size_t n) {
     MixedPlan pl;
     return mixed_plan(n, mixed_max(dtype), &pl);

@@ -147,6 +147,7 @@ int launch_transpose_mul(int dtype, hipStream_t s, const void *in, void *out, si
 // chunk lengths 2^a 3^b 5^c (<= 8192 in f32, <= 4096 in f64) that are not powers of two: mixed-radix passes in one LDS image (k_fft_mixed); window = n reals,
 // tw = e^{-j 2 pi k / n} (n entries); frames from [ head | in ] at any hop
 bool fft_mixed_supported(int dtype, size_t n);
+int fft_mixed_radices(int dtype, size_t n, unsigned char *radices, int cap);
 // the same with the frames starting base0 + f hop samples into `in` and each frame the fold of `branches` windowed chunks
 // (window: branches * n values) - the polyphase channelizer with a bin count that is not a power of two, in one kernel
 int launch_fft_mixed_fold(int dtype, hipStream_t s, const void *head, size_t n_head, const void *in, long base0, size_t hop,
