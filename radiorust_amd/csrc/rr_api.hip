@@ -750,7 +750,7 @@ static bool is_pow2_sz(size_t n) { return n && (n & (n - 1)) == 0; }
 
 // Which kernels transform a chunk of `len` points - ONE decision, used by prepare() and by rr_fourier_route() (host only).
 struct FourierRoute {
-    enum Kind { DIRECT, POW2, BIG_TILE, BIG_TRANSPOSE, BIG_GENERIC, MIXED, TILEM, BS_WAVE, BS_FUSED, BS_LAUNCHES } kind = DIRECT;
+    enum Kind { DIRECT, POW2, BIG_TILE, BIG_TRANSPOSE, BIG_GENERIC, MIXED, TILEM, BS_WAVE, BS_FUSED, BS_FUSED8K, BS_LDS, BS_LAUNCHES } kind = DIRECT;
     size_t N1 = 0, N2 = 0;  // the four-step / two-pass split
     size_t M = 0;           // Bluestein's power-of-two length
 };
@@ -801,6 +801,13 @@ static FourierRoute fourier_route(int dtype, size_t len, bool force_mixed) {
         } else if (!generic && bluestein1024_supported(dtype, len)) {
             r.kind = FourierRoute::BS_WAVE;
             M = 1024;
+        } else if (!generic && bluestein8192_supported(dtype, len)) {
+            r.kind = FourierRoute::BS_FUSED8K;  // f32, 2049 .. 4096 points: one kernel around two 8192-point register transforms
+            M = 8192;
+        } else if (!generic && bluestein_lds_supported(dtype, len, M) &&
+                   ![] { const char *e = std::getenv("RR_FOURIER_BS_LDS"); return e && std::atoi(e) == 0; }()) {
+            // f64 up to 2048 points: one kernel with the transforms as Stockham passes between two LDS images
+            r.kind = FourierRoute::BS_LDS;
         }
         r.M = M;
         return r;
@@ -828,7 +835,8 @@ int rr_fourier::prepare(size_t len) {
     const bool generic = route.kind == FR::BIG_GENERIC;  // (only consulted on the `big` branches below)
     const bool use_mixed = route.kind == FR::MIXED, use_tilem = route.kind == FR::TILEM;
     const size_t tmN1 = route.N1, tmN2 = route.N2;
-    const bool use_bs = route.kind == FR::BS_WAVE || route.kind == FR::BS_FUSED || route.kind == FR::BS_LAUNCHES;
+    const bool use_bs = route.kind == FR::BS_WAVE || route.kind == FR::BS_FUSED || route.kind == FR::BS_FUSED8K || route.kind == FR::BS_LDS ||
+                        route.kind == FR::BS_LAUNCHES;
     auto cast = [&](const std::vector<double> &src, std::vector<unsigned char> &dst) {
         if (dtype == RR_F32) cast_to<float>(src.data(), src.size(), dst);
         else cast_to<double>(src.data(), src.size(), dst);
@@ -961,12 +969,14 @@ int rr_fourier::prepare(size_t len) {
     mixed = use_mixed;
     tilem = use_tilem;
     bs_M = 0;
-    bs_fused = bs_wave = false;
+    bs_fused = bs_wave = bs_lds = bs_fused8k = false;
     big = use_big;
     if (use_bs) {
         const size_t M = route.M;
         bs_fused = route.kind == FR::BS_FUSED;  // k_bluestein4096
         bs_wave = route.kind == FR::BS_WAVE;    // k_bluestein1024
+        bs_lds = route.kind == FR::BS_LDS;      // k_bluestein_lds
+        bs_fused8k = route.kind == FR::BS_FUSED8K;  // k_bluestein8192
         // chirp w_m = e^{+j pi m^2 / n}, the phase reduced exactly (m^2 mod 2n) before it is evaluated
         std::vector<cd> w(len);
         for (size_t m = 0; m < len; ++m) {
@@ -1100,6 +1110,11 @@ int rr_fourier::transform_dev(const void *head, size_t n_head, const void *in, v
     if (!bs_M) return launch_fourier_overlapped(dtype, stream, head, n_head, in, out, n, hop, count, d_window.p, d_tw.p, center_dc);
     if (bs_wave)
         return launch_bluestein1024(stream, head, n_head, in, hop, n, d_bs_c.p, d_bs_B.p, d_bs_w.p, bs_fft->d_tw.p, out, center_dc, count);
+    if (bs_fused8k)
+        return launch_bluestein8192(stream, head, n_head, in, hop, n, d_bs_c.p, d_bs_B.p, d_bs_w.p, bs_fft->d_tw.p, out, center_dc, count);
+    if (bs_lds)
+        return launch_bluestein_lds(dtype, stream, head, n_head, in, hop, n, bs_M, d_bs_c.p, d_bs_B.p, d_bs_w.p, bs_fft->d_tw.p, out,
+                                    center_dc, count);
     if (bs_fused)
         return launch_bluestein4096(stream, head, n_head, in, hop, n, d_bs_c.p, d_bs_B.p, d_bs_w.p, bs_fft->d_tw.p, out, center_dc, count);
     const size_t M = bs_M;
@@ -2511,6 +2526,8 @@ int rr_fourier_route(int dtype, size_t n, char *buf, size_t cap) {
         case FR::TILEM: std::snprintf(buf, cap, "mixed two passes %zu x %zu", r.N1, r.N2); break;
         case FR::BS_WAVE: std::snprintf(buf, cap, "bluestein wave M=%zu", r.M); break;
         case FR::BS_FUSED: std::snprintf(buf, cap, "bluestein one kernel M=%zu", r.M); break;
+        case FR::BS_FUSED8K:
+        case FR::BS_LDS: std::snprintf(buf, cap, "bluestein one kernel M=%zu", r.M); break;
         case FR::BS_LAUNCHES: std::snprintf(buf, cap, "bluestein five launches M=%zu", r.M); break;
     }
     return RR_OK;

@@ -941,6 +941,136 @@ __global__ __launch_bounds__(256) void k_fft8192(const float2 *__restrict__ head
     }
 }
 
+// The same transform as a function for kernels that run it twice (k_bluestein8192): in v[h][k] = x[t + 256 h + 512 k];
+// out v[0][m] = X[t + 256 m], v[1][m] = X[t + 256 (m + 16)], m < 16.  The caller synchronises before the image is reused.
+__device__ __forceinline__ void fft8192_regs(f2 (&v)[2][16], f2 *lds, const float2 *__restrict__ tw, int t) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = t + 256 * h;
+        dft16(v[h]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lds_st(lds + pad16(16 * j + k), v[h][k]);
+    }
+    __syncthreads();
+    {
+        const float2 s1 = tw[32 * (t & 15)];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = t + 256 * h;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[h][k] = lds_ld(lds + pad16(j + 512 * k));
+            apply_twiddle_powers(v[h], (f2){s1.x, s1.y});
+            dft16(v[h]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = t + 256 * h;
+        const int b = (j >> 4) * 256 + (j & 15);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lds_st(lds + pad16(b + 16 * k), v[h][k]);
+    }
+    __syncthreads();
+    {
+        const float2 s2 = tw[t];
+        const f2 w = {s2.x, s2.y};
+        const f2 w2 = cmulf(w, w);
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            v[0][a] = lds_ld(lds + pad16(t + 256 * (2 * a)));
+            v[1][a] = cmulf(lds[pad16(t + 256 * (2 * a + 1))], w);
+        }
+        apply_twiddle_powers(v[0], w2);
+        apply_twiddle_powers(v[1], w2);
+        dft16(v[0]);  // E[m]
+        dft16(v[1]);  // O[m]
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const float2 c = tw[256 * m];  // W_32^m (a scalar read)
+            const f2 o = cmulf(v[1][m], (f2){c.x, c.y});
+            const f2 e = v[0][m];
+            v[0][m] = e + o;
+            v[1][m] = e - o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Kernel 2y  k_bluestein8192: the Fourier block for 2049 .. 4096 points whose length has a prime factor beyond 13 (the others
+// run the mixed-radix passes): Bluestein's algorithm in ONE kernel around two 8192-point transforms in LDS, as
+// k_bluestein4096 does around two 4096-point ones.  The result layout of fft8192_regs - lane t holds X[t + 256 m], m < 32 - is
+// the input layout of the next transform (t + 256 h + 512 k = t + 256 (2 k + h)): between the two transforms the values stay in
+// the lane, only their register names change.  The five launches it replaces took 0.56-0.75 ms per 2^24 samples.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bluestein8192(const float2 *__restrict__ head, long n_head, const float2 *__restrict__ in,
+                                                       long hop, int n, const float2 *__restrict__ c, const float2 *__restrict__ B,
+                                                       const float2 *__restrict__ w, const float2 *__restrict__ tw,
+                                                       float2 *__restrict__ out, int center_dc, unsigned count) {
+    extern __shared__ __attribute__((aligned(16))) char bs8192_smem[];
+    f2 *lds = reinterpret_cast<f2 *>(bs8192_smem);  // 8192 + 512 elements
+    const int t = threadIdx.x;
+    const unsigned fr = blockIdx.x;
+    if (fr >= count) return;
+    const long base = (long)fr * hop - n_head;
+    f2 v[2][16];
+    // (every load at a clamped index and selected afterwards, as k_bluestein4096)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float2 xs[16], cs[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int m = t + 256 * h + 512 * k;
+            const int mc = m < n ? m : n - 1;
+            const long i = base + mc;
+            xs[k] = (i >= 0) ? in[i] : head[n_head + i];
+            cs[k] = c[mc];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const f2 p = cmul((f2){xs[k].x, xs[k].y}, (f2){cs[k].x, cs[k].y});
+            v[h][k] = (t + 256 * h + 512 * k < n) ? p : (f2){0.f, 0.f};
+        }
+    }
+    fft8192_regs(v, lds, tw, t);
+    // * B, and into the next transform's input names: u[h][k] = Z[t + 256 (2 k + h)], Z[t + 256 m] = v[m >> 4][m & 15]
+    f2 u[2][16];
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+        const float2 b = B[t + 256 * m];
+        u[m & 1][m >> 1] = cmul(v[m >> 4][m & 15], (f2){b.x, b.y});
+    }
+    __syncthreads();  // the first transform's last pass has been read
+    fft8192_regs(u, lds, tw, t);
+    // u[m >> 4][m & 15] = DFT(Z)[t + 256 m] = 8192 IDFT(Z)[tau], tau = (8192 - t - 256 m) mod 8192; bins tau < n leave, times conj(chirp[tau])
+    float2 *dst = out + (size_t)fr * n;
+    const int rot = center_dc ? n / 2 : 0;  // rotate_right(n / 2)
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+        const int tau = (8192 - t - 256 * m) & 8191;
+        const float2 wt = w[tau < n ? tau : 0];
+        const f2 r = cmul_conj(u[m >> 4][m & 15], (f2){wt.x, wt.y});
+        int o = tau + rot;
+        if (o >= n) o -= n;
+        if (tau < n) dst[o] = float2{r.x, r.y};
+    }
+}
+
+bool bluestein8192_supported(int dtype, size_t n) { return dtype == RR_F32 && n > 2048 && n <= 4096 && (n & (n - 1)) != 0; }
+
+int launch_bluestein8192(hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n, const void *c,
+                         const void *B, const void *w, const void *tw8192, void *out, bool center_dc, size_t count) {
+    if (count == 0) return RR_OK;
+    if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: too many chunks in one call");
+    const size_t lds = (8192 + 512) * sizeof(float2);
+    RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bluestein8192), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_bluestein8192, dim3((unsigned)count), dim3(256), lds, s, (const float2 *)head, (long)n_head,
+                       (const float2 *)in, (long)hop, (int)n, (const float2 *)c, (const float2 *)B, (const float2 *)w,
+                       (const float2 *)tw8192, (float2 *)out, (int)center_dc, (unsigned)count);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
 int launch_fft8192(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
                    const void *window, const void *tw8192, bool center_dc, size_t hop) {
     if (count == 0) return RR_OK;

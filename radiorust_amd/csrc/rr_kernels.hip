@@ -418,39 +418,10 @@ int launch_update_hist(int dtype, hipStream_t s, const void *old_hist, void *new
 // one workgroup per chunk.  center_dc is an index rotation on the store.
 // (Generic version; the radix-16 register kernel for n = 4096 is in rr_fused.hip.)
 // ---------------------------------------------------------------------------
+// Stockham autosort passes of a power-of-two transform between two LDS images (radix 4 while it fits, then radix 2); the
+// caller has filled `a` and synchronised; returns the image that holds the result (synchronised).
 template <class T>
-// Frames are cut from the stream [ head (n_head samples) | in ] every `hop` samples (hop = n: the
-// plain chunk-by-chunk Fourier; hop < n: the Overlapper's overlapping chunks, chunks.rs:194-242).
-__global__ __launch_bounds__(1024) void k_fft_pow2(const v2<T> *__restrict__ head, long n_head,
-                                                  const v2<T> *__restrict__ in, v2<T> *__restrict__ out, int n,
-                                                  long hop, const T *__restrict__ window,
-                                                  const v2<T> *__restrict__ tw, int center_dc) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    v2<T> *a = reinterpret_cast<v2<T> *>(smem);
-    v2<T> *b = a + n;
-    const size_t chunk = blockIdx.x;
-    const long base = (long)chunk * hop - n_head;
-    v2<T> *dst = out + chunk * (size_t)n;
-    // (four loads in flight per lane: as one loop there is a single load between a wait and the LDS store)
-    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * blockDim.x) {
-        v2<T> v[4];
-        T w[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * (int)blockDim.x;
-            if (i < n) {
-                const long pos = base + i;
-                v[u] = pos >= 0 ? in[pos] : head[n_head + pos];
-                w[u] = window[i];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * (int)blockDim.x;
-            if (i < n) a[i] = v2<T>{v[u].x * w[u], v[u].y * w[u]};
-        }
-    }
-    __syncthreads();
+__device__ __forceinline__ v2<T> *fft_pow2_passes(v2<T> *a, v2<T> *b, int n, const v2<T> *__restrict__ tw) {
     const int half = n >> 1;
     int ns = 1;
     // radix-4 passes while they fit (half the exchanges and barriers of radix 2; the table holds all n twiddles)
@@ -498,12 +469,134 @@ __global__ __launch_bounds__(1024) void k_fft_pow2(const v2<T> *__restrict__ hea
         a = b;
         b = t;
     }
+    return a;
+}
+
+template <class T>
+// Frames are cut from the stream [ head (n_head samples) | in ] every `hop` samples (hop = n: the
+// plain chunk-by-chunk Fourier; hop < n: the Overlapper's overlapping chunks, chunks.rs:194-242).
+__global__ __launch_bounds__(1024) void k_fft_pow2(const v2<T> *__restrict__ head, long n_head,
+                                                  const v2<T> *__restrict__ in, v2<T> *__restrict__ out, int n,
+                                                  long hop, const T *__restrict__ window,
+                                                  const v2<T> *__restrict__ tw, int center_dc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v2<T> *a = reinterpret_cast<v2<T> *>(smem);
+    v2<T> *b = a + n;
+    const size_t chunk = blockIdx.x;
+    const long base = (long)chunk * hop - n_head;
+    v2<T> *dst = out + chunk * (size_t)n;
+    // (four loads in flight per lane: as one loop there is a single load between a wait and the LDS store)
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * blockDim.x) {
+        v2<T> v[4];
+        T w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * (int)blockDim.x;
+            if (i < n) {
+                const long pos = base + i;
+                v[u] = pos >= 0 ? in[pos] : head[n_head + pos];
+                w[u] = window[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * (int)blockDim.x;
+            if (i < n) a[i] = v2<T>{v[u].x * w[u], v[u].y * w[u]};
+        }
+    }
+    __syncthreads();
+    a = fft_pow2_passes<T>(a, b, n, tw);
     const int rot = center_dc ? (n >> 1) : 0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         int o = i + rot;
         if (o >= n) o -= n;
         dst[o] = a[i];
     }
+}
+
+// Bluestein's algorithm in ONE kernel for the lengths whose padded power-of-two length M fits two LDS images (M <= 8192 in f32:
+// 2049 .. 4096 points; M <= 4096 in f64: up to 2048 points) and that have no kernel of their own (k_bluestein1024 / 4096 serve
+// f32 up to 2048 points, the mixed-radix kernels the lengths 2^a 3^b 5^c 7^d 11^e 13^f): a workgroup per chunk,
+//   v = x c (c = window conj(chirp), zero beyond n) -> DFT_M -> conj(. B) (B = DFT_M(chirp, wrapped) / M) -> DFT_M ->
+//   conj(. chirp) -> n bins,
+// the two transforms by the Stockham passes of k_fft_pow2.  The five launches it replaces (k_bs_pre, the transform, k_bs_mul,
+// the transform, k_bs_post) move ~10 M elements through HBM per chunk; here a chunk is read once and written once.
+template <class T>
+__global__ __launch_bounds__(1024) void k_bluestein_lds(const v2<T> *__restrict__ head, long n_head, const v2<T> *__restrict__ in,
+                                                       long hop, int n, int M, const v2<T> *__restrict__ c,
+                                                       const v2<T> *__restrict__ B, const v2<T> *__restrict__ w,
+                                                       const v2<T> *__restrict__ tw, v2<T> *__restrict__ out, int center_dc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v2<T> *a = reinterpret_cast<v2<T> *>(smem);
+    v2<T> *b = a + M;
+    const size_t chunk = blockIdx.x;
+    const long base = (long)chunk * hop - n_head;
+    for (int i0 = threadIdx.x; i0 < M; i0 += 4 * blockDim.x) {
+        v2<T> x[4], cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * (int)blockDim.x;
+            if (i < n) {
+                const long pos = base + i;
+                x[u] = pos >= 0 ? in[pos] : head[n_head + pos];
+                cc[u] = c[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * (int)blockDim.x;
+            if (i < M) a[i] = i < n ? cmul<T>(x[u], cc[u]) : v2<T>{(T)0, (T)0};
+        }
+    }
+    __syncthreads();
+    v2<T> *r = fft_pow2_passes<T>(a, b, M, tw);
+    for (int i = threadIdx.x; i < M; i += blockDim.x) {
+        const v2<T> v = cmul<T>(r[i], B[i]);
+        r[i] = v2<T>{v.x, -v.y};
+    }
+    __syncthreads();
+    r = fft_pow2_passes<T>(r, r == a ? b : a, M, tw);
+    v2<T> *dst = out + chunk * (size_t)n;
+    const int rot = center_dc ? n / 2 : 0;  // rotate_right(n / 2)
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const v2<T> v = cmul<T>(r[k], w[k]);
+        int o = k + rot;
+        if (o >= n) o -= n;
+        dst[o] = v2<T>{v.x, -v.y};
+    }
+}
+
+bool bluestein_lds_supported(int dtype, size_t n, size_t M) {
+    const size_t lim = dtype == RR_F32 ? 8192 : 4096;  // two images within 128 KiB (as k_fft_pow2)
+    return n >= 32 && M >= 64 && M <= lim && M >= 2 * n - 1;
+}
+
+// c, B, w: the tables of the five-launch form (B unpermuted, already divided by M); tw = e^{-j 2 pi k / M} (M entries)
+int launch_bluestein_lds(int dtype, hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n, size_t M,
+                         const void *c, const void *B, const void *w, const void *tw, void *out, bool center_dc, size_t count) {
+    if (count == 0) return RR_OK;
+    if (!bluestein_lds_supported(dtype, n, M)) RR_FAIL(RR_ERR_BAD_ARG, "Bluestein in LDS: %zu points, M = %zu", n, M);
+    if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: too many chunks in one call");
+    unsigned nt = (unsigned)(M / 4);
+    if (nt > 1024) nt = 1024;
+    if (nt < 64) nt = 64;
+    if (dtype == RR_F32) {
+        auto fn = k_bluestein_lds<float>;
+        const size_t lds = 2 * M * sizeof(float2);
+        RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));
+        hipLaunchKernelGGL(fn, dim3((unsigned)count), dim3(nt), lds, s, (const float2 *)head, (long)n_head, (const float2 *)in,
+                           (long)hop, (int)n, (int)M, (const float2 *)c, (const float2 *)B, (const float2 *)w, (const float2 *)tw,
+                           (float2 *)out, (int)center_dc);
+    } else {
+        auto fn = k_bluestein_lds<double>;
+        const size_t lds = 2 * M * sizeof(double2);
+        RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));
+        hipLaunchKernelGGL(fn, dim3((unsigned)count), dim3(nt), lds, s, (const double2 *)head, (long)n_head, (const double2 *)in,
+                           (long)hop, (int)n, (int)M, (const double2 *)c, (const double2 *)B, (const double2 *)w, (const double2 *)tw,
+                           (double2 *)out, (int)center_dc);
+    }
+    RR_HIP(hipGetLastError());
+    return RR_OK;
 }
 
 // Fourier, any other length: direct DFT  X[k] = sum_j (w[j] x[j]) tw[(j k) mod n].

@@ -188,6 +188,14 @@ int launch_fft1024(hipStream_t s, const void *head, size_t n_head, const void *i
 void append_wave1024_seeds(std::vector<float> &twb);
 // k_bluestein4096: chunk lengths 513 .. 2048 that are not powers of two, one kernel per call (tables of rr_fourier::prepare
 // for M = 4096: c[n] = window conj(chirp), B[4096] = DFT(chirp) / 4096, w[n] = chirp; tw4096 as for k_fft4096)
+// Bluestein in one kernel with both transforms as Stockham passes between two LDS images (M <= 8192 in f32, <= 4096 in f64)
+bool bluestein_lds_supported(int dtype, size_t n, size_t M);
+int launch_bluestein_lds(int dtype, hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n, size_t M,
+                         const void *c, const void *B, const void *w, const void *tw, void *out, bool center_dc, size_t count);
+// k_bluestein8192: 2049 .. 4096 points in f32, one kernel around two 8192-point register transforms
+bool bluestein8192_supported(int dtype, size_t n);
+int launch_bluestein8192(hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n, const void *c,
+                         const void *B, const void *w, const void *tw8192, void *out, bool center_dc, size_t count);
 bool bluestein4096_supported(int dtype, size_t n);
 int launch_bluestein4096(hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n, const void *c,
                          const void *B, const void *w, const void *tw4096, void *out, bool center_dc, size_t count);

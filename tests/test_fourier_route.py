@@ -69,10 +69,10 @@ def test_every_route_is_consistent(route, dtype, monkeypatch):
             assert is_pow2(M) and M >= 2 * n - 1 and n >= 32, (n, r)
             if "wave" in r:
                 assert dtype == np.float32 and M == 1024 and n <= 512
-            elif "one kernel" in r:
-                assert dtype == np.float32 and M == 4096 and 512 < n <= 2048
+            elif "one kernel" in r:  # k_bluestein4096 (f32, 513 .. 2048 points) or k_bluestein_lds (two LDS images of M elements)
+                assert M <= one_image and (M < 4 * n or (dtype == np.float32 and M == 4096 and 512 < n <= 2048)), (n, r)
             else:
-                assert M < 4 * n, (n, r)  # the smallest power of two that holds the circular convolution
+                assert M < 4 * n and M > one_image, (n, r)  # the smallest power of two that holds the circular convolution
         else:
             assert r == "direct" and n < 32, (n, r)
         # a length the mixed-radix kernels can serve beyond 2048 points never falls back to the five launches
@@ -83,7 +83,7 @@ def test_every_route_is_consistent(route, dtype, monkeypatch):
 
 def test_switches(route, monkeypatch):
     monkeypatch.setenv("RR_FOURIER_MIXED", "0")
-    assert route(3000).startswith("bluestein five launches M=8192")
+    assert route(3000) == "bluestein one kernel M=8192" and route(5000).startswith("bluestein five launches M=16384")
     assert route(20000).startswith("bluestein five launches M=65536")
     monkeypatch.setenv("RR_FOURIER_MIXED", "2")
     assert route(2000) == "mixed 5 5 5 4 4" and route(1001) == "mixed 13 11 7"

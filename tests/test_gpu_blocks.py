@@ -563,6 +563,7 @@ def test_fourier_reference_kat_on_gpu(rr):
                                       (1 << 21, False),                                                  # (beyond the tile kernel: transposes around the row kernels)
                                       (20000, False), (20000, True), (5000, False), (31, True),          # Bluestein beyond 4096 points; direct below 32
                                       (513, False), (1025, True), (1999, True), (2047, False),           # 513 .. 2048: Bluestein in one kernel (k_bluestein4096)
+                                      (2049, False), (3001, True), (4093, False), (4001, True),          # 2049 .. 4096 with a prime factor beyond 13: k_bluestein8192
                                       (33, False), (100, True), (255, False), (300, True), (511, True)])  # 32 .. 512: a wave per chunk (k_bluestein1024)
 def test_fourier_parity(rr, oracle, n, center):
     x = oracle.synth_iq(12, 0, n)
@@ -575,7 +576,8 @@ def test_fourier_parity(rr, oracle, n, center):
 
 
 @pytest.mark.parametrize("n,center", [(1000, True), (20000, False), (8192, False), (32768, True), (65536, False), (33, False),
-                                      (1 << 14, True), (1 << 17, False), (1 << 20, True)])
+                                      (1 << 14, True), (1 << 17, False), (1 << 20, True),
+                                      (1999, True), (2039, False), (67, True), (2048 - 1, False), (2053, True)])  # k_bluestein_lds up to 2048 points; five launches beyond
 def test_fourier_f64_lengths(rr, oracle, n, center):
     """Complex<f64>: powers of two beyond the LDS kernel (4096) by the four-step transform, every other length >= 32 by
     Bluestein over f64 power-of-two transforms (the twiddles of the four-step split are evaluated in f64 with the
