@@ -145,7 +145,7 @@ int rr_fourier_design_window(size_t n, const double *window_rel, double *values)
 /* Which kernels transform a chunk of n samples (host only, no device needed; the same decision rr_fourier_process takes):
  * writes a short description into buf - "pow2", "pow2 two passes 128 x 256", "pow2 five launches 1024 x 1024",
  * "mixed 5 5 5 4 2" (the radices of the passes), "mixed two passes 125 x 160", "bluestein wave M=1024",
- * "bluestein one kernel M=4096" (M up to 8192 in f32, 4096 in f64), "bluestein five launches M=65536", "direct".  analysis.rs:82-115 accepts any length. */
+ * "bluestein one kernel M=4096" (M up to 8192 in f32, 4096 in f64), "bluestein four launches M=65536" (five / many for other M), "direct".  analysis.rs:82-115 accepts any length. */
 int rr_fourier_route(int dtype, size_t n, char *buf, size_t cap);
 
 /* ------------------------------------------------------------------------ */

@@ -1118,6 +1118,42 @@ int rr_fourier::transform_dev(const void *head, size_t n_head, const void *in, v
     if (bs_fused)
         return launch_bluestein4096(stream, head, n_head, in, hop, n, d_bs_c.p, d_bs_B.p, d_bs_w.p, bs_fft->d_tw.p, out, center_dc, count);
     const size_t M = bs_M;
+    // M = 2^13 / 2^14 .. 2^18 (the two-pass form of the nested transform): FOUR launches - the element-wise stages ride on the
+    // loads and stores of k_fft_tile's passes (x c at the first load, conj(. B) at the second store, conj(. chirp) and the cut to
+    // n bins at the last store): 8 passes over the padded length instead of 14.  RR_FOURIER_BS_FUSED=0 keeps the seven launches.
+    if (bs_fft->big && bs_fft->big_tile && ![] { const char *e = std::getenv("RR_FOURIER_BS_FUSED"); return e && std::atoi(e) == 0; }()) {
+        size_t N1, N2;
+        fft_big_split(M, &N1, &N2);
+        size_t per_pass = ((size_t)1 << 23) / M;
+        if (per_pass < 1) per_pass = 1;
+        if (per_pass > 65535) per_pass = 65535;
+        if (per_pass > count) per_pass = count;
+        RR_TRY(bs_ws[0].reserve(per_pass * M * esz));
+        RR_TRY(bs_ws[1].reserve(per_pass * M * esz));
+        const char *tB = bs_fft->d_tw.as<char>(), *tA = tB + ((size_t)1 << bs_fft->big_h) * esz;
+        const char *tw1 = tB + bs_fft->big_tw1_off * esz, *tw2 = tB + bs_fft->big_tw2_off * esz;
+        const int hh = bs_fft->big_h;
+        for (size_t f0 = 0; f0 < count; f0 += per_pass) {
+            const size_t F = count - f0 < per_pass ? count - f0 : per_pass;
+            const size_t skip = f0 * hop;
+            const char *hd = static_cast<const char *>(head), *src = static_cast<const char *>(in);
+            size_t nh = n_head;
+            if (skip >= n_head) {
+                src += (skip - n_head) * esz;
+                nh = 0;
+            } else {
+                hd += skip * esz;
+                nh = n_head - skip;
+            }
+            RR_TRY(launch_fft_tile_bs(dtype, stream, 0, hd, nh, src, hop, bs_ws[0].p, N1, N2, F, n, d_bs_c.p, tw1, tB, tA, hh, 0));
+            RR_TRY(launch_fft_tile_bs(dtype, stream, 1, nullptr, 0, bs_ws[0].p, 0, bs_ws[1].p, N1, N2, F, n, d_bs_B.p, tw2, nullptr,
+                                      nullptr, 0, 0));
+            RR_TRY(launch_fft_tile_bs(dtype, stream, 2, nullptr, 0, bs_ws[1].p, 0, bs_ws[0].p, N1, N2, F, n, nullptr, tw1, tB, tA, hh, 0));
+            RR_TRY(launch_fft_tile_bs(dtype, stream, 3, nullptr, 0, bs_ws[0].p, 0, static_cast<char *>(out) + f0 * n * esz, N1, N2, F, n,
+                                      d_bs_w.p, tw2, nullptr, nullptr, 0, center_dc ? n / 2 : 0));
+        }
+        return RR_OK;
+    }
     // passes of at most 2^22 workspace elements per buffer (32 MiB each in f32)
     size_t per_pass = ((size_t)1 << 22) / M;
     if (per_pass < 1) per_pass = 1;
@@ -2528,7 +2564,15 @@ int rr_fourier_route(int dtype, size_t n, char *buf, size_t cap) {
         case FR::BS_FUSED: std::snprintf(buf, cap, "bluestein one kernel M=%zu", r.M); break;
         case FR::BS_FUSED8K:
         case FR::BS_LDS: std::snprintf(buf, cap, "bluestein one kernel M=%zu", r.M); break;
-        case FR::BS_LAUNCHES: std::snprintf(buf, cap, "bluestein five launches M=%zu", r.M); break;
+        case FR::BS_LAUNCHES: {
+            // around the nested power-of-two transform: one launch each (M <= 8192 / 4096: five in all), its two passes with the
+            // element-wise stages folded in (four), or its five launches (seventeen)
+            const FourierRoute nested = fourier_route(dtype, r.M, false);
+            const bool fused4 = nested.kind == FR::BIG_TILE &&
+                                ![] { const char *e = std::getenv("RR_FOURIER_BS_FUSED"); return e && std::atoi(e) == 0; }();
+            std::snprintf(buf, cap, "bluestein %s launches M=%zu", fused4 ? "four" : nested.kind == FR::POW2 ? "five" : "many", r.M);
+            break;
+        }
     }
     return RR_OK;
 }

@@ -979,10 +979,26 @@ int launch_transpose_mul(int dtype, hipStream_t s, const void *in, void *out, si
 // in digit-reversed order, which the store undoes in its address.  Twiddles W_Np^k from an LDS copy of the sub-transform's
 // table.  The tile is Np x 128 bytes; used for Np <= 512 (N <= 2^18), beyond that the five-launch form takes over.
 // ---------------------------------------------------------------------------
-template <class T, int MODE>
+// Bluestein's element-wise stages folded into the passes (BS = 1; everything null / 0 otherwise):
+//   pass A load   x c with c = window conj(chirp), zero beyond nvalid, frames from [ head | in ] at a hop  (pre != null)
+//   pass A load   plain                                                                                    (window == null)
+//   pass B store  conj(X[k] post[k]) in natural order                                                      (post != null, nout == 0)
+//   pass B store  the bins k < nout only, conj(X[k] post[k]) at (k + rot) mod nout of the chunk's nout bins  (post != null, nout > 0)
+template <class T>
+struct TileBs {
+    const v2<T> *head;
+    long n_head, hop;
+    const v2<T> *pre;
+    int nvalid;
+    const v2<T> *post;
+    int nout;
+};
+
+template <class T, int MODE, int BS = 0>
 __global__ __launch_bounds__(1024) void k_fft_tile(const v2<T> *__restrict__ in, v2<T> *__restrict__ out, int Np, int lgNp, int No,
                                                    const T *__restrict__ window, const v2<T> *__restrict__ twNp,
-                                                   const v2<T> *__restrict__ tB, const v2<T> *__restrict__ tA, int h, int rot) {
+                                                   const v2<T> *__restrict__ tB, const v2<T> *__restrict__ tA, int h, int rot,
+                                                   TileBs<T> bs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
     constexpr int C = 128 / (int)sizeof(v2<T>);
     v2<T> *const tile = reinterpret_cast<v2<T> *>(tile_raw);
@@ -1003,8 +1019,17 @@ __global__ __launch_bounds__(1024) void k_fft_tile(const v2<T> *__restrict__ in,
                 const int idx = idx0 + u * nt;
                 if (idx < Np * C) {
                     const size_t e = (size_t)(idx / C) * No + g0 + idx % C;
-                    v[u] = in[chunk + e];
-                    w[u] = window[e];
+                    if (BS && bs.pre) {
+                        v[u] = v2<T>{(T)0, (T)0};
+                        if (e < (size_t)bs.nvalid) {
+                            const long g = (long)blockIdx.y * bs.hop - bs.n_head + (long)e;
+                            v[u] = cmul<T>(g >= 0 ? in[g] : bs.head[bs.n_head + g], bs.pre[e]);
+                        }
+                        w[u] = (T)1;
+                    } else {
+                        v[u] = in[chunk + e];
+                        w[u] = (BS && !window) ? (T)1 : window[e];
+                    }
                 }
             }
 #pragma unroll
@@ -1097,6 +1122,17 @@ __global__ __launch_bounds__(1024) void k_fft_tile(const v2<T> *__restrict__ in,
             const unsigned e = (unsigned)k * (unsigned)(g0 + c);  // < N1 N2 <= 2^20
             v = cmul<T>(v, cmul<T>(tA[e >> h], tB[e & ((1u << h) - 1u)]));
             out[chunk + (size_t)k * No + g0 + c] = v;
+        } else if (BS && bs.post) {
+            const size_t ko = (size_t)k * No + g0 + c;  // X[k1 + N1 k2]
+            if (bs.nout == 0) {
+                const v2<T> y = cmul<T>(v, bs.post[ko]);
+                out[chunk + ko] = v2<T>{y.x, -y.y};
+            } else if (ko < (size_t)bs.nout) {
+                const v2<T> y = cmul<T>(v, bs.post[ko]);
+                size_t o = ko + (size_t)rot;  // rotate_right(n / 2)
+                if (o >= (size_t)bs.nout) o -= (size_t)bs.nout;
+                out[(size_t)blockIdx.y * (size_t)bs.nout + o] = v2<T>{y.x, -y.y};
+            }
         } else {
             int kk = k + rot;
             if (kk >= Np) kk -= Np;
@@ -1131,16 +1167,71 @@ static int launch_fft_tile_t(hipStream_t s, int pass, const void *in, void *out,
         auto fn = k_fft_tile<T, 0>;
         RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));
         hipLaunchKernelGGL(fn, grid, dim3((unsigned)nt), lds, s, (const v2<T> *)in, (v2<T> *)out, (int)Np, lg, (int)No,
-                           (const T *)window, (const v2<T> *)twNp, (const v2<T> *)tB, (const v2<T> *)tA, h, 0);
+                           (const T *)window, (const v2<T> *)twNp, (const v2<T> *)tB, (const v2<T> *)tA, h, 0, TileBs<T>{});
     } else {
         auto fn = k_fft_tile<T, 1>;
         RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));
         hipLaunchKernelGGL(fn, grid, dim3((unsigned)nt), lds, s, (const v2<T> *)in, (v2<T> *)out, (int)Np, lg, (int)No,
-                           (const T *)nullptr, (const v2<T> *)twNp, (const v2<T> *)nullptr, (const v2<T> *)nullptr, 0, (int)rot);
+                           (const T *)nullptr, (const v2<T> *)twNp, (const v2<T> *)nullptr, (const v2<T> *)nullptr, 0, (int)rot,
+                           TileBs<T>{});
     }
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
+// The passes with Bluestein's element-wise stages folded in (TileBs): stage 0 = pass A with x c at the load, 1 = pass B with
+// conj(. B) at the store, 2 = pass A plain, 3 = pass B with conj(. chirp), the first n bins only, rotated by rot ELEMENTS.
+template <class T>
+static int launch_fft_tile_bs_t(hipStream_t s, int stage, const void *head, size_t n_head, const void *in, size_t hop, void *out,
+                                size_t N1, size_t N2, size_t count, size_t n, const void *table, const void *twNp, const void *tB,
+                                const void *tA, int h, size_t rot) {
+    constexpr size_t C = 128 / sizeof(v2<T>);
+    const bool passA = stage == 0 || stage == 2;
+    const size_t Np = passA ? N1 : N2, No = passA ? N2 : N1;
+    int lg = 0;
+    while (((size_t)1 << lg) < Np) ++lg;
+    const size_t lds = (passA ? Np * C : C * (Np + 1)) * sizeof(v2<T>) + Np * sizeof(v2<T>);
+    size_t nt = Np * C / 4;
+    if (nt > 1024) nt = 1024;
+    if (nt < 256) nt = 256;
+    const dim3 grid((unsigned)(No / C), (unsigned)count);
+    TileBs<T> bs{};
+    if (stage == 0) {
+        bs.head = (const v2<T> *)head;
+        bs.n_head = (long)n_head;
+        bs.hop = (long)hop;
+        bs.pre = (const v2<T> *)table;
+        bs.nvalid = (int)n;
+    } else if (stage == 1) {
+        bs.post = (const v2<T> *)table;
+    } else if (stage == 3) {
+        bs.post = (const v2<T> *)table;
+        bs.nout = (int)n;
+    }
+    if (passA) {
+        auto fn = k_fft_tile<T, 0, 1>;
+        RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));
+        hipLaunchKernelGGL(fn, grid, dim3((unsigned)nt), lds, s, (const v2<T> *)in, (v2<T> *)out, (int)Np, lg, (int)No,
+                           (const T *)nullptr, (const v2<T> *)twNp, (const v2<T> *)tB, (const v2<T> *)tA, h, 0, bs);
+    } else {
+        auto fn = k_fft_tile<T, 1, 1>;
+        RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds));
+        hipLaunchKernelGGL(fn, grid, dim3((unsigned)nt), lds, s, (const v2<T> *)in, (v2<T> *)out, (int)Np, lg, (int)No,
+                           (const T *)nullptr, (const v2<T> *)twNp, (const v2<T> *)nullptr, (const v2<T> *)nullptr, 0, (int)rot, bs);
+    }
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+int launch_fft_tile_bs(int dtype, hipStream_t s, int stage, const void *head, size_t n_head, const void *in, size_t hop, void *out,
+                       size_t N1, size_t N2, size_t count, size_t n, const void *table, const void *twNp, const void *tB,
+                       const void *tA, int h, size_t rot) {
+    if (count == 0) return RR_OK;
+    if (!fft_tile_supported(dtype, N1, N2) || count > 65535 || n > N1 * N2)
+        RR_FAIL(RR_ERR_BAD_ARG, "tile transform: %zu x %zu x %zu is outside the kernel's range", N1, N2, count);
+    if (dtype == RR_F32)
+        return launch_fft_tile_bs_t<float>(s, stage, head, n_head, in, hop, out, N1, N2, count, n, table, twNp, tB, tA, h, rot);
+    return launch_fft_tile_bs_t<double>(s, stage, head, n_head, in, hop, out, N1, N2, count, n, table, twNp, tB, tA, h, rot);
+}
+
 int launch_fft_tile(int dtype, hipStream_t s, int pass, const void *in, void *out, size_t N1, size_t N2, size_t count,
                     const void *window, const void *twNp, const void *tB, const void *tA, int h, size_t rot) {
     if (count == 0) return RR_OK;

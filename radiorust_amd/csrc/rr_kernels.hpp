@@ -166,6 +166,12 @@ int launch_fft_tilem(int dtype, hipStream_t s, int pass, const void *head, size_
 bool fft_tile_supported(int dtype, size_t N1, size_t N2);
 int launch_fft_tile(int dtype, hipStream_t s, int pass, const void *in, void *out, size_t N1, size_t N2, size_t count,
                     const void *window, const void *twNp, const void *tB, const void *tA, int h, size_t rot);
+// the same passes with Bluestein's element-wise stages folded in: stage 0 = pass A with x * table (c; zero beyond n; frames from
+// [head | in] at a hop), 1 = pass B storing conj(X * table) (B), 2 = pass A plain, 3 = pass B storing the first n bins of
+// conj(X * table) (the chirp), rotated right by rot elements
+int launch_fft_tile_bs(int dtype, hipStream_t s, int stage, const void *head, size_t n_head, const void *in, size_t hop, void *out,
+                       size_t N1, size_t N2, size_t count, size_t n, const void *table, const void *twNp, const void *tB,
+                       const void *tA, int h, size_t rot);
 bool fft_big_supported(size_t n);
 void fft_big_split(size_t n, size_t *N1, size_t *N2);
 int launch_fft_big(int dtype, hipStream_t s, const void *in, void *out, void *ws, size_t n, size_t count, const void *window,

@@ -68,7 +68,7 @@ g = rr.Downsampler.new(4096, 50e6, 40e6, dtype=np.float64); g.set_stream(st)
 dt = timed(lambda: g.process_dev(200e6, d64.data_ptr(), N2, o64.data_ptr(), N2)); line("f64 Downsampler 4 : 1", N2, dt, 20)
 g = rr.Fourier.with_window(rr.Kaiser.with_null_at_bin(2.0), dtype=np.float64); g.set_stream(st)
 dt = timed(lambda: g.process_dev(4096, d64.data_ptr(), N2, o64.data_ptr(), N2)); line("f64 Fourier 4096", N2, dt, 32)
-for nf in (1000, 1999, 20000):
+for nf in (1000, 1999, 20011):
     g = rr.Fourier.with_window(rr.Kaiser.with_null_at_bin(2.0), dtype=np.float64); g.set_stream(st)
     n = N2 // nf * nf
     dt = timed(lambda: g.process_dev(nf, d64.data_ptr(), n, o64.data_ptr(), n)); line(f"f64 Fourier {nf} ({rr.fourier_route(nf, np.float64)})", n, dt, 32)

@@ -83,14 +83,14 @@ def test_every_route_is_consistent(route, dtype, monkeypatch):
 
 def test_switches(route, monkeypatch):
     monkeypatch.setenv("RR_FOURIER_MIXED", "0")
-    assert route(3000) == "bluestein one kernel M=8192" and route(5000).startswith("bluestein five launches M=16384")
-    assert route(20000).startswith("bluestein five launches M=65536")
+    assert route(3000) == "bluestein one kernel M=8192" and route(5000) == "bluestein four launches M=16384"
+    assert route(20000) == "bluestein four launches M=65536" and route(200003) == "bluestein many launches M=524288"
     monkeypatch.setenv("RR_FOURIER_MIXED", "2")
     assert route(2000) == "mixed 5 5 5 4 4" and route(1001) == "mixed 13 11 7"
     monkeypatch.delenv("RR_FOURIER_MIXED")
     assert route(2000) == "bluestein one kernel M=4096" and route(1000) == "mixed 5 5 5 4 2"
     assert route(20000) == "mixed two passes 125 x 160" and route(250000) == "mixed two passes 500 x 500"
-    assert route(91091).startswith("bluestein five launches")  # 7^2 11 13^2: no split into two factors <= 512
+    assert route(91091) == "bluestein four launches M=262144"  # 7^2 11 13^2: no split into two factors <= 512
     assert route(1 << 16) == "pow2 two passes 256 x 256" and route(1 << 20) == "pow2 five launches 1024 x 1024"
     monkeypatch.setenv("RR_FOURIER_BIG", "transpose")
     assert route(1 << 16) == "pow2 five launches 256 x 256"
