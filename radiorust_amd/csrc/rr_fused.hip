@@ -426,7 +426,11 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
                                                  int center_dc, long hop, unsigned count, int branches) {
     __shared__ f2 lds[4096 + 256];
     const int j = threadIdx.x;
-    const unsigned fr = blockIdx.x;  // (frames in reverse order - the most recently written first - measured no different in the chain)
+    // (frames in reverse order - the most recently written first - measured no different in the chain)
+    // FOLD: a frame shares branches - 1 of its chunks with each neighbour: neighbouring frames go to one XCD (workgroups b, b + 8, ..
+    // share one), 8 at a time, so that a chunk is fetched into one L2 instead of into `branches` of them
+    const unsigned fr = FOLD ? blockIdx.x / 64 * 64 + (blockIdx.x % 64 & 7) * 8 + (blockIdx.x % 64 >> 3) : blockIdx.x;
+    if (FOLD && fr >= count) return;
     const long base = (long)fr * hop - n_head;  // index into `in` of this frame's first sample
     float2 *dst = out + (size_t)fr * 4096;
     f2 v[16];
@@ -564,8 +568,8 @@ int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *i
 int launch_chan4096(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
                     const void *window, const void *tw4096, size_t hop, size_t branches) {
     if (count == 0) return RR_OK;
-    if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: too many frames");
-    hipLaunchKernelGGL(k_fft4096<true>, dim3((unsigned)count), dim3(256), 0, s, (const float2 *)head, (long)n_head,
+    if (count > 0x7fffff00ull) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: too many frames");
+    hipLaunchKernelGGL(k_fft4096<true>, dim3((unsigned)((count + 63) / 64 * 64)), dim3(256), 0, s, (const float2 *)head, (long)n_head,
                        (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw4096, 0, (long)hop,
                        (unsigned)count, (int)branches);
     RR_HIP(hipGetLastError());
@@ -751,10 +755,13 @@ template <bool FOLD>
 __global__ __launch_bounds__(128) void k_fft2048(const float2 *__restrict__ head, long n_head,
                                                  const float2 *__restrict__ in, float2 *__restrict__ out,
                                                  const float *__restrict__ window, const float2 *__restrict__ tw,
-                                                 int center_dc, long hop, int branches) {
+                                                 int center_dc, long hop, int branches, unsigned count) {
     __shared__ f2 lds[2048 + 128];
     const int t = threadIdx.x;
-    const long base = (long)blockIdx.x * hop - n_head;
+    // FOLD: neighbouring frames (which share branches - 1 chunks) go to one XCD, 16 at a time (as k_fft4096<true>)
+    const unsigned fr = FOLD ? blockIdx.x / 128 * 128 + (blockIdx.x % 128 & 7) * 16 + (blockIdx.x % 128 >> 3) : blockIdx.x;
+    if (fr >= count) return;
+    const long base = (long)fr * hop - n_head;
     f2 v[16];
     if constexpr (FOLD) {
 #pragma unroll
@@ -815,7 +822,7 @@ __global__ __launch_bounds__(128) void k_fft2048(const float2 *__restrict__ head
     }
     __syncthreads();
     // pass 2 (Ns = 256, radix 8): butterflies j = t and t + 128 over z[j + 256 k]; out X[j + 256 k]
-    f2 *dst = reinterpret_cast<f2 *>(out) + (size_t)blockIdx.x * 2048;
+    f2 *dst = reinterpret_cast<f2 *>(out) + (size_t)fr * 2048;
     const int rot = center_dc ? 1024 : 0;
 #pragma unroll
     for (int sidx = 0; sidx < 2; ++sidx) {
@@ -845,7 +852,7 @@ int launch_fft2048(hipStream_t s, const void *head, size_t n_head, const void *i
     if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fft2048: too many frames");
     hipLaunchKernelGGL(k_fft2048<false>, dim3((unsigned)count), dim3(128), 0, s, (const float2 *)head, (long)n_head,
                        (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw2048, (int)center_dc,
-                       (long)hop, 1);
+                       (long)hop, 1, (unsigned)count);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
@@ -853,10 +860,10 @@ int launch_fft2048(hipStream_t s, const void *head, size_t n_head, const void *i
 int launch_chan2048(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
                     const void *window, const void *tw2048, size_t hop, size_t branches) {
     if (count == 0) return RR_OK;
-    if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: too many frames");
-    hipLaunchKernelGGL(k_fft2048<true>, dim3((unsigned)count), dim3(128), 0, s, (const float2 *)head, (long)n_head,
-                       (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw2048, 0, (long)hop,
-                       (int)branches);
+    if (count > 0x7fffff00ull) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: too many frames");
+    hipLaunchKernelGGL(k_fft2048<true>, dim3((unsigned)((count + 127) / 128 * 128)), dim3(128), 0, s, (const float2 *)head,
+                       (long)n_head, (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw2048, 0, (long)hop,
+                       (int)branches, (unsigned)count);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
