@@ -2882,6 +2882,83 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     for (int k = 0; k < 16; ++k) __builtin_nontemporal_store(X[k], dst + ((l + 64 * k + rot) & 1023));
 }
 
+// The 1024-bin channelizer at hop = 1024 with TWO neighbouring frames per wave: frames 2 q and 2 q + 1 share branches - 1 of
+// their chunks, so the wave reads branches + 1 chunks for two frames instead of 2 branches (8 taps per branch: 9 instead of 16) -
+// k_fft1024<true> is bound by those reads (every frame re-reads its chunks from L2).  Chunk p goes into frame A with the window's
+// segment p and into frame B with segment p - 1.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_chan1024_pair(
+    const float2 *__restrict__ head, long n_head, const float2 *__restrict__ in, float2 *__restrict__ out,
+    const float *__restrict__ window, const float2 *__restrict__ tw, unsigned count, int branches) {
+    __shared__ __attribute__((aligned(16))) f2 lds[kWaveLds];
+    const int l = threadIdx.x;
+    // pairs dealt to the XCDs in a moving window, 16 neighbouring pairs per XCD
+    const unsigned q = blockIdx.x / 128 * 128 + (blockIdx.x % 128 & 7) * 16 + (blockIdx.x % 128 >> 3);
+    const unsigned fa = 2 * q;
+    if (fa >= count) return;
+    const bool has_b = fa + 1 < count;
+    const long base = (long)fa * 1024 - n_head;
+    f2 va[16], vb[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) va[k] = vb[k] = (f2){0.f, 0.f};
+    const int chunks = branches + (has_b ? 1 : 0);
+    for (int p = 0; p < chunks; ++p) {
+        const long bp = base + 1024L * p;
+        f2 x[16];
+        if (bp >= 0) {
+            const f4u *src = reinterpret_cast<const f4u *>(in + bp) + l;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const f4u t = *(src + 64 * k);
+                x[2 * k] = (f2){t.x, t.y};
+                x[2 * k + 1] = (f2){t.z, t.w};
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const long i = bp + 2 * l + j + 128 * k;
+                    const float2 t = (i >= 0) ? in[i] : head[n_head + i];
+                    x[2 * k + j] = (f2){t.x, t.y};
+                }
+        }
+        if (p < branches) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float2 w = *reinterpret_cast<const float2 *>(window + 1024 * p + 2 * l + 128 * k);
+                va[2 * k] = __builtin_elementwise_fma(x[2 * k], (f2){w.x, w.x}, va[2 * k]);
+                va[2 * k + 1] = __builtin_elementwise_fma(x[2 * k + 1], (f2){w.y, w.y}, va[2 * k + 1]);
+            }
+        }
+        if (p >= 1) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float2 w = *reinterpret_cast<const float2 *>(window + 1024 * (p - 1) + 2 * l + 128 * k);
+                vb[2 * k] = __builtin_elementwise_fma(x[2 * k], (f2){w.x, w.x}, vb[2 * k]);
+                vb[2 * k + 1] = __builtin_elementwise_fma(x[2 * k + 1], (f2){w.y, w.y}, vb[2 * k + 1]);
+            }
+        }
+    }
+    f2 t_p1, t_p2[2];
+    {
+        const float4 *tl = reinterpret_cast<const float4 *>(tw + 1024) + l;
+        const float4 s0 = tl[0], s1 = tl[64];
+        t_p1 = (f2){s0.x, s0.y};
+        t_p2[0] = (f2){s0.z, s0.w};
+        t_p2[1] = (f2){s1.x, s1.y};
+    }
+    f2 X[16];
+    wave_dft1024(va, X, lds, l, t_p1, t_p2, [] {});
+    f2 *dst = reinterpret_cast<f2 *>(out) + (size_t)fa * 1024;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) __builtin_nontemporal_store(X[k], dst + (l + 64 * k));
+    if (!has_b) return;
+    wave_sync();  // the first transform's last reads are done
+    wave_dft1024(vb, X, lds, l, t_p1, t_p2, [] {});
+#pragma unroll
+    for (int k = 0; k < 16; ++k) __builtin_nontemporal_store(X[k], dst + 1024 + (l + 64 * k));
+}
+
 int launch_fft1024(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
                    const void *window, const void *tw1024, bool center_dc, size_t hop) {
     if (count == 0) return RR_OK;
@@ -2900,6 +2977,16 @@ int launch_chan1024(hipStream_t s, const void *head, size_t n_head, const void *
                     const void *window, const void *tw1024, size_t hop, size_t branches) {
     if (count == 0) return RR_OK;
     if (count > 0x7fffff00ull) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: too many frames");
+    // critically sampled with at least two taps per branch: two frames per wave (RR_CHAN_PAIR=0 keeps one)
+    static const bool pair = [] { const char *e = std::getenv("RR_CHAN_PAIR"); return !(e && std::atoi(e) == 0); }();
+    if (pair && hop == 1024 && branches >= 2) {
+        const size_t pairs = (count + 1) / 2;
+        const unsigned g2 = (unsigned)((pairs + 127) / 128 * 128);
+        hipLaunchKernelGGL(k_chan1024_pair, dim3(g2), dim3(64), 0, s, (const float2 *)head, (long)n_head, (const float2 *)in,
+                           (float2 *)out, (const float *)window, (const float2 *)tw1024, (unsigned)count, (int)branches);
+        RR_HIP(hipGetLastError());
+        return RR_OK;
+    }
     const unsigned grid = (unsigned)((count + 127) / 128 * 128);
     hipLaunchKernelGGL(k_fft1024<true>, dim3(grid), dim3(64), 0, s, (const float2 *)head, (long)n_head, (const float2 *)in,
                        (float2 *)out, (const float *)window, (const float2 *)tw1024, 0, (long)hop, (unsigned)count,
