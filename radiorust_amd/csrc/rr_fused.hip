@@ -565,9 +565,25 @@ int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *i
 }
 
 // the 4096-bin polyphase channelizer (see k_fft4096<true>)
+__global__ __launch_bounds__(256) void k_chan4096_pair(const float2 *__restrict__ head, long n_head, const float2 *__restrict__ in,
+                                                       float2 *__restrict__ out, const float *__restrict__ window,
+                                                       const float2 *__restrict__ tw, unsigned count, int branches);
+bool chan_pair_enabled() {  // two frames per wave / workgroup where neighbouring frames share chunks (RR_CHAN_PAIR=0: one)
+    static const bool pair = [] { const char *e = std::getenv("RR_CHAN_PAIR"); return !(e && std::atoi(e) == 0); }();
+    return pair;
+}
+
 int launch_chan4096(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
                     const void *window, const void *tw4096, size_t hop, size_t branches) {
     if (count == 0) return RR_OK;
+    if (chan_pair_enabled() && hop == 4096 && branches >= 2 && count <= 0x7fffff00ull) {
+        const size_t pairs = (count + 1) / 2;
+        hipLaunchKernelGGL(k_chan4096_pair, dim3((unsigned)((pairs + 63) / 64 * 64)), dim3(256), 0, s, (const float2 *)head,
+                           (long)n_head, (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw4096,
+                           (unsigned)count, (int)branches);
+        RR_HIP(hipGetLastError());
+        return RR_OK;
+    }
     if (count > 0x7fffff00ull) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: too many frames");
     hipLaunchKernelGGL(k_fft4096<true>, dim3((unsigned)((count + 63) / 64 * 64)), dim3(256), 0, s, (const float2 *)head, (long)n_head,
                        (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw4096, 0, (long)hop,
@@ -1123,6 +1139,58 @@ __device__ __forceinline__ void fft4096_regs(f2 (&v)[16], f2 *lds, const float2 
         apply_twiddle_powers(v, (f2){t.x, t.y});
     }
     dft16(v);
+}
+
+// The 4096-bin channelizer at hop = 4096 with TWO neighbouring frames per workgroup (as k_chan1024_pair): branches + 1 chunk reads
+// for two frames instead of 2 branches; chunk p goes into frame A with the window's segment p and into frame B with segment p - 1.
+__global__ __launch_bounds__(256) void k_chan4096_pair(const float2 *__restrict__ head, long n_head, const float2 *__restrict__ in,
+                                                       float2 *__restrict__ out, const float *__restrict__ window,
+                                                       const float2 *__restrict__ tw, unsigned count, int branches) {
+    __shared__ f2 lds[4096 + 256];
+    const int j = threadIdx.x;
+    // pairs dealt to the XCDs 8 at a time (neighbouring pairs share chunks, too)
+    const unsigned q = blockIdx.x / 64 * 64 + (blockIdx.x % 64 & 7) * 8 + (blockIdx.x % 64 >> 3);
+    const unsigned fa = 2 * q;
+    if (fa >= count) return;
+    const bool has_b = fa + 1 < count;
+    const long base = (long)fa * 4096 - n_head;
+    f2 va[16], vb[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) va[k] = vb[k] = (f2){0.f, 0.f};
+    const int chunks = branches + (has_b ? 1 : 0);
+    for (int p = 0; p < chunks; ++p) {
+        const long bp = base + 4096L * p + j;
+        f2 x[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const long i = bp + 256 * k;
+            const float2 t = (i >= 0) ? in[i] : head[n_head + i];
+            x[k] = (f2){t.x, t.y};
+        }
+        if (p < branches) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float w = window[4096 * p + j + 256 * k];
+                va[k] = __builtin_elementwise_fma(x[k], (f2){w, w}, va[k]);
+            }
+        }
+        if (p >= 1) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float w = window[4096 * (p - 1) + j + 256 * k];
+                vb[k] = __builtin_elementwise_fma(x[k], (f2){w, w}, vb[k]);
+            }
+        }
+    }
+    f2 *dst = reinterpret_cast<f2 *>(out) + (size_t)fa * 4096;
+    fft4096_regs(va, lds, tw, j);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) __builtin_nontemporal_store(va[k], dst + (j + 256 * k));
+    if (!has_b) return;  // (uniform over the workgroup)
+    __syncthreads();  // the first transform's last pass has been read
+    fft4096_regs(vb, lds, tw, j);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) __builtin_nontemporal_store(vb[k], dst + 4096 + (j + 256 * k));
 }
 
 // ---------------------------------------------------------------------------
@@ -2978,8 +3046,7 @@ int launch_chan1024(hipStream_t s, const void *head, size_t n_head, const void *
     if (count == 0) return RR_OK;
     if (count > 0x7fffff00ull) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: too many frames");
     // critically sampled with at least two taps per branch: two frames per wave (RR_CHAN_PAIR=0 keeps one)
-    static const bool pair = [] { const char *e = std::getenv("RR_CHAN_PAIR"); return !(e && std::atoi(e) == 0); }();
-    if (pair && hop == 1024 && branches >= 2) {
+    if (chan_pair_enabled() && hop == 1024 && branches >= 2) {
         const size_t pairs = (count + 1) / 2;
         const unsigned g2 = (unsigned)((pairs + 127) / 128 * 128);
         hipLaunchKernelGGL(k_chan1024_pair, dim3(g2), dim3(64), 0, s, (const float2 *)head, (long)n_head, (const float2 *)in,
