@@ -596,6 +596,81 @@ int launch_chan4096(hipStream_t s, const void *head, size_t n_head, const void *
 // Kernel 2s  k_fft512: window * v -> 512-point forward DFT, radix 8 x 8 x 8, one wave per frame (8 values per
 // lane, wave-local exchanges through a padded 4.5 KiB image).
 // ---------------------------------------------------------------------------
+// the wave-local 512-point transform: in a[k] = x[l + 64 k], out a[k] = X[l + 64 k] (s1 = tw[8 (l mod 8)], s2 = tw[l])
+__device__ __forceinline__ void wave_dft512(f2 (&a)[8], f2 *lds, int l, f2 s1, f2 s2) {
+    dft8(a);  // pass 0 (Ns = 1): out 8 l + k
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lds_st(lds + pad8(8 * l + k), a[k]);
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = lds_ld(lds + pad8(l + 64 * k));
+    twiddle8(a, s1);  // pass 1 (Ns = 8): e^{-j 2 pi (l mod 8) k / 64}; out (l / 8) 64 + l % 8 + 8 k
+    dft8(a);
+    wave_sync();
+    {
+        const int b = (l >> 3) * 64 + (l & 7);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lds_st(lds + pad8(b + 8 * k), a[k]);
+    }
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = lds_ld(lds + pad8(l + 64 * k));
+    twiddle8(a, s2);  // pass 2 (Ns = 64): e^{-j 2 pi l k / 512}; out l + 64 k
+    dft8(a);
+}
+
+// The 512-bin channelizer at hop = 512 with FOUR neighbouring frames per wave (8 values per lane and frame): branches + 3 chunk
+// reads for four frames instead of 4 branches (4 taps per branch: 7 instead of 16); chunk p goes into frame r with the window's
+// segment p - r.
+__global__ __launch_bounds__(64) void k_chan512_quad(const float2 *__restrict__ head, long n_head, const float2 *__restrict__ in,
+                                                     float2 *__restrict__ out, const float *__restrict__ window,
+                                                     const float2 *__restrict__ tw, unsigned count, int branches) {
+    __shared__ f2 lds[512 + 64];
+    const int l = threadIdx.x;
+    const unsigned q = blockIdx.x / 128 * 128 + (blockIdx.x % 128 & 7) * 16 + (blockIdx.x % 128 >> 3);
+    const unsigned f0 = 4 * q;
+    if (f0 >= count) return;
+    const int nfr = count - f0 < 4u ? (int)(count - f0) : 4;
+    const long base = (long)f0 * 512 - n_head;
+    f2 v[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[r][k] = (f2){0.f, 0.f};
+    const int chunks = branches + nfr - 1;
+    for (int p = 0; p < chunks; ++p) {
+        f2 x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const long i = base + 512L * p + l + 64 * k;
+            const float2 t = (i >= 0) ? in[i] : head[n_head + i];
+            x[k] = (f2){t.x, t.y};
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int seg = p - r;
+            if (seg >= 0 && seg < branches && r < nfr) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float w = window[512 * seg + l + 64 * k];
+                    v[r][k] = __builtin_elementwise_fma(x[k], (f2){w, w}, v[r][k]);
+                }
+            }
+        }
+    }
+    const float2 s1 = tw[8 * (l & 7)], s2 = tw[l];
+    f2 *dst = reinterpret_cast<f2 *>(out) + (size_t)f0 * 512;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (r < nfr) {
+            if (r) wave_sync();  // the previous transform's last reads are done
+            wave_dft512(v[r], lds, l, (f2){s1.x, s1.y}, (f2){s2.x, s2.y});
+#pragma unroll
+            for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(v[r][k], dst + 512 * r + (l + 64 * k));
+        }
+    }
+}
+
 // (FOLD: the 512-bin polyphase channelizer - the frame is the fold of `branches` windowed chunks)
 template <bool FOLD>
 __global__ __launch_bounds__(64) void k_fft512(const float2 *__restrict__ head, long n_head,
@@ -634,25 +709,7 @@ __global__ __launch_bounds__(64) void k_fft512(const float2 *__restrict__ head, 
         }
     }
     const float2 s1 = tw[8 * (l & 7)], s2 = tw[l];  // tw[k] = e^{-j 2 pi k / 512}
-    dft8(a);  // pass 0 (Ns = 1): out 8 l + k
-#pragma unroll
-    for (int k = 0; k < 8; ++k) lds_st(lds + pad8(8 * l + k), a[k]);
-    wave_sync();
-#pragma unroll
-    for (int k = 0; k < 8; ++k) a[k] = lds_ld(lds + pad8(l + 64 * k));
-    twiddle8(a, (f2){s1.x, s1.y});  // pass 1 (Ns = 8): e^{-j 2 pi (l mod 8) k / 64}; out (l / 8) 64 + l % 8 + 8 k
-    dft8(a);
-    wave_sync();
-    {
-        const int b = (l >> 3) * 64 + (l & 7);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) lds_st(lds + pad8(b + 8 * k), a[k]);
-    }
-    wave_sync();
-#pragma unroll
-    for (int k = 0; k < 8; ++k) a[k] = lds_ld(lds + pad8(l + 64 * k));
-    twiddle8(a, (f2){s2.x, s2.y});  // pass 2 (Ns = 64): e^{-j 2 pi l k / 512}; out l + 64 k
-    dft8(a);
+    wave_dft512(a, lds, l, (f2){s1.x, s1.y}, (f2){s2.x, s2.y});
     f2 *dst = reinterpret_cast<f2 *>(out) + (size_t)fr * 512;
     const int rot = center_dc ? 256 : 0;
 #pragma unroll
@@ -675,6 +732,14 @@ int launch_chan512(hipStream_t s, const void *head, size_t n_head, const void *i
                    const void *window, const void *tw512, size_t hop, size_t branches) {
     if (count == 0) return RR_OK;
     if (count > 0x7fffff00ull) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: too many frames");
+    if (chan_pair_enabled() && hop == 512 && branches >= 2) {
+        const size_t quads = (count + 3) / 4;
+        hipLaunchKernelGGL(k_chan512_quad, dim3((unsigned)((quads + 127) / 128 * 128)), dim3(64), 0, s, (const float2 *)head,
+                           (long)n_head, (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw512,
+                           (unsigned)count, (int)branches);
+        RR_HIP(hipGetLastError());
+        return RR_OK;
+    }
     const unsigned grid = (unsigned)((count + 127) / 128 * 128);
     hipLaunchKernelGGL(k_fft512<true>, dim3(grid), dim3(64), 0, s, (const float2 *)head, (long)n_head, (const float2 *)in,
                        (float2 *)out, (const float *)window, (const float2 *)tw512, 0, (long)hop, (unsigned)count,
