@@ -831,6 +831,51 @@ int launch_fft_small(hipStream_t s, const void *in, void *out, size_t n, size_t 
 // k_fft4096 (analysis.rs:105-115; rr_stft with 2048-sample spans).  The window table carries a packed copy
 // behind its 2048 entries (wp[16 t + k] = w[t + 128 k], rr_fourier::prepare).
 // ---------------------------------------------------------------------------
+// the 2048-point transform of a 128-lane workgroup (radix 16 x 16 x 8 through one padded image) with the store of its result:
+// in v[k] = x[t + 128 k]; X[j + 256 k] goes to dst[(j + 256 k + rot) mod 2048].  The caller synchronises before the image is reused.
+__device__ __forceinline__ void fft2048_store(f2 (&v)[16], f2 *lds, const float2 *__restrict__ tw, int t, f2 *dst, int rot) {
+    // twiddle seeds: pass 1 e^{-j 2 pi (t mod 16) / 256} = tw[8 (t mod 16)]; pass 2 tw[t], tw[t + 128]  (tw[k] = e^{-j 2 pi k / 2048})
+    const float2 s1 = tw[8 * (t & 15)], s2a = tw[t], s2b = tw[t + 128];
+    // pass 0 (Ns = 1, radix 16): butterflies t over x[t + 128 k]; out 16 t + k
+    dft16(v);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds_st(lds + pad16(16 * t + k), v[k]);
+    __syncthreads();
+    // pass 1 (Ns = 16, radix 16): in y[t + 128 k]; out (t / 16) 256 + t % 16 + 16 k
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = lds_ld(lds + pad16(t + 128 * k));
+    apply_twiddle_powers(v, (f2){s1.x, s1.y});
+    dft16(v);
+    __syncthreads();
+    {
+        const int b = (t >> 4) * 256 + (t & 15);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lds_st(lds + pad16(b + 16 * k), v[k]);
+    }
+    __syncthreads();
+    // pass 2 (Ns = 256, radix 8): butterflies j = t and t + 128 over z[j + 256 k]; out X[j + 256 k]
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+        const int j = t + 128 * sidx;
+        f2 a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = lds_ld(lds + pad16(j + 256 * k));
+        const float2 sw = sidx ? s2b : s2a;
+        const f2 w1 = {sw.x, sw.y};
+        const f2 w2 = cmulf(w1, w1), w3 = cmulf(w2, w1), w4 = cmulf(w2, w2);
+        a[1] = cmulf(a[1], w1);
+        a[2] = cmulf(a[2], w2);
+        a[3] = cmulf(a[3], w3);
+        a[4] = cmulf(a[4], w4);
+        a[5] = cmulf(a[5], cmulf(w4, w1));
+        a[6] = cmulf(a[6], cmulf(w4, w2));
+        a[7] = cmulf(a[7], cmulf(w4, w3));
+        dft8(a);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(a[k], dst + ((j + 256 * k + rot) & 2047));
+    }
+}
+
 // (FOLD: the 2048-bin polyphase channelizer - the frame is the fold of `branches` windowed chunks, window: plain values)
 template <bool FOLD>
 __global__ __launch_bounds__(128) void k_fft2048(const float2 *__restrict__ head, long n_head,
@@ -883,48 +928,54 @@ __global__ __launch_bounds__(128) void k_fft2048(const float2 *__restrict__ head
             }
         }
     }
-    // twiddle seeds: pass 1 e^{-j 2 pi (t mod 16) / 256} = tw[8 (t mod 16)]; pass 2 tw[t], tw[t + 128]  (tw[k] = e^{-j 2 pi k / 2048})
-    const float2 s1 = tw[8 * (t & 15)], s2a = tw[t], s2b = tw[t + 128];
-    // pass 0 (Ns = 1, radix 16): butterflies t over x[t + 128 k]; out 16 t + k
-    dft16(v);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) lds_st(lds + pad16(16 * t + k), v[k]);
-    __syncthreads();
-    // pass 1 (Ns = 16, radix 16): in y[t + 128 k]; out (t / 16) 256 + t % 16 + 16 k
-#pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = lds_ld(lds + pad16(t + 128 * k));
-    apply_twiddle_powers(v, (f2){s1.x, s1.y});
-    dft16(v);
-    __syncthreads();
-    {
-        const int b = (t >> 4) * 256 + (t & 15);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) lds_st(lds + pad16(b + 16 * k), v[k]);
-    }
-    __syncthreads();
-    // pass 2 (Ns = 256, radix 8): butterflies j = t and t + 128 over z[j + 256 k]; out X[j + 256 k]
     f2 *dst = reinterpret_cast<f2 *>(out) + (size_t)fr * 2048;
-    const int rot = center_dc ? 1024 : 0;
+    fft2048_store(v, lds, tw, t, dst, center_dc ? 1024 : 0);
+}
+
+// The 2048-bin channelizer at hop = 2048 with TWO neighbouring frames per workgroup (as k_chan4096_pair)
+__global__ __launch_bounds__(128) void k_chan2048_pair(const float2 *__restrict__ head, long n_head, const float2 *__restrict__ in,
+                                                       float2 *__restrict__ out, const float *__restrict__ window,
+                                                       const float2 *__restrict__ tw, unsigned count, int branches) {
+    __shared__ f2 lds[2048 + 128];
+    const int t = threadIdx.x;
+    const unsigned q = blockIdx.x / 128 * 128 + (blockIdx.x % 128 & 7) * 16 + (blockIdx.x % 128 >> 3);
+    const unsigned fa = 2 * q;
+    if (fa >= count) return;
+    const bool has_b = fa + 1 < count;
+    const long base = (long)fa * 2048 - n_head;
+    f2 va[16], vb[16];
 #pragma unroll
-    for (int sidx = 0; sidx < 2; ++sidx) {
-        const int j = t + 128 * sidx;
-        f2 a[8];
+    for (int k = 0; k < 16; ++k) va[k] = vb[k] = (f2){0.f, 0.f};
+    const int chunks = branches + (has_b ? 1 : 0);
+    for (int p = 0; p < chunks; ++p) {
+        const long bp = base + 2048L * p + t;
+        f2 x[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) a[k] = lds_ld(lds + pad16(j + 256 * k));
-        const float2 sw = sidx ? s2b : s2a;
-        const f2 w1 = {sw.x, sw.y};
-        const f2 w2 = cmulf(w1, w1), w3 = cmulf(w2, w1), w4 = cmulf(w2, w2);
-        a[1] = cmulf(a[1], w1);
-        a[2] = cmulf(a[2], w2);
-        a[3] = cmulf(a[3], w3);
-        a[4] = cmulf(a[4], w4);
-        a[5] = cmulf(a[5], cmulf(w4, w1));
-        a[6] = cmulf(a[6], cmulf(w4, w2));
-        a[7] = cmulf(a[7], cmulf(w4, w3));
-        dft8(a);
+        for (int k = 0; k < 16; ++k) {
+            const long i = bp + 128 * k;
+            const float2 xx = (i >= 0) ? in[i] : head[n_head + i];
+            x[k] = (f2){xx.x, xx.y};
+        }
+        if (p < branches) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(a[k], dst + ((j + 256 * k + rot) & 2047));
+            for (int k = 0; k < 16; ++k) {
+                const float w = window[2048 * p + t + 128 * k];
+                va[k] = __builtin_elementwise_fma(x[k], (f2){w, w}, va[k]);
+            }
+        }
+        if (p >= 1) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float w = window[2048 * (p - 1) + t + 128 * k];
+                vb[k] = __builtin_elementwise_fma(x[k], (f2){w, w}, vb[k]);
+            }
+        }
     }
+    f2 *dst = reinterpret_cast<f2 *>(out) + (size_t)fa * 2048;
+    fft2048_store(va, lds, tw, t, dst, 0);
+    if (!has_b) return;  // (uniform over the workgroup)
+    __syncthreads();  // the first transform's last pass has been read
+    fft2048_store(vb, lds, tw, t, dst + 2048, 0);
 }
 
 int launch_fft2048(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
@@ -942,6 +993,14 @@ int launch_chan2048(hipStream_t s, const void *head, size_t n_head, const void *
                     const void *window, const void *tw2048, size_t hop, size_t branches) {
     if (count == 0) return RR_OK;
     if (count > 0x7fffff00ull) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: too many frames");
+    if (chan_pair_enabled() && hop == 2048 && branches >= 2) {
+        const size_t pairs = (count + 1) / 2;
+        hipLaunchKernelGGL(k_chan2048_pair, dim3((unsigned)((pairs + 127) / 128 * 128)), dim3(128), 0, s, (const float2 *)head,
+                           (long)n_head, (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw2048,
+                           (unsigned)count, (int)branches);
+        RR_HIP(hipGetLastError());
+        return RR_OK;
+    }
     hipLaunchKernelGGL(k_fft2048<true>, dim3((unsigned)((count + 127) / 128 * 128)), dim3(128), 0, s, (const float2 *)head,
                        (long)n_head, (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw2048, 0, (long)hop,
                        (int)branches, (unsigned)count);
