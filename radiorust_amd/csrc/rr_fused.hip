@@ -3074,25 +3074,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     for (int k = 0; k < 16; ++k) __builtin_nontemporal_store(X[k], dst + ((l + 64 * k + rot) & 1023));
 }
 
-// The 1024-bin channelizer at hop = 1024 with TWO neighbouring frames per wave: frames 2 q and 2 q + 1 share branches - 1 of
-// their chunks, so the wave reads branches + 1 chunks for two frames instead of 2 branches (8 taps per branch: 9 instead of 16) -
-// k_fft1024<true> is bound by those reads (every frame re-reads its chunks from L2).  Chunk p goes into frame A with the window's
-// segment p and into frame B with segment p - 1.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_chan1024_pair(
+// The 1024-bin channelizer at hop = 1024 with R neighbouring frames per wave: frames R q .. R q + R - 1 share most of their chunks,
+// so the wave reads branches + R - 1 chunks for R frames instead of R branches (8 taps per branch, R = 2: 9 instead of 16) -
+// k_fft1024<true> is bound by those reads (every frame re-reads its chunks from L2).  Chunk p goes into frame r with the window's
+// segment p - r.
+template <int R>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 2 ? 4 : 2, R == 2 ? 4 : (R == 3 ? 3 : 2)))) void k_chan1024_multi(
     const float2 *__restrict__ head, long n_head, const float2 *__restrict__ in, float2 *__restrict__ out,
     const float *__restrict__ window, const float2 *__restrict__ tw, unsigned count, int branches) {
     __shared__ __attribute__((aligned(16))) f2 lds[kWaveLds];
     const int l = threadIdx.x;
-    // pairs dealt to the XCDs in a moving window, 16 neighbouring pairs per XCD
+    // runs dealt to the XCDs in a moving window, 16 neighbouring runs per XCD
     const unsigned q = blockIdx.x / 128 * 128 + (blockIdx.x % 128 & 7) * 16 + (blockIdx.x % 128 >> 3);
-    const unsigned fa = 2 * q;
-    if (fa >= count) return;
-    const bool has_b = fa + 1 < count;
-    const long base = (long)fa * 1024 - n_head;
-    f2 va[16], vb[16];
+    const unsigned f0 = R * q;
+    if (f0 >= count) return;
+    const int nfr = count - f0 < (unsigned)R ? (int)(count - f0) : R;
+    const long base = (long)f0 * 1024 - n_head;
+    f2 v[R][16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) va[k] = vb[k] = (f2){0.f, 0.f};
-    const int chunks = branches + (has_b ? 1 : 0);
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[r][k] = (f2){0.f, 0.f};
+    const int chunks = branches + nfr - 1;
     for (int p = 0; p < chunks; ++p) {
         const long bp = base + 1024L * p;
         f2 x[16];
@@ -3114,20 +3117,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     x[2 * k + j] = (f2){t.x, t.y};
                 }
         }
-        if (p < branches) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float2 w = *reinterpret_cast<const float2 *>(window + 1024 * p + 2 * l + 128 * k);
-                va[2 * k] = __builtin_elementwise_fma(x[2 * k], (f2){w.x, w.x}, va[2 * k]);
-                va[2 * k + 1] = __builtin_elementwise_fma(x[2 * k + 1], (f2){w.y, w.y}, va[2 * k + 1]);
-            }
-        }
-        if (p >= 1) {
+        for (int r = 0; r < R; ++r) {
+            const int seg = p - r;
+            if (seg >= 0 && seg < branches && r < nfr) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float2 w = *reinterpret_cast<const float2 *>(window + 1024 * (p - 1) + 2 * l + 128 * k);
-                vb[2 * k] = __builtin_elementwise_fma(x[2 * k], (f2){w.x, w.x}, vb[2 * k]);
-                vb[2 * k + 1] = __builtin_elementwise_fma(x[2 * k + 1], (f2){w.y, w.y}, vb[2 * k + 1]);
+                for (int k = 0; k < 8; ++k) {
+                    const float2 w = *reinterpret_cast<const float2 *>(window + 1024 * seg + 2 * l + 128 * k);
+                    v[r][2 * k] = __builtin_elementwise_fma(x[2 * k], (f2){w.x, w.x}, v[r][2 * k]);
+                    v[r][2 * k + 1] = __builtin_elementwise_fma(x[2 * k + 1], (f2){w.y, w.y}, v[r][2 * k + 1]);
+                }
             }
         }
     }
@@ -3139,16 +3138,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         t_p2[0] = (f2){s0.z, s0.w};
         t_p2[1] = (f2){s1.x, s1.y};
     }
-    f2 X[16];
-    wave_dft1024(va, X, lds, l, t_p1, t_p2, [] {});
-    f2 *dst = reinterpret_cast<f2 *>(out) + (size_t)fa * 1024;
+    f2 *dst = reinterpret_cast<f2 *>(out) + (size_t)f0 * 1024;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) __builtin_nontemporal_store(X[k], dst + (l + 64 * k));
-    if (!has_b) return;
-    wave_sync();  // the first transform's last reads are done
-    wave_dft1024(vb, X, lds, l, t_p1, t_p2, [] {});
+    for (int r = 0; r < R; ++r) {
+        if (r < nfr) {
+            if (r) wave_sync();  // the previous transform's last reads are done
+            f2 X[16];
+            wave_dft1024(v[r], X, lds, l, t_p1, t_p2, [] {});
 #pragma unroll
-    for (int k = 0; k < 16; ++k) __builtin_nontemporal_store(X[k], dst + 1024 + (l + 64 * k));
+            for (int k = 0; k < 16; ++k) __builtin_nontemporal_store(X[k], dst + 1024 * r + (l + 64 * k));
+        }
+    }
 }
 
 int launch_fft1024(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
@@ -3171,10 +3171,19 @@ int launch_chan1024(hipStream_t s, const void *head, size_t n_head, const void *
     if (count > 0x7fffff00ull) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: too many frames");
     // critically sampled with at least two taps per branch: two frames per wave (RR_CHAN_PAIR=0 keeps one)
     if (chan_pair_enabled() && hop == 1024 && branches >= 2) {
-        const size_t pairs = (count + 1) / 2;
-        const unsigned g2 = (unsigned)((pairs + 127) / 128 * 128);
-        hipLaunchKernelGGL(k_chan1024_pair, dim3(g2), dim3(64), 0, s, (const float2 *)head, (long)n_head, (const float2 *)in,
-                           (float2 *)out, (const float *)window, (const float2 *)tw1024, (unsigned)count, (int)branches);
+        // frames per wave: 8 taps per branch, per 2^26 samples: 2 frames 0.368 ms, 3 frames 0.354, 4 frames 0.336 (one frame: 0.471);
+        // four from 6 taps per branch on, two below (RR_CHAN1024_RUN = 2 / 3 / 4 overrides)
+        static const int runlen = [] { const char *e = std::getenv("RR_CHAN1024_RUN"); return e ? std::atoi(e) : 0; }();
+        const size_t R = runlen == 3 ? 3 : runlen == 4 ? 4 : runlen == 2 ? 2 : (branches >= 6 ? 4 : 2);
+        const size_t runs = (count + R - 1) / R;
+        const unsigned g2 = (unsigned)((runs + 127) / 128 * 128);
+#define RR_CH1024(RR_)                                                                                                      \
+    hipLaunchKernelGGL(k_chan1024_multi<RR_>, dim3(g2), dim3(64), 0, s, (const float2 *)head, (long)n_head, (const float2 *)in, \
+                       (float2 *)out, (const float *)window, (const float2 *)tw1024, (unsigned)count, (int)branches)
+        if (R == 3) RR_CH1024(3);
+        else if (R == 4) RR_CH1024(4);
+        else RR_CH1024(2);
+#undef RR_CH1024
         RR_HIP(hipGetLastError());
         return RR_OK;
     }
