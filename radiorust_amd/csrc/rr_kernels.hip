@@ -1453,6 +1453,65 @@ __global__ __launch_bounds__(1024) void k_fft_mixed(const v2<T> *__restrict__ he
     }
 }
 
+// Short chunks (a few hundred points): SEVERAL chunks per workgroup, side by side in LDS, their butterflies spread over the
+// workgroup's lanes together - one chunk of 96 points keeps 24 of a wave's 64 lanes busy through four passes and barriers, and
+// a workgroup per chunk is mostly launch and barrier.  fpw chunks per workgroup (fpw n <= 4096 elements), the table W_n in LDS
+// behind them; everything else as k_fft_mixed (one lane per butterfly, in-place passes, the digit reversal at the store).
+template <class T, bool ODD>
+__global__ __launch_bounds__(1024) void k_fft_mixed_multi(const v2<T> *__restrict__ head, long n_head, const v2<T> *__restrict__ in,
+                                                         long base0, long hop, int n, int branches, int fpw, MixedPlan plan,
+                                                         const T *__restrict__ window, const v2<T> *__restrict__ tw_g,
+                                                         v2<T> *__restrict__ out, int center_dc, unsigned count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mixedm_raw[];
+    v2<T> *const x = reinterpret_cast<v2<T> *>(mixedm_raw);
+    v2<T> *const tw = x + fpw * n;
+    const int nt = blockDim.x, t = threadIdx.x;
+    const unsigned fr0 = blockIdx.x * (unsigned)fpw;
+    const int nfr = count - fr0 < (unsigned)fpw ? (int)(count - fr0) : fpw;  // (the grid covers count exactly: fr0 < count)
+    for (int i = t; i < n; i += nt) tw[i] = tw_g[i];
+    const float rn = 1.0f / (float)n;
+    for (int idx = t; idx < nfr * n; idx += nt) {
+        const int f = div_small(idx, rn), i = idx - f * n;
+        const long base = base0 + (long)(fr0 + f) * hop;
+        v2<T> acc = {(T)0, (T)0};
+        for (int pb = 0; pb < branches; ++pb) {
+            const long g = base + i + (long)pb * n;
+            const v2<T> v = g >= 0 ? in[g] : head[n_head + g];
+            const T w = window[i + pb * n];
+            acc.x += v.x * w;
+            acc.y += v.y * w;
+        }
+        x[idx] = acc;
+    }
+    __syncthreads();
+    int L = n;
+    for (int ps = 0; ps < plan.nrad; ++ps) {
+        const int r = plan.radix[ps], q = plan.q[ps], step = n / L, nb = n / r;
+        const float rq = plan.rq[ps], rnb = 1.0f / (float)nb;
+        for (int b = t; b < nfr * nb; b += nt) {
+            const int f = div_small(b, rnb), bb = b - f * nb;
+            const int blk = div_small(bb, rq), j = bb - blk * q;
+            mixed_bfly<T, ODD>(x + f * n + blk * L + j, q, r, tw, j * step, n);
+        }
+        __syncthreads();
+        L = q;
+    }
+    const int rot = center_dc ? n / 2 : 0;  // rotate_right(n / 2)
+    for (int idx = t; idx < nfr * n; idx += nt) {
+        const int f = div_small(idx, rn), i = idx - f * n;
+        int k = 0, mul = 1, rem = i;
+        for (int ps = 0; ps < plan.nrad; ++ps) {
+            const int d = div_small(rem, plan.rq[ps]);
+            rem -= d * plan.q[ps];
+            k += d * mul;
+            mul *= plan.radix[ps];
+        }
+        int o = k + rot;
+        if (o >= n) o -= n;
+        out[(size_t)(fr0 + f) * n + o] = x[idx];
+    }
+}
+
 // n = 2^a 3^b 5^c, not a power of two, at most nmax points: the radices, largest first (5s, 4s, 3s, at most one 2)
 static bool mixed_plan_impl(size_t n, size_t nmax, MixedPlan *pl, bool pow2_too) {
     if (n < 2 || n > nmax || (!pow2_too && (n < 6 || is_pow2_n(n)))) return false;
@@ -1720,6 +1779,43 @@ int launch_fft_mixed_fold(int dtype, hipStream_t s, const void *head, size_t n_h
     unsigned nt = (unsigned)((n / 4 + 63) / 64 * 64);
     if (nt > nt_max) nt = nt_max;
     if (nt < 64) nt = 64;
+    // short chunks: several per workgroup (k_fft_mixed_multi) - as many as make ~2048 elements, at most 16 (RR_FOURIER_MIXED_FPW overrides; 1 = off)
+    {
+        static const int fpw_env = [] { const char *e = std::getenv("RR_FOURIER_MIXED_FPW"); return e ? std::atoi(e) : 0; }();
+        // (per 2^24 samples, several chunks per workgroup / one: 96 points 0.126 / 0.178 ms, 300 0.125 / 0.134, 500 0.123 / 0.112,
+        // 720 0.157 / 0.135, 1000 0.140 / 0.128; the 100-bin channelizer 0.745 / 0.926 ms per 2^26: up to 384 points)
+        size_t fpw = fpw_env > 0 ? (size_t)fpw_env : (n <= 384 ? 2048 / n : 1);
+        if (fpw > 16) fpw = 16;
+        if (fpw * n > 4096) fpw = 4096 / n;
+        if (fpw > count) fpw = count;
+        if (fpw >= 2) {
+            const size_t esz2 = dtype == RR_F32 ? sizeof(float2) : sizeof(double2);
+            const size_t lds2 = (fpw + 1) * n * esz2;
+            unsigned nt2 = (unsigned)((fpw * n / 4 + 63) / 64 * 64);
+            if (nt2 > 512) nt2 = 512;
+            if (nt2 < 64) nt2 = 64;
+            const unsigned grid2 = (unsigned)((count + fpw - 1) / fpw);
+            const bool odd2 = pl.radix[0] > 5;
+#define RR_MIXEDM(TT, VV, OO)                                                                                                  \
+    do {                                                                                                                       \
+        auto fn = k_fft_mixed_multi<TT, OO>;                                                                                   \
+        RR_TRY(set_dyn_lds(reinterpret_cast<const void *>(fn), lds2));                                                         \
+        hipLaunchKernelGGL(fn, dim3(grid2), dim3(nt2), lds2, s, (const VV *)head, (long)n_head, (const VV *)in, base0,         \
+                           (long)hop, (int)n, (int)branches, (int)fpw, pl, (const TT *)window, (const VV *)tw, (VV *)out,      \
+                           (int)center_dc, (unsigned)count);                                                                   \
+    } while (0)
+            if (dtype == RR_F32) {
+                if (odd2) RR_MIXEDM(float, float2, true);
+                else RR_MIXEDM(float, float2, false);
+            } else {
+                if (odd2) RR_MIXEDM(double, double2, true);
+                else RR_MIXEDM(double, double2, false);
+            }
+#undef RR_MIXEDM
+            RR_HIP(hipGetLastError());
+            return RR_OK;
+        }
+    }
     // twiddles in LDS while image + table stay within 32 KiB per workgroup (at least four workgroups per CU)
     static const int twlds_env = [] { const char *e = std::getenv("RR_FOURIER_MIXED_TWLDS"); return e ? std::atoi(e) : 1; }();
     const size_t esz = dtype == RR_F32 ? sizeof(float2) : sizeof(double2);

@@ -49,7 +49,7 @@ for nt in (1024, 2048, 4096, 8192):
     dt = timed(lambda: g.process_dev(2e9, nt, d_in.data_ptr(), n, d_out.data_ptr(), n))
     line(f"Filter n = {nt} (kernel {g.last_kernel()})", n, dt, 16)
 
-for nf in (8192, 16384, 65536, 1 << 18, 1 << 20, 96, 300, 1000, 1001, 1999, 2000, 3000, 3001, 4004, 4093, 4800, 8000, 20000, 77000, 250000, 20011):
+for nf in (8192, 65536, 96, 300, 500, 720, 1000, 1001, 1536, 1999, 2000, 3000, 3001, 4004, 4800, 8000, 20000, 250000, 20011):
     g = rr.Fourier.with_window(rr.Kaiser.with_null_at_bin(2.0))
     g.set_stream(st)
     n = min(N, 1 << 24) // nf * nf
