@@ -1757,7 +1757,7 @@ bool fft_mixed_preferred(int dtype, size_t n) {
     // lengths with a factor 7, 11 or 13 (the R x R butterflies): 1001 points 0.301 ms against k_bluestein4096's 0.219; beyond 2048
     // points, where Bluestein takes five launches, 4004 points 0.225 against 0.635
     if (n % 7 == 0 || n % 11 == 0 || n % 13 == 0) return n > 2048;
-    return n < 288 || (n > 512 && n <= 1280) || n > 2048;
+    return n < 320 || (n > 512 && n <= 1280) || n > 2048;
 }
 int launch_fft_mixed(int dtype, hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n,
                      const void *window, const void *tw, void *out, bool center_dc, size_t count) {
