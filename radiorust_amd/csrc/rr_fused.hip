@@ -2228,9 +2228,12 @@ constexpr int kFrameBlocks = 20;
 // One 1024-sample block of k_ols_wave<4, POLY> as a function (the fused frame kernel's waves run five of them in a
 // row): v = mixed samples in the pair layout, hv = the lane's 16 entries of the polyphase tables G_p; y[c] =
 // result[l + 64 c] of the 256-point inverse.  See k_ols_wave for the passes and the two exchange images.
+#ifndef RR_V_FRAME_GLDS
+#define RR_V_FRAME_GLDS 1  // k_ols_frame: the first half of the tables G_p in LDS (0: all of it from L2, for A/B)
+#endif
 constexpr int kPolyLds = 1136;  // 2 (63 + 72 * 7) + 2 elements
 __device__ __forceinline__ void poly4_block(f2 (&v)[16], f2 (&y)[4], f2 *lds, int l, f2 t_p1, f2 t_p2, const f2 (&t_inv)[3],
-                                            const float2 *__restrict__ G) {
+                                            const float2 *__restrict__ G, const float4 *Glds) {
     const int g = l >> 4, q = l & 15;
     f2 e0[8], e1[8];
 #pragma unroll
@@ -2280,7 +2283,7 @@ __device__ __forceinline__ void poly4_block(f2 (&v)[16], f2 (&y)[4], f2 *lds, in
     // k_ols_wave does: kept through the passes they are 32 registers the frame kernel does not have
     float4 ga[4], gb[4];
 #pragma unroll
-    for (int kp = 0; kp < 4; ++kp) ga[kp] = reinterpret_cast<const float4 *>(G)[l + 64 * kp];
+    for (int kp = 0; kp < 4; ++kp) ga[kp] = RR_V_FRAME_GLDS ? Glds[l + 64 * kp] : reinterpret_cast<const float4 *>(G)[l + 64 * kp];
     f2 d[4][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -2394,6 +2397,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const FrameArgs &a = a_;
     const FrameArgs *ka = (const FrameArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     __shared__ __attribute__((aligned(16))) f2 smem[4 * kPolyLds];  // 4544 elements >= the 4352 of the padded frame image
+#if RR_V_FRAME_GLDS
+    // the first half of the response tables G_p (phases 0 and 1: 4 KiB) in LDS, in the 4.5 KiB per workgroup that four workgroups per
+    // CU leave: every block otherwise pulls all 8 KiB from L2 - as many bytes as its samples, in 8 of its 16 vector-memory instructions
+    __shared__ __attribute__((aligned(16))) float4 gl[256];
+#endif
     f2 *const fr = smem;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     // The frame that does not fill (its samples go to pend_out) is workgroup 0: dispatched first it runs beside the first
@@ -2440,6 +2448,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         t_inv[2] = (f2){s8.x, s8.y};
     }
     f2 *const lds = smem + w * kPolyLds;
+#if RR_V_FRAME_GLDS
+    gl[tid] = reinterpret_cast<const float4 *>(a.H)[tid];
+    __syncthreads();
+    const float4 *const glp = gl;
+#else
+    const float4 *const glp = nullptr;
+#endif
     const long n_clamp = a.n_in - 1024;  // the launcher guarantees n_in >= 1024
     f2 keep[kFrameBlocks / 4][4];
 #pragma unroll
@@ -2516,7 +2531,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 if (r >= a.denom) r -= a.denom;
             }
         }
-        poly4_block(v, keep[kb], lds, l, t_p1, t_p2, t_inv, a.H);
+        poly4_block(v, keep[kb], lds, l, t_p1, t_p2, t_inv, a.H, glp);
         // (one block at a time: without this the five unrolled blocks' loads are all hoisted to the front)
         asm volatile("" : "+v"(keep[kb][0]), "+v"(keep[kb][1]), "+v"(keep[kb][2]), "+v"(keep[kb][3]));
     }
