@@ -1088,61 +1088,6 @@ __global__ __launch_bounds__(256) void k_fft8192(const float2 *__restrict__ head
     }
 }
 
-// The same transform as a function for kernels that run it twice (k_bluestein8192): in v[h][k] = x[t + 256 h + 512 k];
-// out v[0][m] = X[t + 256 m], v[1][m] = X[t + 256 (m + 16)], m < 16.  The caller synchronises before the image is reused.
-__device__ __forceinline__ void fft8192_regs(f2 (&v)[2][16], f2 *lds, const float2 *__restrict__ tw, int t) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int j = t + 256 * h;
-        dft16(v[h]);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) lds_st(lds + pad16(16 * j + k), v[h][k]);
-    }
-    __syncthreads();
-    {
-        const float2 s1 = tw[32 * (t & 15)];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int j = t + 256 * h;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) v[h][k] = lds_ld(lds + pad16(j + 512 * k));
-            apply_twiddle_powers(v[h], (f2){s1.x, s1.y});
-            dft16(v[h]);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int j = t + 256 * h;
-        const int b = (j >> 4) * 256 + (j & 15);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) lds_st(lds + pad16(b + 16 * k), v[h][k]);
-    }
-    __syncthreads();
-    {
-        const float2 s2 = tw[t];
-        const f2 w = {s2.x, s2.y};
-        const f2 w2 = cmulf(w, w);
-#pragma unroll
-        for (int a = 0; a < 16; ++a) {
-            v[0][a] = lds_ld(lds + pad16(t + 256 * (2 * a)));
-            v[1][a] = cmulf(lds[pad16(t + 256 * (2 * a + 1))], w);
-        }
-        apply_twiddle_powers(v[0], w2);
-        apply_twiddle_powers(v[1], w2);
-        dft16(v[0]);  // E[m]
-        dft16(v[1]);  // O[m]
-#pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            const float2 c = tw[256 * m];  // W_32^m (a scalar read)
-            const f2 o = cmulf(v[1][m], (f2){c.x, c.y});
-            const f2 e = v[0][m];
-            v[0][m] = e + o;
-            v[1][m] = e - o;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------
 // Kernel 2y  k_bluestein8192: the Fourier block for 2049 .. 4096 points whose length has a prime factor beyond 13 (the others
 // run the mixed-radix passes): Bluestein's algorithm in ONE kernel around two 8192-point transforms in LDS, as
