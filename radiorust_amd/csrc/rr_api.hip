@@ -91,6 +91,7 @@ int rr_freqshifter::prepare(double sample_rate) {
     denom = de;
     phase_idx = 0;
     shift_changed = false;
+    ++table_version;
     // denom entries + entry 0 once more behind them (k_ols_wave reads the pair (r, r + 1) in one piece)
     // + 8 rotations e^{j 2 pi (128 k numer mod denom) / denom}, k < 8: the fused kernel steps a lane's
     // phasor by 128 samples with one product instead of one more table read
@@ -1532,6 +1533,7 @@ void build_fused_fir_tables(int kind, uint64_t D_, const std::vector<double> &c,
             // forward transform: A/B runs)
             const size_t D = (size_t)D_, NB = 1024 / D, ND = 16 / D;
             std::vector<float> gp(2 * N);
+            if (D == 4) t.G64.assign(1024, cd(0, 0));
             for (size_t pp = 0; pp < D; ++pp)
                 for (size_t k = 0; k < NB; ++k) {
                     cd g(0, 0);
@@ -1543,6 +1545,7 @@ void build_fused_fir_tables(int kind, uint64_t D_, const std::vector<double> &c,
                     const size_t l = k % 64, c = k / 64, i = ND * pp + c, dst = ((i >> 1) * 64 + l) * 2 + (i & 1);
                     gp[2 * dst] = (float)g.real();
                     gp[2 * dst + 1] = (float)g.imag();
+                    if (D == 4) t.G64[256 * pp + k] = g;
                 }
             hb.swap(gp);
             append_wave1024_seeds(twb);
@@ -1578,6 +1581,40 @@ void build_fused_fir_tables(int kind, uint64_t D_, const std::vector<double> &c,
     t.Gp = gp;
 }
 
+// k_ols_frame with the mixer folded into the response tables.  With the NCO's period R a divisor of 8 the mixed block is
+// xs[b0 + i] = x[b0 + i] C e^{j 2 pi i numer / R}, C = p[(idx0 + b0) mod R] (the same for every block of a call: a block is 832 =
+// 8 x 104 samples, a frame 16384), so the phases' transforms are those of the UNMIXED samples moved by s = 1024 numer / R bins
+// (a multiple of 128) and turned by e^{j 2 pi p numer / R}:  X_p[k] = C e^{j 2 pi p numer / R} Xu_p[k - s].  With
+//   G'_p[k] = G_p[(k + s) mod 256] e^{j 2 pi p numer / R}
+// the kernel's sum over the phases is the true spectrum moved by s bins, and its inverse the true result times
+// C (-1)^((s / 128) m): one product per result instead of one per sample, no table read, no phase arithmetic per block.
+int rr_chain::ensure_mixfold() {
+    const int64_t R = fs->denom;
+    int64_t nu = fs->numer % R;
+    if (nu < 0) nu += R;
+    if (mix_numer == nu && mix_denom == R && mix_ctaps_fl == ctaps_fl && mix_ctaps_ds == ctaps_ds) return RR_OK;
+    if (olsG64.size() != 1024) RR_FAIL(RR_ERR_BAD_ARG, "Chain: no polyphase tables to fold the mixer into");
+    const size_t s = (size_t)((1024 * nu / R) % 256);  // R divides 8: whole
+    std::vector<float> gp(2 * 1024);
+    for (size_t pp = 0; pp < 4; ++pp) {
+        const double ang = 2.0 * M_PI * (double)((pp * (size_t)nu) % (size_t)R) / (double)R;
+        const cd rot(std::cos(ang), std::sin(ang));
+        for (size_t k = 0; k < 256; ++k) {
+            const cd g = olsG64[256 * pp + (k + s) % 256] * rot;
+            const size_t l = k % 64, c = k / 64, i = 4 * pp + c, dst = ((i >> 1) * 64 + l) * 2 + (i & 1);
+            gp[2 * dst] = (float)g.real();
+            gp[2 * dst + 1] = (float)g.imag();
+        }
+    }
+    RR_TRY(upload(d_olsHmix, gp.data(), gp.size() * sizeof(float), stream));
+    mix_sigma = (s / 128) & 1 ? -1.f : 1.f;
+    mix_numer = nu;
+    mix_denom = R;
+    mix_ctaps_fl = ctaps_fl;
+    mix_ctaps_ds = ctaps_ds;
+    return RR_OK;
+}
+
 // c = reverse(ir) (*) g in f64, cast to f32; tables by build_fused_fir_tables
 int rr_chain::ensure_ctaps() {
     if (ctaps_fl == fl->design_version && ctaps_ds == ds->design_version) return RR_OK;
@@ -1603,6 +1640,7 @@ int rr_chain::ensure_ctaps() {
         ols_V = t.V;
         ols_poly = t.poly;
         ols_N = t.N;
+        olsG64.swap(t.G64);
     } else {
         RR_TRY(upload(d_ctaps, t.ctaps.data(), t.ctaps.size() * sizeof(float), stream));
         Gp = t.Gp;
@@ -1685,6 +1723,18 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
         a.tw4096 = d_tw4096.p;
         a.V = ols_V;
         a.poly = ols_poly;
+        // NCO periods that divide 8 (the benchmark's fs / 8): the mixer folded into the tables (ensure_mixfold) - once the
+        // mixed-sample history in front of this call has been written under the table in use (RR_FRAME_MIXFOLD=0: never)
+        {
+            const bool off = [] { const char *e = std::getenv("RR_FRAME_MIXFOLD"); return e && std::atoi(e) == 0; }();
+            if (!off && fs->denom >= 1 && 8 % fs->denom == 0 && frame_table_version == fs->table_version && olsG64.size() == 1024) {
+                RR_TRY(ensure_mixfold());
+                a.H = d_olsHmix.p;
+                a.mixfold = true;
+                a.sigma = mix_sigma;
+            }
+            frame_table_version = fs->table_version;
+        }
         // (the launch records its own start / end: marker packets would cost ~4 us of stream time each)
         if (timers.on) timers.begin_ext(ST_FUSED_FIR, &a.ev_start, &a.ev_stop);
         RR_TRY(launch_ols_frame(stream, a, pin, pending_len, pendbuf[po].p, d_out, fo->d_window.p, fo->d_tw.p,
@@ -1700,7 +1750,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
         pend_ptr = pendbuf[po].p;
         pb_cur = po;
         pending_len = rest;
-        last_fused = FK_OLSF;
+        last_fused = a.mixfold ? 6 : FK_OLSF;  // (6: k_ols_frame<true>, the mixer folded into the tables)
         if (n_out) *n_out = nfr * LF;
         return RR_OK;
     }

@@ -12,6 +12,7 @@ struct rr_freqshifter : rr_block {
     double prev_rate = 0.0;
     int64_t numer = 0, denom = 0;
     uint64_t phase_idx = 0;
+    uint64_t table_version = 0;             // counts the recalculations of the table
     std::vector<unsigned char> host_table;  // denom complex<T>
     rr::DevBuf d_table;
     int prepare(double sample_rate);  // the `if recalculate {..}` body
@@ -58,6 +59,7 @@ struct FusedFirTables {
     std::vector<float> ctaps, H, tw;
     int Gp = 0, V = 0, N = 0;
     bool poly = false;  // H = the polyphase tables of k_ols_wave<4, POLY>
+    std::vector<rr::cd> G64;  // D = 4, polyphase: G_p[k] at 256 p + k in f64 (for the variant with the mixer folded in)
 };
 void build_fused_fir_tables(int kind, uint64_t D, const std::vector<double> &c, const std::vector<rr::cd> &cc, FusedFirTables &t);
 
@@ -289,6 +291,14 @@ struct rr_chain : rr_block {
     enum { FK_NONE = 0, FK_DIRECT, FK_OLS, FK_OLSW, FK_OLSF, FK_POLY };  // FK_POLY: k_decim_poly (Downsampler only)
     static int pick_fused_kernel(uint64_t D, size_t lc, bool real_taps, size_t fft_len);
     bool use_frame = false;      // FK_OLSF: k_ols_frame (FIR stage + Fourier in one kernel)
+    // k_ols_frame with the mixer folded into the tables (NCO periods that divide 8): G'_p[k] = G_p[(k + s) mod 256] e^{j 2 pi p numer / R}
+    std::vector<rr::cd> olsG64;
+    rr::DevBuf d_olsHmix;
+    int64_t mix_numer = 0, mix_denom = 0;
+    uint64_t mix_ctaps_fl = ~0ull, mix_ctaps_ds = ~0ull;
+    uint64_t frame_table_version = ~0ull;  // the NCO table the mixed-sample history was last written with by a frame call
+    float mix_sigma = 1.f;
+    int ensure_mixfold();
     rr::DevBuf pendbuf[2];       // its pending decimated samples, ping-pong
     int pb_cur = 0;
     int ensure_xh();

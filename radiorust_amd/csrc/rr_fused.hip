@@ -2327,6 +2327,8 @@ struct FrameArgs {
     unsigned kstep;         // 128 mod denom
     double inv_denom;
     unsigned nfr;           // full frames
+    int mixfold;            // the NCO's period divides 8 and H holds the tables with the mixer folded in (rr_chain::ensure_mixfold)
+    float sigma;            // results at odd indices of a block times sigma (+-1)
 };
 
 // The fused frame kernel, second form (round 2).  What made the first one slower than the two kernels it replaces was
@@ -2338,6 +2340,7 @@ struct FrameArgs {
 #ifndef RR_V_FRAME_LD_NT
 #define RR_V_FRAME_LD_NT 1
 #endif
+template <bool MF>  // MF: the mixer folded into the tables (rr_chain::ensure_mixfold) - an instance of its own without the mixer's code
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ols_frame(FrameArgs a_) {
     const FrameArgs &a = a_;
     const FrameArgs *ka = (const FrameArgs *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -2401,14 +2404,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const float4 *const glp = nullptr;
 #endif
     const long n_clamp = a.n_in - 1024;  // the launcher guarantees n_in >= 1024
+    // mixer folded into the tables: the blocks transform the samples as they are; a block's results times C sigma^(index),
+    // C = nco[ph0] the phasor of a block's first sample (the same for every block of the call)
+    f2 mixfac = {1.f, 0.f};
+    if (MF) {
+        const float2 c0 = a.nco[a.ph0];
+        const float sg = (l & 1) ? a.sigma : 1.f;
+        mixfac = (f2){c0.x * sg, c0.y * sg};
+    }
     f2 keep[kFrameBlocks / 4][4];
 #pragma unroll
     for (int kb = 0; kb < kFrameBlocks / 4; ++kb) {
         const int jb = w + 4 * kb;  // (five neighbouring blocks per wave instead - jb = 5 w + kb - measured 0.171 against 0.159 ms)
         const long b0 = a.e0 - a.V + 4 * (F0 + (long)per_block * jb);
         // phase of the lane's first sample: (idx0 + b0 + 2 l) mod denom, b0 = const + 4 (4096 f + 208 jb)
-        unsigned r;
-        {
+        unsigned r = 0;
+        if (!MF || !(b0 >= 0 && b0 <= n_clamp)) {  // (MF: only the edge blocks look at the table)
             const double dn = (double)a.denom;
             const double prod = (double)a.ph0 + 16384.0 * (double)f + (double)(4 * per_block * jb);
             const double qd = __builtin_floor(prod * a.inv_denom);
@@ -2432,7 +2443,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
                 for (int k = 0; k < 8; ++k) x[k] = RR_V_FRAME_LD_NT ? ld_stream(src + 64 * k) : *(src + 64 * k);
             }
-            if (a.kstep == 0) {
+            if (MF) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v[2 * k] = (f2){x[k].x, x[k].y};
+                    v[2 * k + 1] = (f2){x[k].z, x[k].w};
+                }
+            } else if (a.kstep == 0) {
                 const f4u pp = *reinterpret_cast<const f4u *>(a.nco + r);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -2468,7 +2485,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     const float2 *ptr = inr ? a.in + pos : ka->xh + (hst ? hxe + pos : 0);
                     const float2 xx = *ptr;
                     const f2 p = j ? (f2){pp.z, pp.w} : (f2){pp.x, pp.y};
-                    const f2 pk = {inr ? p.x : (hst ? 1.f : 0.f), inr ? p.y : 0.f};
+                    // (mixer folded in: the block wants the samples UNMIXED - the history, which holds mixed ones, times conj(p))
+                    const f2 pk = MF ? (f2){inr ? 1.f : (hst ? p.x : 0.f), hst ? -p.y : 0.f}
+                                            : (f2){inr ? p.x : (hst ? 1.f : 0.f), inr ? p.y : 0.f};
                     const f2 xv = {(inr || hst) ? xx.x : 0.f, (inr || hst) ? xx.y : 0.f};
                     v[2 * k + j] = cmul(xv, pk);
                 }
@@ -2477,6 +2496,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
         }
         poly4_block(v, keep[kb], lds, l, t_p1, t_p2, t_inv, a.H, glp);
+        if (MF) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) keep[kb][c] = cmul(keep[kb][c], mixfac);
+        }
         // (one block at a time: without this the five unrolled blocks' loads are all hoisted to the front)
         asm volatile("" : "+v"(keep[kb][0]), "+v"(keep[kb][1]), "+v"(keep[kb][2]), "+v"(keep[kb][3]));
     }
@@ -2574,11 +2597,18 @@ int launch_ols_frame(hipStream_t s, const FusedFirArgs &a, const void *pend_in, 
     f.kstep = (unsigned)(128 % den);
     f.inv_denom = 1.0 / (double)den;
     f.nfr = (unsigned)nfr;
+    f.mixfold = a.mixfold ? 1 : 0;
+    f.sigma = a.sigma;
     const unsigned grid = 1u + (unsigned)((nfr + 8 * RR_V_FRAMEWIN - 1) / (8 * RR_V_FRAMEWIN) * (8 * RR_V_FRAMEWIN));
-    if (a.ev_start && a.ev_stop)
-        hipExtLaunchKernelGGL(k_ols_frame, dim3(grid), dim3(256), 0, s, a.ev_start, a.ev_stop, 0, f);
+    if (a.mixfold) {
+        if (a.ev_start && a.ev_stop)
+            hipExtLaunchKernelGGL(k_ols_frame<true>, dim3(grid), dim3(256), 0, s, a.ev_start, a.ev_stop, 0, f);
+        else
+            hipLaunchKernelGGL(k_ols_frame<true>, dim3(grid), dim3(256), 0, s, f);
+    } else if (a.ev_start && a.ev_stop)
+        hipExtLaunchKernelGGL(k_ols_frame<false>, dim3(grid), dim3(256), 0, s, a.ev_start, a.ev_stop, 0, f);
     else
-        hipLaunchKernelGGL(k_ols_frame, dim3(grid), dim3(256), 0, s, f);
+        hipLaunchKernelGGL(k_ols_frame<false>, dim3(grid), dim3(256), 0, s, f);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }

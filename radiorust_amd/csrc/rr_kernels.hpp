@@ -105,6 +105,10 @@ struct FusedFirArgs {
     const void *tw4096 = nullptr;  // e^{-j 2 pi k / 4096}
     int V = 0;                     // overlap (samples), multiple of 256
     bool poly = false;             // k_ols_wave<4>: H holds the polyphase tables G_p (build_fused_fir_tables)
+    // k_ols_frame only: the NCO's period divides 8 and H holds the tables with the mixer folded in - the kernel transforms the
+    // samples as they are and multiplies its results by nco[ph0] sigma^(index): see rr_chain::ensure_mixfold
+    bool mixfold = false;
+    float sigma = 1.f;
     // optional: the launch itself records its start / end in these events (hipExtLaunchKernel):
     // kernel-only timing without marker packets on the stream
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;

@@ -35,7 +35,8 @@ def counter(path, kernel, name):
 f, w = os.path.join(src, "pmc_fetch.summary.txt"), os.path.join(src, "pmc_write.summary.txt")
 if os.path.exists(f) and os.path.exists(w):
     # the chain's dominant kernel: the fused frame kernel where it runs, else the wave-per-block FIR stage
-    kern = "k_ols_frame" if counter(f, "k_ols_frame", "FETCH_SIZE") else "k_ols_wave"
+    kern = ("k_ols_frame<true>" if counter(f, "k_ols_frame<true>", "FETCH_SIZE") else
+            "k_ols_frame" if counter(f, "k_ols_frame", "FETCH_SIZE") else "k_ols_wave")
     fetch, write = counter(f, kern, "FETCH_SIZE"), counter(w, kern, "WRITE_SIZE")
     if fetch and write:
         n = 1 << 26
