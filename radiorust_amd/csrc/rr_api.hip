@@ -1592,18 +1592,25 @@ int rr_chain::ensure_mixfold() {
     const int64_t R = fs->denom;
     int64_t nu = fs->numer % R;
     if (nu < 0) nu += R;
-    if (mix_numer == nu && mix_denom == R && mix_ctaps_fl == ctaps_fl && mix_ctaps_ds == ctaps_ds) return RR_OK;
+    if (mix_numer == nu && mix_denom == R && mix_ctaps_fl == ctaps_fl && mix_ctaps_ds == ctaps_ds && mix_table_version == fs->table_version)
+        return RR_OK;
     if (olsG64.size() != 1024) RR_FAIL(RR_ERR_BAD_ARG, "Chain: no polyphase tables to fold the mixer into");
     const size_t s = (size_t)((1024 * nu / R) % 256);  // R divides 8: whole
-    std::vector<float> gp(2 * 1024);
-    for (size_t pp = 0; pp < 4; ++pp) {
-        const double ang = 2.0 * M_PI * (double)((pp * (size_t)nu) % (size_t)R) / (double)R;
-        const cd rot(std::cos(ang), std::sin(ang));
-        for (size_t k = 0; k < 256; ++k) {
-            const cd g = olsG64[256 * pp + (k + s) % 256] * rot;
-            const size_t l = k % 64, c = k / 64, i = 4 * pp + c, dst = ((i >> 1) * 64 + l) * 2 + (i & 1);
-            gp[2 * dst] = (float)g.real();
-            gp[2 * dst + 1] = (float)g.imag();
+    // one table per phasor C = p[ph] the first sample of a call's blocks can meet (R <= 8 of them, 8 KiB each); the table's own
+    // entries (as the kernel's mixer multiplies by them) in f64
+    std::vector<float> gp(2 * 1024 * (size_t)R);
+    const float *tab = reinterpret_cast<const float *>(fs->host_table.data());
+    for (size_t ph = 0; ph < (size_t)R; ++ph) {
+        const cd C((double)tab[2 * ph], (double)tab[2 * ph + 1]);
+        for (size_t pp = 0; pp < 4; ++pp) {
+            const double ang = 2.0 * M_PI * (double)((pp * (size_t)nu) % (size_t)R) / (double)R;
+            const cd rot = cd(std::cos(ang), std::sin(ang)) * C;
+            for (size_t k = 0; k < 256; ++k) {
+                const cd g = olsG64[256 * pp + (k + s) % 256] * rot;
+                const size_t l = k % 64, c = k / 64, i = 4 * pp + c, dst = ((i >> 1) * 64 + l) * 2 + (i & 1);
+                gp[2 * (1024 * ph + dst)] = (float)g.real();
+                gp[2 * (1024 * ph + dst) + 1] = (float)g.imag();
+            }
         }
     }
     RR_TRY(upload(d_olsHmix, gp.data(), gp.size() * sizeof(float), stream));
@@ -1612,6 +1619,7 @@ int rr_chain::ensure_mixfold() {
     mix_denom = R;
     mix_ctaps_fl = ctaps_fl;
     mix_ctaps_ds = ctaps_ds;
+    mix_table_version = fs->table_version;
     return RR_OK;
 }
 
@@ -1729,7 +1737,10 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
             const bool off = [] { const char *e = std::getenv("RR_FRAME_MIXFOLD"); return e && std::atoi(e) == 0; }();
             if (!off && fs->denom >= 1 && 8 % fs->denom == 0 && frame_table_version == fs->table_version && olsG64.size() == 1024) {
                 RR_TRY(ensure_mixfold());
-                a.H = d_olsHmix.p;
+                // the table for the phasor of this call's blocks' first samples: ph0 = (idx0 + e0 - V - 4 pl) mod R (as launch_ols_frame)
+                int64_t ph = ((int64_t)a.idx0 + a.e0 - a.V - 4 * (int64_t)pending_len) % (int64_t)fs->denom;
+                if (ph < 0) ph += fs->denom;
+                a.H = d_olsHmix.as<char>() + (size_t)ph * 1024 * 2 * sizeof(float);
                 a.mixfold = true;
                 a.sigma = mix_sigma;
             }

@@ -295,7 +295,7 @@ struct rr_chain : rr_block {
     std::vector<rr::cd> olsG64;
     rr::DevBuf d_olsHmix;
     int64_t mix_numer = 0, mix_denom = 0;
-    uint64_t mix_ctaps_fl = ~0ull, mix_ctaps_ds = ~0ull;
+    uint64_t mix_ctaps_fl = ~0ull, mix_ctaps_ds = ~0ull, mix_table_version = ~0ull;
     uint64_t frame_table_version = ~0ull;  // the NCO table the mixed-sample history was last written with by a frame call
     float mix_sigma = 1.f;
     int ensure_mixfold();

@@ -2177,6 +2177,9 @@ constexpr int kFrameBlocks = 20;
 #define RR_V_FRAME_GLDS 1  // k_ols_frame: the first half of the tables G_p in LDS (0: all of it from L2, for A/B)
 #endif
 constexpr int kPolyLds = 1136;  // 2 (63 + 72 * 7) + 2 elements
+// SW: the spectrum is taken 128 bins further on (y[0] <-> y[2], y[1] <-> y[3] in front of the inverse): the results' signs
+// alternate - k_ols_frame<true>'s fold of a mixer with s = 128 (rr_chain::ensure_mixfold)
+template <bool SW>
 __device__ __forceinline__ void poly4_block(f2 (&v)[16], f2 (&y)[4], f2 *lds, int l, f2 t_p1, f2 t_p2, const f2 (&t_inv)[3],
                                             const float2 *__restrict__ G, const float4 *Glds) {
     const int g = l >> 4, q = l & 15;
@@ -2267,6 +2270,13 @@ __device__ __forceinline__ void poly4_block(f2 (&v)[16], f2 (&y)[4], f2 *lds, in
     y[1] = cmac(y[1], d[3][1], (f2){gb[2].z, gb[2].w});
     y[2] = cmac(y[2], d[3][2], (f2){gb[3].x, gb[3].y});
     y[3] = cmac(y[3], d[3][3], (f2){gb[3].z, gb[3].w});
+    if (SW) {
+        const f2 t0 = y[0], t1 = y[1];
+        y[0] = y[2];
+        y[1] = y[3];
+        y[2] = t0;
+        y[3] = t1;
+    }
     // inverse DFT_256 (radix 4 x 4 x 4 x 4, as k_ols_wave<4>: one image layout per exchange, inv256_rd)
     idft4(y[0], y[1], y[2], y[3]);
     wave_sync();
@@ -2340,7 +2350,8 @@ struct FrameArgs {
 #ifndef RR_V_FRAME_LD_NT
 #define RR_V_FRAME_LD_NT 1
 #endif
-template <bool MF>  // MF: the mixer folded into the tables (rr_chain::ensure_mixfold) - an instance of its own without the mixer's code
+// MF: the mixer folded into the tables (rr_chain::ensure_mixfold) - instances of their own without the mixer's code; SW: poly4_block<SW>
+template <bool MF, bool SW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ols_frame(FrameArgs a_) {
     const FrameArgs &a = a_;
     const FrameArgs *ka = (const FrameArgs *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -2404,14 +2415,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const float4 *const glp = nullptr;
 #endif
     const long n_clamp = a.n_in - 1024;  // the launcher guarantees n_in >= 1024
-    // mixer folded into the tables: the blocks transform the samples as they are; a block's results times C sigma^(index),
-    // C = nco[ph0] the phasor of a block's first sample (the same for every block of the call)
-    f2 mixfac = {1.f, 0.f};
-    if (MF) {
-        const float2 c0 = a.nco[a.ph0];
-        const float sg = (l & 1) ? a.sigma : 1.f;
-        mixfac = (f2){c0.x * sg, c0.y * sg};
-    }
+    // mixer folded into the tables (MF): the blocks transform the samples as they are; the phasor of a block's first sample (the same
+    // for every block of the call) is in the table the host picked for this call, the alternating sign in poly4_block<SW>
     f2 keep[kFrameBlocks / 4][4];
 #pragma unroll
     for (int kb = 0; kb < kFrameBlocks / 4; ++kb) {
@@ -2495,11 +2500,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 if (r >= a.denom) r -= a.denom;
             }
         }
-        poly4_block(v, keep[kb], lds, l, t_p1, t_p2, t_inv, a.H, glp);
-        if (MF) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) keep[kb][c] = cmul(keep[kb][c], mixfac);
-        }
+        poly4_block<SW>(v, keep[kb], lds, l, t_p1, t_p2, t_inv, a.H, glp);
         // (one block at a time: without this the five unrolled blocks' loads are all hoisted to the front)
         asm volatile("" : "+v"(keep[kb][0]), "+v"(keep[kb][1]), "+v"(keep[kb][2]), "+v"(keep[kb][3]));
     }
@@ -2600,15 +2601,17 @@ int launch_ols_frame(hipStream_t s, const FusedFirArgs &a, const void *pend_in, 
     f.mixfold = a.mixfold ? 1 : 0;
     f.sigma = a.sigma;
     const unsigned grid = 1u + (unsigned)((nfr + 8 * RR_V_FRAMEWIN - 1) / (8 * RR_V_FRAMEWIN) * (8 * RR_V_FRAMEWIN));
-    if (a.mixfold) {
-        if (a.ev_start && a.ev_stop)
-            hipExtLaunchKernelGGL(k_ols_frame<true>, dim3(grid), dim3(256), 0, s, a.ev_start, a.ev_stop, 0, f);
-        else
-            hipLaunchKernelGGL(k_ols_frame<true>, dim3(grid), dim3(256), 0, s, f);
-    } else if (a.ev_start && a.ev_stop)
-        hipExtLaunchKernelGGL(k_ols_frame<false>, dim3(grid), dim3(256), 0, s, a.ev_start, a.ev_stop, 0, f);
-    else
-        hipLaunchKernelGGL(k_ols_frame<false>, dim3(grid), dim3(256), 0, s, f);
+#define RR_FRAME_LAUNCH(MF_, SW_)                                                                                     \
+    do {                                                                                                               \
+        if (a.ev_start && a.ev_stop)                                                                                   \
+            hipExtLaunchKernelGGL((k_ols_frame<MF_, SW_>), dim3(grid), dim3(256), 0, s, a.ev_start, a.ev_stop, 0, f); \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_ols_frame<MF_, SW_>), dim3(grid), dim3(256), 0, s, f);                               \
+    } while (0)
+    if (a.mixfold && a.sigma < 0.f) RR_FRAME_LAUNCH(true, true);
+    else if (a.mixfold) RR_FRAME_LAUNCH(true, false);
+    else RR_FRAME_LAUNCH(false, false);
+#undef RR_FRAME_LAUNCH
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
