@@ -35,13 +35,13 @@ def counter(path, kernel, name):
 f, w = os.path.join(src, "pmc_fetch.summary.txt"), os.path.join(src, "pmc_write.summary.txt")
 if os.path.exists(f) and os.path.exists(w):
     # the chain's dominant kernel: the fused frame kernel where it runs, else the wave-per-block FIR stage
-    kern = ("k_ols_frame<true>" if counter(f, "k_ols_frame<true>", "FETCH_SIZE") else
+    kern = ("k_ols_frame<true" if counter(f, "k_ols_frame<true", "FETCH_SIZE") else
             "k_ols_frame" if counter(f, "k_ols_frame", "FETCH_SIZE") else "k_ols_wave")
     fetch, write = counter(f, kern, "FETCH_SIZE"), counter(w, kern, "WRITE_SIZE")
     if fetch and write:
         n = 1 << 26
         hbm = (2 * fetch + write) * 1024.0
-        json.dump({"kernel": kern, "samples_per_launch": n, "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB": write,
+        json.dump({"kernel": "k_ols_frame<true, SW>" if kern == "k_ols_frame<true" else kern, "samples_per_launch": n, "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB": write,
                    "correction": "FETCH_SIZE x2 (gfx950 reports 1/2 of wide coalesced reads), WRITE_SIZE as is; separate --pmc passes (scripts/gpu_profiles.sh)",
                    "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": 10.0 * n, "ratio": hbm / (10.0 * n),
                    "source": f"profiles/{rnd}_pmc_fetch.summary.txt, profiles/{rnd}_pmc_write.summary.txt (bench.py --profile: chain launches only)"},
