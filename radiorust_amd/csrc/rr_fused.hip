@@ -2166,7 +2166,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OC
 // history for the next call.
 // ---------------------------------------------------------------------------
 int ols_wave_overlap(size_t Lc, size_t granule);
+#ifndef RR_V_FRAMEWIN
 #define RR_V_FRAMEWIN 1  // frames round robin over the XCDs: 0.1915 ms; a contiguous eighth per XCD (0): 0.1965
+#endif
 // (waves per frame, first form with full-size images: 4 waves 0.233 ms, 5 waves 0.30 (one workgroup per CU), 8 waves 0.26, 10 waves 0.28)
 constexpr int kFrameBlocks = 20;
 
