@@ -312,8 +312,8 @@ int rr_chain_process_dev(rr_chain *h, double sample_rate, const void *d_in,
                          size_t n_in, void *d_out, size_t out_cap, size_t *n_out);
 /* Which kernels the last process call ran: 0 = block-by-block; non-zero = fused
  * (1 direct-form k_mix_fir_decim, 2 overlap-save k_ols_decim4, 3 overlap-save
- * k_ols_wave, each followed by k_fft4096; 4 k_ols_frame: both stages in one kernel; 6 the same with the mixer folded
- * into its response tables - NCO periods that divide 8). */
+ * k_ols_wave, each followed by k_fft4096; 4 k_ols_frame: both stages in one kernel; 6 / 7 k_ols_frame / k_ols_wave
+ * with the mixer folded into the response tables - NCO periods that divide 8). */
 int rr_chain_last_path(const rr_chain *h, int *fused);
 int rr_chain_destroy(rr_chain *h);
 

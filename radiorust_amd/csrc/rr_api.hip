@@ -456,6 +456,7 @@ int rr_downsampler::process_dev(double input_rate, const void *d_in, size_t n_in
             f.tw4096 = f_tw.p;
             f.V = f_V;
             f.poly = f_poly;
+            f.mixfold = true;  // every phasor is 1: the instances without a mixer (k_ols_wave<D, true, true>)
             next.advance(n_in, nullptr);
             if (fast_kind == rr_chain::FK_OLSW)
                 RR_TRY(launch_ols_wave(stream, f));
@@ -1623,6 +1624,25 @@ int rr_chain::ensure_mixfold() {
     return RR_OK;
 }
 
+// NCO periods that divide 8 (the benchmark's fs / 8): the mixer folded into the tables (ensure_mixfold) - once the mixed-sample
+// history in front of this call has been written under the table in use (RR_FRAME_MIXFOLD=0: never).  `back` = how far in front
+// of e0 - V the call's first block starts (the blocks' hop, 832 samples, is a multiple of every such period).
+int rr_chain::fold_mixer(FusedFirArgs &a, int64_t back) {
+    const char *env = std::getenv("RR_FRAME_MIXFOLD");  // (read per call: tests switch it within one process)
+    const bool off = env && std::atoi(env) == 0;
+    if (!off && fs->denom >= 1 && 8 % fs->denom == 0 && frame_table_version == fs->table_version && olsG64.size() == 1024) {
+        RR_TRY(ensure_mixfold());
+        // the table for the phasor of the blocks' first samples: ph0 = (idx0 + e0 - V - back) mod R
+        int64_t ph = ((int64_t)a.idx0 + a.e0 - a.V - back) % (int64_t)fs->denom;
+        if (ph < 0) ph += fs->denom;
+        a.H = d_olsHmix.as<char>() + (size_t)ph * 1024 * 2 * sizeof(float);
+        a.mixfold = true;
+        a.sigma = mix_sigma;
+    }
+    frame_table_version = fs->table_version;
+    return RR_OK;
+}
+
 // c = reverse(ir) (*) g in f64, cast to f32; tables by build_fused_fir_tables
 int rr_chain::ensure_ctaps() {
     if (ctaps_fl == fl->design_version && ctaps_ds == ds->design_version) return RR_OK;
@@ -1731,21 +1751,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
         a.tw4096 = d_tw4096.p;
         a.V = ols_V;
         a.poly = ols_poly;
-        // NCO periods that divide 8 (the benchmark's fs / 8): the mixer folded into the tables (ensure_mixfold) - once the
-        // mixed-sample history in front of this call has been written under the table in use (RR_FRAME_MIXFOLD=0: never)
-        {
-            const bool off = [] { const char *e = std::getenv("RR_FRAME_MIXFOLD"); return e && std::atoi(e) == 0; }();
-            if (!off && fs->denom >= 1 && 8 % fs->denom == 0 && frame_table_version == fs->table_version && olsG64.size() == 1024) {
-                RR_TRY(ensure_mixfold());
-                // the table for the phasor of this call's blocks' first samples: ph0 = (idx0 + e0 - V - 4 pl) mod R (as launch_ols_frame)
-                int64_t ph = ((int64_t)a.idx0 + a.e0 - a.V - 4 * (int64_t)pending_len) % (int64_t)fs->denom;
-                if (ph < 0) ph += fs->denom;
-                a.H = d_olsHmix.as<char>() + (size_t)ph * 1024 * 2 * sizeof(float);
-                a.mixfold = true;
-                a.sigma = mix_sigma;
-            }
-            frame_table_version = fs->table_version;
-        }
+        RR_TRY(fold_mixer(a, 4 * (int64_t)pending_len));  // (the frame's first block starts 4 pl samples earlier, as launch_ols_frame)
         // (the launch records its own start / end: marker packets would cost ~4 us of stream time each)
         if (timers.on) timers.begin_ext(ST_FUSED_FIR, &a.ev_start, &a.ev_stop);
         RR_TRY(launch_ols_frame(stream, a, pin, pending_len, pendbuf[po].p, d_out, fo->d_window.p, fo->d_tw.p,
@@ -1793,9 +1799,10 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
         timers.begin_ext(ST_FUSED_FIR, &a.ev_start, &a.ev_stop);
     else
         tk = timers.begin(ST_FUSED_FIR, stream);
-    if (use_ols && ols_N == 1024)
+    if (use_ols && ols_N == 1024) {
+        if (ols_poly && a.D == 4) RR_TRY(fold_mixer(a, 0));
         RR_TRY(launch_ols_wave(stream, a));
-    else if (use_ols)
+    } else if (use_ols)
         RR_TRY(launch_ols_decim(stream, a));
     else
         RR_TRY(launch_fused_fir(stream, a));
@@ -1835,7 +1842,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     }
     if (!ext) timers.end(tk, stream);
     pending_len = rest;
-    last_fused = use_ols ? (ols_N == 1024 ? FK_OLSW : FK_OLS) : FK_DIRECT;
+    last_fused = use_ols ? (ols_N == 1024 ? (a.mixfold ? 7 : FK_OLSW) : FK_OLS) : FK_DIRECT;  // (7: k_ols_wave<4, true, true>)
     if (n_out) *n_out = wrote;
     return RR_OK;
 }

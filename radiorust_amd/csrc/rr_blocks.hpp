@@ -296,9 +296,10 @@ struct rr_chain : rr_block {
     rr::DevBuf d_olsHmix;
     int64_t mix_numer = 0, mix_denom = 0;
     uint64_t mix_ctaps_fl = ~0ull, mix_ctaps_ds = ~0ull, mix_table_version = ~0ull;
-    uint64_t frame_table_version = ~0ull;  // the NCO table the mixed-sample history was last written with by a frame call
+    uint64_t frame_table_version = ~0ull;  // the NCO table the mixed-sample history was last written with by a k_ols_frame / k_ols_wave call
     float mix_sigma = 1.f;
     int ensure_mixfold();
+    int fold_mixer(rr::FusedFirArgs &a, int64_t back);
     rr::DevBuf pendbuf[2];       // its pending decimated samples, ping-pong
     int pb_cur = 0;
     int ensure_xh();

@@ -1669,7 +1669,9 @@ __device__ __forceinline__ const f2 *inv256_rd(const f2 *lds, int l, int pass) {
     return lds + l;
 }
 
-template <int D, bool POLY>
+// MF: no mixer in the kernel - the stand-alone Downsampler (its table is all ones), or the chain with the mixer folded into the
+// response tables (NCO periods that divide 8, rr_chain::ensure_mixfold; SW: the spectrum taken 128 bins further on, D = 4)
+template <int D, bool POLY, bool MF = false, bool SW = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OCC, RR_V_OLSW_OCC))) void k_ols_wave(
     const float2 *__restrict__ xh, int hx, const float2 *__restrict__ in, long n_in, const float2 *__restrict__ nco,
     unsigned denom, unsigned idx0, const float2 *__restrict__ H, const float2 *__restrict__ tw, int V,
@@ -1792,7 +1794,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OC
     // ---- mix: v[2 k' + j] = xs[b0 + 2 l + j + 128 k'] ------------------------------------------
     // (the NCO table carries entry 0 once more behind entry denom - 1, so the pair r, r + 1 is one 16-byte read)
     f2 v[16];
-    if (interior) {
+    if (interior && MF) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[2 * k] = (f2){x[k].x, x[k].y};
+            v[2 * k + 1] = (f2){x[k].z, x[k].w};
+        }
+    } else if (interior) {
         const f4u pp = *reinterpret_cast<const f4u *>(nco + r);
         if (kstep == 0) {  // the period divides 128: one pair of phasors per lane
 #pragma unroll
@@ -1829,7 +1837,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OC
                 const float2 *ptr = inr ? in + pos : xh + (hst ? hx + pos : 0);
                 const float2 xx = *ptr;
                 const f2 p = j ? (f2){pp.z, pp.w} : (f2){pp.x, pp.y};
-                const f2 pk = {inr ? p.x : (hst ? 1.f : 0.f), inr ? p.y : 0.f};
+                // (MF: the block wants the samples UNMIXED - the history, which holds mixed ones, times conj(p))
+                const f2 pk = MF ? (f2){inr ? 1.f : (hst ? p.x : 0.f), hst ? -p.y : 0.f}
+                                 : (f2){inr ? p.x : (hst ? 1.f : 0.f), inr ? p.y : 0.f};
                 const f2 xv = {(inr || hst) ? xx.x : 0.f, (inr || hst) ? xx.y : 0.f};
                 v[2 * k + j] = cmul(xv, pk);
             }
@@ -2022,6 +2032,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OC
     const unsigned recs = (unsigned)(left < per_block ? left : per_block) * 8u;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + mb, 0, recs, 0x00020000);
     if constexpr (D == 4) {
+        if (SW) {  // results with alternating signs = the spectrum 128 bins further on
+            const f2 t0 = y[0], t1 = y[1];
+            y[0] = y[2];
+            y[1] = y[3];
+            y[2] = t0;
+            y[3] = t1;
+        }
         // ---- inverse DFT_256, Stockham radix 4 x 4: butterfly l reads in[l + 64 c] ------------------
         // Each of the three exchanges has its own image layout (inv256_rd): the LDS serves 8-byte reads in halves of 32 lanes
         // over 64 banks, 8-byte stores in groups of 16 lanes and 16-byte stores in groups of 8 lanes over 32 banks, and one
@@ -2637,17 +2654,29 @@ static int launch_ols_wave_d(hipStream_t s, const FusedFirArgs &a) {
     if (ph < 0) ph += den;
     const unsigned hopm = (unsigned)((int64_t)(1024 - a.V) % den), kstep = (unsigned)(128 % den);
     const unsigned grid = (unsigned)((nblocks + 8 * kWaveWin - 1) / (8 * kWaveWin) * (8 * kWaveWin));
-    if (a.ev_start && a.ev_stop)
-        hipExtLaunchKernelGGL((k_ols_wave<D, POLY>), dim3(grid), dim3(64), 0, s, a.ev_start, a.ev_stop, 0, (const float2 *)a.xh, (int)a.hx,
-                              (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0,
-                              (const float2 *)a.H, (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out,
-                              (long)a.e0, (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, kstep,
-                              1.0 / (double)den);
-    else
-        hipLaunchKernelGGL((k_ols_wave<D, POLY>), dim3(grid), dim3(64), 0, s, (const float2 *)a.xh, (int)a.hx,
-                           (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0,
-                           (const float2 *)a.H, (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out, (long)a.e0,
-                           (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, kstep, 1.0 / (double)den);
+#define RR_OLSW_LAUNCH(MF_, SW_)                                                                                                     \
+    do {                                                                                                                              \
+        if (a.ev_start && a.ev_stop)                                                                                                  \
+            hipExtLaunchKernelGGL((k_ols_wave<D, POLY, MF_, SW_>), dim3(grid), dim3(64), 0, s, a.ev_start, a.ev_stop, 0,              \
+                                  (const float2 *)a.xh, (int)a.hx, (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, \
+                                  a.idx0, (const float2 *)a.H, (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out,         \
+                                  (long)a.e0, (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, kstep,            \
+                                  1.0 / (double)den);                                                                                 \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((k_ols_wave<D, POLY, MF_, SW_>), dim3(grid), dim3(64), 0, s, (const float2 *)a.xh, (int)a.hx,          \
+                               (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0, (const float2 *)a.H,       \
+                               (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out, (long)a.e0, (float2 *)a.xh_out,         \
+                               (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, kstep, 1.0 / (double)den);                           \
+    } while (0)
+    // (a.mixfold: the caller's table is all ones - the stand-alone Downsampler - or a.H holds the tables with the mixer folded in)
+    if constexpr (POLY) {
+        if (a.mixfold && D == 4 && a.sigma < 0.f) RR_OLSW_LAUNCH(true, true);
+        else if (a.mixfold) RR_OLSW_LAUNCH(true, false);
+        else RR_OLSW_LAUNCH(false, false);
+    } else {
+        RR_OLSW_LAUNCH(false, false);
+    }
+#undef RR_OLSW_LAUNCH
     RR_HIP(hipGetLastError());
     return RR_OK;
 }

@@ -509,8 +509,10 @@ def test_chain_frame_kernel_and_two_kernel_calls_in_one_stream(rr, oracle):
         assert rms_rel(a, b) <= 1e-5
 
 
-def test_chain_frame_kernel_with_the_mixer_folded_into_its_tables(rr, oracle, monkeypatch):
-    """NCO periods that divide 8 (shifts by multiples of fs / 8): k_ols_frame<true> transforms the samples unmixed, the mixer
+@pytest.mark.parametrize("kernel", ["olsf", "olsw"])
+def test_chain_frame_kernel_with_the_mixer_folded_into_its_tables(rr, oracle, monkeypatch, kernel):
+    """NCO periods that divide 8 (shifts by multiples of fs / 8): k_ols_frame<true> (and k_ols_wave<4, true, true>, which the
+    chain runs on calls below 2^23 samples) transforms the samples unmixed, the mixer
     sits in the response tables (rr_chain::ensure_mixfold) and in one product per result.  The frame kernel forced onto short
     ragged calls, retunes between shifts with periods 8, 8, 4, 2, 1 and 16 (the last keeps the mixer in the kernel), an
     interrupt; every call against the same stream with the fold switched off, and the whole against the C oracle section by
@@ -525,7 +527,7 @@ def test_chain_frame_kernel_with_the_mixer_folded_into_its_tables(rr, oracle, mo
     d_in = torch.empty(n, dtype=torch.complex64, device="cuda")
     rr.synth_iq_dev(0, st, 9, 0, n, d_in.data_ptr())
     torch.cuda.synchronize()
-    monkeypatch.setenv("RR_FUSED_KERNEL", "olsf")
+    monkeypatch.setenv("RR_FUSED_KERNEL", kernel)
 
     def run(fold):
         monkeypatch.setenv("RR_FRAME_MIXFOLD", "1" if fold else "0")
@@ -544,6 +546,7 @@ def test_chain_frame_kernel_with_the_mixer_folded_into_its_tables(rr, oracle, mo
             torch.cuda.synchronize()
             outs.append(d_out[:w].clone())
             folded.append(g.last_path_mixer_folded())
+            assert g.last_path_kernel() in ("", "k_ols_frame" if kernel == "olsf" else "k_ols_wave")
             off += m
         return outs
 
