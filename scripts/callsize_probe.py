@@ -6,16 +6,17 @@ import torch
 import radiorust_amd as rr
 fs = 200e6
 st = torch.cuda.current_stream().cuda_stream
-N = 1 << 26
+LGS = [int(a) for a in sys.argv[1:]] or [14, 16, 18, 20, 22, 24, 26]  # (up to 28: 2 GiB of input)
+N = 1 << max(LGS)
 d_in = torch.empty(N, dtype=torch.complex64, device="cuda")
 rr.synth_iq_dev(0, st, 1, 0, N, d_in.data_ptr())
 d_out = torch.empty(N // 4 + 8192, dtype=torch.complex64, device="cuda")
 lp = lambda b, f: 1.0 if abs(f) <= 20e6 else 0.0
-for lg in (14, 16, 18, 20, 22, 24, 26):
+for lg in LGS:
     n = 1 << lg
     ch = rr.Chain(shift=25e6, filter_len=64, freq_resp=lp, output_rate=50e6, bandwidth=40e6, fft_len=4096,
                   fft_window=rr.Kaiser.with_null_at_bin(2.0))
-    calls = max(200, min(20000, (1 << 30) // n))
+    calls = max(50 if lg > 26 else 200, min(20000, (1 << 30) // n))
     for _ in range(min(calls, 300)): ch.process_dev(fs, d_in.data_ptr(), n, d_out.data_ptr(), d_out.numel())
     torch.cuda.synchronize()
     t = time.perf_counter()
