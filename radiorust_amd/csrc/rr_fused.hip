@@ -3280,6 +3280,9 @@ int launch_filter_wave(hipStream_t s, const void *hist, size_t hist_len, const v
 // chunks in registers and loads one new chunk (4 loads) per frame; the window values of the lane
 // (4 P) and the three twiddle seeds stay in registers for the whole run.
 // ---------------------------------------------------------------------------
+#ifndef RR_V_CHAN_NT
+#define RR_V_CHAN_NT 2  // bit 0: the pieces by non-temporal loads, bit 1: the bins by non-temporal stores (cfg3: 0.212 / 0.231 / 0.200 / 0.212 ms for 0 .. 3: the pieces neighbouring runs share want their L2 copies)
+#endif
 #define RR_V_CHANWIN 4  // cfg3: one contiguous eighth of the runs per XCD 0.250 ms; windows of 1 .. 6 and 64 runs per XCD 0.222-0.226; 8: 0.232, 16: 0.265, 32: 0.233
 // H = hop / 64: 4 is the critically sampled filterbank (one new chunk of 256 per frame); 2 and 1 are the filterbanks
 // oversampled 2 and 4 times (Rechunker(hop) -> Overlapper -> Fourier -> every P-th bin, hop 128 / 64): the window of
@@ -3314,8 +3317,12 @@ __global__ __launch_bounds__(64) void k_channelizer256(const float2 *__restrict_
     auto load_piece = [&](long qi) -> f2 {
         const long pos = base0 + 64 * qi;
         const float2 *src = pos >= 0 ? in + pos : hist + (hist_len + pos);
+#if RR_V_CHAN_NT & 1
+        return __builtin_nontemporal_load(reinterpret_cast<const f2 *>(src) + l);
+#else
         const float2 v = src[l];
         return (f2){v.x, v.y};
+#endif
     };
     constexpr int NQ = 4 * P;
     f2 xs[NQ];
@@ -3383,10 +3390,14 @@ __global__ __launch_bounds__(64) void k_channelizer256(const float2 *__restrict_
         float2 *dst = out + (size_t)(f0 + it) * 256 + l;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
+#if RR_V_CHAN_NT & 2
+            __builtin_nontemporal_store(y[c], reinterpret_cast<f2 *>(dst) + 64 * c);
+#else
             float2 o;
             o.x = y[c].x;
             o.y = y[c].y;
             dst[64 * c] = o;
+#endif
         }
     }
 }
