@@ -29,6 +29,7 @@
 #include "rr_wave_math.hpp"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 #include <cstring>
 
@@ -172,11 +173,25 @@ __global__ __launch_bounds__(256) void k_decim_poly(DecimArgs a, const uint2 *__
                     step();
                 }
             }
-            for (; q < nld; q += 256) {
-                const f2 v = __builtin_nontemporal_load(src + q);
-                xs[row * S + col] = a.denom ? mix(v) : v;
-                step();
-            }
+            // the rest (fewer than 8 x 256 samples - with a short period, all of the tile) in batches of 4 and 2, so that a lane
+            // still has several loads in flight (3 : 1: tiles of 1584 samples, which took six round trips one behind the other;
+            // one batch of 8 with every load and store predicated was slower everywhere: 10 : 1 0.146 -> 0.160 ms)
+            auto batch = [&](auto nb) {
+                constexpr int NB = decltype(nb)::value;
+                for (; q + (NB - 1) * 256 < nld; q += NB * 256) {
+                    f2 v[NB];
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) v[u] = __builtin_nontemporal_load(src + q + 256 * u);
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        xs[row * S + col] = a.denom ? mix(v[u]) : v[u];
+                        step();
+                    }
+                }
+            };
+            batch(std::integral_constant<int, 4>{});
+            batch(std::integral_constant<int, 2>{});
+            batch(std::integral_constant<int, 1>{});
         } else {
             // edges: the history in front (zeros before it), nothing behind the input
             for (int q = t; q < nld; q += 256) {
@@ -341,7 +356,10 @@ __global__ __launch_bounds__(256) void k_decim_poly_f64(DecimArgs64 a, const Tap
 }  // namespace
 
 // LDS per workgroup: tiles of about 24 KiB (6 workgroups per CU) where the period allows, never more than 64 KiB
-static constexpr size_t kDecimLdsTarget = 24 * 1024, kDecimLdsMax = 64 * 1024;
+#ifndef RR_V_DECIM_LDS_KB
+#define RR_V_DECIM_LDS_KB 26  // (26: 3 : 1 takes tiles of 1024 periods = 24.4 KiB instead of 512)
+#endif
+static constexpr size_t kDecimLdsTarget = RR_V_DECIM_LDS_KB * 1024, kDecimLdsMax = 64 * 1024;
 
 static size_t decim_nc(uint64_t P, size_t L) { return (P - 1 + L + P - 1) / P; }  // tap columns for any phase offset
 
