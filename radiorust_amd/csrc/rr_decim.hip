@@ -308,8 +308,7 @@ __global__ __launch_bounds__(256) void k_decim_poly_f64(DecimArgs64 a, const Tap
         int row = t % P, col = t / P;
         const int dr = 256 % P, dc = 256 / P;
         const bool interior = p_lo >= 0 && p_lo + nld <= a.n_in;
-        for (int q = t; q < nld; q += 256) {
-            const double2 xv = interior ? a.in[p_lo + q] : fetch(p_lo + q);
+        auto put = [&](double2 xv) {
             xs[row * S + col] = (d2){xv.x, xv.y};
             row += dr;
             col += dc;
@@ -317,6 +316,20 @@ __global__ __launch_bounds__(256) void k_decim_poly_f64(DecimArgs64 a, const Tap
                 row -= P;
                 ++col;
             }
+        };
+        int q = t;
+        if (interior) {  // four loads of a lane in flight (as the f32 kernel's batches)
+            const double2 *src = a.in + p_lo;
+            for (; q + 3 * 256 < nld; q += 4 * 256) {
+                double2 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = src[q + 256 * u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) put(v[u]);
+            }
+            for (; q < nld; q += 256) put(src[q]);
+        } else {
+            for (; q < nld; q += 256) put(fetch(p_lo + q));
         }
     }
     __syncthreads();

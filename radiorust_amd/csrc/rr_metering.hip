@@ -207,17 +207,29 @@ __global__ __launch_bounds__(256) void k_upsample_int(const float2 *__restrict__
     const int J = (L - 1) / U;  // the oldest input of output U t is t - J
     f2v *xs = reinterpret_cast<f2v *>(up_smem);  // inputs tile0 - J .. tile0 + 255
     const long tile0 = (long)blockIdx.x * 256;
-    for (int i = threadIdx.x; i < 256 + J; i += 256) {
-        const long t = tile0 - J + i;
-        float2 x;
-        x.x = 0.f;
-        x.y = 0.f;
-        if (t >= 0) {
-            if (t < n_in) x = in[t];
-        } else if (t >= -hn) {
-            x = hist[hn + t];
+    static_assert(256 + kUpJmax <= 3 * 256, "three loads per lane cover the tile");
+    // (all of a lane's loads - up to 3: J <= kUpJmax - requested before the first is stored: one round trip per tile instead of two)
+    {
+        float2 x[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int i = threadIdx.x + 256 * u;
+            const long t = tile0 - J + i;
+            x[u].x = 0.f;
+            x[u].y = 0.f;
+            if (i < 256 + J) {
+                if (t >= 0) {
+                    if (t < n_in) x[u] = in[t];
+                } else if (t >= -hn) {
+                    x[u] = hist[hn + t];
+                }
+            }
         }
-        xs[i] = (f2v){x.x, x.y};
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int i = threadIdx.x + 256 * u;
+            if (i < 256 + J) xs[i] = (f2v){x[u].x, x[u].y};
+        }
     }
     __syncthreads();
     f2v acc[U];
