@@ -134,12 +134,6 @@ __global__ __launch_bounds__(256) void k_decim_poly(DecimArgs a, const uint2 *__
             const float2 rt = a.nco[dph];
             rot = (f2){rt.x, rt.y};
         }
-        auto mix = [&](f2 v) {
-            const float2 pp = a.nco[ph];
-            ph += dph;
-            if (ph >= a.denom) ph -= a.denom;
-            return cmul(v, (f2){pp.x, pp.y});
-        };
         if (interior) {
             const f2 *src = reinterpret_cast<const f2 *>(a.in + p_lo);
             int q = t;
@@ -180,11 +174,21 @@ __global__ __launch_bounds__(256) void k_decim_poly(DecimArgs a, const uint2 *__
                 constexpr int NB = decltype(nb)::value;
                 for (; q + (NB - 1) * 256 < nld; q += NB * 256) {
                     f2 v[NB];
+                    float2 pp[NB];
+                    // (the phasors first, all of them: asked for one by one behind the samples they are a round trip each)
+                    if (a.denom) {
+#pragma unroll
+                        for (int u = 0; u < NB; ++u) {
+                            pp[u] = a.nco[ph];
+                            ph += dph;
+                            if (ph >= a.denom) ph -= a.denom;
+                        }
+                    }
 #pragma unroll
                     for (int u = 0; u < NB; ++u) v[u] = __builtin_nontemporal_load(src + q + 256 * u);
 #pragma unroll
                     for (int u = 0; u < NB; ++u) {
-                        xs[row * S + col] = a.denom ? mix(v[u]) : v[u];
+                        xs[row * S + col] = a.denom ? cmul(v[u], (f2){pp[u].x, pp[u].y}) : v[u];
                         step();
                     }
                 }
