@@ -622,6 +622,8 @@ __device__ __forceinline__ void wave_dft512(f2 (&a)[8], f2 *lds, int l, f2 s1, f
 // The 512-bin channelizer at hop = 512 with FOUR neighbouring frames per wave (8 values per lane and frame): branches + 3 chunk
 // reads for four frames instead of 4 branches (4 taps per branch: 7 instead of 16); chunk p goes into frame r with the window's
 // segment p - r.
+// (WS: the sliding segments - 152 registers, three waves per SIMD; with 2 taps per branch the four waves of the plain form are ahead: 0.199 against 0.213 ms)
+template <bool WS>
 __global__ __launch_bounds__(64) void k_chan512_quad(const float2 *__restrict__ head, long n_head, const float2 *__restrict__ in,
                                                      float2 *__restrict__ out, const float *__restrict__ window,
                                                      const float2 *__restrict__ tw, unsigned count, int branches) {
@@ -638,22 +640,34 @@ __global__ __launch_bounds__(64) void k_chan512_quad(const float2 *__restrict__ 
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[r][k] = (f2){0.f, 0.f};
     const int chunks = branches + nfr - 1;
-    for (int p = 0; p < chunks; ++p) {
-        f2 x[8];
+    // (the window's last four segments stay in registers, segment s in slot s mod 4 - the chunk loop is unrolled by 4 -: one new
+    //  segment per chunk instead of four, as k_chan1024_multi)
+    [[maybe_unused]] float wseg[4][8];
+    for (int p0 = 0; p0 < chunks; p0 += 4) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const long i = base + 512L * p + l + 64 * k;
-            const float2 t = (i >= 0) ? in[i] : head[n_head + i];
-            x[k] = (f2){t.x, t.y};
-        }
+        for (int pi = 0; pi < 4; ++pi) {
+            const int p = p0 + pi;
+            if (p >= chunks) break;
+            if (WS && p < branches) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int seg = p - r;
-            if (seg >= 0 && seg < branches && r < nfr) {
+                for (int k = 0; k < 8; ++k) wseg[pi][k] = window[512 * p + l + 64 * k];
+            }
+            f2 x[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float w = window[512 * seg + l + 64 * k];
-                    v[r][k] = __builtin_elementwise_fma(x[k], (f2){w, w}, v[r][k]);
+            for (int k = 0; k < 8; ++k) {
+                const long i = base + 512L * p + l + 64 * k;
+                const float2 t = (i >= 0) ? in[i] : head[n_head + i];
+                x[k] = (f2){t.x, t.y};
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int seg = p - r;
+                if (seg >= 0 && seg < branches && r < nfr) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float w = WS ? wseg[(pi - r + 4) % 4][k] : window[512 * seg + l + 64 * k];
+                        v[r][k] = __builtin_elementwise_fma(x[k], (f2){w, w}, v[r][k]);
+                    }
                 }
             }
         }
@@ -734,9 +748,14 @@ int launch_chan512(hipStream_t s, const void *head, size_t n_head, const void *i
     if (count > 0x7fffff00ull) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: too many frames");
     if (chan_pair_enabled() && hop == 512 && branches >= 2) {
         const size_t quads = (count + 3) / 4;
-        hipLaunchKernelGGL(k_chan512_quad, dim3((unsigned)((quads + 127) / 128 * 128)), dim3(64), 0, s, (const float2 *)head,
-                           (long)n_head, (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw512,
-                           (unsigned)count, (int)branches);
+        if (branches >= 3)
+            hipLaunchKernelGGL(k_chan512_quad<true>, dim3((unsigned)((quads + 127) / 128 * 128)), dim3(64), 0, s, (const float2 *)head,
+                               (long)n_head, (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw512,
+                               (unsigned)count, (int)branches);
+        else
+            hipLaunchKernelGGL(k_chan512_quad<false>, dim3((unsigned)((quads + 127) / 128 * 128)), dim3(64), 0, s, (const float2 *)head,
+                               (long)n_head, (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw512,
+                               (unsigned)count, (int)branches);
         RR_HIP(hipGetLastError());
         return RR_OK;
     }
@@ -947,27 +966,33 @@ __global__ __launch_bounds__(128) void k_chan2048_pair(const float2 *__restrict_
 #pragma unroll
     for (int k = 0; k < 16; ++k) va[k] = vb[k] = (f2){0.f, 0.f};
     const int chunks = branches + (has_b ? 1 : 0);
-    for (int p = 0; p < chunks; ++p) {
-        const long bp = base + 2048L * p + t;
-        f2 x[16];
+    // (a segment of the window serves frame a at chunk p and frame b at chunk p + 1: it stays in registers in between - the loop
+    //  is unrolled by 2, segment s in slot s mod 2 -, 32 instead of 48 vector-memory instructions per chunk)
+    float wseg[2][16];
+    for (int p0 = 0; p0 < chunks; p0 += 2) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const long i = bp + 128 * k;
-            const float2 xx = (i >= 0) ? in[i] : head[n_head + i];
-            x[k] = (f2){xx.x, xx.y};
-        }
-        if (p < branches) {
+        for (int pi = 0; pi < 2; ++pi) {
+            const int p = p0 + pi;
+            if (p >= chunks) break;
+            if (p < branches) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float w = window[2048 * p + t + 128 * k];
-                va[k] = __builtin_elementwise_fma(x[k], (f2){w, w}, va[k]);
+                for (int k = 0; k < 16; ++k) wseg[pi][k] = window[2048 * p + t + 128 * k];
             }
-        }
-        if (p >= 1) {
+            const long bp = base + 2048L * p + t;
+            f2 x[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const float w = window[2048 * (p - 1) + t + 128 * k];
-                vb[k] = __builtin_elementwise_fma(x[k], (f2){w, w}, vb[k]);
+                const long i = bp + 128 * k;
+                const float2 xx = (i >= 0) ? in[i] : head[n_head + i];
+                x[k] = (f2){xx.x, xx.y};
+            }
+            if (p < branches) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) va[k] = __builtin_elementwise_fma(x[k], (f2){wseg[pi][k], wseg[pi][k]}, va[k]);
+            }
+            if (p >= 1) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) vb[k] = __builtin_elementwise_fma(x[k], (f2){wseg[pi ^ 1][k], wseg[pi ^ 1][k]}, vb[k]);
             }
         }
     }
@@ -1227,27 +1252,33 @@ __global__ __launch_bounds__(256) void k_chan4096_pair(const float2 *__restrict_
 #pragma unroll
     for (int k = 0; k < 16; ++k) va[k] = vb[k] = (f2){0.f, 0.f};
     const int chunks = branches + (has_b ? 1 : 0);
-    for (int p = 0; p < chunks; ++p) {
-        const long bp = base + 4096L * p + j;
-        f2 x[16];
+    // (a segment of the window serves frame a at chunk p and frame b at chunk p + 1: it stays in registers in between - the loop
+    //  is unrolled by 2, segment s in slot s mod 2 -, 32 instead of 48 vector-memory instructions per chunk)
+    float wseg[2][16];
+    for (int p0 = 0; p0 < chunks; p0 += 2) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const long i = bp + 256 * k;
-            const float2 t = (i >= 0) ? in[i] : head[n_head + i];
-            x[k] = (f2){t.x, t.y};
-        }
-        if (p < branches) {
+        for (int pi = 0; pi < 2; ++pi) {
+            const int p = p0 + pi;
+            if (p >= chunks) break;
+            if (p < branches) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float w = window[4096 * p + j + 256 * k];
-                va[k] = __builtin_elementwise_fma(x[k], (f2){w, w}, va[k]);
+                for (int k = 0; k < 16; ++k) wseg[pi][k] = window[4096 * p + j + 256 * k];
             }
-        }
-        if (p >= 1) {
+            const long bp = base + 4096L * p + j;
+            f2 x[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const float w = window[4096 * (p - 1) + j + 256 * k];
-                vb[k] = __builtin_elementwise_fma(x[k], (f2){w, w}, vb[k]);
+                const long i = bp + 256 * k;
+                const float2 xx = (i >= 0) ? in[i] : head[n_head + i];
+                x[k] = (f2){xx.x, xx.y};
+            }
+            if (p < branches) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) va[k] = __builtin_elementwise_fma(x[k], (f2){wseg[pi][k], wseg[pi][k]}, va[k]);
+            }
+            if (p >= 1) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) vb[k] = __builtin_elementwise_fma(x[k], (f2){wseg[pi ^ 1][k], wseg[pi ^ 1][k]}, vb[k]);
             }
         }
     }
@@ -3120,36 +3151,55 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 2 ? 4 :
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[r][k] = (f2){0.f, 0.f};
     const int chunks = branches + nfr - 1;
-    for (int p = 0; p < chunks; ++p) {
-        const long bp = base + 1024L * p;
-        f2 x[16];
-        if (bp >= 0) {
-            const f4u *src = reinterpret_cast<const f4u *>(in + bp) + l;
+    // The window's segment s is used by chunk s + r of frame r: the lane keeps the last R segments in registers (segment s in slot
+    // s mod R - the loop over the chunks is unrolled by R, so the slots are register names) and reads ONE new segment per chunk
+    // instead of R (8 taps per branch, R = 4: 16 instead of 40 vector-memory instructions per chunk).
+#ifndef RR_V_CHAN1024_WSLIDE
+#define RR_V_CHAN1024_WSLIDE 1
+#endif
+    // (R = 2 at four waves per SIMD has no room for the 32 registers: 22 spilled dwords, 2 taps per branch 0.203 -> 0.249 ms; R = 4, 8 taps: 0.328 -> 0.305)
+    constexpr bool WS = RR_V_CHAN1024_WSLIDE && R >= 3;
+    [[maybe_unused]] float2 wseg[R][8];
+    for (int p0 = 0; p0 < chunks; p0 += R) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const f4u t = *(src + 64 * k);
-                x[2 * k] = (f2){t.x, t.y};
-                x[2 * k + 1] = (f2){t.z, t.w};
+        for (int pi = 0; pi < R; ++pi) {
+            const int p = p0 + pi;
+            if (p >= chunks) break;
+            const long bp = base + 1024L * p;
+            if (WS && p < branches) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) wseg[pi][k] = *reinterpret_cast<const float2 *>(window + 1024 * p + 2 * l + 128 * k);
             }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const long i = bp + 2 * l + j + 128 * k;
-                    const float2 t = (i >= 0) ? in[i] : head[n_head + i];
-                    x[2 * k + j] = (f2){t.x, t.y};
-                }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int seg = p - r;
-            if (seg >= 0 && seg < branches && r < nfr) {
+            f2 x[16];
+            if (bp >= 0) {
+                const f4u *src = reinterpret_cast<const f4u *>(in + bp) + l;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const float2 w = *reinterpret_cast<const float2 *>(window + 1024 * seg + 2 * l + 128 * k);
-                    v[r][2 * k] = __builtin_elementwise_fma(x[2 * k], (f2){w.x, w.x}, v[r][2 * k]);
-                    v[r][2 * k + 1] = __builtin_elementwise_fma(x[2 * k + 1], (f2){w.y, w.y}, v[r][2 * k + 1]);
+                    const f4u t = *(src + 64 * k);
+                    x[2 * k] = (f2){t.x, t.y};
+                    x[2 * k + 1] = (f2){t.z, t.w};
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const long i = bp + 2 * l + j + 128 * k;
+                        const float2 t = (i >= 0) ? in[i] : head[n_head + i];
+                        x[2 * k + j] = (f2){t.x, t.y};
+                    }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int seg = p - r;
+                if (seg >= 0 && seg < branches && r < nfr) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float2 w = WS ? wseg[(pi - r + R) % R][k]
+                                                              : *reinterpret_cast<const float2 *>(window + 1024 * seg + 2 * l + 128 * k);
+                        v[r][2 * k] = __builtin_elementwise_fma(x[2 * k], (f2){w.x, w.x}, v[r][2 * k]);
+                        v[r][2 * k + 1] = __builtin_elementwise_fma(x[2 * k + 1], (f2){w.y, w.y}, v[r][2 * k + 1]);
+                    }
                 }
             }
         }
@@ -3196,9 +3246,10 @@ int launch_chan1024(hipStream_t s, const void *head, size_t n_head, const void *
     // critically sampled with at least two taps per branch: two frames per wave (RR_CHAN_PAIR=0 keeps one)
     if (chan_pair_enabled() && hop == 1024 && branches >= 2) {
         // frames per wave: 8 taps per branch, per 2^26 samples: 2 frames 0.368 ms, 3 frames 0.354, 4 frames 0.336 (one frame: 0.471);
-        // four from 6 taps per branch on, two below (RR_CHAN1024_RUN = 2 / 3 / 4 overrides)
+        // with the window's segments kept in registers (R >= 3): 2 / 4 / 6 / 8 / 16 taps per branch 0.200 / 0.233 / 0.270 / 0.309 / 0.447 ms for three frames,
+        // 0.224 / 0.246 / 0.274 / 0.304 / 0.421 for four, 0.210 / 0.266 for two: four from 8 taps per branch on, three below (RR_CHAN1024_RUN = 2 / 3 / 4 overrides)
         static const int runlen = [] { const char *e = std::getenv("RR_CHAN1024_RUN"); return e ? std::atoi(e) : 0; }();
-        const size_t R = runlen == 3 ? 3 : runlen == 4 ? 4 : runlen == 2 ? 2 : (branches >= 6 ? 4 : 2);
+        const size_t R = runlen == 3 ? 3 : runlen == 4 ? 4 : runlen == 2 ? 2 : (branches >= 8 ? 4 : 3);
         const size_t runs = (count + R - 1) / R;
         const unsigned g2 = (unsigned)((runs + 127) / 128 * 128);
 #define RR_CH1024(RR_)                                                                                                      \
