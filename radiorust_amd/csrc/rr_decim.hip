@@ -131,7 +131,11 @@ __global__ __launch_bounds__(256) void k_decim_poly(DecimArgs a, const uint2 *__
             ph = r0;
             dph = 256u % a.denom;
             dph8 = 2048u % a.denom;
-            const float2 rt = a.nco[dph];
+            // the PURE rotation by 256 samples, e^{j 2 pi (256 numer mod denom) / denom}, kept behind the table
+            // (rr_freqshifter::prepare: entry denom + 1 + k steps 128 k samples).  The table's own entry dph is
+            // that rotation times e^{j start_phase} (transform.rs:322-337: after a retune or a rate change the
+            // table starts at the phase of the current phasor), so it must not serve as a step
+            const float2 rt = a.nco[a.denom + 1 + 2];
             rot = (f2){rt.x, rt.y};
         }
         if (interior) {
@@ -434,7 +438,12 @@ void build_decim_poly_taps(const std::vector<double> &ir, uint64_t P, uint64_t Q
 int launch_decim_poly(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *T,
                       uint64_t P, uint64_t Q, int Lp, size_t L, int64_t e_first0, void *out, size_t n_out, void *hist_out,
                       size_t hist_out_len, const void *nco, uint32_t denom, uint32_t idx0, int dtype) {
-    if (n_out == 0) return RR_OK;
+    // the history is written by the LAST tile's workgroup: a call without outputs has no tile, so a caller that
+    // would flip to hist_out afterwards must not come here (rr_downsampler::process_dev: `produce &&`)
+    if (n_out == 0) {
+        if (hist_out) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: k_decim_poly cannot leave a history without producing outputs");
+        return RR_OK;
+    }
     if (dtype == RR_F64) {
         if (nco) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: the fused mixer is f32 only");
         DecimArgs64 a;

@@ -632,3 +632,87 @@ def test_meter_is_the_bandwidth_meter_example(rr, oracle, dtype, tol):
         bw_ref = oracle.bandwidth(0.01, out_rate, b, flt=np.float64)
         bw_got = metering.bandwidth(0.01, out_rate, a.chunk, dtype=dtype)
         assert abs(bw_got - bw_ref) <= 1e-3 * bw_ref + 1e-6
+
+
+def _meter_vs_oracle(rr, oracle, *, fs, out_rate, max_bw, chunk_len, quality, script, seed=43, tol=1e-5):
+    """Drives rr.Meter and the oracle's FreqShifter -> Downsampler -> Filter -> Overlapper -> Fourier side by side through
+    `script`, a list of ("feed", n) / ("shift", hz) / ("rate", hz) steps; returns the number of spectra compared."""
+    resp = lambda _b, f: 1.0 if abs(f) <= max_bw / 2 else 0.0  # noqa: E731
+    total = sum(s[1] for s in script if s[0] == "feed")
+    x = oracle.synth_iq(seed, 0, total)
+    shift0 = next(s[1] for s in script if s[0] == "shift")
+    g = rr.Meter(shift=shift0, output_rate=out_rate, bandwidth=max_bw, chunk_len=chunk_len, freq_resp=resp, overlap=quality,
+                 fft_window=rr.Kaiser.with_null_at_bin(float(quality)))
+    sh = oracle.FreqShifter(1.0, shift0, flt=np.float64)
+    ds = oracle.Downsampler(chunk_len, out_rate, max_bw, flt=np.float64)
+    fl = oracle.Filter(resp, flt=np.float64)
+    fo = oracle.Fourier(oracle.Kaiser.with_null_at_bin(float(quality)), flt=np.float64)
+    hist, ref, got = [], [], []
+    rate, off, first = fs, 0, True
+    for op, v in script:
+        if op == "shift":
+            if not first:
+                g.set_shift(v)
+                sh.set_shift(v)
+            first = False
+            continue
+        if op == "rate":
+            rate = v
+            continue
+        piece = x[off : off + v]
+        off += v
+        out = g.process(rr.Samples(rate, piece))
+        if v >= 4096:
+            assert g.front_fused(), (op, v)  # mixer and decimator as ONE kernel (k_decim_poly with the table riding along)
+        got += out
+        for c in ds.feed(rate, sh.process(rate, piece)):
+            z = fl.process(out_rate, c)
+            if z is not None:
+                hist.append(z)
+                if len(hist) >= quality:
+                    ref.append(fo.process(np.concatenate(hist[-quality:])))
+                    del hist[: len(hist) - (quality - 1)]
+        assert len(got) == len(ref), (op, v, len(got), len(ref))
+    worst = 0.0
+    for a, b in zip(got, ref):
+        worst = max(worst, rms_rel(a.chunk, b))
+    assert worst <= tol, worst
+    return len(ref)
+
+
+@pytest.mark.parametrize("case", ["10to1", "8to3", "tiny_denom", "denom_not_dividing_256"])
+def test_meter_retunes_between_ragged_calls(rr, oracle, case):
+    """The fused front end (FreqShifter riding on k_decim_poly) after `set_shift`: the table is then rebuilt WITH the phase
+    of the current phasor (transform.rs:322-337), so no entry of it is a pure rotation - the kernel's 256-sample steps
+    must come from the rotations kept behind the table.  Ratios 10 : 1 (the example's) and 8 : 3 (simple_receiver.rs:28,
+    the mixer riding along with Q > 1), a two-entry table, and a period that does not divide 256; every call is >= 4096
+    samples and ragged, so the 8-load interior batches, the 4 / 2 / 1 tails and the edge tiles all meet a non-zero
+    start phase."""
+    if case == "8to3":
+        cfg = dict(fs=1024000.0, out_rate=384000.0, max_bw=200e3, chunk_len=256, quality=2)
+        shifts = [33e3, -120.5e3, 7e3, 512e3]
+    elif case == "tiny_denom":
+        cfg = dict(fs=1024000.0, out_rate=102400.0, max_bw=60e3, chunk_len=1024, quality=4)
+        shifts = [512e3, 256e3, -256e3, 341e3]  # periods 2, 4, 4 and 1024
+    elif case == "denom_not_dividing_256":
+        cfg = dict(fs=1024000.0, out_rate=102400.0, max_bw=60e3, chunk_len=1024, quality=4)
+        shifts = [204800.0, 3 * 40960.0, 7 * 10240.0, -3 * 8192.0]  # 1/5, 3/25, 7/100, -3/125 of fs = 2^13 5^3
+    else:
+        cfg = dict(fs=1024000.0, out_rate=102400.0, max_bw=60e3, chunk_len=1024, quality=4)
+        shifts = [12.5e3, -40.123e3, 3.0, 99.999e3]
+    sizes = [70001, 4096, 65536 + 17, 40000, 123457, 50003, 81920, 60001]
+    script = []
+    for i, n in enumerate(sizes):
+        if i % 2 == 0:
+            script.append(("shift", shifts[(i // 2) % len(shifts)]))
+        script.append(("feed", n))
+    assert _meter_vs_oracle(rr, oracle, script=script, **cfg) >= 20
+
+
+def test_meter_sample_rate_change_mid_stream(rr, oracle):
+    """A new input rate recalculates the phase table from the current phasor's phase (transform.rs:318-340) and redesigns the
+    Downsampler (resampling.rs:75-102; 10 : 1 -> 20 : 1 -> 5 : 1); the partly filled output chunk carries on."""
+    script = [("shift", 12.5e3), ("feed", 100001), ("rate", 2048000.0), ("feed", 150003), ("feed", 8192), ("shift", -30e3),
+              ("feed", 90001), ("rate", 512000.0), ("feed", 70001), ("feed", 65536)]
+    n = _meter_vs_oracle(rr, oracle, fs=1024000.0, out_rate=102400.0, max_bw=60e3, chunk_len=1024, quality=4, script=script)
+    assert n >= 20
