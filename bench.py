@@ -152,6 +152,7 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=100.0, help="GPU load before the warm-up steps, for steady clocks")
     ap.add_argument("--no-fused", action="store_true", help="force the block-by-block kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=6.0, help="seconds of CPU work per timed leg of the cpu_baseline")
     ap.add_argument("--time-all", action="store_true", help="time every kernel inside the timed region, not only the dominant one")
     ap.add_argument("--time-every", type=int, default=1,
                     help="inside the timed region one launch in this many of the dominant kernel records its start / end.  "
@@ -162,6 +163,7 @@ def main():
                     help="rank logic rehearsal only: all ranks share cuda:0 and line up over gloo (RCCL refuses two ranks on one GPU)")
     ap.add_argument("--traffic-json", default=None, help="file holding measured HBM bytes per launch (PMC pass)")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the un-timed host-buffer (PCIe-inclusive) leg")
+    ap.add_argument("--no-general-nco", action="store_true", help="skip the un-timed leg with a 40 000-entry phase table")
     ap.add_argument("--no-numa-pin", action="store_true", help="leave the rank's CPU affinity alone")
     ap.add_argument("--profile", action="store_true",
                     help="profiler runs: only the chain's own launches (no block-by-block replay, no copy benchmark, no extra "
@@ -262,6 +264,50 @@ def main():
     fused_kernel = chain.last_path_kernel()
     per_rank_elapsed = ranks.gather_over_ranks(elapsed)
     elapsed = ranks.max_over_ranks(elapsed)
+
+    # General-NCO leg (never `value`): the headline's shift is fs / 8, an NCO period of 8, which lets
+    # the library fold the mixer into the response tables (the device then does nothing for it).  The same chain with
+    # SURVEY 8(a1)'s stress shift - 12.345 MHz at 1 kHz precision: ratio 2469 / 40000, a 40 000-entry table - runs the
+    # kernel instance with the mixer inside; the same K steps, bracketed the same way, reported beside `value`.
+    general = None
+    if not args.no_fused and not args.profile and not args.no_general_nco:
+        gch = rr.Chain(shift=12.345e6, precision=1e3, filter_len=64, freq_resp=lowpass20, output_rate=50e6, bandwidth=40e6,
+                       fft_len=4096, fft_window=rr.Kaiser.with_null_at_bin(2.0), device=local_rank)
+        gch.set_stream(stream)
+        for _ in range(max(args.warmup, 3)):
+            gch.process_dev(fs, d_in.data_ptr(), n, d_out.data_ptr(), cap)
+        lib.rr_chain_timing_enable(gch._h, 2)
+        lib.rr_chain_timing_every(gch._h, 1)
+        lib.rr_chain_timing_reset(gch._h)
+        barrier()
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        for _ in range(args.steps):
+            gch.process_dev(fs, d_in.data_ptr(), n, d_out.data_ptr(), cap)
+        torch.cuda.synchronize()
+        barrier()
+        g_el = ranks.max_over_ranks(time.perf_counter() - tg)
+        g_ms, g_cnt, i = 0.0, 0, 0
+        while lib.rr_chain_timing_stage_name(i):
+            ms, cnt = C.c_double(), C.c_uint64()
+            rr._lib.check(lib.rr_chain_timing_read(gch._h, i, C.byref(ms), C.byref(cnt)))
+            if cnt.value and ms.value / cnt.value > g_ms:
+                g_ms, g_cnt = ms.value / cnt.value, cnt.value
+            i += 1
+        general = {
+            "value": round(whole_job_rate(n, args.steps, world, g_el), 1),
+            "unit": "MSamples/s",
+            "ms_per_step": round(g_el / args.steps * 1e3, 4),
+            "frac": round(ALG_BYTES_PER_SAMPLE * n / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if g_ms else None,
+            "avg_launch_ms": round(g_ms, 5),
+            "launches": g_cnt,
+            "pct_hbm_roofline_whole_chain": round(100.0 * ALG_BYTES_PER_SAMPLE * whole_job_rate(n, args.steps, world, g_el) * 1e6
+                                                  / world / (HBM_PEAK_GBS * 1e9), 3),
+            "kernel": gch.last_path_kernel(),
+            "mixer_folded_into_tables": bool(gch.last_path_mixer_folded()),
+            "shift": "12.345 MHz at 1 kHz precision: 2469 / 40000 of fs, a 40 000-entry phase table",
+        }
+        del gch
 
     # Full-size consistency check (not timed): replay the same calls through the block-by-block
     # kernels and compare the last step's spectra; together with the first-spectrum check against
@@ -380,12 +426,15 @@ def main():
         # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc
         # passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; scripts/gpu_pmc.sh), committed
         # under profiles/; they cannot be collected in the same run as the timing.
-        traffic = None
+        traffic, traffic_source = None, None
         tj = args.traffic_json or os.path.join(ROOT, "profiles", "traffic_fused_fir.json")
         if fused and os.path.exists(tj):
             t = json.load(open(tj))
             if int(t.get("samples_per_launch", 0)) == n and str(t.get("kernel", "")).startswith(fused_kernel):
                 traffic = t.get("hbm_bytes_per_launch")
+                # (not measured in THIS run: PMC passes cannot share a run with the timing; the file says where it was)
+                traffic_source = {"file": os.path.relpath(tj, ROOT), "passes": t.get("source"), "session": t.get("session"),
+                                  "box": t.get("box"), "ratio_to_algorithmic": t.get("ratio")}
         line = {
             "metric": "MSamples/s (complex IQ) through shift->FIR->decimate->FFT chain; % HBM roofline",
             "value": round(value, 1),
@@ -418,6 +467,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "alg_bytes_per_launch": ALG_BYTES_PER_SAMPLE * n,
                 "avg_launch_ms": round(stages[dom]["avg_ms"], 5),
                 "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
@@ -428,24 +478,27 @@ def main():
             "timed_launch_every": max(1, args.time_every) if not (args.no_fused or args.time_all) else 1,
             "kernels_outside_timed_region": {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 5)}
                                              for k, v in other.items()},
+            "general_nco": general,
             "host_fed": host_fed,
             "host_placement": host_infos,
             "parity_first_spectrum_rms": None,  # filled in by the cpu_baseline leg
             "parity_fused_vs_block_by_block_last_step_rms": fused_vs_blocks,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            # the only place the oracle is used: the CPU baseline, and with it the spot check of the
-            # GPU's first spectrum against the f64 oracle run on the same leading samples
-            line["cpu_baseline"], ref0 = cpu_baseline()
-            line["parity_first_spectrum_rms"] = float(np.sqrt(np.sum(np.abs(first_spectrum - ref0) ** 2) / np.sum(np.abs(ref0) ** 2)))
         assert first_frames >= 0
         if args.profile:
             line["profile_run"] = "chain launches only: no replay, no copy benchmark, no extra timing steps"
         if args.rehearse_on_one_gpu:
             line["rehearsal"] = "all ranks shared cuda:0 over gloo: not a measurement"
-        print(json.dumps(line))
-    barrier()  # rank 0's un-timed checks are done before anybody tears the group down
+    barrier()  # rank 0's un-timed GPU checks are done before anybody tears the group down
     ranks.close()
+    if rank == 0:
+        if not args.no_cpu_baseline:
+            # the only place the oracle is used: the CPU baseline, and with it the spot check of the GPU's first spectrum
+            # against the f64 oracle run on the same leading samples.  At any world size: it runs on rank 0 AFTER the
+            # process group is gone, so with N > 1 the other ranks have left and the host's cores are rank 0's alone.
+            line["cpu_baseline"], ref0 = cpu_baseline(args.cpu_budget_s)
+            line["parity_first_spectrum_rms"] = float(np.sqrt(np.sum(np.abs(first_spectrum - ref0) ** 2) / np.sum(np.abs(ref0) ** 2)))
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

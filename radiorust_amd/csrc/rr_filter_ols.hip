@@ -41,6 +41,14 @@ constexpr int kTab = 16 * 15;     // W_256^(r k), r < 16, k = 1 .. 15
 #ifndef RR_V_F4KVOL
 #define RR_V_F4KVOL 1  // 0: plain LDS accesses, which the compiler pairs into ds_read2_b64 / ds_write2_b64 (A/B runs)
 #endif
+#ifndef RR_V_F4K_TAIL
+#define RR_V_F4K_TAIL 0  // 1: the block's last V samples (the next block's first) WITHOUT the streaming hint.  Measured (round 3,
+                         // one session): FETCH_SIZE x 2 = 610.5 MB per 2^26-sample call against 598.3 MB with the hint on every load,
+                         // 0.2704 against 0.2698 ms - two thirds of the overlap hit in L2 either way; the hint stays on
+#endif
+#ifndef RR_V_F4K_DEAD
+#define RR_V_F4K_DEAD 1  // 0: also issue the stores whose 256 lanes all fall outside the block's valid part (A/B runs)
+#endif
 #ifndef RR_V_F4KTAB
 #define RR_V_F4KTAB 1  // 0: the second pass's twiddle powers by a product tree per lane (A/B runs)
 #endif
@@ -118,8 +126,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PARTS ? 3 :
         const long bs = b0 - delay;
         if (blk >= a.blk_lo && blk < a.blk_hi && bs >= 0) {
             const __amdgpu_buffer_rsrc_t rs = rsrc_of(a.in + bs, 32768);
+            // the streaming hint on every load (RR_V_F4K_TAIL: without it on the block's last V samples, which the next
+            // block reads again - no fewer bytes fetched, see above)
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = buf_ld_f2<2>(rs, 8u * j, 2048u * k);
+            for (int k = 0; k < 16; ++k) {
+                if (RR_V_F4K_TAIL && 256 * (k + 1) > hop) v[k] = buf_ld_f2<0>(rs, 8u * j, 2048u * k);
+                else v[k] = buf_ld_f2<2>(rs, 8u * j, 2048u * k);
+            }
         } else {
             // edges: the previous chunk in front (none after a reset), nothing behind the input
 #pragma unroll
@@ -280,6 +293,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PARTS ? 3 :
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const unsigned off = lane_off - (unsigned)(256 * k * esz);
+        // lane j's value k is y[4096 - j - 256 k]: with 256 k > hop no lane's index reaches V (n = 1024: k = 13, 14, 15) - the
+        // descriptor's range check would drop all 256 lanes; a uniform branch drops the instruction
+        if (RR_V_F4K_DEAD && 256 * k > hop) continue;
         if constexpr (OUT16) {
             const __half2 h = __floats2half2_rn(v[k].x, v[k].y);
             __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const unsigned *>(&h), rs, off, 0, 2);

@@ -2389,6 +2389,7 @@ struct FrameArgs {
     unsigned nfr;           // full frames
     int mixfold;            // the NCO's period divides 8 and H holds the tables with the mixer folded in (rr_chain::ensure_mixfold)
     float sigma;            // results at odd indices of a block times sigma (+-1)
+    int nb;                 // blocks per frame: ceil(4096 / ((1024 - V) / 4)) = 18 / 19 / 20 for V = 64 / 128 / 192 (<= kFrameBlocks)
 };
 
 // The fused frame kernel, second form (round 2).  What made the first one slower than the two kernels it replaces was
@@ -2400,8 +2401,18 @@ struct FrameArgs {
 #ifndef RR_V_FRAME_LD_NT
 #define RR_V_FRAME_LD_NT 1
 #endif
+// The last V samples of a block are the first V of the next one.  Loaded with the streaming hint they are gone from L2 when the
+// next block asks for them (PMC round 2: 152.7 KB fetched per frame of 133 KB, i.e. 73 % of the overlap came from HBM twice);
+// the pieces k' >= RR_V_FRAME_LD_TAILK of a block (V = 192: part of piece 6 and piece 7) are therefore loaded WITHOUT the hint.
+#ifndef RR_V_FRAME_LD_TAILK
+#define RR_V_FRAME_LD_TAILK 6
+#endif
+#ifndef RR_V_FRAME_CONSEC
+#define RR_V_FRAME_CONSEC 0  // 1: a wave takes five NEIGHBOURING blocks (jb = 5 w + kb) instead of every fourth (A/B runs)
+#endif
 // MF: the mixer folded into the tables (rr_chain::ensure_mixfold) - instances of their own without the mixer's code; SW: poly4_block<SW>
-template <bool MF, bool SW>
+// FULL: 20 blocks per frame (V = 192, cfg2) - no guard around a wave's blocks; !FULL: 18 / 19 blocks (V = 64 / 128)
+template <bool MF, bool SW, bool FULL = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ols_frame(FrameArgs a_) {
     const FrameArgs &a = a_;
     const FrameArgs *ka = (const FrameArgs *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -2470,7 +2481,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     f2 keep[kFrameBlocks / 4][4];
 #pragma unroll
     for (int kb = 0; kb < kFrameBlocks / 4; ++kb) {
-        const int jb = w + 4 * kb;  // (five neighbouring blocks per wave instead - jb = 5 w + kb - measured 0.171 against 0.159 ms)
+        const int jb = RR_V_FRAME_CONSEC ? 5 * w + kb : w + 4 * kb;  // (five neighbouring blocks per wave instead: measured 0.171 against 0.159 ms)
+        // (shorter responses: V = 64 / 128, 240 / 224 results per block - 18 / 19 blocks cover the frame, the last round's other waves idle)
+        if (!FULL && kb >= 3 && __builtin_amdgcn_readfirstlane(jb) >= a.nb) continue;  // (a wave-uniform branch; rounds 0 .. 2 are always full)
         const long b0 = a.e0 - a.V + 4 * (F0 + (long)per_block * jb);
         // phase of the lane's first sample: (idx0 + b0 + 2 l) mod denom, b0 = const + 4 (4096 f + 208 jb)
         unsigned r = 0;
@@ -2496,7 +2509,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             {
                 const f4u *src = reinterpret_cast<const f4u *>(a.in + b0) + l;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) x[k] = RR_V_FRAME_LD_NT ? ld_stream(src + 64 * k) : *(src + 64 * k);
+                for (int k = 0; k < 8; ++k) x[k] = (RR_V_FRAME_LD_NT && k < RR_V_FRAME_LD_TAILK) ? ld_stream(src + 64 * k) : *(src + 64 * k);
             }
             if (MF) {
 #pragma unroll
@@ -2564,13 +2577,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // valid results tau = l + 64 c >= first; frame-relative index i = per_block * jb + tau - first
 #pragma unroll
     for (int kb = 0; kb < kFrameBlocks / 4; ++kb) {
-        const int jb = w + 4 * kb;  // (five neighbouring blocks per wave instead - jb = 5 w + kb - measured 0.171 against 0.159 ms)
+        const int jb = RR_V_FRAME_CONSEC ? 5 * w + kb : w + 4 * kb;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int tau = l + 64 * c;
             const int i = per_block * jb + tau - first;
             const long m = F0 + i;
-            if (tau >= first && m >= 0 && m < a.n_dec) fr[i] = keep[kb][c];
+            if (tau >= first && m >= 0 && m < a.n_dec && (FULL || jb < a.nb)) fr[i] = keep[kb][c];
         }
     }
     __syncthreads();
@@ -2610,12 +2623,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 bool ols_frame_supported(uint64_t D, size_t Lc, size_t fft_len) {
-    return D == 4 && fft_len == 4096 && Lc >= 1 && ols_wave_overlap(Lc, 64) == 192;  // 208 outputs per block compiled in
+    // overlaps of 64 / 128 / 192 samples = 240 / 224 / 208 results per block, 18 / 19 / 20 blocks per frame (at most kFrameBlocks)
+    return D == 4 && fft_len == 4096 && Lc >= 1 && ols_wave_overlap(Lc, 64) <= 192;
 }
 
 int launch_ols_frame(hipStream_t s, const FusedFirArgs &a, const void *pend_in, size_t pl, void *pend_out, void *spectra,
                      const void *window, const void *tw4096, bool center_dc) {
-    if (a.V != 192) RR_FAIL(RR_ERR_BAD_ARG, "fused frame kernel: overlap %d not instantiated", a.V);
+    if (a.V != 64 && a.V != 128 && a.V != 192) RR_FAIL(RR_ERR_BAD_ARG, "fused frame kernel: overlap %d not supported", a.V);
     const size_t total = pl + a.n_out, nfr = total / 4096;
     if (total == 0) return RR_OK;
     if (a.n_in < 1024) RR_FAIL(RR_ERR_BAD_ARG, "fused frame kernel: needs at least 1024 input samples per call");
@@ -2650,17 +2664,28 @@ int launch_ols_frame(hipStream_t s, const FusedFirArgs &a, const void *pend_in, 
     f.nfr = (unsigned)nfr;
     f.mixfold = a.mixfold ? 1 : 0;
     f.sigma = a.sigma;
+    {
+        const int per_block = (1024 - a.V) / 4;
+        f.nb = (4096 + per_block - 1) / per_block;
+        if (f.nb > kFrameBlocks) RR_FAIL(RR_ERR_BAD_ARG, "fused frame kernel: %d blocks per frame", f.nb);
+    }
     const unsigned grid = 1u + (unsigned)((nfr + 8 * RR_V_FRAMEWIN - 1) / (8 * RR_V_FRAMEWIN) * (8 * RR_V_FRAMEWIN));
-#define RR_FRAME_LAUNCH(MF_, SW_)                                                                                     \
-    do {                                                                                                               \
-        if (a.ev_start && a.ev_stop)                                                                                   \
-            hipExtLaunchKernelGGL((k_ols_frame<MF_, SW_>), dim3(grid), dim3(256), 0, s, a.ev_start, a.ev_stop, 0, f); \
-        else                                                                                                           \
-            hipLaunchKernelGGL((k_ols_frame<MF_, SW_>), dim3(grid), dim3(256), 0, s, f);                               \
+#define RR_FRAME_LAUNCH(MF_, SW_, FU_)                                                                                     \
+    do {                                                                                                                    \
+        if (a.ev_start && a.ev_stop)                                                                                        \
+            hipExtLaunchKernelGGL((k_ols_frame<MF_, SW_, FU_>), dim3(grid), dim3(256), 0, s, a.ev_start, a.ev_stop, 0, f); \
+        else                                                                                                                \
+            hipLaunchKernelGGL((k_ols_frame<MF_, SW_, FU_>), dim3(grid), dim3(256), 0, s, f);                               \
     } while (0)
-    if (a.mixfold && a.sigma < 0.f) RR_FRAME_LAUNCH(true, true);
-    else if (a.mixfold) RR_FRAME_LAUNCH(true, false);
-    else RR_FRAME_LAUNCH(false, false);
+    if (f.nb == kFrameBlocks) {
+        if (a.mixfold && a.sigma < 0.f) RR_FRAME_LAUNCH(true, true, true);
+        else if (a.mixfold) RR_FRAME_LAUNCH(true, false, true);
+        else RR_FRAME_LAUNCH(false, false, true);
+    } else {
+        if (a.mixfold && a.sigma < 0.f) RR_FRAME_LAUNCH(true, true, false);
+        else if (a.mixfold) RR_FRAME_LAUNCH(true, false, false);
+        else RR_FRAME_LAUNCH(false, false, false);
+    }
 #undef RR_FRAME_LAUNCH
     RR_HIP(hipGetLastError());
     return RR_OK;

@@ -21,7 +21,7 @@ for r in range(rounds):
             env["RR_LIB"] = os.path.abspath(lib)
         else:
             env.pop("RR_LIB", None)
-        out = subprocess.run([sys.executable, "bench.py", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"],
+        out = subprocess.run([sys.executable, "bench.py", "--steps", os.environ.get("AB_STEPS", "100"), "--warmup", "3", "--no-cpu-baseline", "--no-general-nco", "--no-host-fed"],
                              env=env, capture_output=True, text=True, timeout=300)
         line = [x for x in out.stdout.splitlines() if x.startswith("{")]
         if not line:

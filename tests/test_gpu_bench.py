@@ -32,13 +32,18 @@ def test_bench_line_contract_small():
     assert d["parity_fused_vs_block_by_block_last_step_rms"] < 1e-5
     # the un-timed host-fed leg (PCIe-inclusive) and the rank's NUMA placement ride along
     assert d["host_fed"]["value"] > 0 and d["host_fed"]["value"] < d["value"] and len(d["host_placement"]) == 1
+    # the general-NCO leg beside `value` (a 40 000-entry phase table: the mixer cannot be folded into the response tables)
+    g = d["general_nco"]
+    assert g["value"] > 0 and 0 < g["frac"] < 1 and not g["mixer_folded_into_tables"] and g["kernel"].startswith("k_ols")
 
 
 def test_bench_spawns_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: two ranks are started by bench.py itself."""
     d = run_bench("--gpus", "2", "--rehearse-on-one-gpu", "--steps", "3", "--warmup", "1", "--samples", str(1 << 22),
-                  "--settle-ms", "0", "--no-cpu-baseline")
+                  "--settle-ms", "0", "--cpu-budget-s", "0.2")
     assert d["n_gpus"] == 2 and len(d["per_rank_MSamples_s"]) == 2
+    # with N > 1 rank 0 still reports the CPU baseline (timed after the process group is gone) and the first-spectrum check
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["parity_first_spectrum_rms"] < 1e-5
     assert "rehearsal" in d
     assert len(d["host_fed"]["per_rank_MSamples_s"]) == 2 and len(d["host_placement"]) == 2
     # whole-job value = both ranks' samples over the slower rank's time
