@@ -314,6 +314,10 @@ int rr_chain_process_dev(rr_chain *h, double sample_rate, const void *d_in,
  * (1 direct-form k_mix_fir_decim, 2 overlap-save k_ols_decim4, 3 overlap-save
  * k_ols_wave, each followed by k_fft4096; 4 k_ols_frame: both stages in one kernel; 6 / 7 k_ols_frame / k_ols_wave
  * with the mixer folded into the response tables - NCO periods that divide 8). */
+/* as rr_stft_set_metering (the rate of the spectra is the chain's output_rate): bandwidth and energy of every spectrum the
+ * chain produces, computed in the kernel that makes it (k_ols_frame / k_fft4096 for 4096-point spectra) */
+int rr_chain_set_metering(rr_chain *h, double double_percentile, double *d_bandwidth,
+                          double *d_energy, size_t cap_frames, int store_spectra);
 int rr_chain_last_path(const rr_chain *h, int *fused);
 int rr_chain_destroy(rr_chain *h);
 
@@ -384,6 +388,18 @@ int rr_stft_process(rr_stft *h, const void *in, size_t n_in, void *out, size_t o
                     size_t *n_out);
 int rr_stft_process_dev(rr_stft *h, const void *d_in, size_t n_in, void *d_out,
                         size_t out_cap, size_t *n_out);
+/* metering::bandwidth (src/metering.rs:41-80) as the pipeline's LAST STEP, the way the reference's only hot-path caller uses
+ * the spectra (examples/bandwidth_meter/main.rs:75-78: `metering::bandwidth(0.01, sample_rate, &chunk)` per Fourier
+ * output).  While set, every process call also writes one f64 per produced spectrum to d_bandwidth[0 .. frames) (and the
+ * spectrum's energy, sum |X|^2, to d_energy if non-NULL), computed behind the transform while the bins are still in
+ * registers (Complex<f32>, 4096-point spectra; other lengths and Complex<f64>: a parallel scan right behind the transform).
+ * store_spectra = 0: the spectra themselves are NOT written - d_out may be NULL, out_cap is ignored, n_out still counts
+ * them.  d_bandwidth = NULL switches the step off.  More spectra in a call than cap_frames: RR_ERR_CAPACITY.
+ * (RR_METER_SERIAL=1 in the environment: the reference's sequential summation order in a kernel of its own, bit-equal to
+ *  rr_bandwidth_dev; the fused form differs from it in the last bits of its f64 sums.) */
+int rr_stft_set_metering(rr_stft *h, double double_percentile, double sample_rate,
+                         double *d_bandwidth, double *d_energy, size_t cap_frames,
+                         int store_spectra);
 int rr_stft_destroy(rr_stft *h);
 
 /* ------------------------------------------------------------------------ */
@@ -425,6 +441,14 @@ int rr_meter_process_dev(rr_meter *h, double sample_rate, const void *d_in, size
                          void *d_out, size_t out_cap, size_t *n_out);
 /* 1 when the last process call ran FreqShifter and Downsampler as ONE kernel (Complex<f32>, calls of >= 4096 samples,
  * any integer or short-period rational ratio: k_decim_poly with the phase table riding along), else 0. */
+/* as rr_stft_set_metering; the rate of the spectra is the Meter's output_rate */
+int rr_meter_set_metering(rr_meter *h, double double_percentile, double *d_bandwidth,
+                          double *d_energy, size_t cap_frames, int store_spectra);
+/* The example's loop body as ONE call (main.rs:75-78): host samples in, one bandwidth per spectrum out (host, blocking);
+ * the spectra are never written anywhere. */
+int rr_meter_process_bandwidth(rr_meter *h, double sample_rate, const void *in, size_t n_in,
+                               double double_percentile, double *bandwidth_out,
+                               size_t cap_frames, size_t *n_frames);
 int rr_meter_last_path(const rr_meter *h, int *front_fused);
 int rr_meter_destroy(rr_meter *h);
 
@@ -492,6 +516,11 @@ int rr_bandwidth_dev(int dtype, int device, void *hip_stream, double double_perc
                      double *d_out);
 int rr_bandwidth(int dtype, int device, double double_percentile, double sample_rate,
                  const void *bins, size_t n, double *out);
+/* the same as a workgroup-wide parallel scan (256 lanes per frame, any n; d_energy may be NULL): what the metered
+ * pipelines run; differs from rr_bandwidth_dev in the last bits of its f64 sums */
+int rr_bandwidth_fast_dev(int dtype, int device, void *hip_stream, double double_percentile,
+                          double sample_rate, const void *d_frames, size_t n, size_t count,
+                          double *d_bandwidth, double *d_energy);
 /* metering::rescale_energy (src/metering.rs:89-109): out = count x resolution Flt */
 int rr_rescale_energy_dev(int dtype, int device, void *hip_stream, const void *d_frames,
                           size_t n, size_t count, size_t resolution, void *d_out);

@@ -152,6 +152,7 @@ SIGNATURES = {
     "rr_chain_process": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
     "rr_chain_enqueue": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
     "rr_chain_process_dev": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
+    "rr_chain_set_metering": (_i, [_vp, _d, _vp, _vp, _sz, _i]),
     "rr_chain_last_path": (_i, [_vp, C.POINTER(_i)]),
     "rr_chain_destroy": (_i, [_vp]),
     "rr_chain_timing_enable": (_i, [_vp, _i]),
@@ -176,11 +177,14 @@ SIGNATURES = {
     "rr_meter_peek": (_i, [_vp, _d, _sz, _psz]),
     "rr_meter_process": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
     "rr_meter_process_dev": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
+    "rr_meter_set_metering": (_i, [_vp, _d, _vp, _vp, _sz, _i]),
+    "rr_meter_process_bandwidth": (_i, [_vp, _d, _vp, _sz, _d, _vp, _sz, _psz]),
     "rr_meter_last_path": (_i, [_vp, C.POINTER(_i)]),
     "rr_meter_destroy": (_i, [_vp]),
     "rr_stft_peek": (_i, [_vp, _sz, _psz]),
     "rr_stft_process": (_i, [_vp, _vp, _sz, _vp, _sz, _psz]),
     "rr_stft_process_dev": (_i, [_vp, _vp, _sz, _vp, _sz, _psz]),
+    "rr_stft_set_metering": (_i, [_vp, _d, _d, _vp, _vp, _sz, _i]),
     "rr_stft_destroy": (_i, [_vp]),
     "rr_upsampler_create": (_i, [_i, _d, _d, _d, _i, C.POINTER(_vp)]),
     "rr_upsampler_peek": (_i, [_vp, _d, _sz, _psz]),
@@ -202,6 +206,7 @@ SIGNATURES = {
     "rr_level": (_i, [_i, _i, _vp, _sz, C.POINTER(_d)]),
     "rr_bandwidth_dev": (_i, [_i, _i, _vp, _d, _d, _vp, _sz, _sz, _vp]),
     "rr_bandwidth": (_i, [_i, _i, _d, _d, _vp, _sz, C.POINTER(_d)]),
+    "rr_bandwidth_fast_dev": (_i, [_i, _i, _vp, _d, _d, _vp, _sz, _sz, _vp, _vp]),
     "rr_rescale_energy_dev": (_i, [_i, _i, _vp, _vp, _sz, _sz, _sz, _vp]),
     "rr_rescale_energy": (_i, [_i, _i, _vp, _sz, _sz, _vp]),
     "rr_gain_dev": (_i, [_i, _i, _vp, _d, _vp, _sz, _vp]),

@@ -485,6 +485,11 @@ class Chain(_Block):
         _lib.check(_lib.lib().rr_chain_last_path(self._h, C.byref(v)))
         return bool(v.value)
 
+    def set_metering(self, double_percentile, d_bandwidth: int, cap_frames: int, d_energy: int = 0, store_spectra: bool = True):
+        """As Meter.set_metering: bandwidth (and energy) of every spectrum the chain produces, from the kernel that makes it."""
+        _lib.check(_lib.lib().rr_chain_set_metering(self._h, float(double_percentile), d_bandwidth or None, d_energy or None,
+                                                    int(cap_frames), int(bool(store_spectra))))
+
     def last_path_kernel(self) -> str:
         """Name of the mix + FIR + decimate kernel the last call ran ("" = block-by-block)."""
         v = C.c_int()
@@ -652,8 +657,15 @@ class Stft(_Block):
 
     def process_dev(self, d_in: int, n_in: int, d_out: int, cap: int) -> int:
         n_out = C.c_size_t()
-        _lib.check(_lib.lib().rr_stft_process_dev(self._h, d_in, n_in, d_out, cap, C.byref(n_out)))
+        _lib.check(_lib.lib().rr_stft_process_dev(self._h, d_in, n_in, d_out or None, cap, C.byref(n_out)))
         return n_out.value
+
+    def set_metering(self, double_percentile, sample_rate, d_bandwidth: int, cap_frames: int, d_energy: int = 0,
+                     store_spectra: bool = True):
+        """metering::bandwidth(double_percentile, sample_rate, spectrum) per spectrum, written to the device array
+        d_bandwidth (f64) by the kernel that makes the spectrum (see Meter.set_metering)."""
+        _lib.check(_lib.lib().rr_stft_set_metering(self._h, float(double_percentile), float(sample_rate), d_bandwidth or None,
+                                                   d_energy or None, int(cap_frames), int(bool(store_spectra))))
 
 
 class Meter(_Block):
@@ -707,6 +719,23 @@ class Meter(_Block):
         N = self.chunk_len * self.overlap
         y = self._host_call(_lib.lib().rr_meter_process, (float(signal.sample_rate),), signal.chunk, frames * N)
         return [Samples(self.output_rate, y[i * N : (i + 1) * N]) for i in range(frames)]
+
+    def set_metering(self, double_percentile, d_bandwidth: int, cap_frames: int, d_energy: int = 0, store_spectra: bool = True):
+        """metering::bandwidth(double_percentile, output_rate, spectrum) per spectrum as the pipeline's last step
+        (examples/bandwidth_meter/main.rs:78), written to the device array d_bandwidth (f64) by the kernel that makes the
+        spectrum; d_bandwidth = 0 switches it off; store_spectra = False: the spectra themselves are not written."""
+        _lib.check(_lib.lib().rr_meter_set_metering(self._h, float(double_percentile), d_bandwidth or None, d_energy or None,
+                                                    int(cap_frames), int(bool(store_spectra))))
+
+    def process_bandwidth(self, signal, double_percentile: float) -> np.ndarray:
+        """The example's loop body as one call: samples in, one bandwidth per spectrum out; the spectra never leave the chip."""
+        x = np.ascontiguousarray(signal.chunk, dtype=self._cdt)
+        frames = self.peek(signal.sample_rate, len(x))
+        out = np.empty(max(frames, 1), dtype=np.float64)
+        n = C.c_size_t()
+        _lib.check(_lib.lib().rr_meter_process_bandwidth(self._h, float(signal.sample_rate), x.ctypes.data, len(x),
+                                                         float(double_percentile), out.ctypes.data, len(out), C.byref(n)))
+        return out[: n.value]
 
     def front_fused(self) -> bool:
         """True when the last call ran FreqShifter + Downsampler as one kernel."""

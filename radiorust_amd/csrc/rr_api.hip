@@ -580,7 +580,10 @@ rr_stft::~rr_stft() { delete fo; }
 int rr_stft::process_dev(const void *d_in_, size_t n_in_, void *d_out, size_t cap, size_t *n_out) {
     if (n_out) *n_out = 0;
     const size_t produce = peek(n_in_);
-    if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Stft: out_cap %zu < %zu", cap, produce);
+    const bool store = !sink.on || sink.store;
+    if (store && produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Stft: out_cap %zu < %zu", cap, produce);
+    if (sink.on && produce / (M * P) > sink.cap)
+        RR_FAIL(RR_ERR_CAPACITY, "Stft: room for %zu bandwidths, the call makes %zu spectra", sink.cap, produce / (M * P));
     if (n_in_ == 0) return RR_OK;
     RR_TRY(select());
     const size_t N = M * P, H = (P - 1) * M, esz = elem_size(dtype);
@@ -614,7 +617,10 @@ int rr_stft::process_dev(const void *d_in_, size_t n_in_, void *d_out, size_t ca
         const size_t n_head = base0 < 0 ? (size_t)(-base0) : 0;
         const char *head = hist[cur].as<char>() + (H - n_head) * esz;
         const char *in0 = d_in + (base0 > 0 ? (size_t)base0 * esz : 0);
-        RR_TRY(fo->transform_dev(head, n_head, in0, d_out, M, frames));
+        if (sink.on)
+            RR_TRY(fo->transform_metered_dev(head, n_head, in0, d_out, M, frames, sink.frame_meter()));
+        else
+            RR_TRY(fo->transform_dev(head, n_head, in0, d_out, M, frames));
     }
     if (H) {
         RR_TRY(launch_update_hist(dtype, stream, hist[cur].p, hist[cur ^ 1].p, H, d_in, n_in));
@@ -1187,6 +1193,34 @@ int rr_fourier::transform_dev(const void *head, size_t n_head, const void *in, v
     return RR_OK;
 }
 
+int rr_fourier::transform_metered_dev(const void *head, size_t n_head, const void *in, void *out, size_t hop, size_t count,
+                                      const rr::FrameMeter &fm) {
+    if (count == 0) return RR_OK;
+    if (!fm.bw) RR_FAIL(RR_ERR_BAD_ARG, "metering: no place for the bandwidths");
+    if (fm.store && !out) RR_FAIL(RR_ERR_BAD_ARG, "null output");
+    const char *se = std::getenv("RR_METER_SERIAL");  // (read per call: tests switch it within one process)
+    const bool serial = se && std::atoi(se) != 0;
+    static const bool generic = [] { const char *e = std::getenv("RR_FOURIER_GENERIC"); return e && std::atoi(e) != 0; }();
+    if (!serial && !generic && dtype == RR_F32 && n == 4096 && !big && !mixed && !tilem && !bs_M) {
+        // the epilogue rides on the transform's kernel: the bins never come back from memory
+        if (stft4096_supported(hop) && count >= 64)
+            return launch_stft4096(stream, head, n_head, in, out, count, d_window.p, d_tw.p, center_dc, hop, &fm);
+        return launch_fft4096(stream, head, n_head, in, out, count, d_window.p, d_tw.p, center_dc, hop, nullptr, nullptr, &fm);
+    }
+    void *o = out;
+    if (!fm.store || !out) {
+        RR_TRY(meter_ws.reserve(count * n * elem_size(dtype)));
+        o = meter_ws.p;
+    }
+    RR_TRY(transform_dev(head, n_head, in, o, hop, count));
+    if (serial) {  // the reference's own summation order (bit-equal to the oracle): the checker path
+        RR_TRY(launch_meter(dtype, stream, 1, fm.double_percentile, fm.sample_rate, o, n, count, fm.bw));
+        if (fm.energy) RR_TRY(launch_meter(dtype, stream, 2, 0.0, 0.0, o, n, count, fm.energy));
+        return RR_OK;
+    }
+    return launch_bandwidth_par(dtype, stream, fm.double_percentile, fm.sample_rate, o, n, count, fm.bw, fm.energy);
+}
+
 int rr_fourier::process_dev(size_t chunk_len, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out) {
     if (n_out) *n_out = 0;
     if (chunk_len == 0) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: chunk_len == 0");
@@ -1284,7 +1318,9 @@ int rr_meter::process_dev(double sample_rate, const void *d_in, size_t n_in, voi
     size_t frames = 0;
     RR_TRY(peek(sample_rate, n_in, &frames));
     const size_t N = chunk_len * overlap;
-    if (frames * N > cap) RR_FAIL(RR_ERR_CAPACITY, "Meter: out_cap %zu < %zu", cap, frames * N);
+    if ((!st->sink.on || st->sink.store) && frames * N > cap) RR_FAIL(RR_ERR_CAPACITY, "Meter: out_cap %zu < %zu", cap, frames * N);
+    if (st->sink.on && frames > st->sink.cap)
+        RR_FAIL(RR_ERR_CAPACITY, "Meter: room for %zu bandwidths, the call makes %zu spectra", st->sink.cap, frames);
     if (n_in == 0) return RR_OK;
     RR_TRY(select());
     set_streams();
@@ -1719,6 +1755,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     const size_t have = pending_len + dec;
     const size_t nfr = have / LF, rest = have - nfr * LF;
     const bool split = (LF == 4096);  // k_fft4096 reads [pending | new] from two places: no copies
+    const bool store = !sink.on || sink.store;
     if (!split && pend_ptr) RR_TRY(materialize());
     FusedFirArgs a;
     a.xh = xh[xh_cur].p;
@@ -1741,7 +1778,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     if (use_frame && n_in >= (frame_forced ? (size_t)1024 : (size_t)1 << 23)) {
         // one kernel: FIR stage + Fourier; the decimated samples stay on chip, only the unfinished
         // frame goes to a small pending buffer
-        if (nfr * LF > cap) RR_FAIL(RR_ERR_CAPACITY, "Chain: out_cap %zu < %zu", cap, nfr * LF);
+        if (store && nfr * LF > cap) RR_FAIL(RR_ERR_CAPACITY, "Chain: out_cap %zu < %zu", cap, nfr * LF);
         RR_TRY(fo->prepare(LF));
         RR_TRY(pendbuf[0].reserve(LF * esz));
         RR_TRY(pendbuf[1].reserve(LF * esz));
@@ -1753,9 +1790,10 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
         a.poly = ols_poly;
         RR_TRY(fold_mixer(a, 4 * (int64_t)pending_len));  // (the frame's first block starts 4 pl samples earlier, as launch_ols_frame)
         // (the launch records its own start / end: marker packets would cost ~4 us of stream time each)
-        if (timers.on) timers.begin_ext(ST_FUSED_FIR, &a.ev_start, &a.ev_stop);
+        if (timers.on && !sink.on) timers.begin_ext(ST_FUSED_FIR, &a.ev_start, &a.ev_stop);
+        const rr::FrameMeter fmv = sink.frame_meter();
         RR_TRY(launch_ols_frame(stream, a, pin, pending_len, pendbuf[po].p, d_out, fo->d_window.p, fo->d_tw.p,
-                                fo->center_dc));
+                                fo->center_dc, sink.on ? &fmv : nullptr));
         xh_cur ^= 1;
         if (left) RR_HIP(hipMemcpyAsync(carry.p, xh[xh_cur].as<char>() + (HX - left) * esz, left * esz, hipMemcpyDeviceToDevice, stream));
         const uint64_t den0 = (uint64_t)fs->denom;
@@ -1793,7 +1831,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     a.poly = ols_poly;
     // k_ols_wave + k_fft4096: the launches record their own start / end (no marker packets, which
     // cost ~4 us of stream time each); the other kernels are bracketed by recorded events
-    const bool ext = timers.on && use_ols && ols_N == 1024 && split && dec > 0;
+    const bool ext = timers.on && use_ols && ols_N == 1024 && split && dec > 0 && !sink.on;
     int tk = -1;
     if (ext)
         timers.begin_ext(ST_FUSED_FIR, &a.ev_start, &a.ev_stop);
@@ -1823,9 +1861,13 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
         tk = timers.next(tk, ST_FOURIER, stream);  // (the carry copy above, if any, counts for the FIR stage)
     }
     if (split) {
-        if (nfr * LF > cap) RR_FAIL(RR_ERR_CAPACITY, "Chain: out_cap %zu < %zu", cap, nfr * LF);
+        if (store && nfr * LF > cap) RR_FAIL(RR_ERR_CAPACITY, "Chain: out_cap %zu < %zu", cap, nfr * LF);
         RR_TRY(fo->prepare(LF));
         const void *head = pend_ptr ? pend_ptr : pending.p;
+        if (sink.on) {
+            fo->stream = stream;
+            RR_TRY(fo->transform_metered_dev(head, pending_len, newv, d_out, 4096, nfr, sink.frame_meter()));
+        } else
         RR_TRY(launch_fft4096(stream, head, pending_len, newv, d_out, nfr, fo->d_window.p, fo->d_tw.p, fo->center_dc, 4096,
                               fa, fb));
         wrote = nfr * LF;
@@ -1837,6 +1879,11 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
             RR_TRY(materialize_pending_append(newv, dec));
         }
     } else {
+        if (sink.on) {
+            RR_TRY(fo->prepare(LF));
+            RR_TRY(fo->transform_metered_dev(nullptr, 0, dbase, d_out, LF, nfr, sink.frame_meter()));
+            wrote = nfr * LF;
+        } else
         RR_TRY(fo->process_dev(LF, dbase, nfr * LF, d_out, cap, &wrote));
         if (rest) RR_HIP(hipMemcpyAsync(pending.p, dbase + nfr * LF * esz, rest * esz, hipMemcpyDeviceToDevice, stream));
     }
@@ -1903,6 +1950,11 @@ int rr_chain::process_generic(double sample_rate, const void *d_in, size_t n_in,
     const size_t nfr = have / L;
     size_t wrote = 0;
     tk = timers.begin(ST_FOURIER, stream);
+    if (sink.on) {
+        RR_TRY(fo->prepare(L));
+        RR_TRY(fo->transform_metered_dev(nullptr, 0, decim.p, d_out, L, nfr, sink.frame_meter()));
+        wrote = nfr * L;
+    } else
     RR_TRY(fo->process_dev(L, decim.p, nfr * L, d_out, cap, &wrote));
     timers.end(tk, stream);
     const size_t rest = have - nfr * L;
@@ -1919,7 +1971,8 @@ int rr_chain::process_dev(double sample_rate, const void *d_in, size_t n_in, voi
         RR_FAIL(RR_ERR_NEED_DESIGN, "Chain: Filter has no design for sample rate %g", sample_rate);
     size_t frames = 0;
     RR_TRY(peek(sample_rate, n_in, &frames));
-    if (frames * p.fft_len > cap) RR_FAIL(RR_ERR_CAPACITY, "Chain: out_cap %zu < %zu", cap, frames * p.fft_len);
+    if ((!sink.on || sink.store) && frames * p.fft_len > cap) RR_FAIL(RR_ERR_CAPACITY, "Chain: out_cap %zu < %zu", cap, frames * p.fft_len);
+    if (sink.on && frames > sink.cap) RR_FAIL(RR_ERR_CAPACITY, "Chain: room for %zu bandwidths, the call makes %zu spectra", sink.cap, frames);
     if (n_in > 0xfffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "Chain: more than 2^32 samples in one call");
     RR_TRY(select());
     // The fused kernels apply when every output of this call is in steady state:
@@ -2446,6 +2499,25 @@ int rr_stft_process(rr_stft *h, const void *in, size_t n_in, void *out, size_t c
     return RR_OK;
     RR_GUARD_END
 }
+static int set_sink(MeterSink &k, double double_percentile, double sample_rate, double *d_bandwidth, double *d_energy,
+                    size_t cap_frames, int store_spectra) {
+    k = MeterSink{};
+    if (!d_bandwidth) return RR_OK;  // off
+    if (!(double_percentile == double_percentile)) RR_FAIL(RR_ERR_BAD_ARG, "metering: double_percentile is NaN");
+    k.on = true;
+    k.dp = double_percentile;
+    k.rate = sample_rate;
+    k.bw = d_bandwidth;
+    k.energy = d_energy;
+    k.cap = cap_frames;
+    k.store = store_spectra ? 1 : 0;
+    return RR_OK;
+}
+int rr_stft_set_metering(rr_stft *h, double double_percentile, double sample_rate, double *d_bandwidth, double *d_energy,
+                         size_t cap_frames, int store_spectra) {
+    RR_CHECK_HANDLE(h, K_STFT);
+    return set_sink(h->sink, double_percentile, sample_rate, d_bandwidth, d_energy, cap_frames, store_spectra);
+}
 int rr_stft_destroy(rr_stft *h) {
     if (!h) return RR_OK;
     RR_CHECK_HANDLE(h, K_STFT);
@@ -2862,6 +2934,11 @@ int rr_chain_process(rr_chain *h, double rate, const void *in, size_t n_in, void
 int rr_chain_enqueue(rr_chain *h, double rate, const void *in, size_t n_in, void *out, size_t cap, size_t *n_out) {
     return chain_host(h, rate, in, n_in, out, cap, n_out, false);
 }
+int rr_chain_set_metering(rr_chain *h, double double_percentile, double *d_bandwidth, double *d_energy, size_t cap_frames,
+                          int store_spectra) {
+    RR_CHECK_HANDLE(h, K_CHAIN);
+    return set_sink(h->sink, double_percentile, h->p.output_rate, d_bandwidth, d_energy, cap_frames, store_spectra);
+}
 int rr_chain_last_path(const rr_chain *h, int *fused) {
     RR_CHECK_HANDLE(h, K_CHAIN);
     *fused = h->last_fused;
@@ -3113,6 +3190,47 @@ int rr_meter_process(rr_meter *h, double sample_rate, const void *in, size_t n_i
         return s;
     }));
     if (n_out) *n_out = got;
+    return RR_OK;
+    RR_GUARD_END
+}
+int rr_meter_set_metering(rr_meter *h, double double_percentile, double *d_bandwidth, double *d_energy, size_t cap_frames,
+                          int store_spectra) {
+    RR_CHECK_HANDLE(h, K_METER);
+    return set_sink(h->st->sink, double_percentile, h->output_rate, d_bandwidth, d_energy, cap_frames, store_spectra);
+}
+// The example's loop body as one call (examples/bandwidth_meter/main.rs:75-78): samples in, one metering::bandwidth per
+// spectrum out - the spectra themselves never leave the chip (they are not even written to device memory).
+int rr_meter_process_bandwidth(rr_meter *h, double sample_rate, const void *in, size_t n_in, double double_percentile,
+                               double *bandwidth_out, size_t cap_frames, size_t *n_frames) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_METER);
+    if (n_frames) *n_frames = 0;
+    if (n_in && !in) RR_FAIL(RR_ERR_BAD_ARG, "null input");
+    size_t frames = 0;
+    RR_TRY(h->peek(sample_rate, n_in, &frames));
+    if (frames > cap_frames) RR_FAIL(RR_ERR_CAPACITY, "Meter: room for %zu bandwidths, the call makes %zu spectra", cap_frames, frames);
+    if (frames && !bandwidth_out) RR_FAIL(RR_ERR_BAD_ARG, "null output");
+    RR_TRY(h->select());
+    const size_t esz = elem_size(h->dtype);
+    RR_TRY(h->stage_in.reserve((n_in ? n_in : 1) * esz));
+    RR_TRY(h->bwbuf.reserve((frames ? frames : 1) * sizeof(double)));
+    if (n_in) RR_HIP(hipMemcpyAsync(h->stage_in.p, in, n_in * esz, hipMemcpyHostToDevice, h->stream));
+    const MeterSink saved = h->st->sink;
+    MeterSink k;
+    k.on = true;
+    k.dp = double_percentile;
+    k.rate = h->output_rate;
+    k.bw = h->bwbuf.as<double>();
+    k.cap = frames;
+    k.store = 0;
+    h->st->sink = k;
+    size_t got = 0;
+    const int rc = h->process_dev(sample_rate, h->stage_in.p, n_in, nullptr, 0, &got);
+    h->st->sink = saved;
+    RR_TRY(rc);
+    if (frames) RR_HIP(hipMemcpyAsync(bandwidth_out, h->bwbuf.p, frames * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    RR_HIP(hipStreamSynchronize(h->stream));
+    if (n_frames) *n_frames = frames;
     return RR_OK;
     RR_GUARD_END
 }

@@ -98,6 +98,25 @@ struct rr_downsampler : rr_block {
     bool can_fuse_mixer(double input_rate, size_t n_in);
 };
 
+// metering::bandwidth as the last step of a pipeline (examples/bandwidth_meter/main.rs:78): while `on`, every spectrum a call
+// produces also gets one f64 in bw[] (and its energy in energy[], if non-null), computed behind the transform
+struct MeterSink {
+    bool on = false;
+    double dp = 0.0, rate = 0.0;
+    double *bw = nullptr, *energy = nullptr;
+    size_t cap = 0;  // frames bw[] / energy[] hold
+    int store = 1;   // 0: the spectra themselves are not written
+    rr::FrameMeter frame_meter() const {
+        rr::FrameMeter fm;
+        fm.double_percentile = dp;
+        fm.sample_rate = rate;
+        fm.bw = bw;
+        fm.energy = energy;
+        fm.store = store;
+        return fm;
+    }
+};
+
 // Fourier — analysis.rs:67-73 (previous_chunk_len, fft, window_values)
 // Rechunker(chunk_len) -> Overlapper(chunk_count) -> Fourier (chunks.rs:42-242, analysis.rs:26-133;
 // the wiring of examples/bandwidth_meter/main.rs:66-69): every chunk_len new samples one windowed
@@ -111,6 +130,7 @@ struct rr_stft : rr_block {
     // the Rechunker's patchwork (chunks.rs:62-64): < M samples waiting for the rest of their chunk
     rr::DevBuf carry, work;
     size_t carry_len = 0;
+    MeterSink sink;  // rr_stft_set_metering
     ~rr_stft() override;
     size_t peek(size_t n_in) const {
         const size_t chunks = (carry_len + n_in) / M, total = have_chunks + chunks;
@@ -130,6 +150,7 @@ struct rr_meter : rr_block {
     size_t chunk_len = 0, overlap = 0;
     double output_rate = 0;
     rr::DevBuf mixed, dec, filt;
+    rr::DevBuf bwbuf;  // rr_meter_process_bandwidth: the call's bandwidths on the device
     bool last_front_fused = false;  // the last call ran FreqShifter + Downsampler as one kernel
     size_t dec_len = 0;  // decimated samples waiting for the rest of their chunk: the Downsampler's partly filled output
                          // chunk (resampling.rs:121-131); it survives events and rate changes like the reference's
@@ -203,6 +224,11 @@ struct rr_fourier : rr_block {
     int prepare(size_t len);
     // `count` windowed transforms of n points over [head | in] at distance hop
     int transform_dev(const void *head, size_t n_head, const void *in, void *out, size_t hop, size_t count);
+    // the same + metering::bandwidth per frame: in the transform's own kernel where one with the epilogue exists (Complex<f32>,
+    // 4096 points), else the transform (into meter_ws when the caller does not want the spectra) and the parallel scan behind it
+    rr::DevBuf meter_ws;
+    int transform_metered_dev(const void *head, size_t n_head, const void *in, void *out, size_t hop, size_t count,
+                              const rr::FrameMeter &fm);
     int process_dev(size_t chunk_len, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
 };
 
@@ -263,6 +289,7 @@ struct rr_chain : rr_block {
     // Downsampler's partly filled output chunk (resampling.rs:121-131)
     rr::DevBuf pending;
     size_t pending_len = 0;
+    MeterSink sink;  // rr_chain_set_metering
     int last_fused = 0;
     StageTimers timers;
     // ---- fused fast path state (rr_api.hip, "fused") ----

@@ -41,6 +41,7 @@
 // is the one build-time switch left for A/B runs (scripts/build_variant.sh).
 #include "rr_blocks.hpp"
 #include "rr_wave_math.hpp"
+#include "rr_meter_dev.hpp"
 
 #include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
@@ -419,11 +420,13 @@ int launch_fused_fir(hipStream_t s, const FusedFirArgs &a) {
 //  moving window no gain)
 // FOLD: the polyphase channelizer with 4096 bins - the frame is the fold of `branches` windowed chunks,
 // v[i] = sum_p w[i + 4096 p] x[base + i + 4096 p] (window: 4096 branches plain values), then the same transform.
-template <bool FOLD>
+// METER: metering::bandwidth (and the frame's energy) computed from the bins while they are still in registers
+// (rr_meter_dev.hpp); fm.store = 0 drops the spectra altogether.
+template <bool FOLD, bool METER = false>
 __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head, long n_head,
                                                  const float2 *__restrict__ in, float2 *__restrict__ out,
                                                  const float *__restrict__ window, const float2 *__restrict__ tw,
-                                                 int center_dc, long hop, unsigned count, int branches) {
+                                                 int center_dc, long hop, unsigned count, int branches, FrameMeter fm = FrameMeter{}) {
     __shared__ f2 lds[4096 + 256];
     const int j = threadIdx.x;
     // (frames in reverse order - the most recently written first - measured no different in the chain)
@@ -539,27 +542,44 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
     }
     dft16(v);
     const int rot = center_dc ? 2048 : 0;
+    if (!METER || fm.store) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int o = (j + 256 * k + rot) & 4095;
-        __builtin_nontemporal_store(v[k], reinterpret_cast<f2 *>(dst) + o);
+        for (int k = 0; k < 16; ++k) {
+            const int o = (j + 256 * k + rot) & 4095;
+            __builtin_nontemporal_store(v[k], reinterpret_cast<f2 *>(dst) + o);
+        }
+    }
+    if constexpr (METER) {
+        double total;
+        const double bw = frame4096_bandwidth(v, lds, j, rot, fm.double_percentile, fm.sample_rate, &total);
+        if (j == 0) {
+            fm.bw[fr] = bw;
+            if (fm.energy) fm.energy[fr] = total;
+        }
     }
 }
 
 int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
                    const void *window, const void *tw4096, bool center_dc, size_t hop, hipEvent_t ev_start,
-                   hipEvent_t ev_stop) {
+                   hipEvent_t ev_stop, const FrameMeter *fm) {
     if (count == 0) return RR_OK;
     if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fft4096: too many frames");
     const unsigned grid = (unsigned)count;
+    if (fm) {
+        hipLaunchKernelGGL((k_fft4096<false, true>), dim3(grid), dim3(256), 0, s, (const float2 *)head, (long)n_head,
+                           (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw4096,
+                           (int)center_dc, (long)hop, (unsigned)count, 1, *fm);
+        RR_HIP(hipGetLastError());
+        return RR_OK;
+    }
     if (ev_start && ev_stop)
         hipExtLaunchKernelGGL(k_fft4096<false>, dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, (const float2 *)head,
                               (long)n_head, (const float2 *)in, (float2 *)out, (const float *)window,
-                              (const float2 *)tw4096, (int)center_dc, (long)hop, (unsigned)count, 1);
+                              (const float2 *)tw4096, (int)center_dc, (long)hop, (unsigned)count, 1, FrameMeter{});
     else
         hipLaunchKernelGGL(k_fft4096<false>, dim3(grid), dim3(256), 0, s, (const float2 *)head, (long)n_head,
                            (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw4096,
-                           (int)center_dc, (long)hop, (unsigned)count, 1);
+                           (int)center_dc, (long)hop, (unsigned)count, 1, FrameMeter{});
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
@@ -587,7 +607,7 @@ int launch_chan4096(hipStream_t s, const void *head, size_t n_head, const void *
     if (count > 0x7fffff00ull) RR_FAIL(RR_ERR_BAD_ARG, "channelizer: too many frames");
     hipLaunchKernelGGL(k_fft4096<true>, dim3((unsigned)((count + 63) / 64 * 64)), dim3(256), 0, s, (const float2 *)head, (long)n_head,
                        (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw4096, 0, (long)hop,
-                       (unsigned)count, (int)branches);
+                       (unsigned)count, (int)branches, FrameMeter{});
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
@@ -1382,11 +1402,11 @@ int launch_bluestein4096(hipStream_t s, const void *head, size_t n_head, const v
 // the hop, i.e. 51 % of the 8 + 32 B per input sample of the 1024 x 4 case.
 // ---------------------------------------------------------------------------
 constexpr unsigned kStftWin = 4;  // neighbouring runs per XCD (they share 4096 - hop samples)
-template <int SH>
+template <int SH, bool METER = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_stft4096(const float2 *__restrict__ head, long n_head,
                                                   const float2 *__restrict__ in, float2 *__restrict__ out,
                                                   const float *__restrict__ window, const float2 *__restrict__ tw,
-                                                  int center_dc, unsigned count, unsigned R, unsigned nruns) {
+                                                  int center_dc, unsigned count, unsigned R, unsigned nruns, FrameMeter fm = FrameMeter{}) {
     __shared__ f2 lds[4096 + 256];
     const int j = threadIdx.x;
     constexpr unsigned G = kStftWin;
@@ -1419,6 +1439,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int rot = center_dc ? 2048 : 0;
 #pragma unroll 1
     for (unsigned i = 0; i < nf; ++i) {
+        // (METER: the lane index is made opaque per frame - hoisted out of the loop, the transform's and the epilogue's lane
+        //  addresses together no longer fit the 168 registers of three waves per SIMD and came back from scratch every frame)
+        int jl = j;
+        if constexpr (METER) asm volatile("" : "+v"(jl));
         f2 v[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = xr[k] * wv[k];
@@ -1430,10 +1454,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int q = 0; q < SH; ++q) xr[16 - SH + q] = ld(nb + j + 256 * (16 - SH + q));
         if (i) __syncthreads();  // the previous frame's last pass has been read
-        fft4096_regs(v, lds, tw, j);
-        float2 *dst = out + (size_t)(f0 + i) * 4096;
+        fft4096_regs(v, lds, tw, jl);
+        if (!METER || fm.store) {
+            float2 *dst = out + (size_t)(f0 + i) * 4096;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) __builtin_nontemporal_store(v[k], reinterpret_cast<f2 *>(dst) + ((j + 256 * k + rot) & 4095));
+            for (int k = 0; k < 16; ++k) __builtin_nontemporal_store(v[k], reinterpret_cast<f2 *>(dst) + ((jl + 256 * k + rot) & 4095));
+        }
+        if constexpr (METER) {  // (the next frame's first barrier separates this frame's last scratch reads from its image stores)
+            double total;
+            const double bw = frame4096_bandwidth(v, lds, jl, rot, fm.double_percentile, fm.sample_rate, &total);
+            if (jl == 0) {
+                fm.bw[f0 + i] = bw;
+                if (fm.energy) fm.energy[f0 + i] = total;
+            }
+        }
     }
 }
 
@@ -1457,7 +1491,7 @@ bool stft4096_supported(size_t hop) { return hop == 256 || hop == 512 || hop == 
 //  k_fft4096: 0.220 against 0.175 ms per 2^26 samples, chain step 0.182 against 0.174)
 
 int launch_stft4096(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
-                    const void *window, const void *tw4096, bool center_dc, size_t hop) {
+                    const void *window, const void *tw4096, bool center_dc, size_t hop, const FrameMeter *fm) {
     if (count == 0) return RR_OK;
     if (count > 0x7fffff00ull) RR_FAIL(RR_ERR_BAD_ARG, "stft4096: too many frames");
     const unsigned R = stft_run_length(count);
@@ -1465,9 +1499,14 @@ int launch_stft4096(hipStream_t s, const void *head, size_t n_head, const void *
     const unsigned grid = (nruns + 8 * kStftWin - 1) / (8 * kStftWin) * (8 * kStftWin);
 #define RR_STFT_CASE(SH)                                                                                                   \
     case 256 * SH:                                                                                                         \
-        hipLaunchKernelGGL(k_stft4096<SH>, dim3(grid), dim3(256), 0, s, (const float2 *)head, (long)n_head,               \
-                           (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw4096, (int)center_dc, \
-                           (unsigned)count, R, nruns);                                                                     \
+        if (fm)                                                                                                            \
+            hipLaunchKernelGGL((k_stft4096<SH, true>), dim3(grid), dim3(256), 0, s, (const float2 *)head, (long)n_head,   \
+                               (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw4096,           \
+                               (int)center_dc, (unsigned)count, R, nruns, *fm);                                            \
+        else                                                                                                               \
+            hipLaunchKernelGGL((k_stft4096<SH, false>), dim3(grid), dim3(256), 0, s, (const float2 *)head, (long)n_head,  \
+                               (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw4096,           \
+                               (int)center_dc, (unsigned)count, R, nruns, FrameMeter{});                                    \
         break;
     switch (hop) {
         RR_STFT_CASE(1)
@@ -2390,6 +2429,7 @@ struct FrameArgs {
     int mixfold;            // the NCO's period divides 8 and H holds the tables with the mixer folded in (rr_chain::ensure_mixfold)
     float sigma;            // results at odd indices of a block times sigma (+-1)
     int nb;                 // blocks per frame: ceil(4096 / ((1024 - V) / 4)) = 18 / 19 / 20 for V = 64 / 128 / 192 (<= kFrameBlocks)
+    FrameMeter fm;          // METER instances: metering::bandwidth per spectrum, computed behind the transform
 };
 
 // The fused frame kernel, second form (round 2).  What made the first one slower than the two kernels it replaces was
@@ -2412,7 +2452,7 @@ struct FrameArgs {
 #endif
 // MF: the mixer folded into the tables (rr_chain::ensure_mixfold) - instances of their own without the mixer's code; SW: poly4_block<SW>
 // FULL: 20 blocks per frame (V = 192, cfg2) - no guard around a wave's blocks; !FULL: 18 / 19 blocks (V = 64 / 128)
-template <bool MF, bool SW, bool FULL = true>
+template <bool MF, bool SW, bool FULL = true, bool METER = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ols_frame(FrameArgs a_) {
     const FrameArgs &a = a_;
     const FrameArgs *ka = (const FrameArgs *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -2616,10 +2656,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     __syncthreads();  // the frame has been read: it becomes the padded exchange image
     fft4096_regs(v, fr, ka->tw4096, tid);
-    float2 *dst = ka->spectra + (size_t)f * 4096;
     const int rot = ka->center_dc ? 2048 : 0;
+    if (!METER || ka->fm.store) {
+        float2 *dst = ka->spectra + (size_t)f * 4096;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) __builtin_nontemporal_store(v[k], reinterpret_cast<f2 *>(dst) + ((tid + 256 * k + rot) & 4095));
+        for (int k = 0; k < 16; ++k) __builtin_nontemporal_store(v[k], reinterpret_cast<f2 *>(dst) + ((tid + 256 * k + rot) & 4095));
+    }
+    if constexpr (METER) {
+        double total;
+        const double bw = frame4096_bandwidth(v, fr, tid, rot, ka->fm.double_percentile, ka->fm.sample_rate, &total);
+        if (tid == 0) {
+            ka->fm.bw[f] = bw;
+            if (ka->fm.energy) ka->fm.energy[f] = total;
+        }
+    }
 }
 
 bool ols_frame_supported(uint64_t D, size_t Lc, size_t fft_len) {
@@ -2628,7 +2678,7 @@ bool ols_frame_supported(uint64_t D, size_t Lc, size_t fft_len) {
 }
 
 int launch_ols_frame(hipStream_t s, const FusedFirArgs &a, const void *pend_in, size_t pl, void *pend_out, void *spectra,
-                     const void *window, const void *tw4096, bool center_dc) {
+                     const void *window, const void *tw4096, bool center_dc, const FrameMeter *fm) {
     if (a.V != 64 && a.V != 128 && a.V != 192) RR_FAIL(RR_ERR_BAD_ARG, "fused frame kernel: overlap %d not supported", a.V);
     const size_t total = pl + a.n_out, nfr = total / 4096;
     if (total == 0) return RR_OK;
@@ -2670,12 +2720,15 @@ int launch_ols_frame(hipStream_t s, const FusedFirArgs &a, const void *pend_in, 
         if (f.nb > kFrameBlocks) RR_FAIL(RR_ERR_BAD_ARG, "fused frame kernel: %d blocks per frame", f.nb);
     }
     const unsigned grid = 1u + (unsigned)((nfr + 8 * RR_V_FRAMEWIN - 1) / (8 * RR_V_FRAMEWIN) * (8 * RR_V_FRAMEWIN));
-#define RR_FRAME_LAUNCH(MF_, SW_, FU_)                                                                                     \
-    do {                                                                                                                    \
-        if (a.ev_start && a.ev_stop)                                                                                        \
-            hipExtLaunchKernelGGL((k_ols_frame<MF_, SW_, FU_>), dim3(grid), dim3(256), 0, s, a.ev_start, a.ev_stop, 0, f); \
-        else                                                                                                                \
-            hipLaunchKernelGGL((k_ols_frame<MF_, SW_, FU_>), dim3(grid), dim3(256), 0, s, f);                               \
+    f.fm = fm ? *fm : FrameMeter{};
+#define RR_FRAME_LAUNCH(MF_, SW_, FU_)                                                                                            \
+    do {                                                                                                                           \
+        if (fm)                                                                                                                    \
+            hipLaunchKernelGGL((k_ols_frame<MF_, SW_, FU_, true>), dim3(grid), dim3(256), 0, s, f);                                \
+        else if (a.ev_start && a.ev_stop)                                                                                          \
+            hipExtLaunchKernelGGL((k_ols_frame<MF_, SW_, FU_, false>), dim3(grid), dim3(256), 0, s, a.ev_start, a.ev_stop, 0, f); \
+        else                                                                                                                       \
+            hipLaunchKernelGGL((k_ols_frame<MF_, SW_, FU_, false>), dim3(grid), dim3(256), 0, s, f);                               \
     } while (0)
     if (f.nb == kFrameBlocks) {
         if (a.mixfold && a.sigma < 0.f) RR_FRAME_LAUNCH(true, true, true);

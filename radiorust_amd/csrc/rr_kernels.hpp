@@ -129,8 +129,16 @@ int launch_ols_wave(hipStream_t s, const FusedFirArgs &a);
 // decimated stream; H / tw4096 fields as for launch_ols_wave).  pend_in: pl decimated samples pending from
 // the previous call; pend_out receives the (pl + n_out) mod 4096 left over; spectra: (pl + n_out) / 4096 frames.
 bool ols_frame_supported(uint64_t D, size_t Lc, size_t fft_len);
+// What a metered kernel needs beside its transform's arguments: metering::bandwidth (metering.rs:41-80) per spectrum, computed
+// behind the transform while the bins are in registers (rr_meter_dev.hpp), and the spectrum's energy sum |X|^2.
+struct FrameMeter {
+    double double_percentile = 0.0, sample_rate = 0.0;
+    double *bw = nullptr;      // one value per frame
+    double *energy = nullptr;  // sum |X|^2 per frame (may be null)
+    int store = 1;             // 0: the spectra are not written at all (the caller only wants the figures)
+};
 int launch_ols_frame(hipStream_t s, const FusedFirArgs &a, const void *pend_in, size_t pl, void *pend_out, void *spectra,
-                     const void *window, const void *tw4096, bool center_dc);
+                     const void *window, const void *tw4096, bool center_dc, const FrameMeter *fm = nullptr);
 bool fused_fir_supported(uint64_t D, size_t Lc);
 int fused_fir_R(uint64_t D);  // outputs per lane of the instantiation for D
 int launch_fused_fir(hipStream_t s, const FusedFirArgs &a);
@@ -227,11 +235,17 @@ int launch_chan4096(hipStream_t s, const void *head, size_t n_head, const void *
 // k_stft4096: runs of overlapping 4096-point frames (hop 256, 512, 1024 or 2048), the sliding window in registers
 bool stft4096_supported(size_t hop);
 int launch_stft4096(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
-                    const void *window, const void *tw4096, bool center_dc, size_t hop);
+                    const void *window, const void *tw4096, bool center_dc, size_t hop, const FrameMeter *fm = nullptr);
 int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
                    const void *window, const void *tw4096, bool center_dc, size_t hop = 4096,
-                   hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                   hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const FrameMeter *fm = nullptr);
 int launch_drop_tail(hipStream_t s, const void *oldh, void *newh, size_t H, size_t drop);
+// metering (rr_metering.hip): the serial kernel (the reference's summation order, bit-equal to the oracle; mode 0 level,
+// 1 bandwidth, 2 sum of energies) and the parallel scan for frames of any length
+int launch_meter(int dtype, hipStream_t s, int mode, double double_percentile, double sample_rate, const void *frames,
+                 size_t n, size_t count, double *out);
+int launch_bandwidth_par(int dtype, hipStream_t s, double double_percentile, double sample_rate, const void *frames, size_t n,
+                         size_t count, double *bw_out, double *energy_out);
 
 // Polyphase channelizer: frame f = FFT_M( sum_{p<P} w[r + M p] x[M (f0 + f) + r + M p] ), r < M,
 // over the virtual stream [ hist (hist_len samples, ends right before in[0]) | in ].

@@ -8,6 +8,7 @@
 // the whole workgroup; no a*b+c contraction anywhere (the reference is Rust).
 #include <cstdlib>
 #include "rr_kernels.hpp"
+#include "rr_meter_dev.hpp"
 
 namespace rr {
 
@@ -37,6 +38,10 @@ __global__ __launch_bounds__(256) void k_meter(const typename V2m<T>::type *__re
         out[blockIdx.x] = total / (double)n;
         return;
     }
+    if (mode == 2) {  // the sum itself (the energy the fused epilogues report beside the bandwidth)
+        out[blockIdx.x] = total;
+        return;
+    }
     const double limit = __dmul_rn(total, double_percentile) / 2.0;
     const int wrap = (n + 1) / 2;
     double used_bins = 0.0;
@@ -57,6 +62,42 @@ __global__ __launch_bounds__(256) void k_meter(const typename V2m<T>::type *__re
     }
     const double bw = __dmul_rn(__dsub_rn((double)n, used_bins), sample_rate) / (double)n;
     out[blockIdx.x] = bw > 0.0 ? bw : 0.0;
+}
+
+// metering::bandwidth for frames of ANY length as a workgroup-wide parallel scan (rr_meter_dev.hpp): what the metered entry
+// points run behind a transform that has no fused epilogue (lengths other than 4096, Complex<f64>), and rr_bandwidth_fast_dev.
+// The energies are recomputed from the bins where they are needed (each bin is read two or three times, from L1 / L2).
+template <class T>
+__global__ __launch_bounds__(256) void k_bandwidth_par(const typename V2m<T>::type *__restrict__ frames, int n, double double_percentile,
+                                                       double sample_rate, double *__restrict__ bw_out, double *__restrict__ energy_out) {
+    __shared__ double scratch[kBwScratch];
+    const typename V2m<T>::type *src = frames + (size_t)blockIdx.x * n;
+    const int wrap = (n + 1) / 2;
+    auto e_at = [&](int s) -> double {
+        const int idx = s < n - wrap ? wrap + s : s - (n - wrap);
+        return (double)norm_sqr_rn(src[idx]);
+    };
+    double total;
+    const double bw = bandwidth_block256<0>(n, (int)threadIdx.x, e_at, double_percentile, sample_rate, scratch, &total);
+    if (threadIdx.x == 0) {
+        bw_out[blockIdx.x] = bw;
+        if (energy_out) energy_out[blockIdx.x] = total;
+    }
+}
+
+int launch_bandwidth_par(int dtype, hipStream_t s, double double_percentile, double sample_rate, const void *frames, size_t n,
+                         size_t count, double *bw_out, double *energy_out) {
+    if (count == 0) return RR_OK;
+    if (n == 0) RR_FAIL(RR_ERR_CONTRACT, "metering: empty chunk");
+    if (n > 0x3fffffffull || count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "metering: size out of range");
+    if (dtype == RR_F32)
+        hipLaunchKernelGGL(k_bandwidth_par<float>, dim3((unsigned)count), dim3(256), 0, s, (const float2 *)frames, (int)n,
+                           double_percentile, sample_rate, bw_out, energy_out);
+    else
+        hipLaunchKernelGGL(k_bandwidth_par<double>, dim3((unsigned)count), dim3(256), 0, s, (const double2 *)frames, (int)n,
+                           double_percentile, sample_rate, bw_out, energy_out);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
 }
 
 __device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
@@ -511,6 +552,12 @@ int rr_bandwidth_dev(int dtype, int device, void *stream, double double_percenti
                      const void *d_frames, size_t n, size_t count, double *d_out) {
     RR_TRY(dev_check(dtype, device));
     return launch_meter(dtype, (hipStream_t)stream, 1, double_percentile, sample_rate, d_frames, n, count, d_out);
+}
+int rr_bandwidth_fast_dev(int dtype, int device, void *stream, double double_percentile, double sample_rate,
+                          const void *d_frames, size_t n, size_t count, double *d_bandwidth, double *d_energy) {
+    RR_TRY(dev_check(dtype, device));
+    if (!d_bandwidth) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    return launch_bandwidth_par(dtype, (hipStream_t)stream, double_percentile, sample_rate, d_frames, n, count, d_bandwidth, d_energy);
 }
 int rr_rescale_energy_dev(int dtype, int device, void *stream, const void *d_frames, size_t n, size_t count,
                           size_t resolution, void *d_out) {

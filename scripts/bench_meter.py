@@ -27,6 +27,23 @@ dt = timeit(lambda: m.process_dev(fs, d_in.data_ptr(), N, d_out.data_ptr(), cap)
 alg = 8 + 0.8 + 0.8 + 0.8 + 0.8 + 3.2  # in, decimated out/in, filtered out/in, spectra out (x4 overlap), per input sample
 print(f"rr_meter (front end fused: {m.front_fused()}): {dt*1e3:.3f} ms per 2^26 input samples = {N/dt/1e9:.1f} GSamples/s; "
       f"{100*alg*N/dt/8e12:.1f} % of the unfused-stage traffic model {alg:.1f} B/sample, {100*(8+3.2)*N/dt/8e12:.1f} % of in + spectra out (11.2 B)")
+# the example's last step (main.rs:78): metering::bandwidth per spectrum.  (a) fused behind the transform, spectra still written;
+# (b) fused, spectra not written at all (the example never looks at them); (c) the serial kernel behind the pipeline (round 2's form)
+import ctypes as C
+frames = cap // 4096
+d_bw = torch.empty(frames, dtype=torch.float64, device="cuda")
+m.set_metering(0.01, d_bw.data_ptr(), frames)
+dt_a = timeit(lambda: m.process_dev(fs, d_in.data_ptr(), N, d_out.data_ptr(), cap))
+m.set_metering(0.01, d_bw.data_ptr(), frames, store_spectra=False)
+dt_b = timeit(lambda: m.process_dev(fs, d_in.data_ptr(), N, 0, 0))
+m.set_metering(0.01, 0, 0)
+L = rr._lib.lib()
+def serial():
+    w = m.process_dev(fs, d_in.data_ptr(), N, d_out.data_ptr(), cap)
+    rr._lib.check(L.rr_bandwidth_dev(0, 0, C.c_void_p(st), 0.01, out_rate, d_out.data_ptr(), 4096, w // 4096, d_bw.data_ptr()))
+dt_c = timeit(serial, K=3)
+print(f"pipeline + metering::bandwidth per spectrum: fused epilogue {dt_a*1e3:.3f} ms = {dt_a/dt:.3f} x the pipeline alone; "
+      f"fused, spectra not written {dt_b*1e3:.3f} ms = {dt_b/dt:.3f} x; serial kernel behind the pipeline {dt_c*1e3:.3f} ms = {dt_c/dt:.3f} x")
 sh = rr.FreqShifter.with_shift(12.5e3); sh.set_stream(st)
 ds = rr.Downsampler.new(1024, out_rate, bw); ds.set_stream(st)
 fl = rr.Filter.new(resp); fl.set_stream(st)

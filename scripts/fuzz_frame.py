@@ -15,8 +15,10 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
 worst, used = 0.0, {}
 for case in range(cases):
-    fs, out_rate, bw = 200e6, 50e6, 40e6           # Downsampler: L = 120
-    filter_len = int(rng.integers(10, 75))         # Lc = L + n - 1 in 129 .. 193
+    fs, out_rate = 200e6, 50e6
+    bw = float(rng.choice([40e6, 30e6, 20e6]))     # Downsampler: L = 120 / 60 / 40
+    L = {40e6: 120, 30e6: 60, 20e6: 40}[bw]
+    filter_len = int(rng.integers(2, 194 - L + 1))  # Lc = L + n - 1 up to 193: overlaps of 64 / 128 / 192 samples
     precision = float(rng.choice([1.0, 1e3, 1e5, 12345.0]))
     shift = float(rng.uniform(-60e6, 60e6)) if rng.random() < 0.6 else float(rng.choice([25e6, 12.5e6, 0.0, -50e6]))
     cut = float(rng.uniform(2e6, 24e6))

@@ -268,6 +268,27 @@ def test_chain_overlap_save_kernel_forced(rr, oracle, monkeypatch, kernel):
         assert rms_rel(a.chunk, b) <= 1e-5
 
 
+@pytest.mark.parametrize("bw,filter_len,shift,precision", [(30e6, 64, 25e6, 1.0), (30e6, 6, 12.345e6, 1e3), (20e6, 20, -50e6, 1.0),
+                                                           (20e6, 90, 12.5e6, 1.0), (30e6, 70, 3.7e6, 1e5), (40e6, 10, 25e6, 1.0)])
+def test_chain_frame_kernel_other_overlaps(rr, oracle, monkeypatch, bw, filter_len, shift, precision):
+    """k_ols_frame for combined responses shorter than cfg2's: Downsamplers of L = 60 (bw 30 MHz) and 40 (20 MHz) with Filters
+    of 6 .. 90 taps give overlaps of 64 / 128 samples - 240 / 224 results per block, 18 / 19 blocks per frame, the waves of
+    the last round partly idle - beside the 192 of cfg2's shape; general and foldable NCO periods, ragged calls."""
+    monkeypatch.setenv("RR_FUSED_KERNEL", "olsf")
+    fs, n = 200e6, 1 << 18
+    params = dict(shift=shift, filter_len=filter_len, freq_resp=lowpass(18e6), output_rate=50e6, bandwidth=bw, fft_len=4096)
+    x = oracle.synth_iq(77, 0, n)
+    t64 = oracle.run_chain(x, fs, flt=np.float64, fft_window=oracle.Kaiser.with_null_at_bin(2.0), precision=precision, **params)[3]
+    g = rr.Chain(**params, precision=precision, fft_window=rr.Kaiser.with_null_at_bin(2.0))
+    out, frame_calls = [], 0
+    for a, b in ((0, 50001), (50001, 120000), (120000, 120000 + 16384 * 5), (120000 + 16384 * 5, n)):
+        out += g.process(rr.Samples(fs, x[a:b]))
+        frame_calls += g.last_path_kernel() == "k_ols_frame"
+    assert frame_calls >= 3 and len(out) == len(t64) == 15
+    for a, b in zip(out, t64):
+        assert rms_rel(a.chunk, b) <= 1e-5
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_chain_wave_kernel_randomised(rr, oracle, seed):
     """k_ols_wave (the default fused kernel for 4x decimation) under random parameters: shifts whose
