@@ -185,6 +185,12 @@ int rr_filter_mark_params_changed(rr_filter *h);
 int rr_filter_design(rr_filter *h, double sample_rate, size_t n,
                      const rr_c64 *resp, const double *window_rel);
 /* Event::is_interrupt() handling (filters.rs:262-265). */
+/* A GainControl (src/blocks/transform.rs:29-92: `sample * gain`, gain cast to Flt) wired BEHIND this block, as the
+ * reference's receiver does behind its last Downsampler (examples/relm_app/simple_receiver.rs:52-56), without a pass of its
+ * own: the gain is folded into the block's response tables on the host (Filter, Downsampler: the device does nothing for it;
+ * results differ from the two-block composition by rounding only) or rides on the store (FmDemod: bit-equal to the
+ * composition).  Takes effect at the next process call (`watch` semantics, transform.rs:64-66); histories are kept. */
+int rr_filter_set_gain(rr_filter *h, double gain);
 int rr_filter_reset(rr_filter *h);
 /* One Signal::Samples message of exactly the designed length n
  * (filters.rs:240-260): n_out = 0 for the first chunk after create/design/
@@ -224,6 +230,7 @@ int rr_downsampler_create(int dtype, double output_rate, double bandwidth,
                           double quality, int device, rr_downsampler **out);
 /* Outputs this message will produce (the `pos` schedule of resampling.rs:110-
  * 112 run ahead without consuming anything). */
+int rr_downsampler_set_gain(rr_downsampler *h, double gain); /* see rr_filter_set_gain */
 int rr_downsampler_peek(rr_downsampler *h, double input_rate, size_t n_in,
                         size_t *n_out);
 int rr_downsampler_process(rr_downsampler *h, double input_rate, const void *in,
@@ -491,6 +498,7 @@ typedef struct rr_fmdemod rr_fmdemod;
 int rr_fmdemod_create(int dtype, double deviation, int device, rr_fmdemod **out);
 /* set_deviation / deviation (modulation.rs:163-170); effective from the next process call */
 int rr_fmdemod_set_deviation(rr_fmdemod *h, double deviation);
+int rr_fmdemod_set_gain(rr_fmdemod *h, double gain); /* see rr_filter_set_gain */
 int rr_fmdemod_deviation(const rr_fmdemod *h, double *deviation);
 int rr_fmdemod_reset(rr_fmdemod *h);
 int rr_fmdemod_process(rr_fmdemod *h, double sample_rate, const void *in, size_t n_in,

@@ -121,6 +121,7 @@ SIGNATURES = {
     "rr_filter_mark_params_changed": (_i, [_vp]),
     "rr_filter_design": (_i, [_vp, _d, _sz, _vp, _vp]),
     "rr_filter_reset": (_i, [_vp]),
+    "rr_filter_set_gain": (_i, [_vp, _d]),
     "rr_filter_process": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
     "rr_filter_enqueue": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
     "rr_filter_process_dev": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
@@ -128,6 +129,7 @@ SIGNATURES = {
     "rr_filter_last_kernel": (_i, [_vp, C.POINTER(_i)]),
     "rr_filter_destroy": (_i, [_vp]),
     "rr_downsampler_create": (_i, [_i, _d, _d, _d, _i, C.POINTER(_vp)]),
+    "rr_downsampler_set_gain": (_i, [_vp, _d]),
     "rr_downsampler_peek": (_i, [_vp, _d, _sz, _psz]),
     "rr_downsampler_process": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
     "rr_downsampler_enqueue": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),
@@ -196,6 +198,7 @@ SIGNATURES = {
     "rr_upsampler_design": (_i, [_d, _d, _d, _d, _psz, _vp, _sz]),
     "rr_fmdemod_create": (_i, [_i, _d, _i, C.POINTER(_vp)]),
     "rr_fmdemod_set_deviation": (_i, [_vp, _d]),
+    "rr_fmdemod_set_gain": (_i, [_vp, _d]),
     "rr_fmdemod_deviation": (_i, [_vp, C.POINTER(_d)]),
     "rr_fmdemod_reset": (_i, [_vp]),
     "rr_fmdemod_process": (_i, [_vp, _d, _vp, _sz, _vp, _sz, _psz]),

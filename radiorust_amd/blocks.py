@@ -167,6 +167,11 @@ class Filter(_Block):
         self._window = window if window is not None else Kaiser.with_null_at_bin(2.0)
         _lib.check(_lib.lib().rr_filter_create(self._code, device, C.byref(self._h)))
 
+    def set_gain(self, gain: float):
+        """A GainControl wired behind this block (transform.rs:29-92), folded into the block's tables: no pass of its own."""
+        _lib.check(_lib.lib().rr_filter_set_gain(self._h, float(gain)))
+        return self
+
     # filters.rs:128-152
     @classmethod
     def new(cls, freq_resp, **kw):
@@ -252,6 +257,11 @@ class Downsampler(_Block):
     @classmethod
     def with_quality(cls, output_chunk_len, output_rate, bandwidth, quality, **kw):
         return cls(output_chunk_len, output_rate, bandwidth, quality, **kw)
+
+    def set_gain(self, gain: float):
+        """A GainControl wired behind this block (examples/relm_app/simple_receiver.rs:52-56), folded into the impulse response."""
+        _lib.check(_lib.lib().rr_downsampler_set_gain(self._h, float(gain)))
+        return self
 
     def ir_len(self) -> int:
         v = C.c_size_t()
@@ -354,6 +364,11 @@ class FmDemod(_Block):
 
     def set_deviation(self, deviation: float):
         _lib.check(_lib.lib().rr_fmdemod_set_deviation(self._h, float(deviation)))
+        return self
+
+    def set_gain(self, gain: float):
+        """A GainControl wired behind the demodulator, applied on the store (bit-equal to the two blocks one after the other)."""
+        _lib.check(_lib.lib().rr_fmdemod_set_gain(self._h, float(gain)))
         return self
 
     def process_raw(self, sample_rate, chunk) -> np.ndarray:

@@ -153,11 +153,36 @@ static uint16_t f32_to_f16_bits(float f) {
     return (uint16_t)(sign | h);
 }
 
+static double gain_as_flt(int dtype, double g) { return dtype == RR_F32 ? (double)(float)g : g; }  // flt!(gain), transform.rs:55
+
 int rr_filter::design(double sample_rate, size_t len, const rr_c64 *resp, const double *window_rel) {
     RR_TRY(select());
     if (len > (size_t(1) << 24)) RR_FAIL(RR_ERR_BAD_ARG, "Filter: chunk length %zu is not supported", len);
     std::vector<cd> g(len);
     RR_TRY(filter_design_taps(len, resp, window_rel, g.data()));
+    taps_base.swap(g);
+    design_rate = sample_rate;
+    return build_tables(true);
+}
+
+int rr_filter::set_gain(double g) {
+    if (g == gain) return RR_OK;
+    gain = g;
+    if (!designed) return RR_OK;
+    RR_TRY(select());
+    return build_tables(false);  // (the previous chunk stays: GainControl has no state of its own)
+}
+
+// every kernel's tables from taps_base * gain
+int rr_filter::build_tables(bool reset_history) {
+    const size_t len = taps_base.size();
+    const double sample_rate = design_rate;
+    std::vector<cd> g(taps_base);
+    {
+        const double gf = gain_as_flt(dtype, gain);
+        if (gf != 1.0)
+            for (cd &v : g) v *= gf;
+    }
     double max_re = 0.0, max_im = 0.0;
     for (const cd &v : g) {
         max_re = std::fmax(max_re, std::fabs(v.real()));
@@ -259,17 +284,18 @@ int rr_filter::design(double sample_rate, size_t len, const rr_c64 *resp, const 
         RR_TRY(upload(d_H, hb2.data(), hb2.size(), stream));
         RR_TRY(upload(d_olstw, tb2.data(), tb2.size(), stream));
     }
+    taps_f64.swap(g);
+    ++design_version;
+    if (!reset_history) return RR_OK;
     const size_t hb = len * elem_size(dtype);
     RR_TRY(hist[0].reserve(hb));
     RR_TRY(hist[1].reserve(hb));
-    taps_f64.swap(g);
     n = len;
     rate = sample_rate;
     designed = true;
     params_changed = false;
     hist_valid = false;  // previous_chunk = None (filters.rs:187)
     cur = 0;
-    ++design_version;
     return RR_OK;
 }
 
@@ -362,19 +388,31 @@ int rr_downsampler::prepare(double input_rate) {
     have_rate = true;
     prev_rate = input_rate;
     L = ir.size();
-    std::vector<unsigned char> bytes;
-    if (dtype == RR_F32)
-        cast_to<float>(ir.data(), L, bytes);
-    else
-        cast_to<double>(ir.data(), L, bytes);
-    RR_TRY(upload(d_ir, bytes.data(), bytes.size(), stream));
-    ir_f64.swap(ir);
+    ir_base.swap(ir);
+    RR_TRY(set_gain(gain));  // ir_f64 = gain * ir_base, uploaded; ++design_version
     const size_t hb = L * elem_size(dtype);
     RR_TRY(hist[0].reserve(hb));
     RR_TRY(hist[1].reserve(hb));
     RR_HIP(hipMemsetAsync(hist[0].p, 0, hb, stream));  // ringbuf = vec![0; ir_len]
     cur = 0;
     sched.configure(input_rate, output_rate);  // pos = 0
+    return RR_OK;
+}
+
+// (also the tail of prepare(): the tables every kernel reads, from ir_base and the gain; history and schedule stay)
+int rr_downsampler::set_gain(double g) {
+    gain = g;
+    if (ir_base.empty()) return RR_OK;
+    RR_TRY(select());
+    const double gf = gain_as_flt(dtype, gain);
+    ir_f64.resize(ir_base.size());
+    for (size_t i = 0; i < ir_base.size(); ++i) ir_f64[i] = gf == 1.0 ? ir_base[i] : gf * ir_base[i];
+    std::vector<unsigned char> bytes;
+    if (dtype == RR_F32)
+        cast_to<float>(ir_f64.data(), ir_f64.size(), bytes);
+    else
+        cast_to<double>(ir_f64.data(), ir_f64.size(), bytes);
+    RR_TRY(upload(d_ir, bytes.data(), bytes.size(), stream));
     ++design_version;
     return RR_OK;
 }
@@ -737,7 +775,7 @@ int rr_fmdemod::process_dev(double sample_rate, const void *d_in, size_t n_in, v
     if (n_in == 0) return RR_OK;
     const double TAU = 6.283185307179586476925286766559;
     const double factor = sample_rate / deviation / TAU;  // modulation.rs:119, cast to Flt by the launcher
-    RR_TRY(launch_fmdemod(dtype, stream, d_in, n_in, d_out, state[cur].p, state[cur ^ 1].p, have_prev ? 1 : 0, factor));
+    RR_TRY(launch_fmdemod(dtype, stream, d_in, n_in, d_out, state[cur].p, state[cur ^ 1].p, have_prev ? 1 : 0, factor, gain));
     cur ^= 1;
     have_prev = true;
     if (n_out) *n_out = n_in;
@@ -2283,6 +2321,12 @@ int rr_filter_design(rr_filter *h, double sample_rate, size_t n, const rr_c64 *r
     return h->design(sample_rate, n, resp, window_rel);
     RR_GUARD_END
 }
+int rr_filter_set_gain(rr_filter *h, double gain) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_FILTER);
+    return h->set_gain(gain);
+    RR_GUARD_END
+}
 int rr_filter_reset(rr_filter *h) {
     RR_CHECK_HANDLE(h, K_FILTER);
     h->hist_valid = false;
@@ -2362,6 +2406,13 @@ int rr_downsampler_create(int dtype, double output_rate, double bandwidth, doubl
     h->quality = quality;
     *out = h;
     return RR_OK;
+    RR_GUARD_END
+}
+int rr_downsampler_set_gain(rr_downsampler *h, double gain) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_DOWNSAMPLER);
+    if (gain == h->gain) return RR_OK;
+    return h->set_gain(gain);
     RR_GUARD_END
 }
 int rr_downsampler_peek(rr_downsampler *h, double input_rate, size_t n_in, size_t *n_out) {
@@ -2628,6 +2679,11 @@ int rr_fmdemod_create(int dtype, double deviation, int device, rr_fmdemod **out)
     *out = h;
     return RR_OK;
     RR_GUARD_END
+}
+int rr_fmdemod_set_gain(rr_fmdemod *h, double gain) {
+    RR_CHECK_HANDLE(h, K_FMDEMOD);
+    h->gain = gain;
+    return RR_OK;
 }
 int rr_fmdemod_set_deviation(rr_fmdemod *h, double deviation) {
     RR_CHECK_HANDLE(h, K_FMDEMOD);

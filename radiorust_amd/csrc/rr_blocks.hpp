@@ -21,6 +21,13 @@ struct rr_freqshifter : rr_block {
 
 // Filter — filters.rs:161-170 (previous_chunk, extended_response, ...)
 struct rr_filter : rr_block {
+    // A GainControl behind the Filter folded into the response: the taps of every kernel's tables are gain_flt * g
+    // (results differ from `sample * gain` by rounding only); set_gain() rebuilds the tables and keeps the history.
+    double gain = 1.0;
+    std::vector<rr::cd> taps_base;  // g[k] of the design, without the gain
+    double design_rate = 0.0;
+    int build_tables(bool reset_history);
+    int set_gain(double g);
     bool designed = false;
     bool params_changed = false;
     double rate = 0.0;
@@ -65,6 +72,12 @@ void build_fused_fir_tables(int kind, uint64_t D, const std::vector<double> &c, 
 
 struct rr_downsampler : rr_block {
     double output_rate = 0, bandwidth = 0, quality = 3.0;
+    // A GainControl behind the Downsampler (examples/relm_app/simple_receiver.rs:52-56) folded into the impulse response:
+    // ir_f64 = gain_flt * ir_base, so every kernel's tables carry it and the device does nothing for it (results differ from
+    // `sample * gain` by rounding only).  gain_flt = the gain cast to Flt, as GainControl casts it (transform.rs:55,64).
+    double gain = 1.0;
+    std::vector<double> ir_base;
+    int set_gain(double g);
     bool have_rate = false;
     double prev_rate = 0.0;
     rr::Schedule sched;
@@ -179,6 +192,7 @@ struct rr_upsampler : rr_block {
 
 struct rr_fmdemod : rr_block {
     double deviation = 0;
+    double gain = 1.0;  // a GainControl behind the demodulator (transform.rs:62-72), applied on the store: exact
     bool have_prev = false;
     rr::DevBuf state[2];  // {previous sample, last output}, ping-pong
     int cur = 0;

@@ -273,7 +273,7 @@ int launch_upsample(int dtype, hipStream_t s, const void *hist, size_t hn, const
 // FmDemod (modulation.rs:121-130): out[t] = (arg(x[t] * conj(x[t-1])) * factor, 0); st_in / st_out:
 // {previous sample, last output}; without a previous sample the first output repeats the last one.
 int launch_fmdemod(int dtype, hipStream_t s, const void *in, size_t n, void *out, const void *st_in, void *st_out,
-                   int have_prev, double factor);
+                   int have_prev, double factor, double gain = 1.0);
 
 // SURVEY §8(d) synthetic IQ, f32
 int launch_synth(hipStream_t s, uint64_t seed, uint64_t t0, size_t n, void *out);

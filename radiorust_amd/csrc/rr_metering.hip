@@ -356,11 +356,11 @@ __device__ __forceinline__ double atan2_t(double y, double x) { return atan2(y, 
 template <class T, class CT>
 __global__ __launch_bounds__(256) void k_fmdemod(const CT *__restrict__ in, long n, CT *__restrict__ out,
                                                  const CT *__restrict__ st_in, CT *__restrict__ st_out,
-                                                 int have_prev, T factor) {
+                                                 int have_prev, T factor, T gain) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const CT cur = in[t];
-    CT o;
+    CT o;  // (the state keeps the demodulator's own output; `gain` - a GainControl behind it, transform.rs:62-72 - rides on the store)
     if (t == 0 && !have_prev) {
         o = st_in[1];  // output_sample keeps its value (zero before the first pair)
     } else {
@@ -372,7 +372,10 @@ __global__ __launch_bounds__(256) void k_fmdemod(const CT *__restrict__ in, long
         o.x = mul_rn(atan2_t(im, re), factor);
         o.y = 0;
     }
-    out[t] = o;
+    CT og;
+    og.x = mul_rn(o.x, gain);
+    og.y = mul_rn(o.y, gain);
+    out[t] = og;
     if (t == n - 1) {
         st_out[0] = cur;
         st_out[1] = o;
@@ -419,7 +422,7 @@ __device__ __forceinline__ float fm_one(float2 cur, float2 pv, float factor) {
 
 __global__ __launch_bounds__(256) void k_fmdemod_pairs(const float2 *__restrict__ in, long n, float2 *__restrict__ out,
                                                        const float2 *__restrict__ st_in, float2 *__restrict__ st_out,
-                                                       int have_prev, float factor) {
+                                                       int have_prev, float factor, float gain) {
     typedef float f4s __attribute__((ext_vector_type(4)));
     const long npair = n >> 1;  // whole pairs; an odd last sample is the last pair's owner's
     const long stride = (long)gridDim.x * 256;
@@ -434,7 +437,8 @@ __global__ __launch_bounds__(256) void k_fmdemod_pairs(const float2 *__restrict_
         else
             o0.x = fm_one(float2{v.x, v.y}, pv, factor);
         o1.x = fm_one(float2{v.z, v.w}, float2{v.x, v.y}, factor);
-        __builtin_nontemporal_store((f4s){o0.x, o0.y, o1.x, o1.y}, reinterpret_cast<f4s *>(out + 2 * ip));
+        __builtin_nontemporal_store((f4s){mul_rn(o0.x, gain), mul_rn(o0.y, gain), mul_rn(o1.x, gain), mul_rn(o1.y, gain)},
+                                    reinterpret_cast<f4s *>(out + 2 * ip));
         if (2 * ip + 2 == n) {
             st_out[0] = float2{v.z, v.w};
             st_out[1] = o1;
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(256) void k_fmdemod_pairs(const float2 *__restrict_
             float2 o;
             o.x = fm_one(cur, float2{v.z, v.w}, factor);
             o.y = 0.f;
-            out[n - 1] = o;
+            out[n - 1] = float2{mul_rn(o.x, gain), 0.f};
             st_out[0] = cur;
             st_out[1] = o;
         }
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(256) void k_fmdemod_pairs(const float2 *__restrict_
 }
 
 int launch_fmdemod(int dtype, hipStream_t s, const void *in, size_t n, void *out, const void *st_in, void *st_out,
-                   int have_prev, double factor) {
+                   int have_prev, double factor, double gain) {
     if (n == 0) return RR_OK;
     static const bool generic = [] {
         const char *e = std::getenv("RR_FMDEMOD_GENERIC");
@@ -484,17 +488,17 @@ int launch_fmdemod(int dtype, hipStream_t s, const void *in, size_t n, void *out
         if (blocks > 256 * 16) blocks = 256 * 16;
         blocks = (blocks + 7) / 8 * 8;
         hipLaunchKernelGGL(k_fmdemod_pairs, dim3((unsigned)blocks), dim3(256), 0, s, (const float2 *)in, (long)n, (float2 *)out,
-                           (const float2 *)st_in, (float2 *)st_out, have_prev, (float)factor);
+                           (const float2 *)st_in, (float2 *)st_out, have_prev, (float)factor, (float)gain);
         RR_HIP(hipGetLastError());
         return RR_OK;
     }
     const unsigned blocks = (unsigned)((n + 255) / 256);
     if (dtype == RR_F32)
         hipLaunchKernelGGL((k_fmdemod<float, float2>), dim3(blocks), dim3(256), 0, s, (const float2 *)in, (long)n,
-                           (float2 *)out, (const float2 *)st_in, (float2 *)st_out, have_prev, (float)factor);
+                           (float2 *)out, (const float2 *)st_in, (float2 *)st_out, have_prev, (float)factor, (float)gain);
     else
         hipLaunchKernelGGL((k_fmdemod<double, double2>), dim3(blocks), dim3(256), 0, s, (const double2 *)in, (long)n,
-                           (double2 *)out, (const double2 *)st_in, (double2 *)st_out, have_prev, factor);
+                           (double2 *)out, (const double2 *)st_in, (double2 *)st_out, have_prev, factor, gain);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }

@@ -144,3 +144,70 @@ def test_fmdemod_interrupt_deviation_events(rr, oracle):
     atol = 4 * np.finfo(np.float32).eps * np.pi * fs / 2500.0 / (2 * np.pi)
     for s, r in ((s1, r1), (s2, r2), (s3, r3)):
         assert np.max(np.abs(s.chunk - r)) <= atol
+
+
+def _rms(a, b):
+    a = np.asarray(a, dtype=np.complex128)
+    b = np.asarray(b, dtype=np.complex128)
+    return float(np.sqrt(np.sum(np.abs(a - b) ** 2) / max(np.sum(np.abs(b) ** 2), 1e-300)))
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 1e-6), (np.float64, 1e-13)])
+def test_gain_control_folded_into_the_block_in_front(rr, oracle, dtype, tol):
+    """rr_*_set_gain: GainControl (transform.rs:29-92) behind a Downsampler (the reference's receiver,
+    simple_receiver.rs:52-56), a Filter and an FmDemod without a pass of its own, against the oracle's two blocks one after
+    the other; gain changes between calls take effect at the next call and keep the histories (watch semantics)."""
+    import torch
+
+    cdt = np.complex64 if dtype == np.float32 else np.complex128
+    x = oracle.synth_iq(12, 0, 200000).astype(cdt)
+    cuts = [0, 30000, 30001, 90000, 200000]
+    gains = [0.25, 0.25, -1.7, 3.0]
+    # Downsampler 8 : 1 (384 k -> 48 k, L = 288: the receiver's last stage, k_ols_wave in f32) and 10 : 1 (k_decim_poly)
+    for out_rate, in_rate, bw in ((48000.0, 384000.0, 40000.0), (102400.0, 1024000.0, 60e3)):
+        g = rr.Downsampler.new(1024, out_rate, bw, dtype=dtype)
+        o = oracle.Downsampler(1024, out_rate, bw, flt=np.float64)
+        for (a, b), gain in zip(zip(cuts[:-1], cuts[1:]), gains):
+            g.set_gain(gain)
+            got = g.process_raw(in_rate, x[a:b])
+            want = oracle.gain(float(np.float32(gain)) if dtype == np.float32 else gain, o.process(in_rate, x[a:b].astype(np.complex128)), np.float64)
+            assert len(got) == len(want)
+            if len(want):
+                assert _rms(got, want) <= max(tol, 1e-12), (out_rate, a, b, _rms(got, want))
+    # Filter, n = 1000: chunk by chunk from the host (short calls), then 40 chunks in one device call (k_filter_blk4096 in f32)
+    resp = lambda _b, f: 1.0 if abs(f) <= 9e3 else 0.0  # noqa: E731
+    f = rr.Filter.new(resp, dtype=dtype)
+    of = oracle.Filter(resp, flt=np.float64)
+    n = 1000
+    pos = 0
+    for gain in (0.5, -2.0, 1.0):
+        f.set_gain(gain)
+        for _ in range(3):
+            chunk = x[pos:pos + n]
+            pos += n
+            got = f.process(rr.Samples(48000.0, chunk))
+            want = of.process(48000.0, chunk.astype(np.complex128))
+            assert (want is None) == (len(got) == 0)
+            if want is not None:
+                assert _rms(got[0].chunk, (float(np.float32(gain)) if dtype == np.float32 else gain) * want) <= 10 * max(tol, 1e-12)
+    f.set_gain(0.125)
+    k = 40
+    d_in = torch.from_numpy(x[pos:pos + k * n]).cuda()
+    d_out = torch.empty(k * n, dtype=d_in.dtype, device="cuda")
+    f.set_stream(torch.cuda.current_stream().cuda_stream)
+    w = f.process_dev(48000.0, n, d_in.data_ptr(), k * n, d_out.data_ptr(), k * n)
+    torch.cuda.synchronize()
+    assert w == k * n
+    want = np.concatenate([of.process(48000.0, x[pos + i * n:pos + (i + 1) * n].astype(np.complex128)) for i in range(k)])
+    assert _rms(d_out.cpu().numpy(), 0.125 * want) <= 10 * max(tol, 1e-12)
+    # FmDemod: FmDemod -> GainControl exactly (the gain rides on the store, the state keeps the demodulator's own output)
+    d = rr.FmDemod(75000.0, dtype=dtype)
+    od = oracle.FmDemod(75000.0, flt=dtype)
+    for (a, b), gain in zip(zip(cuts[:-1], cuts[1:]), gains):
+        d.set_gain(gain)
+        got = d.process_raw(384000.0, x[a:b])
+        want = oracle.gain(gain, od.process(384000.0, x[a:b]), dtype)
+        if dtype == np.float64:
+            assert np.max(np.abs(got - want)) <= 1e-12 * abs(gain)
+        else:
+            assert np.max(np.abs(got - want)) <= 4 * 2.4e-7 * 3.1416 * (384000.0 / 75000.0 / 6.2832) * abs(gain) * 1.01 + 1e-12
