@@ -371,6 +371,43 @@ int rr_channelizer_process_dev(rr_channelizer *h, const void *d_in, size_t n_in,
 int rr_channelizer_destroy(rr_channelizer *h);
 
 /* ------------------------------------------------------------------------ */
+/* ChainBank — K chains with the same parameters whose streams advance in        */
+/* LOCKSTEP (the antennas of an array, the sub-bands of a channelized receiver:   */
+/* the reference runs one tokio task per block and channel, flow.rs:233-267, at   */
+/* chunk sizes of 10^3 .. 10^5 samples, examples/bandwidth_meter/main.rs:56 — a    */
+/* size at which a single channel's call on a GPU is launch-bound).  Every         */
+/* channel is a full rr_chain with its own state (rr_chainbank_channel hands it    */
+/* out; it may be driven alone at any time).  A call gives every channel n_in      */
+/* samples: channel k reads d_in + k * in_stride, writes d_out + k * out_stride    */
+/* (strides in samples).  While all channels are in the steady fused state at the  */
+/* same stream position, the call is TWO launches for all of them (channel =       */
+/* blockIdx.y); otherwise (stream start, after an interrupt or a retune, ragged    */
+/* calls) the channels run one after the other.  Either way each channel's         */
+/* spectra are bit-identical to those of a stand-alone rr_chain fed the same       */
+/* samples in the same calls.  n_out: bins per channel.  All channels share the    */
+/* bank's stream (rr_set_stream).  Complex<f32>, fft_len 4096 for the lockstep     */
+/* step; other parameters run lane by lane.                                        */
+/* ------------------------------------------------------------------------ */
+typedef struct rr_chainbank rr_chainbank;
+int rr_chainbank_create(const rr_chain_params *p, size_t channels, int device,
+                        rr_chainbank **out);
+int rr_chainbank_channels(const rr_chainbank *h, size_t *channels);
+int rr_chainbank_channel(rr_chainbank *h, size_t k, rr_chain **lane); /* owned by the bank */
+int rr_chainbank_set_shift(rr_chainbank *h, double shift);
+int rr_chainbank_filter_needs_design(const rr_chainbank *h, double sample_rate, int *needed);
+int rr_chainbank_filter_mark_params_changed(rr_chainbank *h);
+int rr_chainbank_filter_design(rr_chainbank *h, double sample_rate, const rr_c64 *resp,
+                               const double *window_rel);
+int rr_chainbank_interrupt(rr_chainbank *h);
+int rr_chainbank_peek(rr_chainbank *h, double sample_rate, size_t n_in, size_t *n_frames);
+int rr_chainbank_process_dev(rr_chainbank *h, double sample_rate, const void *d_in,
+                             size_t in_stride, size_t n_in, void *d_out, size_t out_stride,
+                             size_t out_cap, size_t *n_out);
+/* 1 when the last call ran in lockstep (two launches for all channels), 0: lane by lane */
+int rr_chainbank_last_path(const rr_chainbank *h, int *lockstep);
+int rr_chainbank_destroy(rr_chainbank *h);
+
+/* ------------------------------------------------------------------------ */
 /* Overlapped Fourier analysis: the composition            */
 /*   Rechunker(chunk_len) -> Overlapper(chunk_count) -> Fourier::with_window     */
 /* (src/blocks/chunks.rs:42-242, analysis.rs:26-133; the wiring of               */

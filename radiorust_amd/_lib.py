@@ -157,6 +157,18 @@ SIGNATURES = {
     "rr_chain_set_metering": (_i, [_vp, _d, _vp, _vp, _sz, _i]),
     "rr_chain_last_path": (_i, [_vp, C.POINTER(_i)]),
     "rr_chain_destroy": (_i, [_vp]),
+    "rr_chainbank_create": (_i, [C.POINTER(ChainParams), _sz, _i, C.POINTER(_vp)]),
+    "rr_chainbank_channels": (_i, [_vp, _psz]),
+    "rr_chainbank_channel": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "rr_chainbank_set_shift": (_i, [_vp, _d]),
+    "rr_chainbank_filter_needs_design": (_i, [_vp, _d, C.POINTER(_i)]),
+    "rr_chainbank_filter_mark_params_changed": (_i, [_vp]),
+    "rr_chainbank_filter_design": (_i, [_vp, _d, _vp, _vp]),
+    "rr_chainbank_interrupt": (_i, [_vp]),
+    "rr_chainbank_peek": (_i, [_vp, _d, _sz, _psz]),
+    "rr_chainbank_process_dev": (_i, [_vp, _d, _vp, _sz, _sz, _vp, _sz, _sz, _psz]),
+    "rr_chainbank_last_path": (_i, [_vp, C.POINTER(_i)]),
+    "rr_chainbank_destroy": (_i, [_vp]),
     "rr_chain_timing_enable": (_i, [_vp, _i]),
     "rr_chain_timing_every": (_i, [_vp, C.c_uint]),
     "rr_chain_timing_reset": (_i, [_vp]),

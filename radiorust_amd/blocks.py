@@ -683,6 +683,66 @@ class Stft(_Block):
                                                    d_energy or None, int(cap_frames), int(bool(store_spectra))))
 
 
+class ChainBank(_Block):
+    """K chains with the same parameters whose streams advance in lockstep (rr_chainbank_*): a call gives every channel
+    the same number of samples (device pointers, channel k at d_in + k * in_stride samples) and, once all channels are in the
+    steady fused state, runs as two launches for all of them.  Each channel's spectra are bit-identical to a stand-alone
+    Chain's."""
+
+    _destroy = "rr_chainbank_destroy"
+
+    def __init__(self, channels: int, *, shift: float, precision: float = 1.0, filter_len: int, freq_resp,
+                 filter_window: Window | None = None, output_rate: float, bandwidth: float, quality: float = 3.0,
+                 fft_len: int, fft_window: Window | None = None, center_dc: bool = False, dtype=np.float32,
+                 device: int = 0, allow_fused: bool = True):
+        super().__init__()
+        self._code, self._cdt = _dtype_code(dtype)
+        self._freq_resp = freq_resp
+        self._filter_window = filter_window if filter_window is not None else Kaiser.with_null_at_bin(2.0)
+        fw = fft_window if fft_window is not None else Rectangular()
+        spec = fw._spec()
+        if spec is None:
+            raise TypeError("ChainBank needs a built-in fft_window (Rectangular or Kaiser)")
+        self.channels, self.filter_len, self.fft_len = int(channels), int(filter_len), int(fft_len)
+        p = _lib.ChainParams(self._code, float(precision), float(shift), self.filter_len, float(output_rate),
+                             float(bandwidth), float(quality), self.fft_len, spec, int(bool(center_dc)),
+                             int(bool(allow_fused)))
+        _lib.check(_lib.lib().rr_chainbank_create(p, self.channels, device, C.byref(self._h)))
+
+    def set_shift(self, shift: float):
+        _lib.check(_lib.lib().rr_chainbank_set_shift(self._h, float(shift)))
+
+    def interrupt(self):
+        _lib.check(_lib.lib().rr_chainbank_interrupt(self._h))
+
+    def _ensure_design(self, sample_rate: float):
+        needed = C.c_int()
+        _lib.check(_lib.lib().rr_chainbank_filter_needs_design(self._h, sample_rate, C.byref(needed)))
+        if needed.value:
+            resp = sample_freq_resp(self._freq_resp, self.filter_len, sample_rate)
+            win = self._filter_window.sample(self.filter_len)
+            _lib.check(_lib.lib().rr_chainbank_filter_design(self._h, sample_rate, resp.ctypes.data, win.ctypes.data))
+
+    def peek(self, sample_rate, n_in: int) -> int:
+        self._ensure_design(float(sample_rate))
+        v = C.c_size_t()
+        _lib.check(_lib.lib().rr_chainbank_peek(self._h, float(sample_rate), n_in, C.byref(v)))
+        return v.value
+
+    def process_dev(self, sample_rate, d_in: int, in_stride: int, n_in: int, d_out: int, out_stride: int, cap: int) -> int:
+        """Bins written per channel."""
+        self._ensure_design(float(sample_rate))
+        n_out = C.c_size_t()
+        _lib.check(_lib.lib().rr_chainbank_process_dev(self._h, float(sample_rate), d_in, in_stride, n_in, d_out, out_stride,
+                                                       cap, C.byref(n_out)))
+        return n_out.value
+
+    def last_path_lockstep(self) -> bool:
+        v = C.c_int()
+        _lib.check(_lib.lib().rr_chainbank_last_path(self._h, C.byref(v)))
+        return bool(v.value)
+
+
 class Meter(_Block):
     """The reference's own hot-path caller in ITS order (examples/bandwidth_meter/main.rs:53-69) on one device without
     host hops: FreqShifter(shift) -> Downsampler(chunk_len, output_rate, bandwidth, quality) -> Filter(freq_resp; it

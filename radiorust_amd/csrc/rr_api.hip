@@ -1932,6 +1932,183 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     return RR_OK;
 }
 
+// ---- lockstep banks ------------------------------------------------------------------------------------------------
+rr_chain::BankSig rr_chain::bank_signature() const {
+    BankSig g{};
+    g.phase_idx = fs->phase_idx;
+    g.zrun = zrun;
+    g.sched_phase = ds->sched.phase;
+    g.fs_version = fs->table_version;
+    g.frame_version = frame_table_version;
+    g.ctaps_fl = ctaps_fl;
+    g.ctaps_ds = ctaps_ds;
+    g.carry_len = carry_len;
+    g.pending_len = pending_len;
+    g.HX = HX;
+    g.xh_count = xh_count;
+    g.Lc = Lc;
+    g.sched_pos = ds->sched.pos;
+    g.rate = ds->prev_rate;
+    g.xh_cur = xh_cur;
+    g.dec_cur = dec_cur;
+    g.hist_valid = fl->hist_valid ? 1 : 0;
+    g.use_frame = use_frame ? 1 : 0;
+    g.ols_N = ols_N;
+    g.ols_poly = ols_poly ? 1 : 0;
+    g.pend_in_dec = pend_ptr ? (pend_ptr == pendbuf[0].p || pend_ptr == pendbuf[1].p ? 2 : 1) : 0;
+    return g;
+}
+
+// The host half of process_dev + process_fused for the two-kernel step of a whole-chunk call, without a launch: *ok = false
+// means "this call is not such a step" (the caller then drives the lanes one by one).
+int rr_chain::bank_plan(double sample_rate, size_t n_in, size_t cap, BankStep &st, bool *ok) {
+    *ok = false;
+    if (fl->needs_design(sample_rate, p.filter_len)) return RR_OK;
+    if (sink.on || timers.on || dtype != RR_F32 || p.fft_len != 4096) return RR_OK;
+    const bool fused = fused_candidate(sample_rate) && HX != 0 && xh_count >= HX && fl->hist_valid && zrun + 1 >= ds->L && n_in >= HX;
+    if (!fused || carry_len != 0 || n_in % p.filter_len != 0 || n_in > 0xfffffff0ull) return RR_OK;
+    RR_TRY(select());
+    RR_TRY(fs->prepare(sample_rate));
+    RR_TRY(ensure_ctaps());
+    if (!(use_ols && ols_N == 1024 && ols_poly)) return RR_OK;
+    const char *fke = std::getenv("RR_FUSED_KERNEL");
+    const bool frame_forced = fke && !std::strcmp(fke, "olsf");
+    if (use_frame && n_in >= (frame_forced ? (size_t)1024 : (size_t)1 << 23)) return RR_OK;  // (the frame kernel's calls: lane by lane)
+    st.whole = n_in;
+    st.dec = ds->sched.count(n_in);
+    const size_t have = pending_len + st.dec;
+    st.nfr = have / 4096;
+    st.rest = have - st.nfr * 4096;
+    st.n_head = pending_len;
+    if (st.nfr == 0 || st.dec == 0) return RR_OK;  // (no frame completes: the pending chunk is appended to, lane by lane)
+    if (st.nfr * 4096 > cap) RR_FAIL(RR_ERR_CAPACITY, "Chain: out_cap %zu < %zu", cap, st.nfr * 4096);
+    RR_TRY(fo->prepare(4096));
+    rr::FusedFirArgs &a = st.a;
+    a = rr::FusedFirArgs{};
+    a.hx = HX;
+    a.n_in = n_in;
+    a.nco = fs->d_table.p;
+    a.denom = (uint32_t)fs->denom;
+    a.idx0 = (uint32_t)fs->phase_idx;
+    a.n_out = st.dec;
+    a.e0 = (int64_t)ds->sched.first_emit();
+    a.D = (uint32_t)ds->sched.D;
+    a.H = d_olsH.p;
+    a.tw4096 = d_tw4096.p;
+    a.V = ols_V;
+    a.poly = ols_poly;
+    if (a.D == 4) RR_TRY(fold_mixer(a, 0));
+    *ok = true;
+    return RR_OK;
+}
+
+int rr_chain::bank_pointers(const BankStep &st, const void *d_in, void *d_out, rr::BankPtrs &bp) {
+    DevBuf &buf = dec2[dec_cur ^ 1];  // never the buffer the pending samples live in
+    RR_TRY(buf.reserve((st.dec + 2) * elem_size(dtype)));
+    bp.xh = xh[xh_cur].p;
+    bp.in = d_in;
+    bp.dec = buf.p;
+    bp.xh_out = xh[xh_cur ^ 1].p;
+    bp.head = pend_ptr ? pend_ptr : pending.p;
+    bp.out = d_out;
+    return RR_OK;
+}
+
+// (what process_fused does behind its two launches)
+void rr_chain::bank_commit(const BankStep &st, size_t n_in) {
+    const size_t esz = elem_size(dtype);
+    char *newv = dec2[dec_cur ^ 1].as<char>();
+    xh_cur ^= 1;
+    const uint64_t den = (uint64_t)fs->denom;
+    fs->phase_idx = (fs->phase_idx + n_in % den) % den;
+    carry_len = 0;
+    ds->sched.advance(st.whole, nullptr);
+    zrun += st.whole;
+    blocks_stale = true;
+    pend_ptr = newv + (st.nfr * 4096 - pending_len) * esz;
+    dec_cur ^= 1;
+    pending_len = st.rest;
+    frame_table_version = fs->table_version;
+    last_fused = st.a.mixfold ? 7 : FK_OLSW;
+}
+
+rr_chainbank::~rr_chainbank() {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (int i = 0; i < kRing; ++i) {
+        if (h_tab[i]) (void)hipHostFree(h_tab[i]);
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+    }
+    for (rr_chain *c : lanes) delete c;
+}
+
+int rr_chainbank::process_dev(double rate, const void *d_in, size_t in_stride, size_t n_in, void *d_out, size_t out_stride,
+                              size_t cap, size_t *n_out) {
+    if (n_out) *n_out = 0;
+    const size_t K = lanes.size();
+    if (K == 0) return RR_OK;
+    if (n_in > in_stride && K > 1) RR_FAIL(RR_ERR_BAD_ARG, "ChainBank: %zu samples per channel, channels %zu apart", n_in, in_stride);
+    const size_t esz = elem_size(dtype);
+    RR_TRY(select());
+    last_path = 0;
+    rr_chain::BankStep st;
+    bool ok = false;
+    RR_TRY(lanes[0]->bank_plan(rate, n_in, cap, st, &ok));
+    if (ok && st.nfr * 4096 > out_stride && K > 1) RR_FAIL(RR_ERR_CAPACITY, "ChainBank: %zu bins per channel, channels %zu apart", st.nfr * 4096, out_stride);
+    if (ok) {
+        // every lane at the same stream position with the same tables: lane 0's launch parameters are everybody's
+        const rr_chain::BankSig g0 = lanes[0]->bank_signature();
+        for (size_t k = 1; k < K && ok; ++k) {
+            rr_chain *c = lanes[k];
+            if (c->fs->shift_changed || !c->fs->have_rate || c->fs->prev_rate != rate || c->fl->needs_design(rate, c->p.filter_len) ||
+                c->sink.on || c->timers.on) {
+                ok = false;
+                break;
+            }
+            const rr_chain::BankSig g = c->bank_signature();
+            ok = std::memcmp(&g, &g0, sizeof g) == 0;
+        }
+    }
+    if (!ok) {
+        // lane by lane (stream start, after an interrupt or a retune, ragged calls): every lane is a chain of its own
+        size_t got = 0;
+        for (size_t k = 0; k < K; ++k) {
+            lanes[k]->stream = stream;
+            size_t w = 0;
+            RR_TRY(lanes[k]->process_dev(rate, static_cast<const char *>(d_in) + k * in_stride * esz, n_in,
+                                         static_cast<char *>(d_out) + k * out_stride * esz, cap, &w));
+            if (k == 0) got = w;
+            else if (w != got) RR_FAIL(RR_ERR_BAD_ARG, "ChainBank: the channels have left lockstep (%zu against %zu bins)", w, got);
+        }
+        if (n_out) *n_out = got;
+        return RR_OK;
+    }
+    // the channels' buffers -> a table on the device (a ring of page-locked staging tables: the copy of call i may still be
+    // in flight when call i + 1 fills the next one)
+    const int r = ring;
+    ring = (ring + 1) % kRing;
+    if (!h_tab[r]) {
+        RR_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_tab[r]), K * sizeof(rr::BankPtrs), hipHostMallocDefault));  // (K is fixed at creation)
+        RR_HIP(hipEventCreateWithFlags(&ev[r], hipEventDisableTiming));
+    }
+    if (ev_used[r]) RR_HIP(hipEventSynchronize(ev[r]));
+    RR_TRY(d_tab[r].reserve(K * sizeof(rr::BankPtrs)));
+    for (size_t k = 0; k < K; ++k)
+        RR_TRY(lanes[k]->bank_pointers(st, static_cast<const char *>(d_in) + k * in_stride * esz,
+                                       static_cast<char *>(d_out) + k * out_stride * esz, h_tab[r][k]));
+    RR_HIP(hipMemcpyAsync(d_tab[r].p, h_tab[r], K * sizeof(rr::BankPtrs), hipMemcpyHostToDevice, stream));
+    RR_HIP(hipEventRecord(ev[r], stream));
+    ev_used[r] = true;
+    rr_chain *c0 = lanes[0];
+    RR_TRY(launch_ols_wave_bank(stream, st.a, d_tab[r].as<rr::BankPtrs>(), K));
+    RR_TRY(launch_fft4096_bank(stream, d_tab[r].as<rr::BankPtrs>(), K, st.n_head, st.nfr, c0->fo->d_window.p, c0->fo->d_tw.p,
+                               c0->fo->center_dc));
+    for (size_t k = 0; k < K; ++k) lanes[k]->bank_commit(st, n_in);
+    last_path = 1;
+    if (n_out) *n_out = st.nfr * 4096;
+    return RR_OK;
+}
+
 // fewer than fft_len outputs in total: gather [pending | new] into the `pending` buffer
 int rr_chain::materialize_pending_append(const void *newv, size_t dec) {
     const size_t esz = elem_size(dtype);
@@ -2078,13 +2255,16 @@ int rr_device_pci_bus_id(int device, char *out, size_t out_cap) {
     return RR_OK;
 }
 
+static void chain_use_stream(rr_chain *c, hipStream_t st) {
+    c->stream = st;
+    c->fs->stream = c->fl->stream = c->ds->stream = c->fo->stream = st;
+}
 int rr_set_stream(rr_block *h, void *hip_stream) {
     if (!h) RR_FAIL(RR_ERR_BAD_ARG, "null handle");
     h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
-    if (h->kind == K_CHAIN) {
-        rr_chain *c = static_cast<rr_chain *>(h);
-        c->fs->stream = c->fl->stream = c->ds->stream = c->fo->stream = h->stream;
-    }
+    if (h->kind == K_CHAIN) chain_use_stream(static_cast<rr_chain *>(h), h->stream);
+    if (h->kind == K_CHAINBANK)
+        for (rr_chain *c : static_cast<rr_chainbank *>(h)->lanes) chain_use_stream(c, h->stream);
     return RR_OK;
 }
 
@@ -2990,6 +3170,91 @@ int rr_chain_process(rr_chain *h, double rate, const void *in, size_t n_in, void
 int rr_chain_enqueue(rr_chain *h, double rate, const void *in, size_t n_in, void *out, size_t cap, size_t *n_out) {
     return chain_host(h, rate, in, n_in, out, cap, n_out, false);
 }
+// ---- rr_chainbank ----
+int rr_chainbank_create(const rr_chain_params *p, size_t channels, int device, rr_chainbank **out) {
+    RR_GUARD_BEGIN
+    if (!out || !p) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    *out = nullptr;
+    if (channels == 0 || channels > 65535) RR_FAIL(RR_ERR_BAD_ARG, "ChainBank: 1 .. 65535 channels");
+    auto *b = new rr_chainbank;
+    int s = b->init_base(K_CHAINBANK, p->dtype, device);
+    for (size_t k = 0; s == RR_OK && k < channels; ++k) {
+        rr_chain *c = nullptr;
+        s = rr_chain_create(p, device, &c);
+        if (s == RR_OK) {
+            chain_use_stream(c, b->stream);
+            b->lanes.push_back(c);
+        }
+    }
+    if (s != RR_OK) {
+        delete b;
+        return s;
+    }
+    *out = b;
+    return RR_OK;
+    RR_GUARD_END
+}
+int rr_chainbank_channels(const rr_chainbank *h, size_t *channels) {
+    RR_CHECK_HANDLE(h, K_CHAINBANK);
+    if (!channels) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    *channels = h->lanes.size();
+    return RR_OK;
+}
+int rr_chainbank_channel(rr_chainbank *h, size_t k, rr_chain **lane) {
+    RR_CHECK_HANDLE(h, K_CHAINBANK);
+    if (!lane || k >= h->lanes.size()) RR_FAIL(RR_ERR_BAD_ARG, "ChainBank: no channel %zu", k);
+    *lane = h->lanes[k];
+    return RR_OK;
+}
+int rr_chainbank_set_shift(rr_chainbank *h, double shift) {
+    RR_CHECK_HANDLE(h, K_CHAINBANK);
+    for (rr_chain *c : h->lanes) RR_TRY(rr_chain_set_shift(c, shift));
+    return RR_OK;
+}
+int rr_chainbank_filter_needs_design(const rr_chainbank *h, double sample_rate, int *needed) {
+    RR_CHECK_HANDLE(h, K_CHAINBANK);
+    return rr_chain_filter_needs_design(h->lanes[0], sample_rate, needed);
+}
+int rr_chainbank_filter_mark_params_changed(rr_chainbank *h) {
+    RR_CHECK_HANDLE(h, K_CHAINBANK);
+    for (rr_chain *c : h->lanes) RR_TRY(rr_chain_filter_mark_params_changed(c));
+    return RR_OK;
+}
+int rr_chainbank_filter_design(rr_chainbank *h, double sample_rate, const rr_c64 *resp, const double *window_rel) {
+    RR_CHECK_HANDLE(h, K_CHAINBANK);
+    for (rr_chain *c : h->lanes) RR_TRY(rr_chain_filter_design(c, sample_rate, resp, window_rel));
+    return RR_OK;
+}
+int rr_chainbank_interrupt(rr_chainbank *h) {
+    RR_CHECK_HANDLE(h, K_CHAINBANK);
+    for (rr_chain *c : h->lanes) RR_TRY(rr_chain_interrupt(c));
+    return RR_OK;
+}
+int rr_chainbank_peek(rr_chainbank *h, double sample_rate, size_t n_in, size_t *n_frames) {
+    RR_CHECK_HANDLE(h, K_CHAINBANK);
+    return rr_chain_peek(h->lanes[0], sample_rate, n_in, n_frames);
+}
+int rr_chainbank_process_dev(rr_chainbank *h, double rate, const void *d_in, size_t in_stride, size_t n_in, void *d_out,
+                             size_t out_stride, size_t cap, size_t *n_out) {
+    RR_GUARD_BEGIN
+    RR_CHECK_HANDLE(h, K_CHAINBANK);
+    return h->process_dev(rate, d_in, in_stride, n_in, d_out, out_stride, cap, n_out);
+    RR_GUARD_END
+}
+int rr_chainbank_last_path(const rr_chainbank *h, int *lockstep) {
+    RR_CHECK_HANDLE(h, K_CHAINBANK);
+    if (!lockstep) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    *lockstep = h->last_path;
+    return RR_OK;
+}
+int rr_chainbank_destroy(rr_chainbank *h) {
+    if (!h) return RR_OK;
+    RR_CHECK_HANDLE(h, K_CHAINBANK);
+    (void)hipSetDevice(h->device);
+    delete h;
+    return RR_OK;
+}
+
 int rr_chain_set_metering(rr_chain *h, double double_percentile, double *d_bandwidth, double *d_energy, size_t cap_frames,
                           int store_spectra) {
     RR_CHECK_HANDLE(h, K_CHAIN);

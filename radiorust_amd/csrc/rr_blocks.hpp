@@ -349,7 +349,42 @@ struct rr_chain : rr_block {
     int materialize_pending_append(const void *newv, size_t dec);
     int process_fused(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
     int process_generic(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
+    // ---- lockstep banks (rr_chainbank): the two-kernel fused step split into plan / pointers / commit, so that K chains
+    // with the same parameters and the same stream position run their step as ONE launch per kernel ----
+    struct BankStep {
+        rr::FusedFirArgs a;  // the launch parameters every channel shares (no stream pointers)
+        size_t whole = 0, dec = 0, nfr = 0, rest = 0, n_head = 0;
+    };
+    struct BankSig {  // what has to agree between the lanes of a bank for the lockstep step (stream position and table state)
+        uint64_t phase_idx, zrun, sched_phase, fs_version, frame_version, ctaps_fl, ctaps_ds;
+        size_t carry_len, pending_len, HX, xh_count, Lc;
+        double sched_pos, rate;
+        int xh_cur, dec_cur, hist_valid, use_frame, ols_N, ols_poly, pend_in_dec;
+    };
+    BankSig bank_signature() const;
+    int bank_plan(double sample_rate, size_t n_in, size_t cap, BankStep &st, bool *ok);
+    int bank_pointers(const BankStep &st, const void *d_in, void *d_out, rr::BankPtrs &p);
+    void bank_commit(const BankStep &st, size_t n_in);
     ~rr_chain() override;
     int peek(double sample_rate, size_t n_in, size_t *n_frames);
     int process_dev(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out);
+};
+
+// K chains with the same parameters whose streams advance in lockstep (the K antennas of an array, the K sub-bands of a
+// channelized receiver, ...): every lane is a full rr_chain (any lane can be driven alone at any time); when all of them are
+// in the steady fused state at the same stream position, a call runs ONE k_ols_wave_bank and ONE k_fft4096_bank launch for all
+// channels (channel = blockIdx.y) instead of 2 K launches - at the reference's chunk sizes (10^3 .. 10^5 samples,
+// examples/bandwidth_meter/main.rs:56) a single channel's call is launch-bound.
+struct rr_chainbank : rr_block {
+    std::vector<rr_chain *> lanes;
+    static constexpr int kRing = 8;
+    rr::BankPtrs *h_tab[kRing] = {};  // page-locked staging of the channels' buffer tables, used in turn
+    rr::DevBuf d_tab[kRing];
+    hipEvent_t ev[kRing] = {};
+    bool ev_used[kRing] = {};
+    int ring = 0;
+    int last_path = 0;  // 1: the last call ran in lockstep (two launches for all channels), 0: lane by lane
+    ~rr_chainbank() override;
+    int process_dev(double rate, const void *d_in, size_t in_stride, size_t n_in, void *d_out, size_t out_stride, size_t cap,
+                    size_t *n_out);
 };

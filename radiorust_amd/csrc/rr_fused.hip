@@ -423,16 +423,16 @@ int launch_fused_fir(hipStream_t s, const FusedFirArgs &a) {
 // METER: metering::bandwidth (and the frame's energy) computed from the bins while they are still in registers
 // (rr_meter_dev.hpp); fm.store = 0 drops the spectra altogether.
 template <bool FOLD, bool METER = false>
-__global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head, long n_head,
-                                                 const float2 *__restrict__ in, float2 *__restrict__ out,
-                                                 const float *__restrict__ window, const float2 *__restrict__ tw,
-                                                 int center_dc, long hop, unsigned count, int branches, FrameMeter fm = FrameMeter{}) {
+__device__ __forceinline__ void fft4096_body(const float2 *__restrict__ head, long n_head,
+                                             const float2 *__restrict__ in, float2 *__restrict__ out,
+                                             const float *__restrict__ window, const float2 *__restrict__ tw,
+                                             int center_dc, long hop, unsigned count, int branches, const FrameMeter &fm, const unsigned bx) {
     __shared__ f2 lds[4096 + 256];
     const int j = threadIdx.x;
     // (frames in reverse order - the most recently written first - measured no different in the chain)
     // FOLD: a frame shares branches - 1 of its chunks with each neighbour: neighbouring frames go to one XCD (workgroups b, b + 8, ..
     // share one), 8 at a time, so that a chunk is fetched into one L2 instead of into `branches` of them
-    const unsigned fr = FOLD ? blockIdx.x / 64 * 64 + (blockIdx.x % 64 & 7) * 8 + (blockIdx.x % 64 >> 3) : blockIdx.x;
+    const unsigned fr = FOLD ? bx / 64 * 64 + (bx % 64 & 7) * 8 + (bx % 64 >> 3) : bx;
     if (FOLD && fr >= count) return;
     const long base = (long)fr * hop - n_head;  // index into `in` of this frame's first sample
     float2 *dst = out + (size_t)fr * 4096;
@@ -557,6 +557,22 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
             if (fm.energy) fm.energy[fr] = total;
         }
     }
+}
+
+template <bool FOLD, bool METER = false>
+__global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head, long n_head,
+                                                 const float2 *__restrict__ in, float2 *__restrict__ out,
+                                                 const float *__restrict__ window, const float2 *__restrict__ tw,
+                                                 int center_dc, long hop, unsigned count, int branches, FrameMeter fm) {
+    fft4096_body<FOLD, METER>(head, n_head, in, out, window, tw, center_dc, hop, count, branches, fm, blockIdx.x);
+}
+
+// the channels of a bank: frame blockIdx.x of channel blockIdx.y (see k_ols_wave_bank)
+__global__ __launch_bounds__(256) void k_fft4096_bank(const BankPtrs *__restrict__ chan, long n_head, const float *__restrict__ window,
+                                                      const float2 *__restrict__ tw, int center_dc, unsigned count) {
+    const BankPtrs c = chan[blockIdx.y];
+    fft4096_body<false, false>((const float2 *)c.head, n_head, (const float2 *)c.dec, (float2 *)c.out, window, tw, center_dc, 4096L, count,
+                               1, FrameMeter{}, blockIdx.x);
 }
 
 int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
@@ -1741,19 +1757,21 @@ __device__ __forceinline__ const f2 *inv256_rd(const f2 *lds, int l, int pass) {
 
 // MF: no mixer in the kernel - the stand-alone Downsampler (its table is all ones), or the chain with the mixer folded into the
 // response tables (NCO periods that divide 8, rr_chain::ensure_mixfold; SW: the spectrum taken 128 bins further on, D = 4)
+// (the kernel's body as a function of the workgroup index bx: k_ols_wave runs it for one stream, k_ols_wave_bank for the
+//  channels of a bank - the same stream parameters, per-channel pointers, channel = blockIdx.y)
 template <int D, bool POLY, bool MF = false, bool SW = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OCC, RR_V_OLSW_OCC))) void k_ols_wave(
+__device__ __forceinline__ void ols_wave_body(
     const float2 *__restrict__ xh, int hx, const float2 *__restrict__ in, long n_in, const float2 *__restrict__ nco,
     unsigned denom, unsigned idx0, const float2 *__restrict__ H, const float2 *__restrict__ tw, int V,
     float2 *__restrict__ out, long n_out, long e0, float2 *__restrict__ xh_out, int hx_out, unsigned nblocks,
-    unsigned ph0, unsigned hopm, unsigned kstep, double inv_denom) {
+    unsigned ph0, unsigned hopm, unsigned kstep, double inv_denom, const unsigned bx) {
     __shared__ __attribute__((aligned(16))) f2 lds[POLY ? 1136 : kWaveLds];  // (POLY: 2 (63 + 72 * 7) + 2 elements)
     const int l = threadIdx.x;
     // Workgroups b, b+8, .. share an XCD.  Blocks are dealt so that neighbouring blocks run on one XCD - the V
     // samples two neighbours share come from HBM once -, and the XCDs work side by side in a moving window of
     // 8 G blocks (instead of one far-apart eighth of the stream per XCD).
     constexpr unsigned G = kWaveWin;
-    const unsigned grp = blockIdx.x / (8 * G), rem = blockIdx.x % (8 * G);
+    const unsigned grp = bx / (8 * G), rem = bx % (8 * G);
     const unsigned blk = grp * 8 * G + (rem & 7) * G + (rem >> 3);
     if (blk >= nblocks) return;
     static_assert(D == 2 || D == 4 || D == 8, "fold 2, 4 or 8");
@@ -2231,6 +2249,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OC
             __builtin_amdgcn_raw_buffer_store_b64(z[c], rs, off, 0, 2);
         }
     }
+}
+
+template <int D, bool POLY, bool MF = false, bool SW = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OCC, RR_V_OLSW_OCC))) void k_ols_wave(
+    const float2 *__restrict__ xh, int hx, const float2 *__restrict__ in, long n_in, const float2 *__restrict__ nco,
+    unsigned denom, unsigned idx0, const float2 *__restrict__ H, const float2 *__restrict__ tw, int V,
+    float2 *__restrict__ out, long n_out, long e0, float2 *__restrict__ xh_out, int hx_out, unsigned nblocks,
+    unsigned ph0, unsigned hopm, unsigned kstep, double inv_denom) {
+    ols_wave_body<D, POLY, MF, SW>(xh, hx, in, n_in, nco, denom, idx0, H, tw, V, out, n_out, e0, xh_out, hx_out, nblocks, ph0, hopm,
+                                   kstep, inv_denom, blockIdx.x);
+}
+
+// The channels of a bank (rr_chainbank: K independent streams with the same parameters that advance in lockstep): the same
+// launch parameters for all of them, the streams' own buffers from a table, channel = blockIdx.y.
+template <int D, bool POLY, bool MF = false, bool SW = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OCC, RR_V_OLSW_OCC))) void k_ols_wave_bank(
+    const BankPtrs *__restrict__ chan, int hx, long n_in, const float2 *__restrict__ nco, unsigned denom, unsigned idx0,
+    const float2 *__restrict__ H, const float2 *__restrict__ tw, int V, long n_out, long e0, int hx_out, unsigned nblocks,
+    unsigned ph0, unsigned hopm, unsigned kstep, double inv_denom) {
+    const BankPtrs c = chan[blockIdx.y];
+    ols_wave_body<D, POLY, MF, SW>((const float2 *)c.xh, hx, (const float2 *)c.in, n_in, nco, denom, idx0, H, tw, V, (float2 *)c.dec,
+                                   n_out, e0, (float2 *)c.xh_out, hx_out, nblocks, ph0, hopm, kstep, inv_denom, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -2798,6 +2838,49 @@ int launch_ols_wave(hipStream_t s, const FusedFirArgs &a) {
     case 8: return a.poly ? launch_ols_wave_d<8, true>(s, a) : launch_ols_wave_d<8, false>(s, a);
     }
     RR_FAIL(RR_ERR_BAD_ARG, "fused OLS: decimation %u not instantiated", a.D);
+}
+
+template <int D>
+static int launch_ols_wave_bank_d(hipStream_t s, const FusedFirArgs &a, const BankPtrs *d_chan, size_t channels) {
+    const int per_block = (1024 - a.V) / D;
+    const size_t nblocks = (a.n_out + per_block - 1) / per_block;
+    if (nblocks > 0x7ffffff0ull || channels > 65535) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS bank: too many blocks or channels");
+    const int64_t den = (int64_t)a.denom;
+    int64_t ph = ((int64_t)a.idx0 + a.e0 - a.V) % den;
+    if (ph < 0) ph += den;
+    const unsigned hopm = (unsigned)((int64_t)(1024 - a.V) % den), kstep = (unsigned)(128 % den);
+    const unsigned grid = (unsigned)((nblocks + 8 * kWaveWin - 1) / (8 * kWaveWin) * (8 * kWaveWin));
+#define RR_OLSWB_LAUNCH(MF_, SW_)                                                                                                  \
+    hipLaunchKernelGGL((k_ols_wave_bank<D, true, MF_, SW_>), dim3(grid, (unsigned)channels), dim3(64), 0, s, d_chan, (int)a.hx,     \
+                       (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0, (const float2 *)a.H, (const float2 *)a.tw4096, a.V,    \
+                       (long)a.n_out, (long)a.e0, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, kstep, 1.0 / (double)den)
+    if (a.mixfold && D == 4 && a.sigma < 0.f) RR_OLSWB_LAUNCH(true, true);
+    else if (a.mixfold) RR_OLSWB_LAUNCH(true, false);
+    else RR_OLSWB_LAUNCH(false, false);
+#undef RR_OLSWB_LAUNCH
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+int launch_ols_wave_bank(hipStream_t s, const FusedFirArgs &a, const BankPtrs *d_chan, size_t channels) {
+    if (a.n_out == 0 || channels == 0) return RR_OK;
+    if (!a.poly) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS bank: polyphase tables only");
+    switch (a.D) {
+    case 2: return launch_ols_wave_bank_d<2>(s, a, d_chan, channels);
+    case 4: return launch_ols_wave_bank_d<4>(s, a, d_chan, channels);
+    case 8: return launch_ols_wave_bank_d<8>(s, a, d_chan, channels);
+    }
+    RR_FAIL(RR_ERR_BAD_ARG, "fused OLS bank: decimation %u not instantiated", a.D);
+}
+
+int launch_fft4096_bank(hipStream_t s, const BankPtrs *d_chan, size_t channels, size_t n_head, size_t count, const void *window,
+                        const void *tw4096, bool center_dc) {
+    if (count == 0 || channels == 0) return RR_OK;
+    if (count > 0x7fffffffull || channels > 65535) RR_FAIL(RR_ERR_BAD_ARG, "fft4096 bank: too many frames or channels");
+    hipLaunchKernelGGL(k_fft4096_bank, dim3((unsigned)count, (unsigned)channels), dim3(256), 0, s, d_chan, (long)n_head,
+                       (const float *)window, (const float2 *)tw4096, (int)center_dc, (unsigned)count);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
 }
 
 // ---------------------------------------------------------------------------

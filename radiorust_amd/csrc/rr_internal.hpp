@@ -123,7 +123,7 @@ struct UpSchedule {
 };
 
 // ---- block base ------------------------------------------------------------
-enum Kind { K_FREQSHIFTER = 1, K_FILTER, K_DOWNSAMPLER, K_FOURIER, K_CHAIN, K_CHANNELIZER, K_UPSAMPLER, K_FMDEMOD, K_STFT, K_METER };
+enum Kind { K_FREQSHIFTER = 1, K_FILTER, K_DOWNSAMPLER, K_FOURIER, K_CHAIN, K_CHANNELIZER, K_UPSAMPLER, K_FMDEMOD, K_STFT, K_METER, K_CHAINBANK };
 
 }  // namespace rr
 

@@ -128,6 +128,20 @@ int launch_ols_wave(hipStream_t s, const FusedFirArgs &a);
 // k_ols_frame: the same stage + the 4096-point Fourier stage in one kernel (a workgroup per frame of the
 // decimated stream; H / tw4096 fields as for launch_ols_wave).  pend_in: pl decimated samples pending from
 // the previous call; pend_out receives the (pl + n_out) mod 4096 left over; spectra: (pl + n_out) / 4096 frames.
+// One channel of a bank (rr_chainbank) for the two kernels of its lockstep step: the channel's own buffers.
+struct BankPtrs {
+    const void *xh;    // mixed-sample history in front of this call
+    const void *in;    // the call's samples
+    void *dec;         // decimated samples of this call (k_ols_wave's output, k_fft4096's input)
+    void *xh_out;      // history for the next call
+    const void *head;  // decimated samples pending from the previous call (n_head of them)
+    void *out;         // spectra
+};
+// k_ols_wave / k_fft4096 for `channels` streams in ONE launch each: the shared launch parameters in `a` (its xh / in / out /
+// xh_out are ignored), the per-channel buffers in the device array d_chan
+int launch_ols_wave_bank(hipStream_t s, const FusedFirArgs &a, const BankPtrs *d_chan, size_t channels);
+int launch_fft4096_bank(hipStream_t s, const BankPtrs *d_chan, size_t channels, size_t n_head, size_t count, const void *window,
+                        const void *tw4096, bool center_dc);
 bool ols_frame_supported(uint64_t D, size_t Lc, size_t fft_len);
 // What a metered kernel needs beside its transform's arguments: metering::bandwidth (metering.rs:41-80) per spectrum, computed
 // behind the transform while the bins are in registers (rr_meter_dev.hpp), and the spectrum's energy sum |X|^2.

@@ -737,3 +737,52 @@ def test_meter_sample_rate_change_mid_stream(rr, oracle):
               ("feed", 90001), ("rate", 512000.0), ("feed", 70001), ("feed", 65536)]
     n = _meter_vs_oracle(rr, oracle, fs=1024000.0, out_rate=102400.0, max_bw=60e3, chunk_len=1024, quality=4, script=script)
     assert n >= 20
+
+
+@pytest.mark.parametrize("shift,precision", [(25e6, 1.0), (12.345e6, 1e3)])
+def test_chainbank_lockstep_is_bit_identical_to_stand_alone_chains(rr, oracle, shift, precision):
+    """rr_chainbank: K channels through TWO launches per call once they are in the steady state - every channel's spectra
+    bit for bit those of a stand-alone Chain fed the same samples in the same calls (stream start lane by lane, an interrupt
+    and a retune in the middle, a ragged call that takes the bank out of lockstep and back)."""
+    import torch
+
+    fs, K = 200e6, 5
+    n_total = 1 << 19
+    st = torch.cuda.current_stream().cuda_stream
+    d_in = torch.empty(K * n_total, dtype=torch.complex64, device="cuda")
+    for k in range(K):
+        rr.synth_iq_dev(0, st, 100 + k, 0, n_total, d_in.data_ptr() + 8 * k * n_total)
+    torch.cuda.synchronize()
+    params = dict(shift=shift, precision=precision, filter_len=64, freq_resp=lowpass(20e6), output_rate=50e6, bandwidth=40e6,
+                  fft_len=4096, fft_window=rr.Kaiser.with_null_at_bin(2.0))
+    bank = rr.ChainBank(K, **params)
+    bank.set_stream(st)
+    solo = [rr.Chain(**params) for _ in range(K)]
+    for c in solo:
+        c.set_stream(st)
+    cap = 1 << 17
+    out_b = torch.zeros(K * cap, dtype=torch.complex64, device="cuda")
+    out_s = torch.zeros(K * cap, dtype=torch.complex64, device="cuda")
+    sizes = [65536, 65536, 32768, 65536, 16384 + 64, 1000, 65536 - 1064, 65536, 65536, 49152]
+    pos, lock = 0, []
+    for i, n in enumerate(sizes):
+        if i == 4:
+            bank.set_shift(-12.5e6)
+            for c in solo:
+                c.set_shift(-12.5e6)
+        if i == 7:
+            bank.interrupt()
+            for c in solo:
+                c.interrupt()
+        wb = bank.process_dev(fs, d_in.data_ptr() + 8 * pos, n_total, n, out_b.data_ptr(), cap, cap)
+        lock.append(bank.last_path_lockstep())
+        for k, c in enumerate(solo):
+            ws = c.process_dev(fs, d_in.data_ptr() + 8 * (k * n_total + pos), n, out_s.data_ptr() + 8 * k * cap, cap)
+            assert ws == wb, (i, k, ws, wb)
+        torch.cuda.synchronize()
+        for k in range(K):
+            assert torch.equal(out_b[k * cap : k * cap + wb], out_s[k * cap : k * cap + wb]), (i, k)
+        pos += n
+    # lockstep once the histories have filled, lane by lane at the start, after the retune's table change and for the ragged calls
+    assert lock[0] is False and lock[2] is True and lock[3] is True and lock[5] is False and lock[-1] is True, lock
+    assert sum(lock) >= 4, lock
