@@ -1516,11 +1516,17 @@ int rr_chain::peek(double sample_rate, size_t n_in, size_t *n_frames) {
 }
 
 // parameters for which the fused kernels exist at all (independent of stream state)
+static bool chain_poly64_ok(const rr_chain *c, size_t lc) {
+    static const bool off = [] { const char *e = std::getenv("RR_CHAIN_F64_FUSED"); return e && std::atoi(e) == 0; }();
+    return !off && c->fl->real_taps && c->ds->sched.D >= 2 && decim_poly_supported(RR_F64, c->ds->sched.D, 1, lc);
+}
+
 bool rr_chain::fused_candidate(double sample_rate) const {
-    if (!p.allow_fused || dtype != RR_F32) return false;
+    if (!p.allow_fused) return false;
     if (!fl->designed) return false;
     if (!ds->have_rate || ds->prev_rate != sample_rate || !ds->sched.integer_ratio) return false;
     const size_t lc = ds->L + fl->n - 1;
+    if (dtype == RR_F64) return chain_poly64_ok(this, lc);  // (RR_CHAIN_F64_FUSED=0 keeps the four blocks)
     return pick_fused_kernel(ds->sched.D, lc, fl->real_taps, p.fft_len) != FK_NONE;
 }
 
@@ -1731,6 +1737,24 @@ int rr_chain::ensure_ctaps() {
             cc[j + k] += a * (fl->real_taps ? cd(fl->taps_f64[k].real(), 0.0) : fl->taps_f64[k]);
         }
     }
+    if (dtype == RR_F64) {
+        // k_decim_poly_f64's tap list for ir = reverse(c): out[m] = sum_j ir[j] xs[e_m - (Lc - 1) + j] = sum_i c[i] xs[e_m - i]
+        std::vector<double> ir(lc);
+        for (size_t j = 0; j < lc; ++j) ir[j] = c[lc - 1 - j];
+        std::vector<uint32_t> T;
+        const int64_t e0 = 0;
+        int lp = 0;
+        build_decim_poly_taps(ir, ds->sched.D, 1, &e0, T, &lp, RR_F64);
+        RR_TRY(upload(d_ctaps, T.data(), T.size() * sizeof(uint32_t), stream));
+        poly64_Lp = lp;
+        use_poly64 = true;
+        use_frame = use_ols = false;
+        Lc = lc;
+        ctaps_fl = fl->design_version;
+        ctaps_ds = ds->design_version;
+        return RR_OK;
+    }
+    use_poly64 = false;
     const int fk = pick_fused_kernel(ds->sched.D, lc, fl->real_taps, p.fft_len);
     FusedFirTables t;
     build_fused_fir_tables(fk, ds->sched.D, c, cc, t);
@@ -1792,7 +1816,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     const size_t dec = ds->sched.count(whole);
     const size_t have = pending_len + dec;
     const size_t nfr = have / LF, rest = have - nfr * LF;
-    const bool split = (LF == 4096);  // k_fft4096 reads [pending | new] from two places: no copies
+    const bool split = (LF == 4096) && dtype == RR_F32;  // k_fft4096 reads [pending | new] from two places: no copies
     const bool store = !sink.on || sink.store;
     if (!split && pend_ptr) RR_TRY(materialize());
     FusedFirArgs a;
@@ -1875,7 +1899,12 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
         timers.begin_ext(ST_FUSED_FIR, &a.ev_start, &a.ev_stop);
     else
         tk = timers.begin(ST_FUSED_FIR, stream);
-    if (use_ols && ols_N == 1024) {
+    if (use_poly64) {
+        RR_TRY(launch_decim_poly(stream, a.xh, HX, d_in, n_in, d_ctaps.p, ds->sched.D, 1, poly64_Lp, Lc, a.e0, newv, dec, a.xh_out, HX,
+                                 a.nco, a.denom, a.idx0, RR_F64));
+        if (dec == 0)  // (no output, no tile: the history by a launch of its own)
+            RR_FAIL(RR_ERR_BAD_ARG, "Chain: a fused f64 call must produce output");
+    } else if (use_ols && ols_N == 1024) {
         if (ols_poly && a.D == 4) RR_TRY(fold_mixer(a, 0));
         RR_TRY(launch_ols_wave(stream, a));
     } else if (use_ols)
@@ -1927,7 +1956,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     }
     if (!ext) timers.end(tk, stream);
     pending_len = rest;
-    last_fused = use_ols ? (ols_N == 1024 ? (a.mixfold ? 7 : FK_OLSW) : FK_OLS) : FK_DIRECT;  // (7: k_ols_wave<4, true, true>)
+    last_fused = use_poly64 ? FK_POLY : use_ols ? (ols_N == 1024 ? (a.mixfold ? 7 : FK_OLSW) : FK_OLS) : FK_DIRECT;  // (7: k_ols_wave<4, true, true>)
     if (n_out) *n_out = wrote;
     return RR_OK;
 }
@@ -2053,6 +2082,9 @@ int rr_chainbank::process_dev(double rate, const void *d_in, size_t in_stride, s
     last_path = 0;
     rr_chain::BankStep st;
     bool ok = false;
+    // (the plan's one side effect on the lane - fold_mixer notes the table its history is written under - is taken back when
+    //  the step does not run in lockstep: the lane's own call decides again, exactly as a stand-alone chain would)
+    const uint64_t frame_version0 = lanes[0]->frame_table_version;
     RR_TRY(lanes[0]->bank_plan(rate, n_in, cap, st, &ok));
     if (ok && st.nfr * 4096 > out_stride && K > 1) RR_FAIL(RR_ERR_CAPACITY, "ChainBank: %zu bins per channel, channels %zu apart", st.nfr * 4096, out_stride);
     if (ok) {
@@ -2071,6 +2103,7 @@ int rr_chainbank::process_dev(double rate, const void *d_in, size_t in_stride, s
     }
     if (!ok) {
         // lane by lane (stream start, after an interrupt or a retune, ragged calls): every lane is a chain of its own
+        lanes[0]->frame_table_version = frame_version0;
         size_t got = 0;
         for (size_t k = 0; k < K; ++k) {
             lanes[k]->stream = stream;

@@ -332,6 +332,10 @@ struct rr_chain : rr_block {
     enum { FK_NONE = 0, FK_DIRECT, FK_OLS, FK_OLSW, FK_OLSF, FK_POLY };  // FK_POLY: k_decim_poly (Downsampler only)
     static int pick_fused_kernel(uint64_t D, size_t lc, bool real_taps, size_t fft_len);
     bool use_frame = false;      // FK_OLSF: k_ols_frame (FIR stage + Fourier in one kernel)
+    // Complex<f64>: mixer + combined FIR + decimation as ONE pass of k_decim_poly_f64 (the polyphase kernel with the phase table
+    // riding along: 16 B read + 16 / D written per sample instead of the four blocks' 84), then the Fourier block
+    bool use_poly64 = false;
+    int poly64_Lp = 0;
     // k_ols_frame with the mixer folded into the tables (NCO periods that divide 8): G'_p[k] = G_p[(k + s) mod 256] e^{j 2 pi p numer / R}
     std::vector<rr::cd> olsG64;
     rr::DevBuf d_olsHmix;

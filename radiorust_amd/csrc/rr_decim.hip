@@ -281,6 +281,10 @@ struct DecimArgs64 {
     unsigned ntiles;
     double2 *hist_out;
     int hist_out_len;
+    // optional mixer in front (the f64 chain's fused step): samples of `in` times nco[(idx0 + pos) mod denom] as they are staged;
+    // `hist` and `hist_out` hold MIXED samples.  denom = 0: no mixer
+    const double2 *nco;
+    unsigned denom, idx0;
 };
 struct Tap64 {
     double tap;
@@ -299,14 +303,24 @@ __global__ __launch_bounds__(256) void k_decim_poly_f64(DecimArgs64 a, const Tap
     const long a0 = (long)tile * TA;
     const long p_lo = a.p_ref + (long)P * a0;
     const int nld = P * (TA + a.NC);
+    auto mix = [&](double2 x, long pos) -> double2 {  // x * nco[(idx0 + pos) mod denom], pos >= 0
+        const double2 pp = a.nco[(unsigned)(((long)a.idx0 + pos) % (long)a.denom)];
+        double2 r;
+        r.x = x.x * pp.x - x.y * pp.y;
+        r.y = x.x * pp.y + x.y * pp.x;
+        return r;
+    };
     auto fetch = [&](long pos) -> double2 {
         double2 h;
         h.x = 0.0;
         h.y = 0.0;
         if (pos >= 0) {
-            if (pos < a.n_in) h = a.in[pos];
+            if (pos < a.n_in) {
+                h = a.in[pos];
+                if (a.denom) h = mix(h, pos);
+            }
         } else if (pos >= -(long)a.hist_len) {
-            h = a.hist[a.hist_len + pos];
+            h = a.hist[a.hist_len + pos];  // (already mixed)
         }
         return h;
     };
@@ -328,14 +342,47 @@ __global__ __launch_bounds__(256) void k_decim_poly_f64(DecimArgs64 a, const Tap
         int q = t;
         if (interior) {  // four loads of a lane in flight (as the f32 kernel's batches)
             const double2 *src = a.in + p_lo;
+            // the lane's table index walks with its samples: + 256 per load, wrapped (one 64-bit division per lane and tile)
+            unsigned ph = 0, dph = 0;
+            if (a.denom) {
+                ph = (unsigned)(((long)a.idx0 + p_lo + q) % (long)a.denom);
+                dph = 256u % a.denom;
+            }
+            auto next_ph = [&] {
+                const unsigned r = ph;
+                ph += dph;
+                if (ph >= a.denom) ph -= a.denom;
+                return r;
+            };
             for (; q + 3 * 256 < nld; q += 4 * 256) {
-                double2 v[4];
+                double2 v[4], pp[4];
+                if (a.denom) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) pp[u] = a.nco[next_ph()];
+                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) v[u] = src[q + 256 * u];
+                if (a.denom) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double2 x = v[u];
+                        v[u].x = x.x * pp[u].x - x.y * pp[u].y;
+                        v[u].y = x.x * pp[u].y + x.y * pp[u].x;
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) put(v[u]);
             }
-            for (; q < nld; q += 256) put(src[q]);
+            for (; q < nld; q += 256) {
+                double2 x = src[q];
+                if (a.denom) {
+                    const double2 pp = a.nco[next_ph()];
+                    const double2 y = x;
+                    x.x = y.x * pp.x - y.y * pp.y;
+                    x.y = y.x * pp.y + y.y * pp.x;
+                }
+                put(x);
+            }
         } else {
             for (; q < nld; q += 256) put(fetch(p_lo + q));
         }
@@ -445,8 +492,10 @@ int launch_decim_poly(hipStream_t s, const void *hist, size_t hist_len, const vo
         return RR_OK;
     }
     if (dtype == RR_F64) {
-        if (nco) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: the fused mixer is f32 only");
         DecimArgs64 a;
+        a.nco = (const double2 *)nco;
+        a.denom = nco ? denom : 0;
+        a.idx0 = idx0;
         a.hist = (const double2 *)hist;
         a.hist_len = (int)hist_len;
         a.in = (const double2 *)in;

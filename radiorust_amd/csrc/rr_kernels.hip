@@ -1866,6 +1866,9 @@ int launch_fourier_overlapped(int dtype, hipStream_t s, const void *head, size_t
     if (count == 0) return RR_OK;
     RR_TRY(fourier_supported(dtype, n));
     static const bool generic = [] { const char *e = std::getenv("RR_FOURIER_GENERIC"); return e && std::atoi(e) != 0; }();
+    // Complex<f64>, 4096 points: the register kernel of rr_f64.hip (RR_FOURIER_GENERIC=1 keeps the Stockham passes of k_fft_pow2)
+    if (dtype == RR_F64 && n == 4096 && !generic)
+        return launch_fft4096_f64(s, head, n_head, in, out, count, window, twiddle, center_dc, hop);
     if (dtype == RR_F32 && n == 4096 && stft4096_supported(hop) && count >= 64 && !generic)
         return launch_stft4096(s, head, n_head, in, out, count, window, twiddle, center_dc, hop);
     if (dtype == RR_F32 && n == 4096)

@@ -254,6 +254,9 @@ int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *i
                    const void *window, const void *tw4096, bool center_dc, size_t hop = 4096,
                    hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const FrameMeter *fm = nullptr);
 int launch_drop_tail(hipStream_t s, const void *oldh, void *newh, size_t H, size_t drop);
+// Complex<f64>, 4096 points, the lane's values in registers (rr_f64.hip); tw4096[k] = e^{-j 2 pi k / 4096} as double2
+int launch_fft4096_f64(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count, const void *window,
+                       const void *tw4096, bool center_dc, size_t hop);
 // metering (rr_metering.hip): the serial kernel (the reference's summation order, bit-equal to the oracle; mode 0 level,
 // 1 bandwidth, 2 sum of energies) and the parallel scan for frames of any length
 int launch_meter(int dtype, hipStream_t s, int mode, double double_percentile, double sample_rate, const void *frames,

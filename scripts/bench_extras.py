@@ -72,3 +72,12 @@ for nf in (1000, 1999, 20011):
     g = rr.Fourier.with_window(rr.Kaiser.with_null_at_bin(2.0), dtype=np.float64); g.set_stream(st)
     n = N2 // nf * nf
     dt = timed(lambda: g.process_dev(nf, d64.data_ptr(), n, o64.data_ptr(), n)); line(f"f64 Fourier {nf} ({rr.fourier_route(nf, np.float64)})", n, dt, 32)
+# the f64 chain (cfg2's parameters): mixer + Filter + Downsampler as one pass of k_decim_poly_f64, then k_fft4096_f64
+lp20 = lp(20e6)
+for fused in (True, False):
+    ch = rr.Chain(shift=25e6, filter_len=64, freq_resp=lp20, output_rate=50e6, bandwidth=40e6, fft_len=4096,
+                  fft_window=rr.Kaiser.with_null_at_bin(2.0), dtype=np.float64, allow_fused=fused)
+    ch.set_stream(st)
+    co = torch.empty(N2 // 4 + 8192, dtype=torch.complex128, device="cuda")
+    dt = timed(lambda: ch.process_dev(200e6, d64.data_ptr(), N2, co.data_ptr(), co.numel()))
+    line(f"f64 chain cfg2 ({'fused front end: ' + ch.last_path_kernel() if fused else 'block by block'})", N2, dt, 20)

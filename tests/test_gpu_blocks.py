@@ -589,6 +589,32 @@ def test_fourier_f64_lengths(rr, oracle, n, center):
     assert rms_rel(out.chunk, ref) < 1e-11
 
 
+@pytest.mark.parametrize("center", [False, True])
+def test_fourier_f64_4096_register_kernel(rr, oracle, center, monkeypatch):
+    """Complex<f64>, 4096 points: k_fft4096_f64 (the lane's 16 values in registers, radix 16 x 16 x 16) against the f64 oracle
+    at 1e-12, many chunks in one call, overlapping frames through the Stft (hop 1024) as well, and against the Stockham
+    kernel it replaces (RR_FOURIER_GENERIC=1)."""
+    n = 4096
+    x = oracle.synth_iq(21, 0, 9 * n).astype(np.complex128)
+    g = rr.Fourier(rr.Kaiser.with_null_at_bin(2.0), center, dtype=np.float64)
+    of = oracle.Fourier(oracle.Kaiser.with_null_at_bin(2.0), center, flt=np.float64)
+    import torch
+
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.empty(9 * n, dtype=torch.complex128, device="cuda")
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    assert g.process_dev(n, d_in.data_ptr(), 9 * n, d_out.data_ptr(), 9 * n) == 9 * n
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    for k in range(9):
+        assert rms_rel(got[k * n:(k + 1) * n], of.process(x[k * n:(k + 1) * n])) < 1e-12
+    st = rr.Stft(1024, 4, rr.Kaiser.with_null_at_bin(2.0), center_dc=center, dtype=np.float64)
+    out = st.process(rr.Samples(1e6, x))
+    assert len(out) == 33
+    for k in (0, 1, 17, 32):
+        assert rms_rel(out[k].chunk, of.process(x[k * 1024:k * 1024 + 4096])) < 1e-12
+
+
 @pytest.mark.parametrize("n,center", [(6, False), (12, True), (60, False), (96, True), (360, False), (1536, True), (2000, False), (3000, True),
                                       (3072, False), (3125, True), (3840, False), (4000, True), (4050, False), (4095, True),
                                       (4800, False), (6000, True), (7776, False), (8000, True),   # (beyond 4096: f32 only, Bluestein in f64)

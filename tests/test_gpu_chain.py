@@ -192,6 +192,42 @@ def test_chain_f64(rr, oracle):
         assert rms_rel(a.chunk, b) <= 1e-12
 
 
+@pytest.mark.parametrize("shift,precision", [(25e6, 1.0), (12.345e6, 1e3)])
+def test_chain_f64_fused_front_end(rr, oracle, shift, precision):
+    """Complex<f64>: mixer + Filter + Downsampler as ONE pass of k_decim_poly_f64 (the phase table riding along, combined
+    taps) once the chain is in its steady state, then the register-resident 4096-point transform; ragged calls, an
+    interrupt and a retune, against the f64 oracle at 1e-11."""
+    fs, n = 200e6, 1 << 18
+    params = dict(CFG2, shift=shift)
+    x = oracle.synth_iq(14, 0, n).astype(np.complex128)
+    g = rr.Chain(**params, precision=precision, fft_window=rr.Kaiser.with_null_at_bin(2.0), dtype=np.float64)
+    ref = oracle.run_chain(x, fs, flt=np.float64, fft_window=oracle.Kaiser.with_null_at_bin(2.0), precision=precision, **params)[3]
+    out, fused_calls = [], 0
+    cuts = [0, 20000, 20001, 70007, 70071, 150000, 200064, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        out += g.process(rr.Samples(fs, x[a:b]))
+        fused_calls += g.last_path_kernel() == "k_decim_poly"
+    assert fused_calls >= 4, fused_calls
+    assert len(out) == len(ref) == 15
+    for a, b in zip(out, ref):
+        assert rms_rel(a.chunk, b) <= 1e-11
+    # retune + interrupt: against a fresh oracle run is not possible mid-stream; the block-by-block path is the reference
+    g2 = rr.Chain(**params, precision=precision, fft_window=rr.Kaiser.with_null_at_bin(2.0), dtype=np.float64, allow_fused=False)
+    g3 = rr.Chain(**params, precision=precision, fft_window=rr.Kaiser.with_null_at_bin(2.0), dtype=np.float64)
+    y = oracle.synth_iq(15, 0, n).astype(np.complex128)
+    outs = {id(g2): [], id(g3): []}
+    for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        for h in (g2, g3):
+            if i == 3:
+                h.set_shift(-31e6)
+            if i == 5:
+                h.interrupt()
+            outs[id(h)] += h.process(rr.Samples(fs, y[a:b]))
+    assert len(outs[id(g2)]) == len(outs[id(g3)]) >= 10
+    for a, b in zip(outs[id(g3)], outs[id(g2)]):
+        assert rms_rel(a.chunk, b.chunk) <= 1e-11
+
+
 def test_chain_device_api_and_capacity(rr, oracle):
     import ctypes as C
 
