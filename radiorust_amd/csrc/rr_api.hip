@@ -243,6 +243,53 @@ int rr_filter::build_tables(bool reset_history) {
             RR_TRY(upload(d_G4096h, gh.data(), gh.size() * sizeof(uint16_t), stream));
         }
     }
+    // long responses: overlap-save with blocks of 2^14 .. 2^18 points through the two-pass tile transform (RR_FILTER_CONV=0: the
+    // partitions of 2048 taps / k_filter_ols / k_fir as before)
+    use_conv = false;
+    {
+        static const bool conv_off = [] { const char *e = std::getenv("RR_FILTER_CONV"); return e && std::atoi(e) == 0; }();
+        const size_t minlen = dtype == RR_F32 ? 2049 : 4096;
+        if (!conv_off && len >= minlen && len <= ((size_t)1 << 17)) {
+            size_t N = (size_t)1 << (dtype == RR_F32 ? 14 : 13);
+            while (N < 4 * len && N < ((size_t)1 << 18)) N <<= 1;
+            if (N > len) {
+                if (!conv_fft) {
+                    conv_fft = new rr_fourier;
+                    RR_TRY(conv_fft->init_base(K_FOURIER, dtype, device));
+                }
+                conv_fft->stream = stream;
+                RR_TRY(conv_fft->prepare(N));  // rectangular window
+                if (conv_fft->big && conv_fft->big_tile) {
+                    // G' = DFT_N(g) e^{+j 2 pi k V / N} / N with V = len: the block's valid results (circular indices V .. N - 1) come out first
+                    std::vector<cd> gg(N, cd(0, 0));
+                    for (size_t i = 0; i < len; ++i) gg[i] = g[i];
+                    fft_f64(gg, false);
+                    std::vector<double> gd(2 * N), ones(2 * N);
+                    for (size_t k = 0; k < N; ++k) {
+                        const double ang = 2.0 * M_PI * (double)((k * len) % N) / (double)N;
+                        const cd v = gg[k] * cd(std::cos(ang), std::sin(ang)) / (double)N;
+                        gd[2 * k] = v.real();
+                        gd[2 * k + 1] = v.imag();
+                        ones[2 * k] = 1.0;
+                        ones[2 * k + 1] = 0.0;
+                    }
+                    std::vector<unsigned char> gb, ob;
+                    if (dtype == RR_F32) {
+                        cast_to<float>(gd.data(), gd.size(), gb);
+                        cast_to<float>(ones.data(), ones.size(), ob);
+                    } else {
+                        cast_to<double>(gd.data(), gd.size(), gb);
+                        cast_to<double>(ones.data(), ones.size(), ob);
+                    }
+                    RR_TRY(upload(d_convG, gb.data(), gb.size(), stream));
+                    RR_TRY(upload(d_ones, ob.data(), ob.size(), stream));
+                    conv_N = N;
+                    use_conv = true;
+                }
+            }
+        }
+    }
+    if (use_conv) use_ols4096 = big_ols4096 = false, npart = 0;
     {
         const char *e = std::getenv("RR_FILTER_KERNEL");  // "ols4096" / "fir" keep the older kernels (A/B runs, tests)
         use_wave = filter_wave_supported(dtype, len) && !(e && (!std::strcmp(e, "ols4096") || !std::strcmp(e, "fir")));
@@ -299,6 +346,54 @@ int rr_filter::build_tables(bool reset_history) {
     return RR_OK;
 }
 
+rr_filter::~rr_filter() { delete conv_fft; }
+
+// out[m] = sum_k g[k] x[e0 + m - k] for the call's `produce` outputs, e0 = 0 with a previous chunk in hist and n without:
+// block f takes the stream's samples [f hop - V, f hop - V + N), V = n, hop = N - V, and yields outputs [f hop, (f + 1) hop)
+int rr_filter::process_conv(const void *d_in, size_t n_in, void *d_out, size_t produce) {
+    const size_t esz = elem_size(dtype), N = conv_N, V = n, hop = N - V;
+    size_t N1, N2;
+    fft_big_split(N, &N1, &N2);
+    rr_fourier *ff = conv_fft;
+    ff->stream = stream;
+    const char *tB = ff->d_tw.as<char>(), *tA = tB + ((size_t)1 << ff->big_h) * esz;
+    const char *tw1 = tB + ff->big_tw1_off * esz, *tw2 = tB + ff->big_tw2_off * esz;
+    const int hh = ff->big_h;
+    // the stream in front of output 0: the previous chunk (V samples), or - first chunk after a reset - the call's own first chunk
+    const char *head = hist_valid ? hist[cur].as<char>() : static_cast<const char *>(d_in);
+    const char *src = hist_valid ? static_cast<const char *>(d_in) : static_cast<const char *>(d_in) + V * esz;
+    const size_t n_src = hist_valid ? n_in : n_in - V;
+    const size_t frames = (produce + hop - 1) / hop;
+    size_t per_pass = ((size_t)1 << 23) / N;
+    if (per_pass < 1) per_pass = 1;
+    if (per_pass > 65535) per_pass = 65535;
+    if (per_pass > frames) per_pass = frames;
+    RR_TRY(conv_ws[0].reserve(per_pass * N * esz));
+    RR_TRY(conv_ws[1].reserve(per_pass * N * esz));
+    for (size_t f0 = 0; f0 < frames; f0 += per_pass) {
+        const size_t F = frames - f0 < per_pass ? frames - f0 : per_pass;
+        const size_t skip = f0 * hop;  // samples of [head | src] in front of this pass's first block
+        const char *hd = head, *sp = src;
+        size_t nh = V;
+        long lim = (long)n_src;
+        if (skip >= V) {
+            sp += (skip - V) * esz;
+            lim -= (long)(skip - V);
+            nh = 0;
+        } else {
+            hd += skip * esz;
+            nh = V - skip;
+        }
+        RR_TRY(launch_fft_tile_bs(dtype, stream, 0, hd, nh, sp, hop, conv_ws[0].p, N1, N2, F, N, d_ones.p, tw1, tB, tA, hh, 0, lim, 0));
+        RR_TRY(launch_fft_tile_bs(dtype, stream, 1, nullptr, 0, conv_ws[0].p, 0, conv_ws[1].p, N1, N2, F, N, d_convG.p, tw2, nullptr,
+                                  nullptr, 0, 0));
+        RR_TRY(launch_fft_tile_bs(dtype, stream, 2, nullptr, 0, conv_ws[1].p, 0, conv_ws[0].p, N1, N2, F, N, nullptr, tw1, tB, tA, hh, 0));
+        RR_TRY(launch_fft_tile_bs(dtype, stream, 3, nullptr, 0, conv_ws[0].p, 0, static_cast<char *>(d_out) + f0 * hop * esz, N1, N2, F, hop,
+                                  d_ones.p, tw2, nullptr, nullptr, 0, 0, 0, (long)(produce - f0 * hop)));
+    }
+    return RR_OK;
+}
+
 // n = 64, 128: calls that produce fewer samples than this stay on k_fir
 static constexpr size_t kFilterBigCall = 16384;
 
@@ -316,6 +411,15 @@ int rr_filter::process_dev(double sample_rate, const void *d_in, size_t n_in, vo
     if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Filter: out_cap %zu < %zu", cap, produce);
     RR_TRY(select());
     last_kernel = 0;
+    if (produce && use_conv && produce >= 4096 && !out_f16 && !g_f16) {
+        RR_TRY(process_conv(d_in, n_in, d_out, produce));
+        last_kernel = 4;
+        RR_TRY(launch_update_hist(dtype, stream, hist[cur].p, hist[cur ^ 1].p, n, d_in, n_in));
+        cur ^= 1;
+        hist_valid = true;
+        if (n_out) *n_out = produce;
+        return RR_OK;
+    }
     if (produce && use_wave && produce >= kFilterBigCall && !out_f16 && !g_f16) {
         RR_TRY(launch_filter_wave(stream, hist[cur].p, hist_valid ? n : 0, d_in, n_in, d_Hw.p, d_tww.p, wave_V, d_out, produce,
                                   hist_valid ? 0 : (long)n));

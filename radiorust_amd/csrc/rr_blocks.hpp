@@ -28,6 +28,16 @@ struct rr_filter : rr_block {
     double design_rate = 0.0;
     int build_tables(bool reset_history);
     int set_gain(double g);
+    // Long responses (f32: n > 2048, f64: n >= 4096, up to 2^17 taps) at n log n cost: overlap-save with blocks of conv_N = 2^14 .. 2^18
+    // points (>= 4 n where that fits), each block's transform pair as the four passes of the two-pass tile transform (k_fft_tile, as
+    // Bluestein beyond one LDS image): load + pass A, pass B x G, pass A, pass B + cut to the block's valid part.  The response's
+    // spectrum carries the shift that moves the valid part to the front of the block.
+    bool use_conv = false;
+    size_t conv_N = 0;
+    struct rr_fourier *conv_fft = nullptr;  // rectangular-window transform of conv_N points: the tile passes' tables
+    rr::DevBuf d_convG, d_ones, conv_ws[2];
+    int process_conv(const void *d_in, size_t n_in, void *d_out, size_t produce);
+    ~rr_filter() override;
     bool designed = false;
     bool params_changed = false;
     double rate = 0.0;
@@ -304,6 +314,7 @@ struct rr_chain : rr_block {
     rr::DevBuf pending;
     size_t pending_len = 0;
     MeterSink sink;  // rr_chain_set_metering
+    uint64_t mutations = 0;  // counts the entry points that change the chain's state (a bank's cheap "has anyone driven this lane?")
     int last_fused = 0;
     StageTimers timers;
     // ---- fused fast path state (rr_api.hip, "fused") ----
@@ -381,13 +392,9 @@ struct rr_chain : rr_block {
 // examples/bandwidth_meter/main.rs:56) a single channel's call is launch-bound.
 struct rr_chainbank : rr_block {
     std::vector<rr_chain *> lanes;
-    static constexpr int kRing = 8;
-    rr::BankPtrs *h_tab[kRing] = {};  // page-locked staging of the channels' buffer tables, used in turn
-    rr::DevBuf d_tab[kRing];
-    hipEvent_t ev[kRing] = {};
-    bool ev_used[kRing] = {};
-    int ring = 0;
-    int last_path = 0;  // 1: the last call ran in lockstep (two launches for all channels), 0: lane by lane
+    std::vector<uint64_t> seen;  // the lanes' mutation counters when the bank last found (or left) them in lockstep
+    bool verified = false;       // the lanes' signatures agreed and nothing has touched a lane since
+    int last_path = 0;  // 1: the last call ran in lockstep (two launches per 64 channels), 0: lane by lane
     ~rr_chainbank() override;
     int process_dev(double rate, const void *d_in, size_t in_stride, size_t n_in, void *d_out, size_t out_stride, size_t cap,
                     size_t *n_out);

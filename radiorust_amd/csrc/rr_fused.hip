@@ -568,9 +568,9 @@ __global__ __launch_bounds__(256) void k_fft4096(const float2 *__restrict__ head
 }
 
 // the channels of a bank: frame blockIdx.x of channel blockIdx.y (see k_ols_wave_bank)
-__global__ __launch_bounds__(256) void k_fft4096_bank(const BankPtrs *__restrict__ chan, long n_head, const float *__restrict__ window,
+__global__ __launch_bounds__(256) void k_fft4096_bank(const BankTable chan, long n_head, const float *__restrict__ window,
                                                       const float2 *__restrict__ tw, int center_dc, unsigned count) {
-    const BankPtrs c = chan[blockIdx.y];
+    const BankPtrs c = chan.c[blockIdx.y];
     fft4096_body<false, false>((const float2 *)c.head, n_head, (const float2 *)c.dec, (float2 *)c.out, window, tw, center_dc, 4096L, count,
                                1, FrameMeter{}, blockIdx.x);
 }
@@ -2265,10 +2265,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OC
 // launch parameters for all of them, the streams' own buffers from a table, channel = blockIdx.y.
 template <int D, bool POLY, bool MF = false, bool SW = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OCC, RR_V_OLSW_OCC))) void k_ols_wave_bank(
-    const BankPtrs *__restrict__ chan, int hx, long n_in, const float2 *__restrict__ nco, unsigned denom, unsigned idx0,
+    const BankTable chan, int hx, long n_in, const float2 *__restrict__ nco, unsigned denom, unsigned idx0,
     const float2 *__restrict__ H, const float2 *__restrict__ tw, int V, long n_out, long e0, int hx_out, unsigned nblocks,
     unsigned ph0, unsigned hopm, unsigned kstep, double inv_denom) {
-    const BankPtrs c = chan[blockIdx.y];
+    const BankPtrs c = chan.c[blockIdx.y];
     ols_wave_body<D, POLY, MF, SW>((const float2 *)c.xh, hx, (const float2 *)c.in, n_in, nco, denom, idx0, H, tw, V, (float2 *)c.dec,
                                    n_out, e0, (float2 *)c.xh_out, hx_out, nblocks, ph0, hopm, kstep, inv_denom, blockIdx.x);
 }
@@ -2841,10 +2841,10 @@ int launch_ols_wave(hipStream_t s, const FusedFirArgs &a) {
 }
 
 template <int D>
-static int launch_ols_wave_bank_d(hipStream_t s, const FusedFirArgs &a, const BankPtrs *d_chan, size_t channels) {
+static int launch_ols_wave_bank_d(hipStream_t s, const FusedFirArgs &a, const BankTable &d_chan, size_t channels) {
     const int per_block = (1024 - a.V) / D;
     const size_t nblocks = (a.n_out + per_block - 1) / per_block;
-    if (nblocks > 0x7ffffff0ull || channels > 65535) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS bank: too many blocks or channels");
+    if (nblocks > 0x7ffffff0ull || channels > kBankGroup) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS bank: too many blocks or channels");
     const int64_t den = (int64_t)a.denom;
     int64_t ph = ((int64_t)a.idx0 + a.e0 - a.V) % den;
     if (ph < 0) ph += den;
@@ -2862,7 +2862,7 @@ static int launch_ols_wave_bank_d(hipStream_t s, const FusedFirArgs &a, const Ba
     return RR_OK;
 }
 
-int launch_ols_wave_bank(hipStream_t s, const FusedFirArgs &a, const BankPtrs *d_chan, size_t channels) {
+int launch_ols_wave_bank(hipStream_t s, const FusedFirArgs &a, const BankTable &d_chan, size_t channels) {
     if (a.n_out == 0 || channels == 0) return RR_OK;
     if (!a.poly) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS bank: polyphase tables only");
     switch (a.D) {
@@ -2873,10 +2873,10 @@ int launch_ols_wave_bank(hipStream_t s, const FusedFirArgs &a, const BankPtrs *d
     RR_FAIL(RR_ERR_BAD_ARG, "fused OLS bank: decimation %u not instantiated", a.D);
 }
 
-int launch_fft4096_bank(hipStream_t s, const BankPtrs *d_chan, size_t channels, size_t n_head, size_t count, const void *window,
+int launch_fft4096_bank(hipStream_t s, const BankTable &d_chan, size_t channels, size_t n_head, size_t count, const void *window,
                         const void *tw4096, bool center_dc) {
     if (count == 0 || channels == 0) return RR_OK;
-    if (count > 0x7fffffffull || channels > 65535) RR_FAIL(RR_ERR_BAD_ARG, "fft4096 bank: too many frames or channels");
+    if (count > 0x7fffffffull || channels > kBankGroup) RR_FAIL(RR_ERR_BAD_ARG, "fft4096 bank: too many frames or channels");
     hipLaunchKernelGGL(k_fft4096_bank, dim3((unsigned)count, (unsigned)channels), dim3(256), 0, s, d_chan, (long)n_head,
                        (const float *)window, (const float2 *)tw4096, (int)center_dc, (unsigned)count);
     RR_HIP(hipGetLastError());

@@ -1004,6 +1004,9 @@ struct TileBs {
     int nvalid;
     const v2<T> *post;
     int nout;
+    // fast convolution (the long Filter, rr_filter's conv path): frames may reach beyond the input - samples at g >= in_limit
+    // read as zero (0: no limit) - and the last frame's cut may be shorter: nothing is stored at or beyond out_limit (0: no limit)
+    long in_limit, out_limit;
 };
 
 template <class T, int MODE, int BS = 0>
@@ -1035,7 +1038,7 @@ __global__ __launch_bounds__(1024) void k_fft_tile(const v2<T> *__restrict__ in,
                         v[u] = v2<T>{(T)0, (T)0};
                         if (e < (size_t)bs.nvalid) {
                             const long g = (long)blockIdx.y * bs.hop - bs.n_head + (long)e;
-                            v[u] = cmul<T>(g >= 0 ? in[g] : bs.head[bs.n_head + g], bs.pre[e]);
+                            if (bs.in_limit == 0 || g < bs.in_limit) v[u] = cmul<T>(g >= 0 ? in[g] : bs.head[bs.n_head + g], bs.pre[e]);
                         }
                         w[u] = (T)1;
                     } else {
@@ -1143,7 +1146,8 @@ __global__ __launch_bounds__(1024) void k_fft_tile(const v2<T> *__restrict__ in,
                 const v2<T> y = cmul<T>(v, bs.post[ko]);
                 size_t o = ko + (size_t)rot;  // rotate_right(n / 2)
                 if (o >= (size_t)bs.nout) o -= (size_t)bs.nout;
-                st_result<T>(out + ((size_t)blockIdx.y * (size_t)bs.nout + o), v2<T>{y.x, -y.y});
+                const size_t oo = (size_t)blockIdx.y * (size_t)bs.nout + o;
+                if (bs.out_limit == 0 || oo < (size_t)bs.out_limit) st_result<T>(out + oo, v2<T>{y.x, -y.y});
             }
         } else {
             int kk = k + rot;
@@ -1195,7 +1199,7 @@ static int launch_fft_tile_t(hipStream_t s, int pass, const void *in, void *out,
 template <class T>
 static int launch_fft_tile_bs_t(hipStream_t s, int stage, const void *head, size_t n_head, const void *in, size_t hop, void *out,
                                 size_t N1, size_t N2, size_t count, size_t n, const void *table, const void *twNp, const void *tB,
-                                const void *tA, int h, size_t rot) {
+                                const void *tA, int h, size_t rot, long in_limit, long out_limit) {
     constexpr size_t C = 128 / sizeof(v2<T>);
     const bool passA = stage == 0 || stage == 2;
     const size_t Np = passA ? N1 : N2, No = passA ? N2 : N1;
@@ -1207,6 +1211,8 @@ static int launch_fft_tile_bs_t(hipStream_t s, int stage, const void *head, size
     if (nt < 256) nt = 256;
     const dim3 grid((unsigned)(No / C), (unsigned)count);
     TileBs<T> bs{};
+    bs.in_limit = in_limit;
+    bs.out_limit = out_limit;
     if (stage == 0) {
         bs.head = (const v2<T> *)head;
         bs.n_head = (long)n_head;
@@ -1235,13 +1241,13 @@ static int launch_fft_tile_bs_t(hipStream_t s, int stage, const void *head, size
 }
 int launch_fft_tile_bs(int dtype, hipStream_t s, int stage, const void *head, size_t n_head, const void *in, size_t hop, void *out,
                        size_t N1, size_t N2, size_t count, size_t n, const void *table, const void *twNp, const void *tB,
-                       const void *tA, int h, size_t rot) {
+                       const void *tA, int h, size_t rot, long in_limit, long out_limit) {
     if (count == 0) return RR_OK;
     if (!fft_tile_supported(dtype, N1, N2) || count > 65535 || n > N1 * N2)
         RR_FAIL(RR_ERR_BAD_ARG, "tile transform: %zu x %zu x %zu is outside the kernel's range", N1, N2, count);
     if (dtype == RR_F32)
-        return launch_fft_tile_bs_t<float>(s, stage, head, n_head, in, hop, out, N1, N2, count, n, table, twNp, tB, tA, h, rot);
-    return launch_fft_tile_bs_t<double>(s, stage, head, n_head, in, hop, out, N1, N2, count, n, table, twNp, tB, tA, h, rot);
+        return launch_fft_tile_bs_t<float>(s, stage, head, n_head, in, hop, out, N1, N2, count, n, table, twNp, tB, tA, h, rot, in_limit, out_limit);
+    return launch_fft_tile_bs_t<double>(s, stage, head, n_head, in, hop, out, N1, N2, count, n, table, twNp, tB, tA, h, rot, in_limit, out_limit);
 }
 
 int launch_fft_tile(int dtype, hipStream_t s, int pass, const void *in, void *out, size_t N1, size_t N2, size_t count,

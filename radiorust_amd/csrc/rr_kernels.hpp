@@ -137,10 +137,16 @@ struct BankPtrs {
     const void *head;  // decimated samples pending from the previous call (n_head of them)
     void *out;         // spectra
 };
-// k_ols_wave / k_fft4096 for `channels` streams in ONE launch each: the shared launch parameters in `a` (its xh / in / out /
-// xh_out are ignored), the per-channel buffers in the device array d_chan
-int launch_ols_wave_bank(hipStream_t s, const FusedFirArgs &a, const BankPtrs *d_chan, size_t channels);
-int launch_fft4096_bank(hipStream_t s, const BankPtrs *d_chan, size_t channels, size_t n_head, size_t count, const void *window,
+// The channels' buffers travel as a KERNEL ARGUMENT (64 channels x 48 bytes = 3 KiB of the 4 KiB an argument block may have):
+// no table in device memory, no copy in front of the launch; banks of more than 64 channels take a launch per 64.
+constexpr size_t kBankGroup = 64;
+struct BankTable {
+    BankPtrs c[kBankGroup];
+};
+// k_ols_wave / k_fft4096 for `channels` <= kBankGroup streams in ONE launch each: the shared launch parameters in `a` (its
+// xh / in / out / xh_out are ignored), the per-channel buffers in `tab`
+int launch_ols_wave_bank(hipStream_t s, const FusedFirArgs &a, const BankTable &tab, size_t channels);
+int launch_fft4096_bank(hipStream_t s, const BankTable &tab, size_t channels, size_t n_head, size_t count, const void *window,
                         const void *tw4096, bool center_dc);
 bool ols_frame_supported(uint64_t D, size_t Lc, size_t fft_len);
 // What a metered kernel needs beside its transform's arguments: metering::bandwidth (metering.rs:41-80) per spectrum, computed
@@ -197,7 +203,7 @@ int launch_fft_tile(int dtype, hipStream_t s, int pass, const void *in, void *ou
 // conj(X * table) (the chirp), rotated right by rot elements
 int launch_fft_tile_bs(int dtype, hipStream_t s, int stage, const void *head, size_t n_head, const void *in, size_t hop, void *out,
                        size_t N1, size_t N2, size_t count, size_t n, const void *table, const void *twNp, const void *tB,
-                       const void *tA, int h, size_t rot);
+                       const void *tA, int h, size_t rot, long in_limit = 0, long out_limit = 0);
 bool fft_big_supported(size_t n);
 void fft_big_split(size_t n, size_t *N1, size_t *N2);
 int launch_fft_big(int dtype, hipStream_t s, const void *in, void *out, void *ws, size_t n, size_t count, const void *window,

@@ -18,94 +18,142 @@
 
 namespace rr {
 
-// scratch: kBwScratch doubles of LDS that nobody else touches between the first and the last barrier in here.
+// scratch: kBwScratch doubles of LDS that nobody else touches between the first barrier in here and the caller's next one.
 // e_at(s): energy (as f64) of scan position s in FORWARD order, 0 <= s < n; any lane may call it for any s.
-// All 256 lanes of the workgroup must call this (it contains workgroup barriers).  Returns the bandwidth in every lane;
-// *total_out (if non-null, in every lane) = the sum of all energies.
+// All 256 lanes of the workgroup must call this (it contains workgroup barriers).  The result - the bandwidth, and in
+// *total_out the sum of all energies - is valid in LANE 0 ONLY (return value 0 elsewhere): the other three waves leave after
+// the second barrier and go on with the caller's next piece of work while wave 0 finishes.
 //
 // Three levels, so that almost nothing runs on more than a few lanes (a full prefix scan of f64 values over 256 lanes -
 // twelve 64-bit lane shuffles per direction - cost as many instructions as half the 4096-point transform in front of it):
-//   A  every lane: the sum of its own C energies, for both directions             -> P[dir][256]
-//   B  16 lanes per direction: the sums of 16 neighbouring P                        -> Q[dir][16]
-//   C  ONE lane per direction walks Q, then the 16 P of the group where the running sum crosses the limit, then the C
-//      energies of that lane's range - the reference's loop, with whole groups added at once in front of the crossing.
-constexpr int kBwScratch = 2 * 256 + 2 * 16 + 4;
+//   A  every lane: the sum of its own C energies                                                   -> P[256]
+//      (the reverse walk uses the same sums from the other end: a sum of 16 values does not depend on the direction beyond
+//       its last bits)
+//   B  16 lanes of wave 0: the sums of 16 neighbouring P                                           -> Q[16]
+//   C  lane 0 (forward) and lane 32 (reverse) of wave 0 walk Q, then the 16 P of the group where the running sum crosses
+//      the limit, then the C energies of that lane's range - the reference's loop, with whole groups added at once in front
+//      of the crossing.  Every level's 16 values are fetched together and walked in registers (fetched one by one inside the
+//      loop the walk was 48 dependent LDS round trips: 3 us per spectrum).
+constexpr int kBwScratch = 256 + 16 + 4;
 template <int C, class EnergyAt>
 __device__ __forceinline__ double bandwidth_block256(int n, int j, EnergyAt &&e_at, double double_percentile, double sample_rate,
                                                      double *scratch, double *total_out) {
     const int c = C > 0 ? C : (n + 255) / 256;
-    double *P = scratch, *Q = scratch + 512, *R = scratch + 544;
+    double *P = scratch, *Q = scratch + 256, *R = scratch + 272;
     {
         const int lo = j * c < n ? j * c : n, hi = (j + 1) * c < n ? (j + 1) * c : n;
-        double pf = 0.0, pr = 0.0;  // (reverse position r is forward position n - 1 - r)
+        double pf = 0.0;
         if (C > 0) {
 #pragma unroll
             for (int i = 0; i < (C > 0 ? C : 1); ++i)
                 if (lo + i < hi) pf += e_at(lo + i);
-#pragma unroll
-            for (int i = 0; i < (C > 0 ? C : 1); ++i)
-                if (lo + i < hi) pr += e_at(n - 1 - (lo + i));
         } else {
-            for (int s = lo; s < hi; ++s) {
-                pf += e_at(s);
-                pr += e_at(n - 1 - s);
-            }
+            for (int s = lo; s < hi; ++s) pf += e_at(s);
         }
         P[j] = pf;
-        P[256 + j] = pr;
     }
     __syncthreads();
-    const int dir = j >> 6, t = j & 63;  // waves 0 and 1 do the rest: forward and reverse
-    if (dir < 2 && t < 16) {
-        const double *p = P + 256 * dir + 16 * t;
+    if (j >= 64) return 0.0;  // (wave-uniform: waves 1 .. 3 are done)
+    if (j < 16) {
         double x[16], q = 0.0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) x[i] = p[i];
+        for (int i = 0; i < 16; ++i) x[i] = P[16 * j + i];
 #pragma unroll
         for (int i = 0; i < 16; ++i) q += x[i];
-        Q[16 * dir + t] = q;
+        Q[j] = q;
     }
-    __syncthreads();
-    if (dir < 2 && t == 0) {
-        // the reference's total is ONE sum, used for both directions: the forward groups' (both walking lanes add the same 16)
-        double total = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double used = 0.0, total = 0.0;
+    if (j == 0 || j == 32) {
+        const bool rev = j == 32;
+        // (every level's values are fetched in WALK order - the addresses follow the direction, the register indices do not)
+        double x[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) total += Q[i];
+        for (int i = 0; i < 16; ++i) x[i] = Q[i];
+        // the reference's total is ONE sum, used for both directions: both walking lanes add the same 16 values in the same order
+#pragma unroll
+        for (int i = 0; i < 16; ++i) total += x[i];
+        if (rev) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] = Q[15 - i];
+        }
         const double limit = total * double_percentile / 2.0;
-        double used = (double)n;  // no crossing (total <= limit): every bin is "used" (the reference's loop runs to its end)
+        used = (double)n;  // no crossing (total <= limit): every bin is "used" (the reference's loop runs to its end)
         double cum = 0.0;
-        int g = 0;
-        for (; g < 16; ++g) {
-            const double nw = cum + Q[16 * dir + g];
-            if (nw > limit) break;
-            cum = nw;
+        int g = 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const double nw = cum + x[i];
+            if (g == 16) {
+                if (nw > limit) g = i;
+                else cum = nw;
+            }
         }
         if (g < 16) {
-            int b = 16 * g;
-            for (; b < 16 * g + 15; ++b) {  // (the last of the group takes the crossing if rounding hides it from the others)
-                const double nw = cum + P[256 * dir + b];
-                if (nw > limit) break;
-                cum = nw;
-            }
-            const int lo = b * c < n ? b * c : n, hi = (b + 1) * c < n ? (b + 1) * c : n;
-            used = (double)hi;  // (crossing lost to rounding at the range's end: all of the range's bins)
-            for (int s = lo; s < hi; ++s) {
-                const double nw = cum + e_at(dir ? n - 1 - s : s);
-                if (nw > limit) {
-                    used = (double)s + (limit - cum) / (nw - cum);
-                    break;
+            const int gb = rev ? 15 - g : g;  // the group in forward numbering
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] = P[16 * gb + (rev ? 15 - i : i)];
+            int b = 15;  // (the last of the group takes the crossing if rounding hides it from the others)
+            {
+                bool found = false;
+#pragma unroll
+                for (int i = 0; i < 15; ++i) {
+                    const double nw = cum + x[i];
+                    if (!found) {
+                        if (nw > limit) {
+                            found = true;
+                            b = i;
+                        } else {
+                            cum = nw;
+                        }
+                    }
                 }
-                cum = nw;
+            }
+            const int bf = 16 * gb + (rev ? 15 - b : b);  // the lane (forward numbering) whose range holds the crossing
+            const int lo = bf * c < n ? bf * c : n, hi = (bf + 1) * c < n ? (bf + 1) * c : n;
+            // walk positions: forward lo .. hi - 1 (walk index = s), reverse hi - 1 .. lo (walk index = n - 1 - s)
+            const int w0 = rev ? n - hi : lo;  // walk index of the range's first bin in this direction
+            used = (double)(w0 + (hi - lo));   // (crossing lost to rounding at the range's end: all of the range's bins)
+            if (C > 0) {
+                double ev[C > 0 ? C : 1];
+#pragma unroll
+                for (int i = 0; i < (C > 0 ? C : 1); ++i) ev[i] = (lo + i < hi) ? e_at(rev ? hi - 1 - i : lo + i) : 0.0;
+                bool found = false;
+#pragma unroll
+                for (int i = 0; i < (C > 0 ? C : 1); ++i) {
+                    const double nw = cum + ev[i];
+                    if (!found && lo + i < hi) {
+                        if (nw > limit) {
+                            found = true;
+                            used = (double)(w0 + i) + (limit - cum) / (nw - cum);
+                        } else {
+                            cum = nw;
+                        }
+                    }
+                }
+            } else {
+                for (int i = 0; lo + i < hi; ++i) {
+                    const double nw = cum + e_at(rev ? hi - 1 - i : lo + i);
+                    if (nw > limit) {
+                        used = (double)(w0 + i) + (limit - cum) / (nw - cum);
+                        break;
+                    }
+                    cum = nw;
+                }
             }
         }
-        R[dir] = used;
-        if (dir == 0) R[2] = total;
+        if (rev) R[0] = used;
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (j != 0) return 0.0;
     double used_bins = 0.0;
+    used_bins += used;
     used_bins += R[0];
-    used_bins += R[1];
-    if (total_out) *total_out = R[2];
+    if (total_out) *total_out = total;
     const double bw = ((double)n - used_bins) * sample_rate / (double)n;
     return bw > 0.0 ? bw : 0.0;
 }
@@ -118,7 +166,7 @@ typedef float rr_f2m __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double frame4096_bandwidth(const rr_f2m (&v)[16], void *lds, int j, int rot, double double_percentile,
                                                       double sample_rate, double *total_out) {
     float *e = reinterpret_cast<float *>(lds);
-    double *scratch = reinterpret_cast<double *>(e + 4096);  // kBwScratch doubles: 4.3 KiB behind the 16 KiB of energies
+    double *scratch = reinterpret_cast<double *>(e + 4096);  // kBwScratch doubles: 2.2 KiB behind the 16 KiB of energies
     __syncthreads();  // the transform's last reads of the image are done
     {
 #pragma clang fp contract(off)

@@ -247,6 +247,41 @@ def test_filter_f64_long(rr, oracle, n):
     assert rms_rel(np.concatenate(got), np.concatenate(ref)) < 1e-12
 
 
+@pytest.mark.parametrize("n,dtype,tol", [(4096, np.float32, 1e-5), (8192, np.float32, 1e-5), (16384, np.float32, 1e-5), (3000, np.float32, 1e-5),
+                                          (8192, np.float64, 1e-11), (5000, np.float64, 1e-11)])
+def test_filter_long_responses_at_n_log_n(rr, oracle, n, dtype, tol):
+    """Responses beyond 2048 taps (simple_receiver.rs:28-37 builds a Filter on 16384-sample chunks, i.e. 16384 taps): overlap-
+    save with blocks of 2^14 .. 2^16 points through the two-pass tile transform (rr_filter::process_conv) instead of partitions
+    of 2048 taps - several chunks per call, single chunks, an interrupt in between, device pointers; against the f64 oracle."""
+    import torch
+
+    fs = 1024000.0
+    cdt = np.complex64 if dtype == np.float32 else np.complex128
+    chunks = 13
+    x = oracle.synth_iq(19, 0, n * chunks).astype(cdt)
+    g = rr.Filter.new(lowpass(100e3), dtype=dtype)
+    o = oracle.Filter(lowpass(100e3), flt=np.float64)
+    st = torch.cuda.current_stream().cuda_stream
+    g.set_stream(st)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.zeros(n * chunks, dtype=d_in.dtype, device="cuda")
+    esz = x.itemsize
+    pos = 0
+    for k, interrupt in ((3, False), (1, False), (5, False), (2, True), (2, False)):
+        if interrupt:
+            g.process(rr.EventSignal(rr.SamplesLost()))
+            o.interrupt()
+        w = g.process_dev(fs, n, d_in.data_ptr() + esz * pos, k * n, d_out.data_ptr(), k * n)
+        torch.cuda.synchronize()
+        assert g.last_kernel() == 4, g.last_kernel()
+        ref = [o.process(fs, x[pos + i * n:pos + (i + 1) * n].astype(np.complex128)) for i in range(k)]
+        ref = np.concatenate([r for r in ref if r is not None] or [np.empty(0, np.complex128)])
+        assert w == len(ref)
+        if w:
+            assert rms_rel(d_out[:w].cpu().numpy(), ref) <= tol, (k, rms_rel(d_out[:w].cpu().numpy(), ref))
+        pos += k * n
+
+
 def test_filter_deemphasis_of_simple_receiver(rr, oracle):
     """examples/relm_app/simple_receiver.rs:43-49: the audio Filter behind the FM demodulator - rectangular window,
     complex response built from blocks::filters::deemphasis_factor(50e-6, f) on 20 Hz .. 16 kHz, DC bin blocked -
