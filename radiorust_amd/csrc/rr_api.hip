@@ -411,7 +411,7 @@ int rr_filter::process_dev(double sample_rate, const void *d_in, size_t n_in, vo
     if (produce > cap) RR_FAIL(RR_ERR_CAPACITY, "Filter: out_cap %zu < %zu", cap, produce);
     RR_TRY(select());
     last_kernel = 0;
-    if (produce && use_conv && produce >= 4096 && !out_f16 && !g_f16) {
+    if (produce && use_conv && !out_f16 && !g_f16) {
         RR_TRY(process_conv(d_in, n_in, d_out, produce));
         last_kernel = 4;
         RR_TRY(launch_update_hist(dtype, stream, hist[cur].p, hist[cur ^ 1].p, n, d_in, n_in));
@@ -2168,10 +2168,6 @@ void rr_chain::bank_commit(const BankStep &st, size_t n_in) {
 rr_chainbank::~rr_chainbank() {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
-    for (int i = 0; i < kRing; ++i) {
-        if (h_tab[i]) (void)hipHostFree(h_tab[i]);
-        if (ev[i]) (void)hipEventDestroy(ev[i]);
-    }
     for (rr_chain *c : lanes) delete c;
 }
 
@@ -2192,25 +2188,33 @@ int rr_chainbank::process_dev(double rate, const void *d_in, size_t in_stride, s
     RR_TRY(lanes[0]->bank_plan(rate, n_in, cap, st, &ok));
     if (ok && st.nfr * 4096 > out_stride && K > 1) RR_FAIL(RR_ERR_CAPACITY, "ChainBank: %zu bins per channel, channels %zu apart", st.nfr * 4096, out_stride);
     if (ok) {
-        // every lane at the same stream position with the same tables: lane 0's launch parameters are everybody's
-        const rr_chain::BankSig g0 = lanes[0]->bank_signature();
-        for (size_t k = 1; k < K && ok; ++k) {
-            rr_chain *c = lanes[k];
-            if (c->fs->shift_changed || !c->fs->have_rate || c->fs->prev_rate != rate || c->fl->needs_design(rate, c->p.filter_len) ||
-                c->sink.on || c->timers.on) {
-                ok = false;
-                break;
+        // every lane at the same stream position with the same tables: lane 0's launch parameters are everybody's.  The full
+        // comparison runs when somebody has touched a lane since the bank last saw them agree (the lanes count their mutating
+        // entry points); in a steady stream of bank calls it is one comparison per lane
+        if (seen.size() != K) seen.assign(K, ~0ull), verified = false;
+        bool touched = !verified;
+        for (size_t k = 0; k < K && !touched; ++k) touched = lanes[k]->mutations != seen[k];
+        if (touched) {
+            verified = false;
+            const rr_chain::BankSig g0 = lanes[0]->bank_signature();
+            for (size_t k = 1; k < K && ok; ++k) {
+                rr_chain *c = lanes[k];
+                if (c->fs->shift_changed || !c->fs->have_rate || c->fs->prev_rate != rate || c->fl->needs_design(rate, c->p.filter_len) ||
+                    c->sink.on || c->timers.on) {
+                    ok = false;
+                    break;
+                }
+                const rr_chain::BankSig g = c->bank_signature();
+                ok = std::memcmp(&g, &g0, sizeof g) == 0;
             }
-            const rr_chain::BankSig g = c->bank_signature();
-            ok = std::memcmp(&g, &g0, sizeof g) == 0;
         }
     }
     if (!ok) {
         // lane by lane (stream start, after an interrupt or a retune, ragged calls): every lane is a chain of its own
         lanes[0]->frame_table_version = frame_version0;
+        verified = false;
         size_t got = 0;
         for (size_t k = 0; k < K; ++k) {
-            lanes[k]->stream = stream;
             size_t w = 0;
             RR_TRY(lanes[k]->process_dev(rate, static_cast<const char *>(d_in) + k * in_stride * esz, n_in,
                                          static_cast<char *>(d_out) + k * out_stride * esz, cap, &w));
@@ -2220,27 +2224,22 @@ int rr_chainbank::process_dev(double rate, const void *d_in, size_t in_stride, s
         if (n_out) *n_out = got;
         return RR_OK;
     }
-    // the channels' buffers -> a table on the device (a ring of page-locked staging tables: the copy of call i may still be
-    // in flight when call i + 1 fills the next one)
-    const int r = ring;
-    ring = (ring + 1) % kRing;
-    if (!h_tab[r]) {
-        RR_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_tab[r]), K * sizeof(rr::BankPtrs), hipHostMallocDefault));  // (K is fixed at creation)
-        RR_HIP(hipEventCreateWithFlags(&ev[r], hipEventDisableTiming));
-    }
-    if (ev_used[r]) RR_HIP(hipEventSynchronize(ev[r]));
-    RR_TRY(d_tab[r].reserve(K * sizeof(rr::BankPtrs)));
-    for (size_t k = 0; k < K; ++k)
-        RR_TRY(lanes[k]->bank_pointers(st, static_cast<const char *>(d_in) + k * in_stride * esz,
-                                       static_cast<char *>(d_out) + k * out_stride * esz, h_tab[r][k]));
-    RR_HIP(hipMemcpyAsync(d_tab[r].p, h_tab[r], K * sizeof(rr::BankPtrs), hipMemcpyHostToDevice, stream));
-    RR_HIP(hipEventRecord(ev[r], stream));
-    ev_used[r] = true;
+    // the channels' buffers travel in the launches' argument blocks, 64 channels per launch
     rr_chain *c0 = lanes[0];
-    RR_TRY(launch_ols_wave_bank(stream, st.a, d_tab[r].as<rr::BankPtrs>(), K));
-    RR_TRY(launch_fft4096_bank(stream, d_tab[r].as<rr::BankPtrs>(), K, st.n_head, st.nfr, c0->fo->d_window.p, c0->fo->d_tw.p,
-                               c0->fo->center_dc));
-    for (size_t k = 0; k < K; ++k) lanes[k]->bank_commit(st, n_in);
+    for (size_t k0 = 0; k0 < K; k0 += rr::kBankGroup) {
+        const size_t G = K - k0 < rr::kBankGroup ? K - k0 : rr::kBankGroup;
+        rr::BankTable tab;
+        for (size_t k = 0; k < G; ++k)
+            RR_TRY(lanes[k0 + k]->bank_pointers(st, static_cast<const char *>(d_in) + (k0 + k) * in_stride * esz,
+                                                static_cast<char *>(d_out) + (k0 + k) * out_stride * esz, tab.c[k]));
+        RR_TRY(launch_ols_wave_bank(stream, st.a, tab, G));
+        RR_TRY(launch_fft4096_bank(stream, tab, G, st.n_head, st.nfr, c0->fo->d_window.p, c0->fo->d_tw.p, c0->fo->center_dc));
+    }
+    for (size_t k = 0; k < K; ++k) {
+        lanes[k]->bank_commit(st, n_in);
+        seen[k] = lanes[k]->mutations;
+    }
+    verified = true;
     last_path = 1;
     if (n_out) *n_out = st.nfr * 4096;
     return RR_OK;
@@ -2318,6 +2317,7 @@ int rr_chain::process_generic(double sample_rate, const void *d_in, size_t n_in,
 }
 
 int rr_chain::process_dev(double sample_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out) {
+    ++mutations;
     if (n_out) *n_out = 0;
     if (fl->needs_design(sample_rate, p.filter_len))
         RR_FAIL(RR_ERR_NEED_DESIGN, "Chain: Filter has no design for sample rate %g", sample_rate);
@@ -3207,6 +3207,7 @@ int rr_chain_create(const rr_chain_params *p, int device, rr_chain **out) {
 }
 int rr_chain_set_shift(rr_chain *h, double shift) {
     RR_CHECK_HANDLE(h, K_CHAIN);
+    ++h->mutations;
     h->fs->shift = shift;
     h->fs->shift_changed = true;
     return RR_OK;
@@ -3219,12 +3220,14 @@ int rr_chain_filter_needs_design(const rr_chain *h, double sample_rate, int *nee
 }
 int rr_chain_filter_mark_params_changed(rr_chain *h) {
     RR_CHECK_HANDLE(h, K_CHAIN);
+    ++h->mutations;
     h->fl->params_changed = true;
     return RR_OK;
 }
 int rr_chain_filter_design(rr_chain *h, double sample_rate, const rr_c64 *resp, const double *window_rel) {
     RR_GUARD_BEGIN
     RR_CHECK_HANDLE(h, K_CHAIN);
+    ++h->mutations;
     // the Downsampler keeps running across a Filter redesign: give it its ring back first
     RR_TRY(h->materialize());
     if (h->fl->designed && sample_rate != h->fl->rate && h->carry_len) {
@@ -3246,6 +3249,7 @@ int rr_chain_filter_design(rr_chain *h, double sample_rate, const rr_c64 *resp, 
 int rr_chain_interrupt(rr_chain *h) {
     RR_GUARD_BEGIN
     RR_CHECK_HANDLE(h, K_CHAIN);
+    ++h->mutations;
     // The Rechunker in front of the Filter drops its patchwork (chunks.rs:80-88)
     // and the Filter its previous chunk (filters.rs:262-265); the other blocks
     // only forward the event.
@@ -3395,6 +3399,7 @@ int rr_chainbank_destroy(rr_chainbank *h) {
 int rr_chain_set_metering(rr_chain *h, double double_percentile, double *d_bandwidth, double *d_energy, size_t cap_frames,
                           int store_spectra) {
     RR_CHECK_HANDLE(h, K_CHAIN);
+    ++h->mutations;
     return set_sink(h->sink, double_percentile, h->p.output_rate, d_bandwidth, d_energy, cap_frames, store_spectra);
 }
 int rr_chain_last_path(const rr_chain *h, int *fused) {
@@ -3404,6 +3409,7 @@ int rr_chain_last_path(const rr_chain *h, int *fused) {
 }
 int rr_chain_timing_enable(rr_chain *h, int on) {
     RR_CHECK_HANDLE(h, K_CHAIN);
+    ++h->mutations;
     h->timers.on = on != 0;
     h->timers.only_stage = on == 2 ? ST_FUSED_FIR : -1;
     return RR_OK;
