@@ -248,7 +248,11 @@ int rr_filter::build_tables(bool reset_history) {
     use_conv = false;
     {
         static const bool conv_off = [] { const char *e = std::getenv("RR_FILTER_CONV"); return e && std::atoi(e) == 0; }();
-        const size_t minlen = dtype == RR_F32 ? 2049 : 4096;
+        // f32: the partitions of 2048 taps (one launch, n / 2048 + 1 transforms of 4096 points per block) stay ahead of the four
+        // passes over HBM up to 8192 taps (measured, profiles/r03_extras.txt); RR_FILTER_CONV_MIN moves the threshold (A/B runs)
+        const char *me = std::getenv("RR_FILTER_CONV_MIN");  // (per design: tests move it within one process)
+        const size_t min32 = me ? (size_t)std::atol(me) : (size_t)16384;
+        const size_t minlen = dtype == RR_F32 ? min32 : 4096;
         if (!conv_off && len >= minlen && len <= ((size_t)1 << 17)) {
             size_t N = (size_t)1 << (dtype == RR_F32 ? 14 : 13);
             while (N < 4 * len && N < ((size_t)1 << 18)) N <<= 1;

@@ -551,8 +551,9 @@ __device__ __forceinline__ void fft4096_body(const float2 *__restrict__ head, lo
     }
     if constexpr (METER) {
         double total;
-        const double bw = frame4096_bandwidth(v, lds, j, rot, fm.double_percentile, fm.sample_rate, &total);
-        if (j == 0) {
+        const int tw_ = (int)(fr & 3u);  // (the finishing wave rotates with the frame: rr_meter_dev.hpp)
+        const double bw = frame4096_bandwidth(v, lds, j, rot, fm.double_percentile, fm.sample_rate, &total, tw_);
+        if (j == 64 * tw_) {
             fm.bw[fr] = bw;
             if (fm.energy) fm.energy[fr] = total;
         }
@@ -1478,8 +1479,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
         if constexpr (METER) {  // (the next frame's first barrier separates this frame's last scratch reads from its image stores)
             double total;
-            const double bw = frame4096_bandwidth(v, lds, jl, rot, fm.double_percentile, fm.sample_rate, &total);
-            if (jl == 0) {
+            const int tw_ = (int)((f0 + i) & 3u);
+            const double bw = frame4096_bandwidth(v, lds, jl, rot, fm.double_percentile, fm.sample_rate, &total, tw_);
+            if (jl == 64 * tw_) {
                 fm.bw[f0 + i] = bw;
                 if (fm.energy) fm.energy[f0 + i] = total;
             }
@@ -1764,13 +1766,14 @@ __device__ __forceinline__ void ols_wave_body(
     const float2 *__restrict__ xh, int hx, const float2 *__restrict__ in, long n_in, const float2 *__restrict__ nco,
     unsigned denom, unsigned idx0, const float2 *__restrict__ H, const float2 *__restrict__ tw, int V,
     float2 *__restrict__ out, long n_out, long e0, float2 *__restrict__ xh_out, int hx_out, unsigned nblocks,
-    unsigned ph0, unsigned hopm, unsigned kstep, double inv_denom, const unsigned bx) {
+    unsigned ph0, unsigned hopm, unsigned kstep, double inv_denom, const unsigned bx, const unsigned G) {
     __shared__ __attribute__((aligned(16))) f2 lds[POLY ? 1136 : kWaveLds];  // (POLY: 2 (63 + 72 * 7) + 2 elements)
     const int l = threadIdx.x;
     // Workgroups b, b+8, .. share an XCD.  Blocks are dealt so that neighbouring blocks run on one XCD - the V
     // samples two neighbours share come from HBM once -, and the XCDs work side by side in a moving window of
     // 8 G blocks (instead of one far-apart eighth of the stream per XCD).
-    constexpr unsigned G = kWaveWin;
+    // (G = kWaveWin, a constant, in k_ols_wave; the banks' launches - many short streams - take a smaller window so that a
+    //  channel's grid is not rounded up to 512 workgroups: 64 channels x 2^16 samples were 5056 blocks in 32768 workgroups)
     const unsigned grp = bx / (8 * G), rem = bx % (8 * G);
     const unsigned blk = grp * 8 * G + (rem & 7) * G + (rem >> 3);
     if (blk >= nblocks) return;
@@ -2258,7 +2261,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OC
     float2 *__restrict__ out, long n_out, long e0, float2 *__restrict__ xh_out, int hx_out, unsigned nblocks,
     unsigned ph0, unsigned hopm, unsigned kstep, double inv_denom) {
     ols_wave_body<D, POLY, MF, SW>(xh, hx, in, n_in, nco, denom, idx0, H, tw, V, out, n_out, e0, xh_out, hx_out, nblocks, ph0, hopm,
-                                   kstep, inv_denom, blockIdx.x);
+                                   kstep, inv_denom, blockIdx.x, kWaveWin);
 }
 
 // The channels of a bank (rr_chainbank: K independent streams with the same parameters that advance in lockstep): the same
@@ -2267,10 +2270,10 @@ template <int D, bool POLY, bool MF = false, bool SW = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OCC, RR_V_OLSW_OCC))) void k_ols_wave_bank(
     const BankTable chan, int hx, long n_in, const float2 *__restrict__ nco, unsigned denom, unsigned idx0,
     const float2 *__restrict__ H, const float2 *__restrict__ tw, int V, long n_out, long e0, int hx_out, unsigned nblocks,
-    unsigned ph0, unsigned hopm, unsigned kstep, double inv_denom) {
+    unsigned ph0, unsigned hopm, unsigned kstep, double inv_denom, unsigned gwin) {
     const BankPtrs c = chan.c[blockIdx.y];
     ols_wave_body<D, POLY, MF, SW>((const float2 *)c.xh, hx, (const float2 *)c.in, n_in, nco, denom, idx0, H, tw, V, (float2 *)c.dec,
-                                   n_out, e0, (float2 *)c.xh_out, hx_out, nblocks, ph0, hopm, kstep, inv_denom, blockIdx.x);
+                                   n_out, e0, (float2 *)c.xh_out, hx_out, nblocks, ph0, hopm, kstep, inv_denom, blockIdx.x, gwin);
 }
 
 // ---------------------------------------------------------------------------
@@ -2704,8 +2707,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     if constexpr (METER) {
         double total;
-        const double bw = frame4096_bandwidth(v, fr, tid, rot, ka->fm.double_percentile, ka->fm.sample_rate, &total);
-        if (tid == 0) {
+        const int tw_ = (int)(f & 3u);
+        const double bw = frame4096_bandwidth(v, fr, tid, rot, ka->fm.double_percentile, ka->fm.sample_rate, &total, tw_);
+        if (tid == 64 * tw_) {
             ka->fm.bw[f] = bw;
             if (ka->fm.energy) ka->fm.energy[f] = total;
         }
@@ -2849,11 +2853,13 @@ static int launch_ols_wave_bank_d(hipStream_t s, const FusedFirArgs &a, const Ba
     int64_t ph = ((int64_t)a.idx0 + a.e0 - a.V) % den;
     if (ph < 0) ph += den;
     const unsigned hopm = (unsigned)((int64_t)(1024 - a.V) % den), kstep = (unsigned)(128 % den);
-    const unsigned grid = (unsigned)((nblocks + 8 * kWaveWin - 1) / (8 * kWaveWin) * (8 * kWaveWin));
+    // window of neighbouring blocks per XCD: the stream kernel's 64 for long calls, 8 / 1 for short ones (the grid is rounded up to 8 windows)
+    const unsigned gwin = nblocks >= 4096 ? kWaveWin : (nblocks >= 64 ? 8u : 1u);
+    const unsigned grid = (unsigned)((nblocks + 8 * gwin - 1) / (8 * gwin) * (8 * gwin));
 #define RR_OLSWB_LAUNCH(MF_, SW_)                                                                                                  \
     hipLaunchKernelGGL((k_ols_wave_bank<D, true, MF_, SW_>), dim3(grid, (unsigned)channels), dim3(64), 0, s, d_chan, (int)a.hx,     \
                        (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0, (const float2 *)a.H, (const float2 *)a.tw4096, a.V,    \
-                       (long)a.n_out, (long)a.e0, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, kstep, 1.0 / (double)den)
+                       (long)a.n_out, (long)a.e0, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, kstep, 1.0 / (double)den, gwin)
     if (a.mixfold && D == 4 && a.sigma < 0.f) RR_OLSWB_LAUNCH(true, true);
     else if (a.mixfold) RR_OLSWB_LAUNCH(true, false);
     else RR_OLSWB_LAUNCH(false, false);

@@ -21,8 +21,8 @@ namespace rr {
 // scratch: kBwScratch doubles of LDS that nobody else touches between the first barrier in here and the caller's next one.
 // e_at(s): energy (as f64) of scan position s in FORWARD order, 0 <= s < n; any lane may call it for any s.
 // All 256 lanes of the workgroup must call this (it contains workgroup barriers).  The result - the bandwidth, and in
-// *total_out the sum of all energies - is valid in LANE 0 ONLY (return value 0 elsewhere): the other three waves leave after
-// the second barrier and go on with the caller's next piece of work while wave 0 finishes.
+// *total_out the sum of all energies - is valid in ONE LANE ONLY (lane 64 * tail_wave; return value 0 elsewhere): the other
+// three waves leave after the second barrier and go on with the caller's next piece of work while that wave finishes.
 //
 // Three levels, so that almost nothing runs on more than a few lanes (a full prefix scan of f64 values over 256 lanes -
 // twelve 64-bit lane shuffles per direction - cost as many instructions as half the 4096-point transform in front of it):
@@ -35,9 +35,13 @@ namespace rr {
 //      of the crossing.  Every level's 16 values are fetched together and walked in registers (fetched one by one inside the
 //      loop the walk was 48 dependent LDS round trips: 3 us per spectrum).
 constexpr int kBwScratch = 256 + 16 + 4;
+// tail_wave (0 .. 3): the wave that finishes (B, C) - callers rotate it from spectrum to spectrum: a workgroup's wave i sits on
+// SIMD i, so with always the same wave one SIMD of the CU carried every workgroup's serial tail (+ 16 % on the Stft kernel,
+// + 4 % rotated).  The result is valid in lane 64 * tail_wave.
 template <int C, class EnergyAt>
-__device__ __forceinline__ double bandwidth_block256(int n, int j, EnergyAt &&e_at, double double_percentile, double sample_rate,
-                                                     double *scratch, double *total_out) {
+__device__ __forceinline__ double bandwidth_block256(int n, int j_, EnergyAt &&e_at, double double_percentile, double sample_rate,
+                                                     double *scratch, double *total_out, int tail_wave = 0) {
+    int j = j_;
     const int c = C > 0 ? C : (n + 255) / 256;
     double *P = scratch, *Q = scratch + 256, *R = scratch + 272;
     {
@@ -53,7 +57,8 @@ __device__ __forceinline__ double bandwidth_block256(int n, int j, EnergyAt &&e_
         P[j] = pf;
     }
     __syncthreads();
-    if (j >= 64) return 0.0;  // (wave-uniform: waves 1 .. 3 are done)
+    if ((j >> 6) != tail_wave) return 0.0;  // (wave-uniform: the other three waves are done)
+    j &= 63;
     if (j < 16) {
         double x[16], q = 0.0;
 #pragma unroll
@@ -164,7 +169,7 @@ __device__ __forceinline__ double bandwidth_block256(int n, int j, EnergyAt &&e_
 // reference computes it, num-complex: re * re + im * im, no contraction) go there in scan order, 16 KiB, the scratch behind them.
 typedef float rr_f2m __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double frame4096_bandwidth(const rr_f2m (&v)[16], void *lds, int j, int rot, double double_percentile,
-                                                      double sample_rate, double *total_out) {
+                                                      double sample_rate, double *total_out, int tail_wave = 0) {
     float *e = reinterpret_cast<float *>(lds);
     double *scratch = reinterpret_cast<double *>(e + 4096);  // kBwScratch doubles: 2.2 KiB behind the 16 KiB of energies
     __syncthreads();  // the transform's last reads of the image are done
@@ -178,7 +183,8 @@ __device__ __forceinline__ double frame4096_bandwidth(const rr_f2m (&v)[16], voi
         }
     }
     __syncthreads();
-    return bandwidth_block256<16>(4096, j, [&](int s) { return (double)e[s]; }, double_percentile, sample_rate, scratch, total_out);
+    return bandwidth_block256<16>(4096, j, [&](int s) { return (double)e[s]; }, double_percentile, sample_rate, scratch, total_out,
+                                  tail_wave);
 }
 
 }  // namespace rr

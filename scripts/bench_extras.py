@@ -42,12 +42,19 @@ for M, P, hop in ((256, 4, 256), (256, 4, 128), (256, 4, 64), (100, 4, 100), (10
     line(f"Channelizer {M} bins x {P} taps/branch, hop {hop}", n, dt, 8 + 8 * M / hop)
 
 lp = lambda cut: (lambda b, f: 1.0 if abs(f) <= cut else 0.0)
-for nt in (1024, 2048, 4096, 8192):
+for nt, conv_min in ((1024, None), (2048, None), (4096, None), (8192, None), (16384, None), (32768, None), (65536, None),
+                     (4096, 2049), (8192, 2049), (16384, 1 << 20), (32768, 1 << 20)):
+    # (kernel 2: k_filter_blk4096, partitions of 2048 taps beyond 2048; kernel 4: overlap-save through the tile passes)
+    if conv_min is None:
+        os.environ.pop("RR_FILTER_CONV_MIN", None)
+    else:
+        os.environ["RR_FILTER_CONV_MIN"] = str(conv_min)
     g = rr.Filter.new(lp(0.2e9))
     g.set_stream(st)
     n = N // nt * nt
-    dt = timed(lambda: g.process_dev(2e9, nt, d_in.data_ptr(), n, d_out.data_ptr(), n))
-    line(f"Filter n = {nt} (kernel {g.last_kernel()})", n, dt, 16)
+    dt = timed(lambda: g.process_dev(2e9, nt, d_in.data_ptr(), n, d_out.data_ptr(), n), k=3)
+    line(f"Filter n = {nt} (kernel {g.last_kernel()}{'' if conv_min is None else ', RR_FILTER_CONV_MIN=' + str(conv_min)})", n, dt, 16)
+os.environ.pop("RR_FILTER_CONV_MIN", None)
 
 for nf in (8192, 65536, 96, 300, 500, 720, 1000, 1001, 1536, 1999, 2000, 3000, 3001, 4004, 4800, 8000, 20000, 250000, 20011):
     g = rr.Fourier.with_window(rr.Kaiser.with_null_at_bin(2.0))

@@ -41,7 +41,9 @@ CTRS="$SQ1" pmc pmc_sq1 $B
 CTRS="$SQ2" pmc pmc_sq2 $B
 CTRS="FETCH_SIZE" pmc pmc_fetch $B
 CTRS="WRITE_SIZE" pmc pmc_write $B
-step cfg5prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg5prof" -- python3 scripts/prof_cfg5.py 40
+# (400 launches: the power controller's first 50 ms after an idle gap - faster, then slower than the steady state - are
+#  diluted; 40 launches from idle measured its transient, not the kernel)
+step cfg5prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg5prof" -- python3 scripts/prof_cfg5.py 400
 find "$OUT/cfg5prof" -name '*kernel_stats*.csv' | head -1 | xargs -r -I{} cp {} "$OUT/cfg5_kernel_stats.csv"
 CTRS="$SQ1" pmc cfg5_pmc_sq1 scripts/prof_cfg5.py
 CTRS="$SQ2" pmc cfg5_pmc_sq2 scripts/prof_cfg5.py
@@ -56,5 +58,9 @@ step decim_ab 300 python3 scripts/bench_decim_ab.py
 step meter 200 python3 scripts/bench_meter.py
 step meterprof 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/meterprof" -- python3 scripts/prof_meter.py
 find "$OUT/meterprof" -name '*kernel_stats*.csv' | head -1 | xargs -r -I{} cp {} "$OUT/meter_kernel_stats.csv"
+step clock 300 python3 scripts/clock_probe.py --seconds 4 idle cfg5 chain copy cfg5 chain
+grep -h '^CLOCK_PROBE_JSON' "$OUT/clock.log" | python3 scripts/clock_summary.py > "$OUT/clock_power.txt" || true
+step bank 300 python3 scripts/callsize_probe.py bank 64 12 14 16 18
+step callsize 300 python3 scripts/callsize_probe.py 14 16 18 20 22 24 26
 step smoke 300 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
 echo "=== done"

@@ -249,12 +249,13 @@ def test_filter_f64_long(rr, oracle, n):
 
 @pytest.mark.parametrize("n,dtype,tol", [(4096, np.float32, 1e-5), (8192, np.float32, 1e-5), (16384, np.float32, 1e-5), (3000, np.float32, 1e-5),
                                           (8192, np.float64, 1e-11), (5000, np.float64, 1e-11)])
-def test_filter_long_responses_at_n_log_n(rr, oracle, n, dtype, tol):
+def test_filter_long_responses_at_n_log_n(rr, oracle, n, dtype, tol, monkeypatch):
     """Responses beyond 2048 taps (simple_receiver.rs:28-37 builds a Filter on 16384-sample chunks, i.e. 16384 taps): overlap-
     save with blocks of 2^14 .. 2^16 points through the two-pass tile transform (rr_filter::process_conv) instead of partitions
     of 2048 taps - several chunks per call, single chunks, an interrupt in between, device pointers; against the f64 oracle."""
     import torch
 
+    monkeypatch.setenv("RR_FILTER_CONV_MIN", "2049")  # (the default threshold for f32 is 16384 taps: below it the partitions are ahead)
     fs = 1024000.0
     cdt = np.complex64 if dtype == np.float32 else np.complex128
     chunks = 13
