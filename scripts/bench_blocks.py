@@ -85,3 +85,20 @@ sf.set_stream(st)
 N = NS
 run("Stft 1024 x 4 (example's analysis)", 40, lambda: sf.process_dev(d_in.data_ptr(), NS, d_big.data_ptr(), NO + 8192))
 N = NO
+# chain shapes beside cfg2's: other decimations, Fourier lengths and response lengths; roofline = 8 + 8 / D B
+lp = lambda b, f: 1.0 if abs(f) <= 20e6 else 0.0
+for name, kw, D in (("chain 4:1 / FFT 4096, Lc 183 (cfg2)", dict(shift=25e6, filter_len=64, output_rate=50e6, bandwidth=40e6, fft_len=4096), 4),
+                    ("chain 4:1 / FFT 4096, general NCO (2469/40000)", dict(shift=12.345e6, precision=1e3, filter_len=64, output_rate=50e6, bandwidth=40e6, fft_len=4096), 4),
+                    ("chain 4:1 / FFT 4096, Lc 123 (V = 128)", dict(shift=25e6, filter_len=64, output_rate=50e6, bandwidth=30e6, fft_len=4096), 4),
+                    ("chain 4:1 / FFT 4096, Lc 59 (V = 64)", dict(shift=25e6, filter_len=20, output_rate=50e6, bandwidth=20e6, fft_len=4096), 4),
+                    ("chain 8:1 / FFT 1024", dict(shift=25e6, filter_len=64, output_rate=25e6, bandwidth=20e6, fft_len=1024), 8),
+                    ("chain 2:1 / FFT 8192", dict(shift=25e6, filter_len=64, output_rate=100e6, bandwidth=80e6, fft_len=8192), 2),
+                    ("chain 4:1 / FFT 1024", dict(shift=25e6, filter_len=64, output_rate=50e6, bandwidth=40e6, fft_len=1024), 4),
+                    ("chain 8:1 / FFT 4096", dict(shift=25e6, filter_len=64, output_rate=25e6, bandwidth=20e6, fft_len=4096), 8)):
+    ch = rr.Chain(freq_resp=lp, fft_window=rr.Kaiser.with_null_at_bin(2.0), **kw)
+    ch.set_stream(st)
+    cap = N // D + 2 * kw["fft_len"]
+    co = torch.empty(cap, dtype=torch.complex64, device="cuda")
+    run(name, 8 + 8 / D, lambda: ch.process_dev(fs, d_in.data_ptr(), N, co.data_ptr(), cap))
+    print("   kernel:", ch.last_path_kernel(), " mixer folded:", ch.last_path_mixer_folded())
+    del ch, co
