@@ -104,10 +104,28 @@ where
         let freq_resp: Box<dyn FreqRespFunc + Send + Sync> = Box::new(freq_resp);
         spawn(async move {
             let mut buf_pool = PinnedChunkBufPool::<Complex<Flt>>::new();
+            let mut prev_sample_rate: Option<f64> = None;
             loop {
                 let Ok(signal) = receiver.recv().await else { return; };
                 match signal {
                     Signal::Samples { sample_rate, chunk: input_chunk } => {
+                        // The Rechunker inside the chain holds < filter_len samples between calls.  A chunk at another
+                        // sample rate makes it drop them and report SamplesLost - an interrupt for the Filter behind it
+                        // (chunks.rs:72-92; the header's protocol around rr_chain_pending)
+                        if prev_sample_rate.map_or(false, |r| r != sample_rate) {
+                            let mut held = 0usize;
+                            if check(unsafe { ffi::rr_chain_pending(handle.get(), &mut held) }).is_err() {
+                                return;
+                            }
+                            if held > 0 {
+                                if check(unsafe { ffi::rr_chain_interrupt(handle.get()) }).is_err() {
+                                    return;
+                                }
+                                let Ok(()) = sender.send(Signal::new_event(crate::blocks::chunks::events::SamplesLost)).await
+                                else { return; };
+                            }
+                        }
+                        prev_sample_rate = Some(sample_rate);
                         if shift_recv.has_changed().unwrap_or(false) {
                             let shift = *shift_recv.borrow_and_update();
                             if check(unsafe { ffi::rr_chain_set_shift(handle.get(), shift) }).is_err() {
@@ -176,7 +194,19 @@ where
                         }
                     }
                     Signal::Event(event) => {
-                        if event.is_interrupt() {
+                        // ANY event while the Rechunker holds samples: they are dropped and SamplesLost goes out in front of
+                        // the event (chunks.rs:80-88) - which interrupts the Filter; otherwise only an interrupting event does
+                        let mut held = 0usize;
+                        if check(unsafe { ffi::rr_chain_pending(handle.get(), &mut held) }).is_err() {
+                            return;
+                        }
+                        if held > 0 {
+                            if check(unsafe { ffi::rr_chain_interrupt(handle.get()) }).is_err() {
+                                return;
+                            }
+                            let Ok(()) = sender.send(Signal::new_event(crate::blocks::chunks::events::SamplesLost)).await
+                            else { return; };
+                        } else if event.is_interrupt() {
                             // the Filter drops its history, the other three keep their state
                             // (filters.rs:262-265; transform.rs:357-359, resampling.rs:135-137, analysis.rs:122-124)
                             if check(unsafe { ffi::rr_chain_interrupt(handle.get()) }).is_err() {
