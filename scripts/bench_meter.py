@@ -32,18 +32,28 @@ print(f"rr_meter (front end fused: {m.front_fused()}): {dt*1e3:.3f} ms per 2^26 
 import ctypes as C
 frames = cap // 4096
 d_bw = torch.empty(frames, dtype=torch.float64, device="cuda")
-m.set_metering(0.01, d_bw.data_ptr(), frames)
-dt_a = timeit(lambda: m.process_dev(fs, d_in.data_ptr(), N, d_out.data_ptr(), cap))
-m.set_metering(0.01, d_bw.data_ptr(), frames, store_spectra=False)
-dt_b = timeit(lambda: m.process_dev(fs, d_in.data_ptr(), N, 0, 0))
-m.set_metering(0.01, 0, 0)
 L = rr._lib.lib()
+def plain():
+    m.set_metering(0.01, 0, 0)
+    return timeit(lambda: m.process_dev(fs, d_in.data_ptr(), N, d_out.data_ptr(), cap), K=30)
+def fused():
+    m.set_metering(0.01, d_bw.data_ptr(), frames)
+    return timeit(lambda: m.process_dev(fs, d_in.data_ptr(), N, d_out.data_ptr(), cap), K=30)
+def fused_nostore():
+    m.set_metering(0.01, d_bw.data_ptr(), frames, store_spectra=False)
+    return timeit(lambda: m.process_dev(fs, d_in.data_ptr(), N, 0, 0), K=30)
+# (the three forms in turn, five rounds, medians: the card's power state moves single runs by several per cent)
+rounds = [(plain(), fused(), fused_nostore()) for _ in range(5)]
+med = lambda i: sorted(r[i] for r in rounds)[len(rounds) // 2]
+dt0, dt_a, dt_b = med(0), med(1), med(2)
+m.set_metering(0.01, 0, 0)
 def serial():
     w = m.process_dev(fs, d_in.data_ptr(), N, d_out.data_ptr(), cap)
     rr._lib.check(L.rr_bandwidth_dev(0, 0, C.c_void_p(st), 0.01, out_rate, d_out.data_ptr(), 4096, w // 4096, d_bw.data_ptr()))
 dt_c = timeit(serial, K=3)
-print(f"pipeline + metering::bandwidth per spectrum: fused epilogue {dt_a*1e3:.3f} ms = {dt_a/dt:.3f} x the pipeline alone; "
-      f"fused, spectra not written {dt_b*1e3:.3f} ms = {dt_b/dt:.3f} x; serial kernel behind the pipeline {dt_c*1e3:.3f} ms = {dt_c/dt:.3f} x")
+print(f"pipeline alone {dt0*1e3:.4f} ms (median of 5 rounds of 30 calls, the forms in turn); + metering::bandwidth per spectrum: "
+      f"fused epilogue {dt_a*1e3:.4f} ms = {dt_a/dt0:.3f} x; fused, spectra not written {dt_b*1e3:.4f} ms = {dt_b/dt0:.3f} x; "
+      f"serial kernel behind the pipeline {dt_c*1e3:.3f} ms = {dt_c/dt0:.3f} x")
 sh = rr.FreqShifter.with_shift(12.5e3); sh.set_stream(st)
 ds = rr.Downsampler.new(1024, out_rate, bw); ds.set_stream(st)
 fl = rr.Filter.new(resp); fl.set_stream(st)
