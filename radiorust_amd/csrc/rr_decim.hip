@@ -1,7 +1,7 @@
 // rr_decim.hip — the Downsampler (resampling.rs:103-133) for ANY integer ratio and for rational ratios
 // P : Q with a short period, Complex<f32>, real impulse response, on gfx950.
 //
-// The fused overlap-save kernels of rr_fused.hip serve the ratios 2, 4 and 8.  Everything else used to run
+// The fused overlap-save kernels of rr_ols.hip serve the ratios 2, 4 and 8.  Everything else used to run
 // the generic gather kernel k_fir at 12 % of its roofline — among it the reference's own pipelines
 // (examples/bandwidth_meter/main.rs:56: 1024 k -> 102.4 k = 10 : 1, L = 145; simple_receiver.rs:28: 1024 k ->
 // 384 k = 8 : 3, L = 34).  With a long impulse response and a large ratio the direct form is cheap in

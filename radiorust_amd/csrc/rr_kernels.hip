@@ -3,7 +3,7 @@
 // This file holds the GENERIC kernels: they accept every parameter set the
 // reference blocks accept (any tap count, any resampling schedule, any chunk
 // length) and are used block-by-block.  The fused fast path for the
-// FreqShifter->Filter->Downsampler->Fourier chain lives in rr_fused.hip.
+// FreqShifter->Filter->Downsampler->Fourier chain lives in rr_ols.hip and rr_fft_regs.hip.
 //
 // These are vector (VALU + LDS) kernels: FIR dot products and FFT butterflies
 // over Complex<f32>/<f64>; no MFMA (not a dense contraction).
@@ -428,7 +428,7 @@ int launch_update_hist(int dtype, hipStream_t s, const void *old_hist, void *new
 // ---------------------------------------------------------------------------
 // Fourier, power-of-two length: window * x -> Stockham autosort radix-2 in LDS,
 // one workgroup per chunk.  center_dc is an index rotation on the store.
-// (Generic version; the radix-16 register kernel for n = 4096 is in rr_fused.hip.)
+// (Generic version; the radix-16 register kernel for n = 4096 is in rr_fft_regs.hip.)
 // ---------------------------------------------------------------------------
 // Stockham autosort passes of a power-of-two transform between two LDS images (radix 4 while it fits, then radix 2); the
 // caller has filled `a` and synchronised; returns the image that holds the result (synchronised).

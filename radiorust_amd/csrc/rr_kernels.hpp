@@ -81,7 +81,7 @@ int launch_fourier(int dtype, hipStream_t s, const void *in, void *out, size_t n
 int launch_fourier_overlapped(int dtype, hipStream_t s, const void *head, size_t n_head, const void *in, void *out,
                               size_t n, size_t hop, size_t count, const void *window, const void *twiddle, bool center_dc);
 
-// ---- fused fast path (rr_fused.hip), Complex<f32> only ------------------------
+// ---- fused fast path (rr_ols.hip, rr_fft_regs.hip), Complex<f32> only ------------------------
 // v[m] = sum_i c[i] xs[e0 + D m - i]; xs = NCO-mixed input.  Virtual stream:
 // positions [-hx, 0) come from `xh` (already mixed), [0, n_in) from `in` (raw,
 // mixed on load with nco[(idx0 + pos) mod denom]).  `taps`: Gp*D floats in step
@@ -281,7 +281,7 @@ bool channelizer_fused_supported(int dtype, size_t M, size_t P, size_t hop);
 int launch_chan_fold(int dtype, hipStream_t s, const void *hist, size_t hist_len, const void *in, long base0, size_t hop,
                      size_t M, size_t P, size_t frames, const void *window, void *out);
 // f32, M = 256, P in {1, 2, 3, 4, 6, 8} at hop 256 or P in {2, 4, 8} at hop 128 / 64 (the oversampled filterbanks): one wave
-// per run of frames, sliding window of samples in registers, radix-4 DFT_256 with wave-local exchanges (rr_fused.hip)
+// per run of frames, sliding window of samples in registers, radix-4 DFT_256 with wave-local exchanges (rr_channelizer.hip)
 bool channelizer256_supported(int dtype, size_t M, size_t P, size_t hop = 256);
 int launch_channelizer256(hipStream_t s, const void *hist, size_t hist_len, const void *in, long base0, size_t P,
                           size_t nframes, const void *window, const void *tw, void *out, size_t hop = 256);

@@ -1,5 +1,5 @@
 // rr_wave_math.hpp — packed complex f32 arithmetic and in-register DFT butterflies shared by the
-// gfx950 kernels (rr_fused.hip, rr_filter_ols.hip, rr_decim.hip): a complex lives in one 64-bit VGPR pair,
+// gfx950 kernels (rr_ols.hip, rr_fft_regs.hip, rr_bluestein.hip, rr_channelizer.hip, rr_filter_ols.hip, rr_decim.hip): a complex lives in one 64-bit VGPR pair,
 // every helper is one or two VOP3P instructions.  Device code only.
 #pragma once
 #include <hip/hip_runtime.h>
