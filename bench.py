@@ -305,9 +305,24 @@ def main():
             "pct_hbm_roofline_whole_chain": round(100.0 * ALG_BYTES_PER_SAMPLE * whole_job_rate(n, args.steps, world, g_el) * 1e6
                                                   / world / (HBM_PEAK_GBS * 1e9), 3),
             "kernel": gch.last_path_kernel(),
-            "mixer_folded_into_tables": bool(gch.last_path_mixer_folded()),
+            "mixer": ("behind the filter: the blocks transform the samples as they are with the tables of c[i] w^-i, each result times "
+                      "the phase table's entry at its position (k_ols_frame<.., GP>: any NCO period)"
+                      if gch.last_path_mixer_folded() else "in front of the block transform, in the kernel"),
             "shift": "12.345 MHz at 1 kHz precision: 2469 / 40000 of fs, a 40 000-entry phase table",
         }
+        if rank == 0:
+            # the same calls through the block-by-block kernels (FreqShifter, Filter, Downsampler, Fourier one at a time)
+            gref = rr.Chain(shift=12.345e6, precision=1e3, filter_len=64, freq_resp=lowpass20, output_rate=50e6, bandwidth=40e6,
+                            fft_len=4096, fft_window=rr.Kaiser.with_null_at_bin(2.0), device=local_rank, allow_fused=False)
+            gref.set_stream(stream)
+            d_ref_g = torch.empty(cap, dtype=torch.complex64, device="cuda")
+            wrote = 0
+            for _ in range(max(args.warmup, 3) + args.steps):
+                wrote = gref.process_dev(fs, d_in.data_ptr(), n, d_ref_g.data_ptr(), cap)
+            torch.cuda.synchronize()
+            a, b = d_out_g[:wrote], d_ref_g[:wrote]
+            general["parity_vs_block_by_block"] = float((torch.linalg.vector_norm(a - b) / torch.linalg.vector_norm(b)).item())
+            del gref, d_ref_g
         del gch, d_out_g
 
     # Full-size consistency check (not timed): replay the same calls through the block-by-block

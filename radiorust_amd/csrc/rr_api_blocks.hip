@@ -35,14 +35,17 @@ int rr_freqshifter::prepare(double sample_rate) {
     // denom entries + entry 0 once more behind them (k_ols_wave reads the pair (r, r + 1) in one piece)
     // + 8 rotations e^{j 2 pi (128 k numer mod denom) / denom}, k < 8: the fused kernel steps a lane's
     // phasor by 128 samples with one product instead of one more table read
-    host_table.resize(((size_t)de + 1 + 8) * esz);
+    // + 64 lane constants e^{j 2 pi (4 l numer mod denom) / denom}, l < 64: k_ols_frame<.., GP> makes the phasor of a lane's result
+    // from the block's own (one scalar read) and its constant
+    host_table.resize(((size_t)de + 1 + 8 + 64) * esz);
     if (dtype == RR_F32)
         nco_table<float>(nu, de, (float)start, reinterpret_cast<float *>(host_table.data()));
     else
         nco_table<double>(nu, de, start, reinterpret_cast<double *>(host_table.data()));
     std::memcpy(host_table.data() + (size_t)de * esz, host_table.data(), esz);
-    for (int k = 0; k < 8; ++k) {
-        const int64_t i = (int64_t)(((__int128)128 * k * (__int128)nu) % (__int128)de);
+    for (int k = 0; k < 8 + 64; ++k) {
+        const int64_t step = k < 8 ? 128 * k : 4 * (k - 8);
+        const int64_t i = (int64_t)(((__int128)step * (__int128)nu) % (__int128)de);
         const double ang = 2.0 * M_PI * (double)i / (double)de;
         unsigned char *dst = host_table.data() + ((size_t)de + 1 + k) * esz;
         if (dtype == RR_F32) {

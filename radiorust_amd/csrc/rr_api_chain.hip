@@ -383,7 +383,7 @@ int rr_chain::ensure_mixfold() {
 // NCO periods that divide 8 (the benchmark's fs / 8): the mixer folded into the tables (ensure_mixfold) - once the mixed-sample
 // history in front of this call has been written under the table in use (RR_FRAME_MIXFOLD=0: never).  `back` = how far in front
 // of e0 - V the call's first block starts (the blocks' hop, 832 samples, is a multiple of every such period).
-int rr_chain::fold_mixer(FusedFirArgs &a, int64_t back) {
+int rr_chain::fold_mixer(FusedFirArgs &a, int64_t back, bool frame) {
     const char *env = std::getenv("RR_FRAME_MIXFOLD");  // (read per call: tests switch it within one process)
     const bool off = env && std::atoi(env) == 0;
     if (!off && fs->denom >= 1 && 8 % fs->denom == 0 && frame_table_version == fs->table_version && olsG64.size() == 1024) {
@@ -395,7 +395,42 @@ int rr_chain::fold_mixer(FusedFirArgs &a, int64_t back) {
         a.mixfold = true;
         a.sigma = mix_sigma;
     }
+    else if (!off && frame && use_frame && fs->denom > 8 && frame_table_version == fs->table_version && !ctaps_cc.empty()) {
+        const char *eg = std::getenv("RR_FRAME_GENFOLD");  // (=0: the mixer in front of the transform, A/B runs and tests)
+        if (!(eg && std::atoi(eg) == 0)) {
+            RR_TRY(ensure_genfold());
+            a.H = d_olsHgen.p;
+            a.genfold = true;
+        }
+    }
     frame_table_version = fs->table_version;
+    return RR_OK;
+}
+
+// k_ols_frame<.., GP>: every other NCO period - the mixer moved BEHIND the filter.  The phase table is p[t] = p0 w^t,
+// w = e^{j 2 pi numer / denom}, so  sum_i c[i] x[t - i] p[t - i] = p[t] sum_i (c[i] w^-i) x[t - i]: the tables of the response
+// c[i] w^-i (complex also where c is real), applied to the samples as they are; the kernel multiplies each result by the table's
+// entry at its position.  w^-i from the reduced index (i numer mod denom) in f64.
+int rr_chain::ensure_genfold() {
+    const int64_t R = fs->denom;
+    int64_t nu = fs->numer % R;
+    if (nu < 0) nu += R;
+    if (gen_numer == nu && gen_denom == R && gen_ctaps_fl == ctaps_fl && gen_ctaps_ds == ctaps_ds) return RR_OK;
+    const size_t lc = ctaps_cc.size();
+    std::vector<double> c(lc, 0.0);
+    std::vector<cd> cc(lc);
+    for (size_t i = 0; i < lc; ++i) {
+        const int64_t ri = (int64_t)(((__int128)i * (__int128)nu) % (__int128)R);
+        const double ang = -2.0 * M_PI * (double)ri / (double)R;
+        cc[i] = ctaps_cc[i] * cd(std::cos(ang), std::sin(ang));
+    }
+    FusedFirTables t;
+    build_fused_fir_tables(FK_OLSF, ds->sched.D, c, cc, t);
+    RR_TRY(upload(d_olsHgen, t.H.data(), t.H.size() * sizeof(float), stream));
+    gen_numer = nu;
+    gen_denom = R;
+    gen_ctaps_fl = ctaps_fl;
+    gen_ctaps_ds = ctaps_ds;
     return RR_OK;
 }
 
@@ -436,6 +471,7 @@ int rr_chain::ensure_ctaps() {
     build_fused_fir_tables(fk, ds->sched.D, c, cc, t);
     use_frame = fk == FK_OLSF;
     use_ols = fk != FK_DIRECT;
+    if (use_frame) ctaps_cc = cc; else ctaps_cc.clear();
     if (use_ols) {
         RR_TRY(upload(d_olsH, t.H.data(), t.H.size() * sizeof(float), stream));
         RR_TRY(upload(d_tw4096, t.tw.data(), t.tw.size() * sizeof(float), stream));
@@ -526,7 +562,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
         a.tw4096 = d_tw4096.p;
         a.V = ols_V;
         a.poly = ols_poly;
-        RR_TRY(fold_mixer(a, 4 * (int64_t)pending_len));  // (the frame's first block starts 4 pl samples earlier, as launch_ols_frame)
+        RR_TRY(fold_mixer(a, 4 * (int64_t)pending_len, true));  // (the frame's first block starts 4 pl samples earlier, as launch_ols_frame)
         // (the launch records its own start / end: marker packets would cost ~4 us of stream time each)
         if (timers.on && !sink.on) timers.begin_ext(ST_FUSED_FIR, &a.ev_start, &a.ev_stop);
         const rr::FrameMeter fmv = sink.frame_meter();
@@ -543,7 +579,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
         pend_ptr = pendbuf[po].p;
         pb_cur = po;
         pending_len = rest;
-        last_fused = a.mixfold ? 6 : FK_OLSF;  // (6: k_ols_frame<true>, the mixer folded into the tables)
+        last_fused = a.genfold ? 8 : a.mixfold ? 6 : FK_OLSF;  // (6: k_ols_frame<true>, the mixer folded into the tables; 8: <.., GP>, behind the filter)
         if (n_out) *n_out = nfr * LF;
         return RR_OK;
     }

@@ -350,12 +350,17 @@ struct rr_chain : rr_block {
     // k_ols_frame with the mixer folded into the tables (NCO periods that divide 8): G'_p[k] = G_p[(k + s) mod 256] e^{j 2 pi p numer / R}
     std::vector<rr::cd> olsG64;
     rr::DevBuf d_olsHmix;
+    rr::DevBuf d_olsHgen;                 // k_ols_frame<.., GP>: tables of the response c[i] w^-i (ensure_genfold)
+    std::vector<rr::cd> ctaps_cc;         // the combined taps in f64 (frame kernel only)
+    int64_t gen_numer = -1, gen_denom = -1;
+    uint64_t gen_ctaps_fl = ~0ull, gen_ctaps_ds = ~0ull;
+    int ensure_genfold();
     int64_t mix_numer = 0, mix_denom = 0;
     uint64_t mix_ctaps_fl = ~0ull, mix_ctaps_ds = ~0ull, mix_table_version = ~0ull;
     uint64_t frame_table_version = ~0ull;  // the NCO table the mixed-sample history was last written with by a k_ols_frame / k_ols_wave call
     float mix_sigma = 1.f;
     int ensure_mixfold();
-    int fold_mixer(rr::FusedFirArgs &a, int64_t back);
+    int fold_mixer(rr::FusedFirArgs &a, int64_t back, bool frame = false);  // (frame: k_ols_frame - the one with the GP instance)
     rr::DevBuf pendbuf[2];       // its pending decimated samples, ping-pong
     int pb_cur = 0;
     int ensure_xh();

@@ -109,6 +109,10 @@ struct FusedFirArgs {
     // samples as they are and multiplies its results by nco[ph0] sigma^(index): see rr_chain::ensure_mixfold
     bool mixfold = false;
     float sigma = 1.f;
+    // k_ols_frame only: ANY NCO period with the mixer moved behind the filter - H holds the tables of the response c[i] w^-i
+    // (rr_chain::ensure_genfold), the kernel transforms the samples as they are and multiplies its results by the phase table's
+    // entries at their positions
+    bool genfold = false;
     // optional: the launch itself records its start / end in these events (hipExtLaunchKernel):
     // kernel-only timing without marker packets on the stream
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;

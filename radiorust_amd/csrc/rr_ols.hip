@@ -573,6 +573,14 @@ __device__ __forceinline__ const f2 *inv256_rd(const f2 *lds, int l, int pass) {
     return lds + l;
 }
 
+// a read whose address is the same for the whole wave, from memory no kernel of the launch writes: through the constant address
+// space it becomes an s_load (a plain global pointer gives a vector load per lane once the kernel has stored anything)
+__device__ __forceinline__ float2 ld_uniform(const float2 *p) {
+    typedef float __attribute__((ext_vector_type(2))) v2;
+    const v2 v = *(const v2 __attribute__((address_space(4))) *)(unsigned long long)p;
+    return float2{v.x, v.y};
+}
+
 // MF: no mixer in the kernel - the stand-alone Downsampler (its table is all ones), or the chain with the mixer folded into the
 // response tables (NCO periods that divide 8, rr_chain::ensure_mixfold; SW: the spectrum taken 128 bins further on, D = 4)
 // (the kernel's body as a function of the workgroup index bx: k_ols_wave runs it for one stream, k_ols_wave_bank for the
@@ -724,7 +732,7 @@ __device__ __forceinline__ void ols_wave_body(
             v[1] = cmul((f2){x[0].z, x[0].w}, p1);
 #pragma unroll
             for (int k = 1; k < 8; ++k) {
-                const float2 rt = nco[denom + 1 + k];  // uniform address: a scalar read
+                const float2 rt = ld_uniform(nco + (denom + 1 + k));  // uniform address: a scalar read
                 const f2 rot = {rt.x, rt.y};
                 v[2 * k] = cmul((f2){x[k].x, x[k].y}, cmul(p0, rot));
                 v[2 * k + 1] = cmul((f2){x[k].z, x[k].w}, cmul(p1, rot));
@@ -1311,7 +1319,12 @@ struct FrameArgs {
 #endif
 // MF: the mixer folded into the tables (rr_chain::ensure_mixfold) - instances of their own without the mixer's code; SW: poly4_block<SW>
 // FULL: 20 blocks per frame (V = 192, cfg2) - no guard around a wave's blocks; !FULL: 18 / 19 blocks (V = 64 / 128)
-template <bool MF, bool SW, bool FULL = true, bool METER = false>
+// GP (with MF): ANY NCO period - the mixer moved behind the filter.  The phase table is a geometric sequence p[t] = p0 w^t, so
+//   sum_i c[i] x[t - i] p[t - i] = p[t] sum_i (c[i] w^-i) x[t - i]:
+// the blocks transform the samples as they are with the tables of the response c[i] w^-i (host, rr_chain::ensure_genfold), and the
+// 4 results a lane keeps per block are multiplied by p at their own positions (one table read per lane and block + the three
+// rotations by 256 samples kept behind the table): 14 packed instructions per block instead of the 60 of the mixer in front.
+template <bool MF, bool SW, bool FULL = true, bool METER = false, bool GP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ols_frame(FrameArgs a_) {
     const FrameArgs &a = a_;
     const FrameArgs *ka = (const FrameArgs *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1378,22 +1391,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // mixer folded into the tables (MF): the blocks transform the samples as they are; the phasor of a block's first sample (the same
     // for every block of the call) is in the table the host picked for this call, the alternating sign in poly4_block<SW>
     f2 keep[kFrameBlocks / 4][4];
+    // phase of a block's first sample: (idx0 + b0) mod denom, b0 = const + 4 (4096 f + per_block jb)
+    auto block_phase = [&](int jb) -> unsigned {
+        const double dn = (double)a.denom;
+        const double prod = (double)a.ph0 + 16384.0 * (double)f + (double)(4 * per_block * jb);
+        const double qd = __builtin_floor(prod * a.inv_denom);
+        double rd = __builtin_fma(-qd, dn, prod);
+        if (rd < 0.0) rd += dn;
+        if (rd >= dn) rd -= dn;
+        return (unsigned)rd;
+    };
+    // GP: the phasors of the wave's five blocks read up front (scalar reads: no SMEM result is outstanding inside the blocks, whose
+    // LDS exchanges count on lgkmcnt) + the lane's constant e^{j 2 pi 4 l numer / denom} and the three rotations by 256 results
+    [[maybe_unused]] float2 rot128[7];  // (mixer in front, general period: the seven steps by 128 samples - scalar reads, up front)
+    if constexpr (!MF) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) rot128[k - 1] = ld_uniform(a.nco + (a.denom + 1 + k));
+    }
+    [[maybe_unused]] f2 glane = {1.f, 0.f};
+    [[maybe_unused]] unsigned rdv[kFrameBlocks / 4];
+    [[maybe_unused]] float2 pgv[kFrameBlocks / 4], rtv[3];
+    if constexpr (GP) {
+        const float2 gl_ = a.nco[a.denom + 9 + l];
+        glane = (f2){gl_.x, gl_.y};
+#pragma unroll
+        for (int kb = 0; kb < kFrameBlocks / 4; ++kb) {
+            rdv[kb] = __builtin_amdgcn_readfirstlane(block_phase(RR_V_FRAME_CONSEC ? 5 * w + kb : w + 4 * kb));
+            pgv[kb] = ld_uniform(a.nco + rdv[kb]);
+        }
+#pragma unroll
+        for (int c = 1; c < 4; ++c) rtv[c - 1] = ld_uniform(a.nco + (a.denom + 1 + 2 * c));  // e^{j 2 pi (256 c numer mod denom) / denom}
+    }
 #pragma unroll
     for (int kb = 0; kb < kFrameBlocks / 4; ++kb) {
         const int jb = RR_V_FRAME_CONSEC ? 5 * w + kb : w + 4 * kb;  // (five neighbouring blocks per wave instead: measured 0.171 against 0.159 ms)
         // (shorter responses: V = 64 / 128, 240 / 224 results per block - 18 / 19 blocks cover the frame, the last round's other waves idle)
         if (!FULL && kb >= 3 && __builtin_amdgcn_readfirstlane(jb) >= a.nb) continue;  // (a wave-uniform branch; rounds 0 .. 2 are always full)
         const long b0 = a.e0 - a.V + 4 * (F0 + (long)per_block * jb);
-        // phase of the lane's first sample: (idx0 + b0 + 2 l) mod denom, b0 = const + 4 (4096 f + 208 jb)
+        // phase of the lane's first sample: (idx0 + b0 + 2 l) mod denom
         unsigned r = 0;
         if (!MF || !(b0 >= 0 && b0 <= n_clamp)) {  // (MF: only the edge blocks look at the table)
-            const double dn = (double)a.denom;
-            const double prod = (double)a.ph0 + 16384.0 * (double)f + (double)(4 * per_block * jb);
-            const double qd = __builtin_floor(prod * a.inv_denom);
-            double rd = __builtin_fma(-qd, dn, prod);
-            if (rd < 0.0) rd += dn;
-            if (rd >= dn) rd -= dn;
-            r = (unsigned)rd + 2u * (unsigned)l;
+            unsigned rd0;
+            if constexpr (GP) rd0 = rdv[kb];
+            else rd0 = block_phase(jb);
+            r = rd0 + 2u * (unsigned)l;
             if (a.denom >= 128u) {
                 if (r >= a.denom) r -= a.denom;
             } else if ((a.denom & (a.denom - 1u)) == 0u) {
@@ -1433,8 +1474,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 v[1] = cmul((f2){x[0].z, x[0].w}, p1);
 #pragma unroll
                 for (int k = 1; k < 8; ++k) {
-                    const float2 rt = a.nco[a.denom + 1 + k];  // uniform address: a scalar read
-                    const f2 rot = {rt.x, rt.y};
+                    const f2 rot = {rot128[k - 1].x, rot128[k - 1].y};
                     v[2 * k] = cmul((f2){x[k].x, x[k].y}, cmul(p0, rot));
                     v[2 * k + 1] = cmul((f2){x[k].z, x[k].w}, cmul(p1, rot));
                 }
@@ -1463,6 +1503,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
         }
         poly4_block<SW>(v, keep[kb], lds, l, t_p1, t_p2, t_inv, a.H, glp);
+        if constexpr (GP) {
+            // result tau = l + 64 c of the block sits at input position b0 + 4 tau
+            const f2 gph = cmul((f2){pgv[kb].x, pgv[kb].y}, glane);
+            keep[kb][0] = cmul(keep[kb][0], gph);
+#pragma unroll
+            for (int c = 1; c < 4; ++c) keep[kb][c] = cmul(keep[kb][c], cmul(gph, (f2){rtv[c - 1].x, rtv[c - 1].y}));
+        }
         // (one block at a time: without this the five unrolled blocks' loads are all hoisted to the front)
         asm volatile("" : "+v"(keep[kb][0]), "+v"(keep[kb][1]), "+v"(keep[kb][2]), "+v"(keep[kb][3]));
     }
@@ -1581,23 +1628,25 @@ int launch_ols_frame(hipStream_t s, const FusedFirArgs &a, const void *pend_in, 
     }
     const unsigned grid = 1u + (unsigned)((nfr + 8 * RR_V_FRAMEWIN - 1) / (8 * RR_V_FRAMEWIN) * (8 * RR_V_FRAMEWIN));
     f.fm = fm ? *fm : FrameMeter{};
-#define RR_FRAME_LAUNCH(MF_, SW_, FU_)                                                                                            \
-    do {                                                                                                                           \
-        if (fm)                                                                                                                    \
-            hipLaunchKernelGGL((k_ols_frame<MF_, SW_, FU_, true>), dim3(grid), dim3(256), 0, s, f);                                \
-        else if (a.ev_start && a.ev_stop)                                                                                          \
-            hipExtLaunchKernelGGL((k_ols_frame<MF_, SW_, FU_, false>), dim3(grid), dim3(256), 0, s, a.ev_start, a.ev_stop, 0, f); \
-        else                                                                                                                       \
-            hipLaunchKernelGGL((k_ols_frame<MF_, SW_, FU_, false>), dim3(grid), dim3(256), 0, s, f);                               \
+#define RR_FRAME_LAUNCH(MF_, SW_, FU_, GP_)                                                                                            \
+    do {                                                                                                                                \
+        if (fm)                                                                                                                         \
+            hipLaunchKernelGGL((k_ols_frame<MF_, SW_, FU_, true, GP_>), dim3(grid), dim3(256), 0, s, f);                                \
+        else if (a.ev_start && a.ev_stop)                                                                                               \
+            hipExtLaunchKernelGGL((k_ols_frame<MF_, SW_, FU_, false, GP_>), dim3(grid), dim3(256), 0, s, a.ev_start, a.ev_stop, 0, f); \
+        else                                                                                                                            \
+            hipLaunchKernelGGL((k_ols_frame<MF_, SW_, FU_, false, GP_>), dim3(grid), dim3(256), 0, s, f);                               \
     } while (0)
     if (f.nb == kFrameBlocks) {
-        if (a.mixfold && a.sigma < 0.f) RR_FRAME_LAUNCH(true, true, true);
-        else if (a.mixfold) RR_FRAME_LAUNCH(true, false, true);
-        else RR_FRAME_LAUNCH(false, false, true);
+        if (a.genfold) RR_FRAME_LAUNCH(true, false, true, true);
+        else if (a.mixfold && a.sigma < 0.f) RR_FRAME_LAUNCH(true, true, true, false);
+        else if (a.mixfold) RR_FRAME_LAUNCH(true, false, true, false);
+        else RR_FRAME_LAUNCH(false, false, true, false);
     } else {
-        if (a.mixfold && a.sigma < 0.f) RR_FRAME_LAUNCH(true, true, false);
-        else if (a.mixfold) RR_FRAME_LAUNCH(true, false, false);
-        else RR_FRAME_LAUNCH(false, false, false);
+        if (a.genfold) RR_FRAME_LAUNCH(true, false, false, true);
+        else if (a.mixfold && a.sigma < 0.f) RR_FRAME_LAUNCH(true, true, false, false);
+        else if (a.mixfold) RR_FRAME_LAUNCH(true, false, false, false);
+        else RR_FRAME_LAUNCH(false, false, false, false);
     }
 #undef RR_FRAME_LAUNCH
     RR_HIP(hipGetLastError());
