@@ -320,8 +320,8 @@ int rr_chain_process_dev(rr_chain *h, double sample_rate, const void *d_in,
 /* Which kernels the last process call ran: 0 = block-by-block; non-zero = fused
  * (1 direct-form k_mix_fir_decim, 2 overlap-save k_ols_decim4, 3 overlap-save
  * k_ols_wave, each followed by k_fft4096; 4 k_ols_frame: both stages in one kernel; 6 / 7 k_ols_frame / k_ols_wave
- * with the mixer folded into the response tables - NCO periods that divide 8; 8 k_ols_frame with the mixer moved
- * behind the filter - every other NCO period). */
+ * with the mixer folded into the response tables - NCO periods that divide 8; 8 / 9 k_ols_frame / k_ols_wave with the
+ * mixer moved behind the filter - every other NCO period). */
 /* as rr_stft_set_metering (the rate of the spectra is the chain's output_rate): bandwidth and energy of every spectrum the
  * chain produces, computed in the kernel that makes it (k_ols_frame / k_fft4096 for 4096-point spectra) */
 int rr_chain_set_metering(rr_chain *h, double double_percentile, double *d_bandwidth,

@@ -35,16 +35,18 @@ int rr_freqshifter::prepare(double sample_rate) {
     // denom entries + entry 0 once more behind them (k_ols_wave reads the pair (r, r + 1) in one piece)
     // + 8 rotations e^{j 2 pi (128 k numer mod denom) / denom}, k < 8: the fused kernel steps a lane's
     // phasor by 128 samples with one product instead of one more table read
-    // + 64 lane constants e^{j 2 pi (4 l numer mod denom) / denom}, l < 64: k_ols_frame<.., GP> makes the phasor of a lane's result
-    // from the block's own (one scalar read) and its constant
-    host_table.resize(((size_t)de + 1 + 8 + 64) * esz);
+    // + 3 x 64 lane constants w^(4 l), w^(1024 - 2 l), w^(8 (l mod 32)), w = e^{j 2 pi numer / denom}, l < 64: the kernels with the
+    // mixer behind the filter (k_ols_frame / k_ols_wave<.., GP>) make the phasor of a lane's result from the block's own (one
+    // scalar read) and the lane's constant - results l + 64 c at 4 : 1, (512 - l - 64 k) mod 512 at 2 : 1, (l mod 32) + 32 c at 8 : 1
+    host_table.resize(((size_t)de + 1 + 8 + 192) * esz);
     if (dtype == RR_F32)
         nco_table<float>(nu, de, (float)start, reinterpret_cast<float *>(host_table.data()));
     else
         nco_table<double>(nu, de, start, reinterpret_cast<double *>(host_table.data()));
     std::memcpy(host_table.data() + (size_t)de * esz, host_table.data(), esz);
-    for (int k = 0; k < 8 + 64; ++k) {
-        const int64_t step = k < 8 ? 128 * k : 4 * (k - 8);
+    for (int k = 0; k < 8 + 192; ++k) {
+        const int l = (k - 8) & 63;
+        const int64_t step = k < 8 ? 128 * k : k < 72 ? 4 * l : k < 136 ? 1024 - 2 * l : 8 * (l & 31);
         const int64_t i = (int64_t)(((__int128)step * (__int128)nu) % (__int128)de);
         const double ang = 2.0 * M_PI * (double)i / (double)de;
         unsigned char *dst = host_table.data() + ((size_t)de + 1 + k) * esz;
@@ -522,6 +524,17 @@ int rr_downsampler::process_dev(double input_rate, const void *d_in, size_t n_in
             return RR_OK;
         }
         if (nco) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: a mixer can only ride along with k_decim_poly (can_fuse_mixer)");
+        if (fast_kind == rr_chain::FK_SELECT) {
+            next.advance(n_in, nullptr);
+            RR_TRY(launch_decim_select(stream, hist[cur].p, L, d_in, n_in, f_H.p, f_tw.p, f_V, d_out, produce, sched.ra, sched.rb,
+                                       (uint64_t)sched.pos));
+            RR_TRY(launch_update_hist(dtype, stream, hist[cur].p, hist[cur ^ 1].p, L, d_in, n_in));
+            sched = next;
+            cur ^= 1;
+            last_kernel = fast_kind;
+            if (n_out) *n_out = produce;
+            return RR_OK;
+        }
         if (fast_kind != rr_chain::FK_NONE && sched.integer_ratio) {
             // the chain's kernels with every phasor = 1: out[m] = sum_i c[i] x[e0 + D m - i], c = reverse(ir);
             // the kernel's last workgroup leaves the last L samples as the next call's history
@@ -575,6 +588,22 @@ int rr_downsampler::process_dev(double input_rate, const void *d_in, size_t n_in
         a.D = (uint32_t)sched.D;
         if (sched.D > 0xffffffffull) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: decimation factor too large");
         next.advance(n_in, nullptr);
+    } else if (sched.periodic && sched.P < (1ull << 31) && sched.Q <= (1u << 22)) {
+        // integer rates: the first Q releases (closed form), repeated every P inputs - no list of the call's length
+        next.advance(n_in, nullptr);
+        if (produce) {
+            std::vector<int64_t> ef(sched.Q);
+            sched.first_emits(sched.Q, ef.data());
+            emit.resize(sched.Q);
+            for (size_t b = 0; b < sched.Q; ++b) emit[b] = (uint32_t)ef[b];
+            RR_TRY(d_emit.reserve(sched.Q * sizeof(uint32_t)));
+            RR_HIP(hipMemcpyAsync(d_emit.p, emit.data(), sched.Q * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            RR_HIP(hipStreamSynchronize(stream));  // `emit` is reused by the next call
+        }
+        a.emit = d_emit.as<uint32_t>();
+        a.period_p = (uint32_t)sched.P;
+        a.period_q = (uint32_t)sched.Q;
+        a.max_step = (uint32_t)std::ceil(input_rate / output_rate) + 1;
     } else {
         next.advance(n_in, &emit);
         if (produce) {
@@ -619,6 +648,10 @@ int rr_downsampler::ensure_fast() {
     // (f64: no fused overlap-save kernels, the polyphase kernel for every periodic ratio it fits)
     int kind = (dtype == RR_F32 && sched.integer_ratio) ? rr_chain::pick_fused_kernel(sched.D, L, true, 0) : rr_chain::FK_NONE;
     if (kind == rr_chain::FK_OLSF) kind = rr_chain::FK_OLSW;
+    // RR_DOWNSAMPLER_SELECT=1: k_filter_wave<true> for every pair of integer rates it takes (A/B runs, tests)
+    const char *se = std::getenv("RR_DOWNSAMPLER_SELECT");
+    const bool force_select = se && std::atoi(se) != 0 && decim_select_supported(dtype, sched.ra, sched.rb, L);
+    if (force_select) kind = rr_chain::FK_NONE;
     {
         // RR_DOWNSAMPLER_POLY=1: k_decim_poly also where a fused kernel applies (A/B runs)
         const char *pe = std::getenv("RR_DOWNSAMPLER_POLY");
@@ -626,9 +659,24 @@ int rr_downsampler::ensure_fast() {
     }
     if (kind == rr_chain::FK_NONE) {
         // every other integer ratio, and rational ratios with a short period (the tap table follows per call)
-        if (decim_poly_supported(dtype, sched.P, sched.Q, L)) {
+        if (decim_poly_supported(dtype, sched.P, sched.Q, L) && !force_select) {
             fast_kind = rr_chain::FK_POLY;
             poly_version = ~0ull;
+        } else if (decim_select_supported(dtype, sched.ra, sched.rb, L)) {
+            // every other pair of integer rates (48 000 -> 44 100: 160 : 147): the response at every position, as the Filter's
+            // k_filter_wave, and the results of the releasing positions stored (k_filter_wave<true>)
+            std::vector<double> c(L);
+            std::vector<cd> cc(L);
+            for (size_t i = 0; i < L; ++i) {
+                c[i] = ir_f64[L - 1 - i];
+                cc[i] = cd(c[i], 0.0);
+            }
+            FusedFirTables t;
+            build_fused_fir_tables(rr_chain::FK_OLSW, 1, c, cc, t);
+            RR_TRY(upload(f_H, t.H.data(), t.H.size() * sizeof(float), stream));
+            RR_TRY(upload(f_tw, t.tw.data(), t.tw.size() * sizeof(float), stream));
+            f_V = t.V;
+            fast_kind = rr_chain::FK_SELECT;
         }
         return RR_OK;
     }

@@ -386,7 +386,7 @@ int rr_chain::ensure_mixfold() {
 int rr_chain::fold_mixer(FusedFirArgs &a, int64_t back, bool frame) {
     const char *env = std::getenv("RR_FRAME_MIXFOLD");  // (read per call: tests switch it within one process)
     const bool off = env && std::atoi(env) == 0;
-    if (!off && fs->denom >= 1 && 8 % fs->denom == 0 && frame_table_version == fs->table_version && olsG64.size() == 1024) {
+    if (!off && a.D == 4 && fs->denom >= 1 && 8 % fs->denom == 0 && frame_table_version == fs->table_version && olsG64.size() == 1024) {
         RR_TRY(ensure_mixfold());
         // the table for the phasor of the blocks' first samples: ph0 = (idx0 + e0 - V - back) mod R
         int64_t ph = ((int64_t)a.idx0 + a.e0 - a.V - back) % (int64_t)fs->denom;
@@ -395,7 +395,7 @@ int rr_chain::fold_mixer(FusedFirArgs &a, int64_t back, bool frame) {
         a.mixfold = true;
         a.sigma = mix_sigma;
     }
-    else if (!off && frame && use_frame && fs->denom > 8 && frame_table_version == fs->table_version && !ctaps_cc.empty()) {
+    else if (!off && (frame ? use_frame : true) && ols_poly && ols_N == 1024 && frame_table_version == fs->table_version && !ctaps_cc.empty()) {
         const char *eg = std::getenv("RR_FRAME_GENFOLD");  // (=0: the mixer in front of the transform, A/B runs and tests)
         if (!(eg && std::atoi(eg) == 0)) {
             RR_TRY(ensure_genfold());
@@ -425,7 +425,8 @@ int rr_chain::ensure_genfold() {
         cc[i] = ctaps_cc[i] * cd(std::cos(ang), std::sin(ang));
     }
     FusedFirTables t;
-    build_fused_fir_tables(FK_OLSF, ds->sched.D, c, cc, t);
+    build_fused_fir_tables(use_frame ? FK_OLSF : FK_OLSW, ds->sched.D, c, cc, t);  // (the same tables at 4 : 1: the frame kernel's blocks are k_ols_wave<4>'s)
+    if (!t.poly) RR_FAIL(RR_ERR_BAD_ARG, "Chain: no polyphase tables for the mixer behind the filter");
     RR_TRY(upload(d_olsHgen, t.H.data(), t.H.size() * sizeof(float), stream));
     gen_numer = nu;
     gen_denom = R;
@@ -471,7 +472,7 @@ int rr_chain::ensure_ctaps() {
     build_fused_fir_tables(fk, ds->sched.D, c, cc, t);
     use_frame = fk == FK_OLSF;
     use_ols = fk != FK_DIRECT;
-    if (use_frame) ctaps_cc = cc; else ctaps_cc.clear();
+    if (fk == FK_OLSF || fk == FK_OLSW) ctaps_cc = cc; else ctaps_cc.clear();
     if (use_ols) {
         RR_TRY(upload(d_olsH, t.H.data(), t.H.size() * sizeof(float), stream));
         RR_TRY(upload(d_tw4096, t.tw.data(), t.tw.size() * sizeof(float), stream));
@@ -617,7 +618,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
         if (dec == 0)  // (no output, no tile: the history by a launch of its own)
             RR_FAIL(RR_ERR_BAD_ARG, "Chain: a fused f64 call must produce output");
     } else if (use_ols && ols_N == 1024) {
-        if (ols_poly && a.D == 4) RR_TRY(fold_mixer(a, 0));
+        if (ols_poly) RR_TRY(fold_mixer(a, 0));
         RR_TRY(launch_ols_wave(stream, a));
     } else if (use_ols)
         RR_TRY(launch_ols_decim(stream, a));
@@ -668,7 +669,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     }
     if (!ext) timers.end(tk, stream);
     pending_len = rest;
-    last_fused = use_poly64 ? FK_POLY : use_ols ? (ols_N == 1024 ? (a.mixfold ? 7 : FK_OLSW) : FK_OLS) : FK_DIRECT;  // (7: k_ols_wave<4, true, true>)
+    last_fused = use_poly64 ? FK_POLY : use_ols ? (ols_N == 1024 ? (a.genfold ? 9 : a.mixfold ? 7 : FK_OLSW) : FK_OLS) : FK_DIRECT;  // (7: k_ols_wave<4, true, true>)
     if (n_out) *n_out = wrote;
     return RR_OK;
 }
@@ -738,7 +739,7 @@ int rr_chain::bank_plan(double sample_rate, size_t n_in, size_t cap, BankStep &s
     a.tw4096 = d_tw4096.p;
     a.V = ols_V;
     a.poly = ols_poly;
-    if (a.D == 4) RR_TRY(fold_mixer(a, 0));
+    RR_TRY(fold_mixer(a, 0));
     *ok = true;
     return RR_OK;
 }
@@ -770,7 +771,7 @@ void rr_chain::bank_commit(const BankStep &st, size_t n_in) {
     dec_cur ^= 1;
     pending_len = st.rest;
     frame_table_version = fs->table_version;
-    last_fused = st.a.mixfold ? 7 : FK_OLSW;
+    last_fused = st.a.genfold ? 9 : st.a.mixfold ? 7 : FK_OLSW;
 }
 
 rr_chainbank::~rr_chainbank() {

@@ -340,7 +340,7 @@ struct rr_chain : rr_block {
     int ols_N = 4096;  // 4096: k_ols_decim4 (workgroup per block), 1024: k_ols_wave (wave per block)
     rr::DevBuf d_olsH, d_tw4096;
     bool fused_candidate(double sample_rate) const;
-    enum { FK_NONE = 0, FK_DIRECT, FK_OLS, FK_OLSW, FK_OLSF, FK_POLY };  // FK_POLY: k_decim_poly (Downsampler only)
+    enum { FK_NONE = 0, FK_DIRECT, FK_OLS, FK_OLSW, FK_OLSF, FK_POLY, FK_SELECT = 10 };  // FK_POLY: k_decim_poly, FK_SELECT: k_filter_wave<true> (Downsampler only)
     static int pick_fused_kernel(uint64_t D, size_t lc, bool real_taps, size_t fft_len);
     bool use_frame = false;      // FK_OLSF: k_ols_frame (FIR stage + Fourier in one kernel)
     // Complex<f64>: mixer + combined FIR + decimation as ONE pass of k_decim_poly_f64 (the polyphase kernel with the phase table

@@ -180,13 +180,20 @@ __global__ __launch_bounds__(256) void k_fir(const v2<T> *__restrict__ hist, lon
                                              const v2<T> *__restrict__ in, long n_in,
                                              const typename TapType<T, CT>::type *__restrict__ taps, int K,
                                              v2<T> *__restrict__ out, size_t n_out, unsigned long long e0, uint32_t D,
-                                             const uint32_t *__restrict__ emit, uint32_t outs_per_block, int Kc) {
+                                             const uint32_t *__restrict__ emit, uint32_t outs_per_block, int Kc,
+                                             uint32_t period_p, uint32_t period_q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     v2<T> *xs = reinterpret_cast<v2<T> *>(smem);
     const size_t m0 = (size_t)blockIdx.x * outs_per_block;
     if (m0 >= n_out) return;
     const size_t m1 = (m0 + outs_per_block < n_out) ? m0 + outs_per_block : n_out;
-    auto e_of = [&](size_t m) -> long { return LIST ? (long)emit[m] : (long)(e0 + m * (unsigned long long)D); };
+    auto e_of = [&](size_t m) -> long {
+        if (LIST && period_q) {  // a periodic schedule: its first period_q positions, repeated every period_p inputs
+            const size_t q = m / period_q;
+            return (long)(q * period_p + emit[m - q * period_q]);
+        }
+        return LIST ? (long)emit[m] : (long)(e0 + m * (unsigned long long)D);
+    };
     const long hi = e_of(m1 - 1);
     // Long responses are taken Kc taps at a time (Kc = K when the whole span fits the LDS tile): per pass the
     // tile holds the samples those taps touch, the partial sums stay in registers.  With more than one pass a
@@ -299,7 +306,8 @@ static int launch_fir_t(hipStream_t s, const FirArgs &a) {
     if (blocks > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fir: too many workgroups");
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), lds, s, (const v2<T> *)a.hist, (long)a.hist_len,
                        (const v2<T> *)a.in, (long)a.n_in, (const typename TapType<T, CT>::type *)a.taps, (int)a.K,
-                       (v2<T> *)a.out, a.n_out, (unsigned long long)a.e0, a.D, a.emit, (uint32_t)opb, (int)Kc);
+                       (v2<T> *)a.out, a.n_out, (unsigned long long)a.e0, a.D, a.emit, (uint32_t)opb, (int)Kc, a.period_p,
+                       a.period_q);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }

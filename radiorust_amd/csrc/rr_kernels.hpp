@@ -32,6 +32,9 @@ struct FirArgs {
     uint32_t D = 1;
     const uint32_t *emit = nullptr;
     uint32_t max_step = 1;  // upper bound of e_{m+1} - e_m (list mode)
+    // period_q != 0: `emit` holds the first period_q positions of a periodic schedule, e_m = (m / period_q) period_p + emit[m mod period_q]
+    // (no list of the call's length, no host loop over its samples)
+    uint32_t period_p = 0, period_q = 0;
 };
 int launch_fir(int dtype, hipStream_t s, const FirArgs &a);
 
@@ -124,6 +127,17 @@ int launch_ols_decim(hipStream_t s, const FusedFirArgs &a);
 // go in the H / tw4096 fields, V = ols_wave_overlap(Lc)
 // k_filter_wave: the Filter alone, one wave per 1024-sample block (n - 1 <= 384, f32); H / tw as for k_ols_wave
 bool filter_wave_supported(int dtype, size_t n);
+// k_filter_wave<true> (the Downsampler for any periodic schedule): the schedule's constants, host side of launch_decim_select
+struct SelectArgs {
+    uint32_t ra = 0, rb = 0;       // input / output rate (integers, rb < ra < 2^31)
+    uint32_t kr = 0, kq = 0;       // 128 rb = kq ra + kr
+    uint32_t hr = 0, hq = 0;       // hop rb = hq ra + hr
+    uint32_t base_r = 0, base_q = 0;  // pos + V (ra - rb) = base_q ra + base_r
+    double inv_ra = 0.0;
+};
+bool decim_select_supported(int dtype, uint64_t ra, uint64_t rb, size_t L);
+int launch_decim_select(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *H, const void *tw,
+                        int V, void *out, size_t n_out, uint64_t ra, uint64_t rb, uint64_t pos);
 int launch_filter_wave(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *H,
                        const void *tw, int V, void *out, size_t n_out, long e0);
 bool ols_wave_supported(uint64_t D, size_t Lc);

@@ -585,7 +585,11 @@ __device__ __forceinline__ float2 ld_uniform(const float2 *p) {
 // response tables (NCO periods that divide 8, rr_chain::ensure_mixfold; SW: the spectrum taken 128 bins further on, D = 4)
 // (the kernel's body as a function of the workgroup index bx: k_ols_wave runs it for one stream, k_ols_wave_bank for the
 //  channels of a bank - the same stream parameters, per-channel pointers, channel = blockIdx.y)
-template <int D, bool POLY, bool MF = false, bool SW = false>
+// GP (with MF, POLY): ANY NCO period with the mixer moved behind the filter - see k_ols_frame<.., GP>: H holds the tables of the
+// response c[i] w^-i, the results are multiplied by the phase table's entries at their positions b0 + D tau: the block's own
+// phasor (a scalar read) x the lane's constant (behind the table: w^(4 l), w^(1024 - 2 l), w^(8 (l mod 32)) for D = 4, 2, 8)
+// x the rotations by 128 samples.  1024 / D products per block instead of 1024.
+template <int D, bool POLY, bool MF = false, bool SW = false, bool GP = false>
 __device__ __forceinline__ void ols_wave_body(
     const float2 *__restrict__ xh, int hx, const float2 *__restrict__ in, long n_in, const float2 *__restrict__ nco,
     unsigned denom, unsigned idx0, const float2 *__restrict__ H, const float2 *__restrict__ tw, int V,
@@ -647,6 +651,13 @@ __device__ __forceinline__ void ols_wave_body(
         const f4u *src = reinterpret_cast<const f4u *>(in + b0) + l;
 #pragma unroll
         for (int k = 0; k < 8; ++k) x[k] = ld_stream(src + 64 * k);
+    }
+    [[maybe_unused]] f2 gph = {1.f, 0.f};  // GP: the phasor of the lane's result c = 0
+    [[maybe_unused]] float2 gpb, gpl;
+    if constexpr (GP) {
+        static_assert(MF && POLY && !SW, "GP: the blocks transform the samples as they are, polyphase tables");
+        gpb = ld_uniform(nco + __builtin_amdgcn_readfirstlane(base));
+        gpl = nco[denom + 9 + (D == 4 ? 0 : D == 2 ? 64 : 128) + l];
     }
     const int g = l >> 4, q = l & 15;
     // seeds: pass 1 tw[8 (l mod 8)]; pass 2 tw[l], tw[l + 64]; inverse (D = 4) tw[64 (l mod 4)], tw[16 (l mod 16)], tw[4 l];
@@ -1000,6 +1011,15 @@ __device__ __forceinline__ void ols_wave_body(
         // Buffer stores: the lanes outside the block's valid part (and behind the end of the output)
         // carry an out-of-range offset and are dropped by the address check - four stores in
         // straight-line code, with the streaming hint.
+        if constexpr (GP) {  // result tau = l + 64 c at b0 + 4 tau
+            gph = cmul((f2){gpb.x, gpb.y}, (f2){gpl.x, gpl.y});
+            y[0] = cmul(y[0], gph);
+#pragma unroll
+            for (int c = 1; c < 4; ++c) {
+                const float2 rt = ld_uniform(nco + (denom + 1 + 2 * c));
+                y[c] = cmul(y[c], cmul(gph, (f2){rt.x, rt.y}));
+            }
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int tau = l + 64 * c;
@@ -1029,6 +1049,15 @@ __device__ __forceinline__ void ols_wave_body(
         twiddle8(y, t_inv[1]);  // pass 2 (Ns = 64): e^{-j 2 pi l k / 512}; out l + 64 k
         dft8(y);
         // y[k] = DFT(Y)[l + 64 k] = result[(512 - l - 64 k) mod 512]
+        if constexpr (GP) {  // result tau at b0 + 2 tau: w^(2 tau) = w^(1024 - 2 l) conj(w^(128 k)), and 1 for tau = 0 (lane 0, k = 0)
+            gph = cmul((f2){gpb.x, gpb.y}, (f2){gpl.x, gpl.y});
+            y[0] = cmul(y[0], l == 0 ? (f2){gpb.x, gpb.y} : gph);
+#pragma unroll
+            for (int k = 1; k < 8; ++k) {
+                const float2 rt = ld_uniform(nco + (denom + 1 + k));
+                y[k] = cmul(y[k], cmul_conj(gph, (f2){rt.x, rt.y}));
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int tau = (512 - l - 64 * k) & 511;
@@ -1069,6 +1098,15 @@ __device__ __forceinline__ void ols_wave_body(
             }
             wave_sync();
         }
+        if constexpr (GP) {  // result tau = j + 32 c at b0 + 8 tau
+            gph = cmul((f2){gpb.x, gpb.y}, (f2){gpl.x, gpl.y});
+            z[0] = cmul(z[0], gph);
+#pragma unroll
+            for (int c = 1; c < 4; ++c) {
+                const float2 rt = ld_uniform(nco + (denom + 1 + 2 * c));
+                z[c] = cmul(z[c], cmul(gph, (f2){rt.x, rt.y}));
+            }
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int tau = j + 32 * c;
@@ -1078,25 +1116,25 @@ __device__ __forceinline__ void ols_wave_body(
     }
 }
 
-template <int D, bool POLY, bool MF = false, bool SW = false>
+template <int D, bool POLY, bool MF = false, bool SW = false, bool GP = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OCC, RR_V_OLSW_OCC))) void k_ols_wave(
     const float2 *__restrict__ xh, int hx, const float2 *__restrict__ in, long n_in, const float2 *__restrict__ nco,
     unsigned denom, unsigned idx0, const float2 *__restrict__ H, const float2 *__restrict__ tw, int V,
     float2 *__restrict__ out, long n_out, long e0, float2 *__restrict__ xh_out, int hx_out, unsigned nblocks,
     unsigned ph0, unsigned hopm, unsigned kstep, double inv_denom) {
-    ols_wave_body<D, POLY, MF, SW>(xh, hx, in, n_in, nco, denom, idx0, H, tw, V, out, n_out, e0, xh_out, hx_out, nblocks, ph0, hopm,
+    ols_wave_body<D, POLY, MF, SW, GP>(xh, hx, in, n_in, nco, denom, idx0, H, tw, V, out, n_out, e0, xh_out, hx_out, nblocks, ph0, hopm,
                                    kstep, inv_denom, blockIdx.x, kWaveWin);
 }
 
 // The channels of a bank (rr_chainbank: K independent streams with the same parameters that advance in lockstep): the same
 // launch parameters for all of them, the streams' own buffers from a table, channel = blockIdx.y.
-template <int D, bool POLY, bool MF = false, bool SW = false>
+template <int D, bool POLY, bool MF = false, bool SW = false, bool GP = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_OLSW_OCC, RR_V_OLSW_OCC))) void k_ols_wave_bank(
     const BankTable chan, int hx, long n_in, const float2 *__restrict__ nco, unsigned denom, unsigned idx0,
     const float2 *__restrict__ H, const float2 *__restrict__ tw, int V, long n_out, long e0, int hx_out, unsigned nblocks,
     unsigned ph0, unsigned hopm, unsigned kstep, double inv_denom, unsigned gwin) {
     const BankPtrs c = chan.c[blockIdx.y];
-    ols_wave_body<D, POLY, MF, SW>((const float2 *)c.xh, hx, (const float2 *)c.in, n_in, nco, denom, idx0, H, tw, V, (float2 *)c.dec,
+    ols_wave_body<D, POLY, MF, SW, GP>((const float2 *)c.xh, hx, (const float2 *)c.in, n_in, nco, denom, idx0, H, tw, V, (float2 *)c.dec,
                                    n_out, e0, (float2 *)c.xh_out, hx_out, nblocks, ph0, hopm, kstep, inv_denom, blockIdx.x, gwin);
 }
 
@@ -1672,27 +1710,29 @@ static int launch_ols_wave_d(hipStream_t s, const FusedFirArgs &a) {
     if (ph < 0) ph += den;
     const unsigned hopm = (unsigned)((int64_t)(1024 - a.V) % den), kstep = (unsigned)(128 % den);
     const unsigned grid = (unsigned)((nblocks + 8 * kWaveWin - 1) / (8 * kWaveWin) * (8 * kWaveWin));
-#define RR_OLSW_LAUNCH(MF_, SW_)                                                                                                     \
+#define RR_OLSW_LAUNCH(MF_, SW_, GP_)                                                                                                 \
     do {                                                                                                                              \
         if (a.ev_start && a.ev_stop)                                                                                                  \
-            hipExtLaunchKernelGGL((k_ols_wave<D, POLY, MF_, SW_>), dim3(grid), dim3(64), 0, s, a.ev_start, a.ev_stop, 0,              \
+            hipExtLaunchKernelGGL((k_ols_wave<D, POLY, MF_, SW_, GP_>), dim3(grid), dim3(64), 0, s, a.ev_start, a.ev_stop, 0,         \
                                   (const float2 *)a.xh, (int)a.hx, (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, \
                                   a.idx0, (const float2 *)a.H, (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out,         \
                                   (long)a.e0, (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, kstep,            \
                                   1.0 / (double)den);                                                                                 \
         else                                                                                                                          \
-            hipLaunchKernelGGL((k_ols_wave<D, POLY, MF_, SW_>), dim3(grid), dim3(64), 0, s, (const float2 *)a.xh, (int)a.hx,          \
+            hipLaunchKernelGGL((k_ols_wave<D, POLY, MF_, SW_, GP_>), dim3(grid), dim3(64), 0, s, (const float2 *)a.xh, (int)a.hx,     \
                                (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0, (const float2 *)a.H,       \
                                (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out, (long)a.e0, (float2 *)a.xh_out,         \
                                (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, kstep, 1.0 / (double)den);                           \
     } while (0)
     // (a.mixfold: the caller's table is all ones - the stand-alone Downsampler - or a.H holds the tables with the mixer folded in)
     if constexpr (POLY) {
-        if (a.mixfold && D == 4 && a.sigma < 0.f) RR_OLSW_LAUNCH(true, true);
-        else if (a.mixfold) RR_OLSW_LAUNCH(true, false);
-        else RR_OLSW_LAUNCH(false, false);
+        if (a.genfold) RR_OLSW_LAUNCH(true, false, true);
+        else if (a.mixfold && D == 4 && a.sigma < 0.f) RR_OLSW_LAUNCH(true, true, false);
+        else if (a.mixfold) RR_OLSW_LAUNCH(true, false, false);
+        else RR_OLSW_LAUNCH(false, false, false);
     } else {
-        RR_OLSW_LAUNCH(false, false);
+        if (a.genfold) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS: the mixer behind the filter wants the polyphase tables");
+        RR_OLSW_LAUNCH(false, false, false);
     }
 #undef RR_OLSW_LAUNCH
     RR_HIP(hipGetLastError());
@@ -1721,13 +1761,14 @@ static int launch_ols_wave_bank_d(hipStream_t s, const FusedFirArgs &a, const Ba
     // window of neighbouring blocks per XCD: the stream kernel's 64 for long calls, 8 / 1 for short ones (the grid is rounded up to 8 windows)
     const unsigned gwin = nblocks >= 4096 ? kWaveWin : (nblocks >= 64 ? 8u : 1u);
     const unsigned grid = (unsigned)((nblocks + 8 * gwin - 1) / (8 * gwin) * (8 * gwin));
-#define RR_OLSWB_LAUNCH(MF_, SW_)                                                                                                  \
-    hipLaunchKernelGGL((k_ols_wave_bank<D, true, MF_, SW_>), dim3(grid, (unsigned)channels), dim3(64), 0, s, d_chan, (int)a.hx,     \
+#define RR_OLSWB_LAUNCH(MF_, SW_, GP_)                                                                                                 \
+    hipLaunchKernelGGL((k_ols_wave_bank<D, true, MF_, SW_, GP_>), dim3(grid, (unsigned)channels), dim3(64), 0, s, d_chan, (int)a.hx,     \
                        (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0, (const float2 *)a.H, (const float2 *)a.tw4096, a.V,    \
                        (long)a.n_out, (long)a.e0, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, kstep, 1.0 / (double)den, gwin)
-    if (a.mixfold && D == 4 && a.sigma < 0.f) RR_OLSWB_LAUNCH(true, true);
-    else if (a.mixfold) RR_OLSWB_LAUNCH(true, false);
-    else RR_OLSWB_LAUNCH(false, false);
+    if (a.genfold) RR_OLSWB_LAUNCH(true, false, true);
+    else if (a.mixfold && D == 4 && a.sigma < 0.f) RR_OLSWB_LAUNCH(true, true, false);
+    else if (a.mixfold) RR_OLSWB_LAUNCH(true, false, false);
+    else RR_OLSWB_LAUNCH(false, false, false);
 #undef RR_OLSWB_LAUNCH
     RR_HIP(hipGetLastError());
     return RR_OK;
@@ -1753,10 +1794,18 @@ int launch_ols_wave_bank(hipStream_t s, const FusedFirArgs &a, const BankTable &
 // (radix 8 x 16 x 8 on sample pairs); the inverse is the same routine on conj(Y) - Y leaves the forward
 // transform as Y[l + 64 k] and goes through LDS once more to come back in the pair layout.  All
 // exchanges are wave-local (no workgroup barrier); 16 waves per CU.
+//
+// SEL: the Downsampler for ANY periodic schedule (integer rates ra > rb, resampling.rs:103-112: input t releases an output when
+// pos + (t + 1) rb crosses a multiple of ra) - the response is applied at every input position as above and only the results at
+// the releasing positions are stored, out[m] for the m-th release.  Which of a lane's 16 positions release, and which m they
+// carry, follows from F(t) = pos + t rb (mod ra, and its quotient) by whole-number steps: per block and per lane one reduction
+// in f64 (exact below 2^53), then additions with a wrap - no table, no period length in the kernel.  HBM sees 8 B in and
+// 8 rb / ra B out per sample; the arithmetic is the Filter's, whatever the ratio (48 000 -> 44 100: P : Q = 160 : 147).
+template <bool SEL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_FLTWOCC, RR_V_FLTWOCC))) void k_filter_wave(
     const float2 *__restrict__ hist, int hist_len, const float2 *__restrict__ in, long n_in,
     const float2 *__restrict__ H, const float2 *__restrict__ tw, int V, float2 *__restrict__ out, long n_out, long e0,
-    unsigned nblocks) {
+    unsigned nblocks, const SelectArgs sel) {
     __shared__ __attribute__((aligned(16))) f2 lds[kWaveLds];
     const int l = threadIdx.x;
     // workgroups b, b + 8, .. share an XCD: neighbouring blocks (which share V samples) on one XCD
@@ -1816,6 +1865,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_FLTWOCC
     }
     wave_sync();  // the forward image has been read
     wave_dft1024_t(X, v, lds, l, t_p1, t_p2);
+    if constexpr (SEL) {
+        // F(t) = base0 + blk hop rb + t rb for the block's element t (position e0 - V + blk hop + t), base0 = pos + V (ra - rb) >= 0:
+        // the V positions in front of the block's first result count as V releases more (C below), which keeps F non-negative.
+        // Element t releases iff (F mod ra) + rb >= ra, and then carries m = floor(F / ra) - V.
+        const double dra = (double)sel.ra;
+        auto reduce = [&](double x, unsigned &r) -> unsigned {  // x = q ra + r, exact
+            double q = __builtin_floor(x * sel.inv_ra);
+            double rr = __builtin_fma(-q, dra, x);
+            if (rr < 0.0) { rr += dra; q -= 1.0; }
+            if (rr >= dra) { rr -= dra; q += 1.0; }
+            r = (unsigned)rr;
+            return (unsigned)q;
+        };
+        unsigned Rb, R;
+        const unsigned qb = reduce((double)sel.base_r + (double)blk * (double)sel.hr, Rb);
+        const long mbase = (long)sel.base_q + (long)blk * (long)sel.hq + (long)qb - V;  // m of a release at the block's F = Rb
+        unsigned C = reduce((double)Rb + (double)(2 * l) * (double)sel.rb, R);         // releases since the block's F = Rb
+        const long left = n_out - mbase;  // (> 0: a block holds a position of the call, its release lies within n_out or behind it)
+        const unsigned recs = (unsigned)(left < 2048 ? left : 2048) * 8u;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + mbase, 0, recs, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int t = 2 * l + 128 * k;
+            const f2 y0 = {v[2 * k].x, -v[2 * k].y}, y1 = {v[2 * k + 1].x, -v[2 * k + 1].y};
+            const unsigned a0 = R + sel.rb;  // (< 2^32: ra < 2^31)
+            const bool em0 = a0 >= sel.ra;
+            const unsigned R1 = em0 ? a0 - sel.ra : a0, C1 = C + (em0 ? 1u : 0u);
+            const bool em1 = R1 + sel.rb >= sel.ra;
+            const unsigned off0 = (t >= V && em0) ? C * 8u : 0xffffffffu, off1 = (t >= V && em1) ? C1 * 8u : 0xffffffffu;
+            __builtin_amdgcn_raw_buffer_store_b64(y0, rs, off0, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(y1, rs, off1, 0, 0);
+            const unsigned a2 = R + sel.kr;  // 128 positions on
+            const bool w2 = a2 >= sel.ra;
+            R = w2 ? a2 - sel.ra : a2;
+            C += sel.kq + (w2 ? 1u : 0u);
+        }
+        return;
+    }
     const long mb = (long)blk * hop;
     const long left = n_out - mb;
     const unsigned recs = (unsigned)(left < hop ? left : hop) * 8u;
@@ -1843,9 +1930,43 @@ int launch_filter_wave(hipStream_t s, const void *hist, size_t hist_len, const v
     const size_t nblocks = (n_out + hop - 1) / hop;
     if (nblocks > 0x7ffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "Filter: too many blocks");
     const size_t grid = (nblocks + 8 * RR_V_FLTWWIN - 1) / (8 * RR_V_FLTWWIN) * (8 * RR_V_FLTWWIN);
-    hipLaunchKernelGGL(k_filter_wave, dim3((unsigned)grid), dim3(64), 0, s, (const float2 *)hist, (int)hist_len,
+    hipLaunchKernelGGL(k_filter_wave<false>, dim3((unsigned)grid), dim3(64), 0, s, (const float2 *)hist, (int)hist_len,
                        (const float2 *)in, (long)n_in, (const float2 *)H, (const float2 *)tw, V, (float2 *)out, (long)n_out,
-                       e0, (unsigned)nblocks);
+                       e0, (unsigned)nblocks, SelectArgs{});
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+bool decim_select_supported(int dtype, uint64_t ra, uint64_t rb, size_t L) {
+    return filter_wave_supported(dtype, L) && rb >= 1 && rb < ra && ra < (1ull << 31);
+}
+
+// The Downsampler through k_filter_wave<true>: out[m] = sum_i c[i] x[e_m - i] for the releases e_m of the periodic schedule
+// (ra, rb, pos) among the n_in positions of the call; H = the tables of c = reverse(ir) as the Filter's.
+int launch_decim_select(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *H, const void *tw,
+                        int V, void *out, size_t n_out, uint64_t ra, uint64_t rb, uint64_t pos) {
+    if (n_out == 0 || n_in == 0) return RR_OK;
+    if (!(rb >= 1 && rb < ra && ra < (1ull << 31) && pos < ra) || V < 2 || V > 384 || (V & 1))
+        RR_FAIL(RR_ERR_BAD_ARG, "Downsampler (select): rates %llu : %llu, pos %llu, overlap %d", (unsigned long long)ra,
+                (unsigned long long)rb, (unsigned long long)pos, V);
+    const size_t hop = 1024 - V;
+    const size_t nblocks = (n_in + hop - 1) / hop;  // the response at every position of the call
+    if (nblocks > 0x3fffffull) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler (select): too many blocks");  // (blk hr stays below 2^53)
+    SelectArgs a;
+    a.ra = (uint32_t)ra;
+    a.rb = (uint32_t)rb;
+    a.inv_ra = 1.0 / (double)ra;
+    a.kr = (uint32_t)((128 * rb) % ra);
+    a.kq = (uint32_t)((128 * rb) / ra);
+    a.hr = (uint32_t)((hop * rb) % ra);
+    a.hq = (uint32_t)((hop * rb) / ra);
+    const uint64_t base0 = pos + (uint64_t)V * (ra - rb);
+    a.base_r = (uint32_t)(base0 % ra);
+    a.base_q = (uint32_t)(base0 / ra);
+    const size_t grid = (nblocks + 8 * RR_V_FLTWWIN - 1) / (8 * RR_V_FLTWWIN) * (8 * RR_V_FLTWWIN);
+    hipLaunchKernelGGL(k_filter_wave<true>, dim3((unsigned)grid), dim3(64), 0, s, (const float2 *)hist, (int)hist_len,
+                       (const float2 *)in, (long)n_in, (const float2 *)H, (const float2 *)tw, V, (float2 *)out, (long)n_out,
+                       0l, (unsigned)nblocks, a);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }

@@ -458,7 +458,12 @@ FAST_CASES = [
     (2560000.0, 40000.0, 30000.0, 1.5, 5),    # 64 : 1, L = 768: tiles of 64 periods
     (45000.0, 40000.0, 30000.0, 1.0, 5),      # 9 : 8, the longest period served
     (512000.0, 1000.0, 700.0, 2.0, 0),        # 512 : 1, L = 6827: beyond k_decim_poly's LDS -> k_fir, 8 outputs per workgroup, the taps in passes
-    (48000.0, 44100.0, 30000.0, 2.0, 0),      # 160 : 147: period too long -> k_fir with the emission list
+    # every other pair of integer rates: the response at every position, the releasing ones stored - k_filter_wave<true> (10)
+    (48000.0, 44100.0, 30000.0, 2.0, 10),     # 160 : 147, L = 14
+    (48000.0, 44100.0, 40000.0, 3.0, 10),     # 160 : 147, L = 71
+    (1024000.0, 44100.0, 20000.0, 3.0, 10),   # 10240 : 441, L = 255
+    (220500.0, 48000.0, 40000.0, 2.0, 10),    # 147 : 32, L = 111
+    (1024000.0, 44100.0, 30000.0, 3.0, 0),    # L = 436: beyond k_filter_wave's overlap -> k_fir with the emission list
 ]
 
 
@@ -505,6 +510,28 @@ def test_downsampler_f64_polyphase_kernel(rr, oracle, fin, fout, bw, q):
         if len(y) > 8:
             assert rms_rel(y, r) <= 1e-12
     assert kernels == [5, 0, 5, 0, 5], kernels
+
+
+@pytest.mark.parametrize("fin,fout,bw,q", [(200e6, 50e6, 40e6, 3.0), (1024000.0, 384000.0, 200000.0, 3.0), (48000.0, 32000.0, 20000.0, 2.0),
+                                          (1024000.0, 102400.0, 60000.0, 3.0), (45000.0, 44999.0, 30000.0, 1.0), (2.0e9, 1.9e9, 1.0e9, 2.0)])
+def test_downsampler_select_kernel_on_request(rr, oracle, monkeypatch, fin, fout, bw, q):
+    """RR_DOWNSAMPLER_SELECT=1: k_filter_wave<true> for every pair of integer rates it takes - the ratios the other kernels
+    serve by default, a period of 45 000 inputs (almost every position releases) and rates close to the kernel's 2^31 limit;
+    ragged calls, a short one on k_fir in between."""
+    monkeypatch.setenv("RR_DOWNSAMPLER_SELECT", "1")
+    n = 200000
+    x = oracle.synth_iq(12, 0, n)
+    cuts = [0, 4096, 4100, 9099, 60000, 60001, 140001, n]
+    g = rr.Downsampler.with_quality(1000, fout, bw, q)
+    o64 = oracle.Downsampler(1000, fout, bw, q, flt=np.float64)
+    kernels = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        y, r = g.process_raw(fin, x[a:b]), o64.process(fin, x[a:b])
+        kernels.append(g.last_kernel())
+        assert len(y) == len(r)
+        if len(y) > 50:
+            check(y, r)
+    assert kernels == [10, 0, 10, 10, 0, 10, 10], (kernels, g.ir_len())
 
 
 def test_downsampler_fast_path_can_be_switched_off(rr, oracle, monkeypatch):

@@ -571,8 +571,8 @@ def test_chain_frame_kernel_with_the_mixer_folded_into_its_tables(rr, oracle, mo
     """NCO periods that divide 8 (shifts by multiples of fs / 8): k_ols_frame<true> (and k_ols_wave<4, true, true>, which the
     chain runs on calls below 2^23 samples) transforms the samples unmixed, the mixer
     sits in the response tables (rr_chain::ensure_mixfold) and in one product per result.  The frame kernel forced onto short
-    ragged calls, retunes between shifts with periods 8, 8, 4, 2, 1 and 16 (the last: k_ols_frame<.., GP>, the mixer behind the
-    filter; k_ols_wave keeps it in front), an
+    ragged calls, retunes between shifts with periods 8, 8, 4, 2, 1 and 16 (the last: the GP instances, the mixer behind the
+    filter), an
     interrupt; every call against the same stream with the fold switched off, and the whole against the C oracle section by
     section (a retune keeps the phase continuous: transform.rs:322-325)."""
     import torch
@@ -612,7 +612,7 @@ def test_chain_frame_kernel_with_the_mixer_folded_into_its_tables(rr, oracle, mo
     got = run(True)
     # folded: every frame call under a period that divides 8, except the first one after a retune (the history in front of it
     # was written under the old table) and the calls that restart block by block (the first of the stream, after the interrupt)
-    assert sum(folded) >= 5 and not folded[0] and not folded[12] and folded[13] == (kernel == "olsf"), folded
+    assert sum(folded) >= 5 and not folded[0] and not folded[12] and folded[13], folded
     folded = []
     ref = run(False)
     assert not any(folded)
@@ -636,9 +636,11 @@ def test_chain_frame_kernel_with_the_mixer_folded_into_its_tables(rr, oracle, mo
         assert rms_rel(a, b) <= 1e-5
 
 
-def test_chain_frame_kernel_with_the_mixer_behind_the_filter(rr, oracle, monkeypatch):
-    """Every NCO period that does not divide 8: k_ols_frame<.., GP> transforms the samples as they are with the tables of the
-    response c[i] w^-i (rr_chain::ensure_genfold) and multiplies its results by the phase table's entries at their positions.
+@pytest.mark.parametrize("kernel,out_rate,bw", [("olsf", 50e6, 40e6), ("olsw", 50e6, 40e6), ("olsw", 25e6, 20e6), ("olsw", 100e6, 80e6)])
+def test_chain_frame_kernel_with_the_mixer_behind_the_filter(rr, oracle, monkeypatch, kernel, out_rate, bw):
+    """Every NCO period that does not divide 8 (and every period at 2 : 1 and 8 : 1): k_ols_frame<.., GP> and
+    k_ols_wave<D, .., GP> transform the samples as they are with the tables of the
+    response c[i] w^-i (rr_chain::ensure_genfold) and multiply their results by the phase table's entries at their positions.
     Periods 40000 (the bench's general_nco leg: 12.345 MHz at precision 1e3), 16, 200 (below the 256 results of a block: the
     index reduction by %), 2000 and 40000 again with another numerator; ragged calls, retunes, an interrupt; every call against
     the same stream with the mixer in front of the transform (RR_FRAME_GENFOLD=0), the first section against the C oracle."""
@@ -653,8 +655,9 @@ def test_chain_frame_kernel_with_the_mixer_behind_the_filter(rr, oracle, monkeyp
     d_in = torch.empty(n, dtype=torch.complex64, device="cuda")
     rr.synth_iq_dev(0, st, 11, 0, n, d_in.data_ptr())
     torch.cuda.synchronize()
-    monkeypatch.setenv("RR_FUSED_KERNEL", "olsf")
-    params = dict(CFG2, shift=shifts[0], precision=1e3)
+    monkeypatch.setenv("RR_FUSED_KERNEL", kernel)
+    params = dict(CFG2, shift=shifts[0], precision=1e3, output_rate=out_rate, bandwidth=bw)
+    D = int(fs / out_rate)
 
     def run(fold):
         monkeypatch.setenv("RR_FRAME_GENFOLD", "1" if fold else "0")
@@ -666,14 +669,14 @@ def test_chain_frame_kernel_with_the_mixer_behind_the_filter(rr, oracle, monkeyp
                 g.set_shift(shifts[(i // 3) % len(shifts)])
             if i == 10:
                 g.interrupt()
-            cap = (m // 4 // 4096 + 2) * 4096
+            cap = (m // D // 4096 + 2) * 4096
             d_out = torch.empty(cap, dtype=torch.complex64, device="cuda")
             torch.cuda.synchronize()
             w = g.process_dev(fs, d_in.data_ptr() + 8 * off, m, d_out.data_ptr(), cap)
             torch.cuda.synchronize()
             outs.append(d_out[:w].clone())
             folded.append(g.last_path_mixer_folded())
-            assert g.last_path_kernel() in ("", "k_ols_frame")
+            assert g.last_path_kernel() in ("", "k_ols_frame" if kernel == "olsf" else "k_ols_wave")
             off += m
         return outs
 
@@ -693,13 +696,13 @@ def test_chain_frame_kernel_with_the_mixer_behind_the_filter(rr, oracle, monkeyp
             fa, fb = a.view(-1, 4096), b.view(-1, 4096)
             err = (torch.linalg.vector_norm(fa - fb, dim=1) / torch.linalg.vector_norm(fb, dim=1)).max().item()
             assert err <= 3e-6, err
-    assert total >= 60 * 4096
-    K = 5
-    x = d_in[: (K + 2) * 16384].cpu().numpy()
-    want = oracle.run_chain_c(x, fs, shift=shifts[0], precision=1e3, filter_len=64, freq_resp=lowpass(20e6), output_rate=50e6,
-                              bandwidth=40e6, fft_len=4096, fft_window=oracle.Kaiser.with_null_at_bin(2.0), flt=np.float64,
+    assert total >= 240 // D * 4096
+    K = 20 // D
+    x = d_in[: (K + 2) * 4096 * D].cpu().numpy()
+    want = oracle.run_chain_c(x, fs, shift=shifts[0], precision=1e3, filter_len=64, freq_resp=lowpass(20e6), output_rate=out_rate,
+                              bandwidth=bw, fft_len=4096, fft_window=oracle.Kaiser.with_null_at_bin(2.0), flt=np.float64,
                               threads=4, max_frames=K + 1)[0][:K]
-    y = torch.cat(got[:2])[: K * 4096].cpu().numpy().reshape(K, 4096)
+    y = torch.cat(got[:3])[: K * 4096].cpu().numpy().reshape(K, 4096)
     for a, b in zip(y, want):
         assert rms_rel(a, b) <= 1e-5
 
