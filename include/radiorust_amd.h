@@ -215,8 +215,10 @@ int rr_filter_process_dev_f16(rr_filter *h, double sample_rate, const void *d_in
                               int response_f16);
 /* Which kernel the last process call ran: 0 k_fir (direct form, any n, any dtype), 1 k_filter_ols
  * (2n-point overlap-save, the reference's recipe), 2 k_filter_blk4096 (4096-point blocks),
- * 3 k_filter_wave (a wave per 1024-sample block; f32, n <= 385, calls of >= 16384 outputs).
- * RR_FILTER_KERNEL=ols4096|fir in the environment (read at design time) keeps the older kernels. */
+ * 3 k_filter_wave (a wave per 1024-sample block; f32, n <= 385, calls of >= 16384 outputs),
+ * 4 the blocks of 2^14 .. 2^18 points through the tile transform (n >= 16384), 5 k_filter_blk16k
+ * (16384-point blocks in LDS; f32, n = 2049 .. 8192).
+ * RR_FILTER_KERNEL=ols4096|fir|parts in the environment (read at design time) keeps the older kernels. */
 int rr_filter_last_kernel(const rr_filter *h, int *kernel);
 int rr_filter_destroy(rr_filter *h);
 

@@ -187,6 +187,41 @@ int rr_filter::build_tables(bool reset_history) {
             RR_TRY(upload(d_G4096h, gh.data(), gh.size() * sizeof(uint16_t), stream));
         }
     }
+    // 2049 .. 8192 taps: blocks of 8192 / 16 384 points in LDS, one forward and one inverse transform per block
+    // (RR_FILTER_KERNEL=parts keeps the partitions of 2048 taps: A/B runs, tests; RR_FILTER_BLOCK=8192|16384 picks the block)
+    use_ols16k = false;
+    {
+        const char *e = std::getenv("RR_FILTER_KERNEL");
+        const char *be = std::getenv("RR_FILTER_BLOCK");
+        const size_t forced = be ? (size_t)std::atol(be) : 0;
+        const bool want = npart || (forced && len > 1024);
+        if (want && filter_blkbig_supported(dtype, len) && !(e && (!std::strcmp(e, "parts") || !std::strcmp(e, "fir") || !std::strcmp(e, "ols4096")))) {
+            const size_t V = (len + 63) / 64 * 64;
+            // measured (profiles/r03_extras.txt, ms per 2^26 samples): 3072 taps 0.376 with blocks of 8192 (two workgroups per CU)
+            // against ~0.43 with 16 384; 4096 taps 0.469 against 0.450
+            size_t N = V <= 3072 ? 8192 : 16384;
+            if ((forced == 8192 || forced == 16384) && V <= forced / 2) N = forced;
+            std::vector<cd> gg(N, cd(0, 0));
+            for (size_t i = 0; i < len; ++i) gg[i] = g[i];
+            fft_f64(gg, false);
+            std::vector<float> gb(2 * N), twb(2 * N);
+            const size_t T = N / 16;
+            for (size_t i = 0; i < N; ++i) {
+                // pair-interleaved for 16-byte reads: Gp[kp][j] = {G[j + 2 T kp], G[j + 2 T kp + T]}, j < T
+                const size_t kp = i / (2 * T), r = i % (2 * T), dst = (kp * T + r % T) * 2 + r / T;
+                gb[2 * dst] = (float)(gg[i].real() / (double)N);
+                gb[2 * dst + 1] = (float)(gg[i].imag() / (double)N);
+                const double ang = -2.0 * M_PI * (double)i / (double)N;
+                twb[2 * i] = (float)std::cos(ang);
+                twb[2 * i + 1] = (float)std::sin(ang);
+            }
+            RR_TRY(upload(d_G16k, gb.data(), gb.size() * sizeof(float), stream));
+            RR_TRY(upload(d_tw16k, twb.data(), twb.size() * sizeof(float), stream));
+            V16k = V;
+            N16k = N;
+            use_ols16k = true;
+        }
+    }
     // long responses: overlap-save with blocks of 2^14 .. 2^18 points through the two-pass tile transform (RR_FILTER_CONV=0: the
     // partitions of 2048 taps / k_filter_ols / k_fir as before)
     use_conv = false;
@@ -237,7 +272,7 @@ int rr_filter::build_tables(bool reset_history) {
             }
         }
     }
-    if (use_conv) use_ols4096 = big_ols4096 = false, npart = 0;
+    if (use_conv) use_ols4096 = big_ols4096 = use_ols16k = false, npart = 0;
     {
         const char *e = std::getenv("RR_FILTER_KERNEL");  // "ols4096" / "fir" keep the older kernels (A/B runs, tests)
         use_wave = filter_wave_supported(dtype, len) && !(e && (!std::strcmp(e, "ols4096") || !std::strcmp(e, "fir")));
@@ -372,6 +407,14 @@ int rr_filter::process_dev(double sample_rate, const void *d_in, size_t n_in, vo
         RR_TRY(launch_filter_wave(stream, hist[cur].p, hist_valid ? n : 0, d_in, n_in, d_Hw.p, d_tww.p, wave_V, d_out, produce,
                                   hist_valid ? 0 : (long)n));
         last_kernel = 3;
+    } else if (produce && use_ols16k && !out_f16 && !g_f16) {
+        last_kernel = 5;
+        RR_TRY(launch_filter_blkbig(stream, N16k, hist[cur].p, hist_valid ? n : 0, d_in, n_in, d_G16k.p, d_tw16k.p, V16k, d_out, produce,
+                                    hist_valid ? 0 : (long)n, hist[cur ^ 1].p, n));
+        cur ^= 1;
+        hist_valid = true;
+        if (n_out) *n_out = produce;
+        return RR_OK;
     } else if (produce && npart) {
         last_kernel = 2;
         // out[m] = sum_p sum_{k < 2048} g[2048 p + k] x[e0 + m - 2048 p - k]: partition p is the 2048-tap kernel run on
@@ -527,7 +570,7 @@ int rr_downsampler::process_dev(double input_rate, const void *d_in, size_t n_in
         if (fast_kind == rr_chain::FK_SELECT) {
             next.advance(n_in, nullptr);
             RR_TRY(launch_decim_select(stream, hist[cur].p, L, d_in, n_in, f_H.p, f_tw.p, f_V, d_out, produce, sched.ra, sched.rb,
-                                       (uint64_t)sched.pos));
+                                       sched.pos_units()));
             RR_TRY(launch_update_hist(dtype, stream, hist[cur].p, hist[cur ^ 1].p, L, d_in, n_in));
             sched = next;
             cur ^= 1;

@@ -50,10 +50,13 @@ struct rr_filter : rr_block {
     bool use_ols4096 = false;      // f32, n = 129 .. 2048: 4096-point blocks, radix-16 kernel
     size_t npart = 0;              // f32, n > 2048: that kernel once per partition of 2048 taps, accumulating
     bool big_ols4096 = false;      // f32, n in {64, 128}: the same for calls of >= 16384 outputs
+    bool use_ols16k = false;       // f32, n = 2049 .. 8192: k_filter_blkbig<N> (blocks of 8192 / 16 384 points in LDS)
+    rr::DevBuf d_G16k, d_tw16k;
+    size_t V16k = 0, N16k = 0;
     bool use_wave = false;         // f32, n <= 385: k_filter_wave (a wave per 1024-block) for calls of >= 16384 outputs
     rr::DevBuf d_Hw, d_tww;        // its tables (DFT_1024(g) / 1024 pair-interleaved; twiddles + lane seeds)
     int wave_V = 0;
-    int last_kernel = 0;           // 0 k_fir, 1 k_filter_ols (2n-point), 2 k_filter_blk4096, 3 k_filter_wave
+    int last_kernel = 0;           // 0 k_fir, 1 k_filter_ols (2n-point), 2 k_filter_blk4096, 3 k_filter_wave, 4 tile-transform blocks, 5 k_filter_blk16k
     rr::DevBuf d_G4096, d_tw4096;
     rr::DevBuf d_G4096h;           // the same table rounded to IEEE half (rr_filter_process_dev_f16's option)
     rr::DevBuf hist[2];            // previous_chunk (n samples), ping-pong

@@ -278,8 +278,17 @@ void Schedule::configure(double in_rate, double out_rate) {
     phase = 0;
     periodic = false;
     ra = rb = P = Q = 0;
-    if (is_integral(in_rate) && is_integral(out_rate) && out_rate >= 1.0 && in_rate >= out_rate) {
-        const uint64_t a = static_cast<uint64_t>(in_rate), b = static_cast<uint64_t>(out_rate);
+    scale = 1.0;
+    // the smallest s with both rates whole multiples of 2^-s; every sum and difference of resampling.rs:110-112 is then a multiple of
+    // 2^-s below in + out, exact in f64 while (in + out) 2^s <= 2^53
+    int sh = 0;
+    while (sh <= 40 && std::isfinite(in_rate) && std::isfinite(out_rate) && out_rate > 0.0 &&
+           !(is_integral(std::ldexp(in_rate, sh)) && is_integral(std::ldexp(out_rate, sh))))
+        ++sh;
+    const double in_s = std::ldexp(in_rate, sh), out_s = std::ldexp(out_rate, sh);
+    if (sh <= 40 && is_integral(in_s) && is_integral(out_s) && out_s >= 1.0 && in_s >= out_s && in_s + out_s <= 9007199254740992.0) {
+        scale = std::ldexp(1.0, sh);
+        const uint64_t a = static_cast<uint64_t>(in_s), b = static_cast<uint64_t>(out_s);
         uint64_t x = a, y = b;
         while (y) {
             const uint64_t t = x % y;
@@ -300,8 +309,8 @@ void Schedule::configure(double in_rate, double out_rate) {
 }
 
 // periodic schedules: pos is an integer in [0, ra); after n inputs pos + n rb has crossed ra that many times
-static inline unsigned __int128 sched_total(double pos, uint64_t rb, size_t n) {
-    return (unsigned __int128)static_cast<uint64_t>(pos) + (unsigned __int128)rb * n;
+static inline unsigned __int128 sched_total(uint64_t pos_units, uint64_t rb, size_t n) {
+    return (unsigned __int128)pos_units + (unsigned __int128)rb * n;
 }
 
 void Schedule::first_emits(size_t count, int64_t *e) const {
@@ -310,7 +319,7 @@ void Schedule::first_emits(size_t count, int64_t *e) const {
         return;
     }
     // output m is released by the first input t (0-based) with pos + (t + 1) rb >= (m + 1) ra
-    const uint64_t p0 = static_cast<uint64_t>(pos);
+    const uint64_t p0 = pos_units();
     for (size_t m = 0; m < count; ++m) {
         const unsigned __int128 need = (unsigned __int128)(m + 1) * ra - p0;
         e[m] = (int64_t)((need + rb - 1) / rb) - 1;
@@ -319,7 +328,7 @@ void Schedule::first_emits(size_t count, int64_t *e) const {
 
 size_t Schedule::count(size_t n_in) const {
     if (integer_ratio) return n_in > phase ? (n_in - 1 - phase) / D + 1 : 0;
-    if (periodic) return (size_t)(sched_total(pos, rb, n_in) / ra);
+    if (periodic) return (size_t)(sched_total(pos_units(), rb, n_in) / ra);
     double p = pos;
     size_t c = 0;
     for (size_t t = 0; t < n_in; ++t) {
@@ -346,8 +355,8 @@ size_t Schedule::advance(size_t n_in, std::vector<uint32_t> *emit) {
         return c;
     }
     if (periodic && !emit) {
-        const unsigned __int128 tot = sched_total(pos, rb, n_in);
-        pos = static_cast<double>((uint64_t)(tot % ra));
+        const unsigned __int128 tot = sched_total(pos_units(), rb, n_in);
+        pos = static_cast<double>((uint64_t)(tot % ra)) / scale;
         return (size_t)(tot / ra);
     }
     if (emit) emit->clear();

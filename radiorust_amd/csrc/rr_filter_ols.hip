@@ -305,6 +305,181 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PARTS ? 3 :
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// k_filter_blk16k: the same fast convolution with blocks of 16 384 points for responses of 2049 .. 8192 taps: ONE forward and
+// one inverse transform per block, 16 384 - V results valid (n = 4096: 75 %) - the partitions of 2048 taps above run n / 2048 + 1
+// transforms of 4096 points for 2049 results (n = 4096: 6 transformed samples per result against 2.7 here).
+// A workgroup of 1024 lanes per block, 16 values per lane, Stockham radix 16 x 16 x 16 x 4 through ONE image in LDS (128 KiB +
+// the padding of the first exchange: one workgroup per CU, 4 waves per SIMD).  Butterfly i of a pass of radix R behind Ns
+// points reads in[i + k N / R], multiplies by W_(Ns R)^((i mod Ns) k) and writes (i div Ns) Ns R + (i mod Ns) + k Ns:
+//   pass 0  R = 16, Ns = 1     lane j = butterfly j            out 16 j + k             (image padded 17 per 16)
+//   pass 1  R = 16, Ns = 16    twiddles W_256^((j mod 16) k)   out (j div 16) 256 + (j mod 16) + 16 k
+//   pass 2  R = 16, Ns = 256   W_4096^((j mod 256) k)          out (j div 256) 4096 + (j mod 256) + 256 k
+//   pass 3  R = 4,  Ns = 4096  butterflies i = j + 1024 c, c < 4: the lane's values v[c + 4 k], W_16384^((j + 1024 c) k); X[i + 4096 k]
+//                              comes out in v[c + 4 k]: v[kk] = X[j + 1024 kk], natural order
+// The inverse is the forward routine with the result index reversed, as above.
+// ---------------------------------------------------------------------------
+struct BlkBigArgs {
+    const float2 *hist;
+    int hist_len;
+    const float2 *in;
+    long n_in;
+    const void *G;       // pair-interleaved: Gp[kp][j] = {G[j + 2 T kp], G[j + 2 T kp + T]}, j < T = N / 16
+    const float2 *tw;    // e^{-j 2 pi k / N}
+    int V;
+    float2 *out;
+    long n_out;
+    long e0;
+    unsigned nblocks;
+    unsigned blk_lo, blk_hi;  // the blocks that lie entirely inside the input
+    float2 *hist_out;
+    int hist_out_len;
+};
+
+// N = 16384: 1024 lanes, last pass radix 4, one workgroup per CU (136 KiB of LDS); N = 8192: 512 lanes, last pass radix 2 (its
+// butterflies i = j + 512 c, c < 8, over v[c + 8 k]), two workgroups per CU
+template <int N>
+__global__ __launch_bounds__(N / 16) void k_filter_blkbig(BlkBigArgs a) {
+    constexpr int T = N / 16, R3 = N / 4096, NB = 16 / R3;  // lanes; radix of the last pass; its butterflies per lane
+    static_assert(N == 8192 || N == 16384, "blocks of 8192 or 16384 points");
+    extern __shared__ __attribute__((aligned(16))) f2 dynbig[];
+    f2 *const img = dynbig;
+    f2 *const tab = dynbig + (N + N / 16);  // pad16(N - 1) = N + N / 16 - 2
+    const int j = threadIdx.x;
+    const int hop = N - a.V;
+    // neighbouring blocks (which share V samples) on one XCD, in a window of 8 x 4 blocks
+    constexpr unsigned W = 4;
+    const unsigned grp = blockIdx.x / (8 * W), rem = blockIdx.x % (8 * W);
+    const unsigned blk = grp * 8 * W + (rem & 7) * W + (rem >> 3);
+    if (blk >= a.nblocks) return;
+    const long b0 = a.e0 - a.V + (long)blk * hop;
+
+    f2 v[16];  // v[k] = x[b0 + j + T k]
+    if (blk >= a.blk_lo && blk < a.blk_hi) {
+        const __amdgpu_buffer_rsrc_t rs = rsrc_of(a.in + b0, 8u * N);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = buf_ld_f2<2>(rs, 8u * j, 8u * T * k);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const long pos = b0 + j + T * k;
+            float2 xv;
+            xv.x = 0.f;
+            xv.y = 0.f;
+            if (pos >= 0) {
+                if (pos < a.n_in) xv = a.in[pos];
+            } else if (pos >= -(long)a.hist_len) {
+                xv = a.hist[a.hist_len + pos];
+            }
+            v[k] = (f2){xv.x, xv.y};
+        }
+    }
+    f2 s2, s3;
+    {
+        const float2 t2 = a.tw[(N / 4096) * (j & 255)], t3 = a.tw[j];
+        s2 = (f2){t2.x, t2.y};
+        s3 = (f2){t3.x, t3.y};
+    }
+    if (j < kTab) {  // W_256^(r k), r < 16, k = 1 .. 15
+        const int r = j / 15, k = j - 15 * r + 1;
+        const float2 t = a.tw[((N / 256) * r * k) & (N - 1)];
+        tab[j] = (f2){t.x, t.y};
+    }
+    if (a.hist_out && blk == a.nblocks - 1) {  // the next call's history = the last samples of [ hist | in ]
+        for (int i = j; i < a.hist_out_len; i += T) {
+            const long pos = a.n_in - a.hist_out_len + i;
+            float2 h;
+            h.x = 0.f;
+            h.y = 0.f;
+            if (pos >= 0) h = a.in[pos];
+            else if (pos >= -(long)a.hist_len) h = a.hist[a.hist_len + pos];
+            a.hist_out[i] = h;
+        }
+    }
+
+    const f2 *const rd = img + (j + (j >> 4));                 // pad16(j + T k) = rd + (T + T / 16) k
+    f2 *const w0 = img + 17 * j;                                // pad16(16 j + k) = w0 + k
+    f2 *const w1 = img + ((j >> 4) * 256 + (j & 15));           // + 16 k
+    f2 *const w2 = img + ((j >> 8) * 4096 + (j & 255));         // + 256 k
+    const f2 *const rd1 = img + j;                              // j + T k = rd1 + T k
+    const f2 *const trow = tab + 15 * (j & 15) - 1;             // W_256^((j mod 16) k) = trow[k]
+    const __amdgpu_buffer_rsrc_t rsG = rsrc_of(a.G, 8u * N);
+
+    auto transform = [&](bool pre_barrier, auto &&late) {
+        dft16(v);
+        if (pre_barrier) lds_bar();  // the previous transform's last reads are done
+#pragma unroll
+        for (int k = 0; k < 16; ++k) img_st(w0 + k, v[k]);
+        lds_bar();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = img_ld(rd + (T + T / 16) * k);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], lds_ldv(trow + k));
+        dft16(v);
+        lds_bar();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) img_st(w1 + 16 * k, v[k]);
+        lds_bar();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = img_ld(rd1 + T * k);
+        twiddle16(v, s2);
+        dft16(v);
+        lds_bar();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) img_st(w2 + 256 * k, v[k]);
+        lds_bar();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = img_ld(rd1 + T * k);
+        late();
+        // last pass: NB butterflies of radix R3 over v[c + NB k], twiddles (W_N^j W_16^c)^k
+        constexpr float WR[8] = {1.f, 0.92387953251128673848f, 0.70710678118654752440f, 0.38268343236508978178f,
+                                 0.f, -0.38268343236508978178f, -0.70710678118654752440f, -0.92387953251128673848f};
+        constexpr float WI[8] = {0.f, -0.38268343236508978178f, -0.70710678118654752440f, -0.92387953251128673848f,
+                                 -1.f, -0.92387953251128673848f, -0.70710678118654752440f, -0.38268343236508978178f};
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            const f2 t1 = c == 0 ? s3 : cmulc(s3, WR[c], WI[c]);
+            if constexpr (R3 == 4) {
+                const f2 t2 = cmul(t1, t1), t3 = cmul(t2, t1);
+                v[c + 4] = cmul(v[c + 4], t1);
+                v[c + 8] = cmul(v[c + 8], t2);
+                v[c + 12] = cmul(v[c + 12], t3);
+                dft4(v[c], v[c + 4], v[c + 8], v[c + 12]);
+            } else {
+                const f2 b = cmul(v[c + 8], t1), s = v[c] + b;
+                v[c + 8] = v[c] - b;
+                v[c] = s;
+            }
+        }
+    };
+
+    float4 g4[8];
+    transform(false, [&] {
+#pragma unroll
+        for (int kp = 0; kp < 8; ++kp) g4[kp] = buf_ld_f4<0>(rsG, 16u * j, 16u * T * kp);
+    });
+#pragma unroll
+    for (int kp = 0; kp < 8; ++kp) {
+        v[2 * kp] = cmul(v[2 * kp], (f2){g4[kp].x, g4[kp].y});
+        v[2 * kp + 1] = cmul(v[2 * kp + 1], (f2){g4[kp].z, g4[kp].w});
+    }
+    transform(true, [] {});
+
+    // y[t] = v[k] with t = (N - (j + T k)) mod N; valid for t >= V: output mbase + t - V = mbase + hop - j - T k
+    // (t = 0 lands on `hop`, t < V wraps to a huge offset: the descriptor's range check drops both)
+    const long mbase = (long)blk * hop;
+    const long left = a.n_out - mbase;
+    const unsigned recs = (unsigned)(left < hop ? left : hop) * 8u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.out + mbase, 0, recs, 0x00020000);
+    const unsigned lane_off = (unsigned)(hop - j) * 8u;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (T * k > hop) continue;  // (no lane's index reaches V: a uniform branch drops the instruction)
+        __builtin_amdgcn_raw_buffer_store_b64(v[k], rs, lane_off - (unsigned)(T * k * 8), 0, 2);
+    }
+}
+
 }  // namespace
 
 int launch_filter_blk4096(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *G,
@@ -355,6 +530,53 @@ int launch_filter_blk4096(hipStream_t s, const void *hist, size_t hist_len, cons
     }
     RR_HIP(hipGetLastError());
     return RR_OK;
+}
+
+bool filter_blkbig_supported(int dtype, size_t n) { return dtype == RR_F32 && n >= 2 && n - 1 <= 8192; }
+
+template <int N>
+static int launch_filter_blkbig_n(hipStream_t s, BlkBigArgs &a, size_t n_in, size_t n_out, long e0) {
+    const size_t hop = N - a.V;
+    const size_t nblocks = (n_out + hop - 1) / hop;
+    if (nblocks > 0x7ffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "Filter: too many blocks");
+    a.nblocks = (unsigned)nblocks;
+    {
+        const long first = e0 - a.V;
+        long lo = first >= 0 ? 0 : (-first + (long)hop - 1) / (long)hop;
+        long hi = ((long)n_in - N - first) >= 0 ? ((long)n_in - N - first) / (long)hop + 1 : 0;
+        if (hi > (long)nblocks) hi = (long)nblocks;
+        if (lo > hi) lo = hi;
+        a.blk_lo = (unsigned)lo;
+        a.blk_hi = (unsigned)hi;
+    }
+    constexpr size_t lds = (size_t)(N + N / 16 + kTab) * sizeof(f2);
+    // (per launch: the attribute belongs to the device the call runs on)
+    RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_filter_blkbig<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned grid = (unsigned)((nblocks + 31) / 32 * 32);
+    hipLaunchKernelGGL(k_filter_blkbig<N>, dim3(grid), dim3(N / 16), lds, s, a);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// N = 8192 or 16384 points per block, overlap V >= n - 1 (V < N); G = DFT_N(g) / N pair-interleaved, twN = e^{-j 2 pi k / N}
+int launch_filter_blkbig(hipStream_t s, size_t N, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *G,
+                         const void *twN, size_t V, void *out, size_t n_out, long e0, void *hist_out, size_t hist_out_len) {
+    if (n_out == 0) return RR_OK;
+    if ((N != 8192 && N != 16384) || V < 1 || V > N / 2) RR_FAIL(RR_ERR_BAD_ARG, "Filter: overlap %zu / blocks of %zu points", V, N);
+    BlkBigArgs a;
+    a.hist = (const float2 *)hist;
+    a.hist_len = (int)hist_len;
+    a.in = (const float2 *)in;
+    a.n_in = (long)n_in;
+    a.G = G;
+    a.tw = (const float2 *)twN;
+    a.V = (int)V;
+    a.out = (float2 *)out;
+    a.n_out = (long)n_out;
+    a.e0 = e0;
+    a.hist_out = (float2 *)hist_out;
+    a.hist_out_len = (int)hist_out_len;
+    return N == 8192 ? launch_filter_blkbig_n<8192>(s, a, n_in, n_out, e0) : launch_filter_blkbig_n<16384>(s, a, n_in, n_out, e0);
 }
 
 }  // namespace rr

@@ -103,8 +103,12 @@ struct Schedule {
     // Both rates integral (every f64 operation of resampling.rs:110-112 is then exact): the schedule is periodic,
     // every P = in / g inputs release Q = out / g outputs (g = gcd).  count() and advance() without an emit list run
     // in closed form; first_emits() gives the 0-based input indices that trigger the next `count` outputs.
+    // The same holds for rates that are whole multiples of 2^-s as long as (in + out) 2^s <= 2^53 (48000 -> 44100.5: s = 1):
+    // ra, rb are the rates times `scale` = 2^s, `pos` stays in the reference's units (pos_units() = pos * scale, exact).
     bool periodic = false;
     uint64_t ra = 0, rb = 0, P = 0, Q = 0;
+    double scale = 1.0;
+    uint64_t pos_units() const { return static_cast<uint64_t>(pos * scale); }
     void first_emits(size_t count, int64_t *e) const;
 };
 

@@ -52,6 +52,11 @@ int launch_filter_ols(int dtype, hipStream_t s, const void *hist, const void *in
 // hist_out (may be null) receives the last hist_out_len samples of [ hist | in ] - the next call's history -
 // written by the kernel itself (only when n_out > 0, i.e. when a kernel is launched).
 bool filter_ols4096_supported(int dtype, size_t n);
+// k_filter_blkbig<N>: blocks of N = 8192 / 16384 points in LDS (responses of up to N / 2 + 1 taps in one forward and one inverse
+// transform per block); G = DFT_N(g) / N pair-interleaved {G[j + 2 T kp], G[j + 2 T kp + T]}, T = N / 16, twN = e^{-j 2 pi k / N}
+bool filter_blkbig_supported(int dtype, size_t n);
+int launch_filter_blkbig(hipStream_t s, size_t N, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *G,
+                         const void *twN, size_t V, void *out, size_t n_out, long e0, void *hist_out, size_t hist_out_len);
 int launch_filter_blk4096(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *G,
                           const void *tw4096, size_t n, void *out, size_t n_out, long e0, bool out_f16, bool g_f16,
                           void *hist_out, size_t hist_out_len, bool accumulate = false, size_t nparts = 1);

@@ -283,6 +283,43 @@ def test_filter_long_responses_at_n_log_n(rr, oracle, n, dtype, tol, monkeypatch
         pos += k * n
 
 
+@pytest.mark.parametrize("n", [2049, 3000, 4096, 5000, 8192])
+def test_filter_blocks_of_16384_points(rr, oracle, n):
+    """2049 .. 8192 taps in f32: k_filter_blk16k - blocks of 16 384 points in LDS, one forward and one inverse transform per
+    block (kernel 5).  Several chunks per call, single chunks, an interrupt in between, a ragged tail of blocks; against the f64
+    oracle, call by call and chunk by chunk."""
+    import torch
+
+    fs = 1024000.0
+    chunks = 23
+    x = oracle.synth_iq(23, 0, n * chunks).astype(np.complex64)
+    g = rr.Filter.new(lowpass(100e3))
+    o = oracle.Filter(lowpass(100e3), flt=np.float64)
+    st = torch.cuda.current_stream().cuda_stream
+    g.set_stream(st)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.zeros(n * chunks, dtype=d_in.dtype, device="cuda")
+    pos = 0
+    for k, interrupt in ((3, False), (1, False), (9, False), (2, True), (1, False), (7, False)):
+        if interrupt:
+            g.process(rr.EventSignal(rr.SamplesLost()))
+            o.interrupt()
+        w = g.process_dev(fs, n, d_in.data_ptr() + 8 * pos, k * n, d_out.data_ptr(), k * n)
+        torch.cuda.synchronize()
+        assert g.last_kernel() == 5, g.last_kernel()
+        ref = [o.process(fs, x[pos + i * n:pos + (i + 1) * n].astype(np.complex128)) for i in range(k)]
+        ref = np.concatenate([r for r in ref if r is not None] or [np.empty(0, np.complex128)])
+        assert w == len(ref)
+        if w:
+            e = rms_rel(d_out[:w].cpu().numpy(), ref)
+            assert e <= 1e-5, (k, e)
+            # every chunk on its own too (a wrong block would hide in the overall RMS)
+            got = d_out[:w].cpu().numpy()
+            for i in range(0, w, n):
+                assert rms_rel(got[i:i + n], ref[i:i + n]) <= 1e-5, (k, i)
+        pos += k * n
+
+
 def test_filter_deemphasis_of_simple_receiver(rr, oracle):
     """examples/relm_app/simple_receiver.rs:43-49: the audio Filter behind the FM demodulator - rectangular window,
     complex response built from blocks::filters::deemphasis_factor(50e-6, f) on 20 Hz .. 16 kHz, DC bin blocked -

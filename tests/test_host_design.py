@@ -158,6 +158,21 @@ def test_schedule_vs_oracle(L, oracle, fin, fout):
         assert all_emit == onp.emit_indices(total, fin, fout).tolist()
 
 
+@pytest.mark.parametrize("fin,fout", [(48000.0, 44100.5), (1000.25, 333.125), (3.5, 2.25), (1024000.0, 44100.0), (2.0 ** 40 + 0.5, 2.0 ** 39 + 0.25),
+                                      (48000.0, 44100.1)])
+def test_schedule_closed_form_for_dyadic_rates(L, fin, fout):
+    """Rates that are whole multiples of 2^-s (every f64 has such an s; the sums of resampling.rs:110-112 stay exact while
+    (in + out) 2^s <= 2^53) run the closed form: counts and the accumulator after ragged pieces equal the sample loop's
+    (the call with an emit list runs the loop).  44100.1 needs s = 37 - beyond 2^53, the loop on both sides."""
+    pos_loop, pos_closed = C.c_double(0.0), C.c_double(0.0)
+    for n in (1, 2, 997, 1000, 4097, 30000, 1):
+        c1, c2 = C.c_size_t(), C.c_size_t()
+        emit = np.empty(n + 1, dtype=np.uint32)
+        assert L.rr_downsampler_schedule(fin, fout, n, C.byref(pos_loop), emit.ctypes.data, emit.size, C.byref(c1)) == 0
+        assert L.rr_downsampler_schedule(fin, fout, n, C.byref(pos_closed), None, 0, C.byref(c2)) == 0
+        assert c1.value == c2.value and pos_loop.value == pos_closed.value, (n, c1.value, c2.value, pos_loop.value, pos_closed.value)
+
+
 @pytest.mark.parametrize("n", [1, 3, 4, 256, 1000, 4096])
 def test_fourier_window_vs_oracle(L, oracle, n):
     import radiorust_amd as rr
