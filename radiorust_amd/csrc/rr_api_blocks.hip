@@ -222,7 +222,7 @@ int rr_filter::build_tables(bool reset_history) {
             use_ols16k = true;
         }
     }
-    // long responses: overlap-save with blocks of 2^14 .. 2^18 points through the two-pass tile transform (RR_FILTER_CONV=0: the
+    // long responses: overlap-save with blocks of 2^15 (f64: 2^13) .. 2^18 points through the two-pass tile transform (RR_FILTER_CONV=0: the
     // partitions of 2048 taps / k_filter_ols / k_fir as before)
     use_conv = false;
     {
@@ -233,7 +233,7 @@ int rr_filter::build_tables(bool reset_history) {
         const size_t min32 = me ? (size_t)std::atol(me) : (size_t)16384;
         const size_t minlen = dtype == RR_F32 ? min32 : 4096;
         if (!conv_off && len >= minlen && len <= ((size_t)1 << 17)) {
-            size_t N = (size_t)1 << (dtype == RR_F32 ? 14 : 13);
+            size_t N = (size_t)1 << (dtype == RR_F32 ? 15 : 13);  // (the lengths of the two-pass tile transform: f32 beyond k_fft16384's one image)
             while (N < 4 * len && N < ((size_t)1 << 18)) N <<= 1;
             if (N > len) {
                 if (!conv_fft) {

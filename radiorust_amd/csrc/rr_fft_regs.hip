@@ -8,6 +8,7 @@
 #include "rr_wave_math.hpp"
 #include "rr_meter_dev.hpp"
 #include "rr_fft_regs.hpp"
+#include "rr_fft_big.hpp"
 
 #include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
@@ -213,6 +214,49 @@ int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *i
 }
 
 // the 4096-bin polyphase channelizer (see k_fft4096<true>)
+// ---------------------------------------------------------------------------
+// Kernel 2y  k_fft16384: window * v -> 16 384-point forward DFT in ONE pass over HBM: a workgroup of 1024 lanes per frame, 16
+// values per lane, the transform of rr_fft_big.hpp (radix 16 x 16 x 16 x 4 through one 136 KiB image in LDS, one workgroup per
+// CU) - the two passes of k_fft_tile move every sample through HBM twice.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_fft16384(const float2 *__restrict__ head, long n_head, const float2 *__restrict__ in,
+                                                   float2 *__restrict__ out, const float *__restrict__ window,
+                                                   const float2 *__restrict__ tw, int center_dc, long hop) {
+    constexpr int N = 16384, T = N / 16;
+    extern __shared__ __attribute__((aligned(16))) f2 fft16k_smem[];
+    f2 *const img = fft16k_smem;
+    const int j = threadIdx.x;
+    const long base = (long)blockIdx.x * hop - n_head;
+    f2 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const long i = base + j + T * k;
+        const float2 x = (i >= 0) ? in[i] : head[n_head + i];
+        const float w = window[j + T * k];
+        v[k] = (f2){x.x * w, x.y * w};
+    }
+    BigFftLane<N> ln;
+    ln.init(tw, img + (N + N / 16), j);
+    big_fft<N>(v, img, ln, j, false, [] {});
+    f2 *dst = reinterpret_cast<f2 *>(out) + (size_t)blockIdx.x * N;
+    const int rot = center_dc ? N / 2 : 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) __builtin_nontemporal_store(v[k], dst + ((j + T * k + rot) & (N - 1)));
+}
+
+int launch_fft16384(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count, const void *window,
+                    const void *tw16384, bool center_dc, size_t hop) {
+    if (count == 0) return RR_OK;
+    if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fft16384: too many frames");
+    constexpr size_t lds = (size_t)big_fft_lds_elems<16384>() * sizeof(f2);
+    // (per launch: the attribute belongs to the device the call runs on)
+    RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft16384), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_fft16384, dim3((unsigned)count), dim3(1024), lds, s, (const float2 *)head, (long)n_head, (const float2 *)in,
+                       (float2 *)out, (const float *)window, (const float2 *)tw16384, (int)center_dc, (long)hop);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
 __global__ __launch_bounds__(256) void k_chan4096_pair(const float2 *__restrict__ head, long n_head, const float2 *__restrict__ in,
                                                        float2 *__restrict__ out, const float *__restrict__ window,
                                                        const float2 *__restrict__ tw, unsigned count, int branches);

@@ -25,6 +25,7 @@
 // (git tag cfg5-variants-kept holds them).
 #include "rr_blocks.hpp"
 #include "rr_wave_math.hpp"
+#include "rr_fft_big.hpp"
 
 #include <hip/hip_fp16.h>
 
@@ -307,18 +308,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PARTS ? 3 :
 
 
 // ---------------------------------------------------------------------------
-// k_filter_blk16k: the same fast convolution with blocks of 16 384 points for responses of 2049 .. 8192 taps: ONE forward and
-// one inverse transform per block, 16 384 - V results valid (n = 4096: 75 %) - the partitions of 2048 taps above run n / 2048 + 1
-// transforms of 4096 points for 2049 results (n = 4096: 6 transformed samples per result against 2.7 here).
-// A workgroup of 1024 lanes per block, 16 values per lane, Stockham radix 16 x 16 x 16 x 4 through ONE image in LDS (128 KiB +
-// the padding of the first exchange: one workgroup per CU, 4 waves per SIMD).  Butterfly i of a pass of radix R behind Ns
-// points reads in[i + k N / R], multiplies by W_(Ns R)^((i mod Ns) k) and writes (i div Ns) Ns R + (i mod Ns) + k Ns:
-//   pass 0  R = 16, Ns = 1     lane j = butterfly j            out 16 j + k             (image padded 17 per 16)
-//   pass 1  R = 16, Ns = 16    twiddles W_256^((j mod 16) k)   out (j div 16) 256 + (j mod 16) + 16 k
-//   pass 2  R = 16, Ns = 256   W_4096^((j mod 256) k)          out (j div 256) 4096 + (j mod 256) + 256 k
-//   pass 3  R = 4,  Ns = 4096  butterflies i = j + 1024 c, c < 4: the lane's values v[c + 4 k], W_16384^((j + 1024 c) k); X[i + 4096 k]
-//                              comes out in v[c + 4 k]: v[kk] = X[j + 1024 kk], natural order
-// The inverse is the forward routine with the result index reversed, as above.
+// k_filter_blkbig<N>: the same fast convolution with blocks of N = 8192 / 16 384 points for responses of 2049 .. 8192 taps: ONE
+// forward and one inverse transform per block, N - V results valid (n = 4096 with 16 384 points: 75 %) - the partitions of 2048
+// taps above run n / 2048 + 1 transforms of 4096 points for 2049 results (n = 4096: 6 transformed samples per result against
+// 2.7 here).  The transform: rr_fft_big.hpp (N / 16 lanes, 16 values per lane, radix 16 x 16 x 16 x N / 4096 through ONE image
+// in LDS).  The inverse is the forward routine with the result index reversed, as above.
 // ---------------------------------------------------------------------------
 struct BlkBigArgs {
     const float2 *hist;
@@ -341,11 +335,11 @@ struct BlkBigArgs {
 // butterflies i = j + 512 c, c < 8, over v[c + 8 k]), two workgroups per CU
 template <int N>
 __global__ __launch_bounds__(N / 16) void k_filter_blkbig(BlkBigArgs a) {
-    constexpr int T = N / 16, R3 = N / 4096, NB = 16 / R3;  // lanes; radix of the last pass; its butterflies per lane
+    constexpr int T = N / 16;  // lanes
     static_assert(N == 8192 || N == 16384, "blocks of 8192 or 16384 points");
     extern __shared__ __attribute__((aligned(16))) f2 dynbig[];
     f2 *const img = dynbig;
-    f2 *const tab = dynbig + (N + N / 16);  // pad16(N - 1) = N + N / 16 - 2
+    f2 *const tab = dynbig + (N + N / 16);
     const int j = threadIdx.x;
     const int hop = N - a.V;
     // neighbouring blocks (which share V samples) on one XCD, in a window of 8 x 4 blocks
@@ -375,17 +369,8 @@ __global__ __launch_bounds__(N / 16) void k_filter_blkbig(BlkBigArgs a) {
             v[k] = (f2){xv.x, xv.y};
         }
     }
-    f2 s2, s3;
-    {
-        const float2 t2 = a.tw[(N / 4096) * (j & 255)], t3 = a.tw[j];
-        s2 = (f2){t2.x, t2.y};
-        s3 = (f2){t3.x, t3.y};
-    }
-    if (j < kTab) {  // W_256^(r k), r < 16, k = 1 .. 15
-        const int r = j / 15, k = j - 15 * r + 1;
-        const float2 t = a.tw[((N / 256) * r * k) & (N - 1)];
-        tab[j] = (f2){t.x, t.y};
-    }
+    BigFftLane<N> ln;
+    ln.init(a.tw, tab, j);
     if (a.hist_out && blk == a.nblocks - 1) {  // the next call's history = the last samples of [ hist | in ]
         for (int i = j; i < a.hist_out_len; i += T) {
             const long pos = a.n_in - a.hist_out_len + i;
@@ -398,64 +383,9 @@ __global__ __launch_bounds__(N / 16) void k_filter_blkbig(BlkBigArgs a) {
         }
     }
 
-    const f2 *const rd = img + (j + (j >> 4));                 // pad16(j + T k) = rd + (T + T / 16) k
-    f2 *const w0 = img + 17 * j;                                // pad16(16 j + k) = w0 + k
-    f2 *const w1 = img + ((j >> 4) * 256 + (j & 15));           // + 16 k
-    f2 *const w2 = img + ((j >> 8) * 4096 + (j & 255));         // + 256 k
-    const f2 *const rd1 = img + j;                              // j + T k = rd1 + T k
-    const f2 *const trow = tab + 15 * (j & 15) - 1;             // W_256^((j mod 16) k) = trow[k]
     const __amdgpu_buffer_rsrc_t rsG = rsrc_of(a.G, 8u * N);
-
-    auto transform = [&](bool pre_barrier, auto &&late) {
-        dft16(v);
-        if (pre_barrier) lds_bar();  // the previous transform's last reads are done
-#pragma unroll
-        for (int k = 0; k < 16; ++k) img_st(w0 + k, v[k]);
-        lds_bar();
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = img_ld(rd + (T + T / 16) * k);
-#pragma unroll
-        for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], lds_ldv(trow + k));
-        dft16(v);
-        lds_bar();
-#pragma unroll
-        for (int k = 0; k < 16; ++k) img_st(w1 + 16 * k, v[k]);
-        lds_bar();
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = img_ld(rd1 + T * k);
-        twiddle16(v, s2);
-        dft16(v);
-        lds_bar();
-#pragma unroll
-        for (int k = 0; k < 16; ++k) img_st(w2 + 256 * k, v[k]);
-        lds_bar();
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = img_ld(rd1 + T * k);
-        late();
-        // last pass: NB butterflies of radix R3 over v[c + NB k], twiddles (W_N^j W_16^c)^k
-        constexpr float WR[8] = {1.f, 0.92387953251128673848f, 0.70710678118654752440f, 0.38268343236508978178f,
-                                 0.f, -0.38268343236508978178f, -0.70710678118654752440f, -0.92387953251128673848f};
-        constexpr float WI[8] = {0.f, -0.38268343236508978178f, -0.70710678118654752440f, -0.92387953251128673848f,
-                                 -1.f, -0.92387953251128673848f, -0.70710678118654752440f, -0.38268343236508978178f};
-#pragma unroll
-        for (int c = 0; c < NB; ++c) {
-            const f2 t1 = c == 0 ? s3 : cmulc(s3, WR[c], WI[c]);
-            if constexpr (R3 == 4) {
-                const f2 t2 = cmul(t1, t1), t3 = cmul(t2, t1);
-                v[c + 4] = cmul(v[c + 4], t1);
-                v[c + 8] = cmul(v[c + 8], t2);
-                v[c + 12] = cmul(v[c + 12], t3);
-                dft4(v[c], v[c + 4], v[c + 8], v[c + 12]);
-            } else {
-                const f2 b = cmul(v[c + 8], t1), s = v[c] + b;
-                v[c + 8] = v[c] - b;
-                v[c] = s;
-            }
-        }
-    };
-
     float4 g4[8];
-    transform(false, [&] {
+    big_fft<N>(v, img, ln, j, false, [&] {
 #pragma unroll
         for (int kp = 0; kp < 8; ++kp) g4[kp] = buf_ld_f4<0>(rsG, 16u * j, 16u * T * kp);
     });
@@ -464,7 +394,7 @@ __global__ __launch_bounds__(N / 16) void k_filter_blkbig(BlkBigArgs a) {
         v[2 * kp] = cmul(v[2 * kp], (f2){g4[kp].x, g4[kp].y});
         v[2 * kp + 1] = cmul(v[2 * kp + 1], (f2){g4[kp].z, g4[kp].w});
     }
-    transform(true, [] {});
+    big_fft<N>(v, img, ln, j, true, [] {});
 
     // y[t] = v[k] with t = (N - (j + T k)) mod N; valid for t >= V: output mbase + t - V = mbase + hop - j - T k
     // (t = 0 lands on `hop`, t < V wraps to a huge offset: the descriptor's range check drops both)
@@ -549,7 +479,7 @@ static int launch_filter_blkbig_n(hipStream_t s, BlkBigArgs &a, size_t n_in, siz
         a.blk_lo = (unsigned)lo;
         a.blk_hi = (unsigned)hi;
     }
-    constexpr size_t lds = (size_t)(N + N / 16 + kTab) * sizeof(f2);
+    constexpr size_t lds = (size_t)big_fft_lds_elems<N>() * sizeof(f2);
     // (per launch: the attribute belongs to the device the call runs on)
     RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_filter_blkbig<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((nblocks + 31) / 32 * 32);

@@ -663,7 +663,14 @@ __global__ __launch_bounds__(256) void k_dft_direct(const v2<T> *__restrict__ in
 }
 
 static bool is_pow2(size_t n) { return n && (n & (n - 1)) == 0; }
-static size_t pow2_limit(int dtype) { return dtype == RR_F32 ? 8192 : 4096; }  // 2 LDS buffers <= 128 KiB
+// one LDS tile: 2 buffers <= 128 KiB for k_fft_pow2; f32 16 384 points through k_fft16384's single image (RR_FOURIER_16K=0: the two
+// passes of k_fft_tile as before - A/B runs, tests)
+static size_t pow2_limit(int dtype) {
+    const char *e16 = std::getenv("RR_FOURIER_16K");  // (read per design: tests switch it within one process)
+    const bool no16k = e16 && std::atoi(e16) == 0;
+    static const bool generic = [] { const char *e = std::getenv("RR_FOURIER_GENERIC"); return e && std::atoi(e) != 0; }();
+    return dtype == RR_F32 ? ((no16k || generic) ? 8192 : 16384) : 4096;
+}
 
 bool fourier_pow2_path(int dtype, size_t n) { return is_pow2(n) && n >= 2 && n <= pow2_limit(dtype); }
 
@@ -1891,6 +1898,8 @@ int launch_fourier_overlapped(int dtype, hipStream_t s, const void *head, size_t
         return launch_fft_small(s, in, out, n, count, window, twiddle, center_dc);
     if (dtype == RR_F32 && n == 8192 && !generic)
         return launch_fft8192(s, head, n_head, in, out, count, window, twiddle, center_dc, hop);
+    if (dtype == RR_F32 && n == 16384)  // (pow2_limit: only without RR_FOURIER_GENERIC / RR_FOURIER_16K=0)
+        return launch_fft16384(s, head, n_head, in, out, count, window, twiddle, center_dc, hop);
     if (dtype == RR_F32 && n == 512 && !generic)
         return launch_fft512(s, head, n_head, in, out, count, window, twiddle, center_dc, hop);
     if (dtype == RR_F32 && n == 2048 && !generic)

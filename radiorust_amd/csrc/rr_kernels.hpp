@@ -231,6 +231,9 @@ bool fft_big_supported(size_t n);
 void fft_big_split(size_t n, size_t *N1, size_t *N2);
 int launch_fft_big(int dtype, hipStream_t s, const void *in, void *out, void *ws, size_t n, size_t count, const void *window,
                    const void *tw1, const void *tw2, bool center_dc);
+// k_fft16384: 1024 lanes per 16384-sample frame (rr_fft_big.hpp), plain window and twiddle tables
+int launch_fft16384(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count, const void *window,
+                    const void *tw16384, bool center_dc, size_t hop);
 // k_fft8192: 256 lanes per 8192-sample frame, 32 values per lane (plain window and twiddle tables)
 int launch_fft8192(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
                    const void *window, const void *tw8192, bool center_dc, size_t hop);

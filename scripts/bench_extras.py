@@ -56,7 +56,7 @@ for nt, conv_min in ((1024, None), (2048, None), (4096, None), (8192, None), (16
     line(f"Filter n = {nt} (kernel {g.last_kernel()}{'' if conv_min is None else ', RR_FILTER_CONV_MIN=' + str(conv_min)})", n, dt, 16)
 os.environ.pop("RR_FILTER_CONV_MIN", None)
 # the block length of k_filter_blkbig (kernel 5) against the default's; RR_FILTER_KERNEL=parts: the partitions of 2048 taps
-for nt, blk, kern in ((1536, 8192, None), (2048, 8192, None), (2048, 16384, None), (3072, 8192, None), (4096, 8192, None), (4096, None, "parts"), (8192, None, "parts")):
+for nt, blk, kern in ((1536, 8192, None), (2048, 8192, None), (2048, 16384, None), (3072, 8192, None), (3072, 16384, None), (4096, 8192, None), (4096, None, "parts"), (8192, None, "parts")):
     os.environ.pop("RR_FILTER_BLOCK", None)
     os.environ.pop("RR_FILTER_KERNEL", None)
     if blk:
@@ -71,7 +71,7 @@ for nt, blk, kern in ((1536, 8192, None), (2048, 8192, None), (2048, 16384, None
 os.environ.pop("RR_FILTER_BLOCK", None)
 os.environ.pop("RR_FILTER_KERNEL", None)
 
-for nf in (8192, 65536, 96, 300, 500, 720, 1000, 1001, 1536, 1999, 2000, 3000, 3001, 4004, 4800, 8000, 20000, 250000, 20011):
+for nf in (8192, 16384, 32768, 65536, 96, 300, 500, 720, 1000, 1001, 1536, 1999, 2000, 3000, 3001, 4004, 4800, 5000, 8000, 20000, 250000, 20011):
     g = rr.Fourier.with_window(rr.Kaiser.with_null_at_bin(2.0))
     g.set_stream(st)
     n = min(N, 1 << 24) // nf * nf

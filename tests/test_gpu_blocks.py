@@ -785,6 +785,7 @@ def test_fourier_big_two_pass_against_the_transposes(rr, oracle, monkeypatch, dt
     2^18 points) against the five-launch form (RR_FOURIER_BIG=transpose) and the oracle."""
     import torch
 
+    monkeypatch.setenv("RR_FOURIER_16K", "0")  # (16 384 points in f32 otherwise run k_fft16384, one pass)
     for n, chunks, center in ((1 << 14, 5, False), (1 << 15, 3, True), (1 << 16, 3, True)):
         x = oracle.synth_iq(21, 0, n * chunks).astype(np.complex128 if dtype == np.float64 else np.complex64)
         o = oracle.Fourier(oracle.Kaiser.with_null_at_bin(2.0), center, flt=np.float64)
@@ -853,10 +854,11 @@ def test_fourier_batched_device_api(rr, oracle):
     check(d_out.cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("n,center", [(1024, False), (1024, True), (256, False), (2048, False), (2048, True), (512, False), (512, True), (8192, True), (64, False), (64, True), (128, False), (128, True)])
+@pytest.mark.parametrize("n,center", [(1024, False), (1024, True), (256, False), (2048, False), (2048, True), (512, False), (512, True), (8192, True), (64, False), (64, True), (128, False), (128, True),
+                                      (16384, False), (16384, True)])
 def test_fourier_wave_kernels_batched(rr, oracle, n, center, monkeypatch):
-    """Chunks of 512 / 1024 (k_fft512 / k_fft1024: a wave per chunk), 2048 (k_fft2048: 128 lanes per chunk) and 256
-    (the channelizer's one-branch case) in f32: many chunks per call on the device, every chunk against the f64 oracle."""
+    """Chunks of 512 / 1024 (k_fft512 / k_fft1024: a wave per chunk), 2048 (k_fft2048: 128 lanes per chunk), 16 384 (k_fft16384: a
+    workgroup of 1024 lanes per chunk, one pass over HBM) and 256 (the channelizer's one-branch case) in f32: many chunks per call on the device, every chunk against the f64 oracle."""
     import torch
 
     k = 301 if n < 8192 else 40  # (301: the last wave of the 64- / 128-point kernels is partly empty)
