@@ -79,13 +79,15 @@ struct FourierRoute {
     size_t N1 = 0, N2 = 0;  // the four-step / two-pass split
     size_t M = 0;           // Bluestein's power-of-two length
 };
-static FourierRoute fourier_route(int dtype, size_t len, bool force_mixed) {
+static FourierRoute fourier_route(int dtype, size_t len, bool force_mixed, bool prefer_tile = false) {
     FourierRoute r;
     const bool pow2 = is_pow2_sz(len);
     const bool generic = [] { const char *e = std::getenv("RR_FOURIER_GENERIC"); return e && std::atoi(e) != 0; }();
     const int mixed_env = [] { const char *e = std::getenv("RR_FOURIER_MIXED"); return e ? std::atoi(e) : 1; }();  // 0 never, 2 wherever it applies
     if (pow2) {
-        if (len < 4 || fourier_pow2_path(dtype, len)) {  // (a chunk of 1 sample is a power of two, too)
+        // (Bluestein's inner transform of 16 384 points stays on the two passes of k_fft_tile: four launches with the chirp products in
+        //  their loads and stores against five around k_fft16384)
+        if (len < 4 || (fourier_pow2_path(dtype, len) && !(prefer_tile && len > 8192))) {  // (a chunk of 1 sample is a power of two, too)
             r.kind = FourierRoute::POW2;
             return r;
         }
@@ -154,7 +156,7 @@ int rr_fourier::prepare(size_t len) {
     }
     std::vector<double> vals(len);
     RR_TRY(fourier_design_window(len, rel.data(), vals.data()));
-    const FourierRoute route = fourier_route(dtype, len, force_mixed);
+    const FourierRoute route = fourier_route(dtype, len, force_mixed, prefer_tile);
     using FR = FourierRoute;
     const bool use_big = route.kind == FR::BIG_TILE || route.kind == FR::BIG_TRANSPOSE || route.kind == FR::BIG_GENERIC;
     const bool generic = route.kind == FR::BIG_GENERIC;  // (only consulted on the `big` branches below)
@@ -343,6 +345,7 @@ int rr_fourier::prepare(size_t len) {
             RR_TRY(bs_fft->init_base(K_FOURIER, dtype, device));
         }
         bs_fft->stream = stream;
+        bs_fft->prefer_tile = true;
         RR_TRY(bs_fft->prepare(M));  // rectangular window: all ones
         bs_M = M;
     }
@@ -619,7 +622,7 @@ int rr_stft_create(int dtype, size_t chunk_len, size_t chunk_count, const rr_win
     // overlapped frames: the power-of-two kernels of one LDS tile, or Bluestein over power-of-two transforms (>= 32 points)
     if (!fourier_pow2_path(dtype, N) && !(N >= 32 && (N & (N - 1)) != 0 && N <= ((size_t)1 << 23)))
         RR_FAIL(RR_ERR_BAD_ARG, "Stft: chunk_len * chunk_count = %zu: powers of two up to %u, or any other length of 32 .. 2^23", N,
-                dtype == RR_F32 ? 8192u : 4096u);
+                dtype == RR_F32 ? 16384u : 4096u);
     if (window->kind != RR_WIN_RECTANGULAR && window->kind != RR_WIN_KAISER)
         RR_FAIL(RR_ERR_BAD_ARG, "Stft: window must be a built-in window");
     auto *h = new rr_stft;
@@ -727,7 +730,7 @@ int rr_fourier_route(int dtype, size_t n, char *buf, size_t cap) {
         case FR::BS_LAUNCHES: {
             // around the nested power-of-two transform: one launch each (M <= 8192 / 4096: five in all), its two passes with the
             // element-wise stages folded in (four), or its five launches (seventeen)
-            const FourierRoute nested = fourier_route(dtype, r.M, false);
+            const FourierRoute nested = fourier_route(dtype, r.M, false, true);
             const bool fused4 = nested.kind == FR::BIG_TILE &&
                                 ![] { const char *e = std::getenv("RR_FOURIER_BS_FUSED"); return e && std::atoi(e) == 0; }();
             std::snprintf(buf, cap, "bluestein %s launches M=%zu", fused4 ? "four" : nested.kind == FR::POW2 ? "five" : "many", r.M);

@@ -236,6 +236,7 @@ struct rr_fourier : rr_block {
     // Bluestein for lengths that are not powers of two (n >= 32, either dtype): two transforms of bs_M points
     // by a nested rectangular-window Fourier, tables c = window * conj(chirp), B = F(chirp) / M, w = chirp
     bool force_mixed = false;  // set by the Channelizer: k_fft_mixed wherever it applies (the fold rides on its load)
+    bool prefer_tile = false;  // set on Bluestein's inner transform: 16 384 points through k_fft_tile too (its passes carry the chirp products)
     bool mixed = false;     // 2^a 3^b 5^c points (<= 8192 in f32, <= 4096 in f64), not a power of two: k_fft_mixed (one launch, n log n work)
     // 2^a 3^b 5^c points beyond one LDS image (up to 512 x 512): two passes, k_fft_tilem; d_tw = twN1 | twN2 | T1 | T2
     bool tilem = false;

@@ -42,6 +42,7 @@ def test_every_route_is_consistent(route, dtype, monkeypatch):
     monkeypatch.delenv("RR_FOURIER_BIG", raising=False)
     C = 16 if dtype == np.float32 else 8
     one_image = 8192 if dtype == np.float32 else 4096
+    pow2_image = 16384 if dtype == np.float32 else 4096  # (f32: k_fft16384's single image of 16 384 points)
     seen = set()
     for n in LENGTHS:
         r = route(n, dtype)
@@ -49,7 +50,7 @@ def test_every_route_is_consistent(route, dtype, monkeypatch):
         if is_pow2(n):
             assert r.startswith("pow2"), (n, r)
             m = re.match(r"pow2 (two passes|five launches|strided) (\d+) x (\d+)$", r)
-            if n <= one_image:
+            if n <= pow2_image:
                 assert r == "pow2", (n, r)
             else:
                 assert m and int(m.group(2)) * int(m.group(3)) == n, (n, r)
