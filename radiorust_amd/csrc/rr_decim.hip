@@ -421,6 +421,198 @@ __global__ __launch_bounds__(256) void k_decim_poly_f64(DecimArgs64 a, const Tap
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// k_decim_poly_f64r<R>: the same sums with R = 4 or 8 neighbouring periods per lane.  k_decim_poly_f64 reads 16 bytes of LDS for
+// every pair of f64 FMAs - 1 KiB per wave and tap against the CU's 128 bytes per clock: LDS-bound at a fifth of the f64 rate
+// (measured: 0.18 ms per 2^24 samples at 4 : 1 with 184 taps, exactly 8 clocks per wave and tap).  Outputs a and a + 1 of one phase
+// b use the same row of the staged samples one column apart, x[r][a + c] and x[r][a + 1 + c]: a lane that owns the periods
+// R l .. R l + R - 1 walks a row once - sample X_i = x[r][R l + c_lo + i] feeds acc_u += tap[i - u] X_i, u < R - and reads each
+// sample ONCE for up to R taps: 1 / R of the LDS traffic, 2 R FMAs per read.  The columns are staged in R interleaved sets
+// (column = R cc + s: set s, place cc), so that the lanes of a wave read neighbouring 16-byte elements whatever i is.
+// Taps: per (phase b, row r) the first column c_lo and a run of `steps` f64 taps (zeros behind the row's own), read through the
+// scalar cache (from LDS they cost the same 1 KiB per wave as a sample: uniform or not, a read returns 16 bytes to every lane).
+// P >= 1 (P = Q = 1: a plain FIR).
+// ---------------------------------------------------------------------------
+struct DecimArgsR4 {
+    const double2 *hist;
+    int hist_len;
+    const double2 *in;
+    long n_in;
+    int P, Q;
+    long p_ref;
+    double2 *out;
+    long n_out;
+    int TA, SR, steps, NCX;  // periods per tile (a multiple of 64 R); places per row of a set; tap steps per row (a multiple of 4); staged columns beyond TA
+    unsigned ntiles;
+    double2 *hist_out;
+    int hist_out_len;
+    const double2 *nco;
+    unsigned denom, idx0;
+    const int *CL;      // c_lo[b P + r]
+    const double *TE;   // `steps` taps per (b, r)
+};
+
+__device__ __forceinline__ double ld_uniform_f64(const double *p) {  // (an s_load: see ld_uniform in rr_ols.hip)
+    return *(const double __attribute__((address_space(4))) *)(unsigned long long)p;
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_decim_poly_f64r(DecimArgsR4 a) {
+    extern __shared__ __attribute__((aligned(16))) char decim_smem[];
+    const int P = a.P, Q = a.Q, TA = a.TA, SR = a.SR, steps = a.steps;
+    d2 *const xs = reinterpret_cast<d2 *>(decim_smem);                 // R sets x P rows x SR places
+    d2 *const ost = xs + (size_t)R * P * SR;                            // Q > 1: TA Q outputs in their order
+    const int t = threadIdx.x;
+    constexpr unsigned G = 8;
+    const unsigned grp = blockIdx.x / (8 * G), rem = blockIdx.x % (8 * G);
+    const unsigned tile = grp * 8 * G + (rem & 7) * G + (rem >> 3);
+    if (tile >= a.ntiles) return;
+    const long a0 = (long)tile * TA;
+    const long p_lo = a.p_ref + (long)P * a0;
+    const int nld = P * (TA + a.NCX);
+    auto mix = [&](double2 x, long pos) -> double2 {  // x * nco[(idx0 + pos) mod denom], pos >= 0
+        const double2 pp = a.nco[(unsigned)(((long)a.idx0 + pos) % (long)a.denom)];
+        double2 r;
+        r.x = x.x * pp.x - x.y * pp.y;
+        r.y = x.x * pp.y + x.y * pp.x;
+        return r;
+    };
+    auto fetch = [&](long pos) -> double2 {
+        double2 h;
+        h.x = 0.0;
+        h.y = 0.0;
+        if (pos >= 0) {
+            if (pos < a.n_in) {
+                h = a.in[pos];
+                if (a.denom) h = mix(h, pos);
+            }
+        } else if (pos >= -(long)a.hist_len) {
+            h = a.hist[a.hist_len + pos];  // (already mixed)
+        }
+        return h;
+    };
+    if (a.hist_out && tile == a.ntiles - 1)
+        for (int i = t; i < a.hist_out_len; i += 256) a.hist_out[i] = fetch(a.n_in - a.hist_out_len + i);
+    {
+        int row = t % P, col = t / P;
+        const int dr = 256 % P, dc = 256 / P;
+        const bool interior = p_lo >= 0 && p_lo + nld <= a.n_in;
+        auto put = [&](double2 xv) {
+            xs[((col & (R - 1)) * P + row) * SR + (col / R)] = (d2){xv.x, xv.y};
+            row += dr;
+            col += dc;
+            if (row >= P) {
+                row -= P;
+                ++col;
+            }
+        };
+        int q = t;
+        if (interior) {
+            const double2 *src = a.in + p_lo;
+            unsigned ph = 0, dph = 0;
+            if (a.denom) {
+                ph = (unsigned)(((long)a.idx0 + p_lo + q) % (long)a.denom);
+                dph = 256u % a.denom;
+            }
+            auto next_ph = [&] {
+                const unsigned r = ph;
+                ph += dph;
+                if (ph >= a.denom) ph -= a.denom;
+                return r;
+            };
+            for (; q + 3 * 256 < nld; q += 4 * 256) {
+                double2 v[4], pp[4];
+                if (a.denom) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) pp[u] = a.nco[next_ph()];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = src[q + 256 * u];
+                if (a.denom) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double2 x = v[u];
+                        v[u].x = x.x * pp[u].x - x.y * pp[u].y;
+                        v[u].y = x.x * pp[u].y + x.y * pp[u].x;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) put(v[u]);
+            }
+            for (; q < nld; q += 256) {
+                double2 x = src[q];
+                if (a.denom) {
+                    const double2 pp = a.nco[next_ph()];
+                    const double2 y = x;
+                    x.x = y.x * pp.x - y.y * pp.y;
+                    x.y = y.x * pp.y + y.y * pp.x;
+                }
+                put(x);
+            }
+        } else {
+            for (; q < nld; q += 256) put(fetch(p_lo + q));
+        }
+    }
+    __syncthreads();
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    const int segs = TA / (64 * R), ntask = Q * segs;  // a wave takes 64 R periods of one phase
+    for (int task = w; task < ntask; task += 4) {
+        const int b = task / segs, seg = task - b * segs;
+        const int lb = seg * 64 + lane;  // the lane's periods: R lb .. R lb + R - 1
+        d2 acc[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) acc[u] = (d2){0.0, 0.0};
+        for (int r = 0; r < P; ++r) {
+            const int c_lo = a.CL[b * P + r];  // (uniform: a scalar read)
+            const double *te = a.TE + (size_t)(b * P + r) * steps;
+            double tp[R];  // te[i0 - R + k], k < R: the taps in front of the chunk (zeros in front of the row's first)
+#pragma unroll
+            for (int k = 0; k < R; ++k) tp[k] = 0.0;
+            for (int i0 = 0; i0 < steps; i0 += 4) {
+                double tc[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tc[k] = ld_uniform_f64(te + i0 + k);
+                d2 X[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int ci = c_lo + i0 + k;
+                    X[k] = xs[((ci & (R - 1)) * P + r) * SR + (ci / R) + lb];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                    for (int u = 0; u < R; ++u) {
+                        const double tv = k >= u ? tc[k - u] : tp[R + k - u];  // te[i0 + k - u]
+                        acc[u] = __builtin_elementwise_fma(X[k], (d2){tv, tv}, acc[u]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k + 4 < R; ++k) tp[k] = tp[k + 4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tp[R - 4 + k] = tc[k];
+            }
+        }
+        if (Q == 1) {
+            const long m = a0 + R * lb;
+#pragma unroll
+            for (int u = 0; u < R; ++u)
+                if (m + u < a.n_out) reinterpret_cast<d2 *>(a.out)[m + u] = acc[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < R; ++u) ost[Q * (R * lb + u) + b] = acc[u];
+        }
+    }
+    if (Q > 1) {
+        __syncthreads();
+        const long m0 = (long)Q * a0;
+        for (int i = t; i < TA * Q; i += 256) {
+            const long m = m0 + i;
+            if (m < a.n_out) reinterpret_cast<d2 *>(a.out)[m] = ost[i];
+        }
+    }
+}
+
 }  // namespace
 
 // LDS per workgroup: tiles of about 24 KiB (6 workgroups per CU) where the period allows, never more than 64 KiB
@@ -430,6 +622,44 @@ __global__ __launch_bounds__(256) void k_decim_poly_f64(DecimArgs64 a, const Tap
 static constexpr size_t kDecimLdsTarget = RR_V_DECIM_LDS_KB * 1024, kDecimLdsMax = 64 * 1024;
 
 static size_t decim_nc(uint64_t P, size_t L) { return (P - 1 + L + P - 1) / P; }  // tap columns for any phase offset
+
+// k_decim_poly_f64r4's tile: steps per row, staged columns beyond TA, places per row of a set, LDS bytes (0: does not fit)
+struct DecimR4Plan {
+    int R = 0, TA = 0, SR = 0, steps = 0, NCX = 0;
+    size_t lds = 0;
+};
+static DecimR4Plan decim_r4_plan(size_t P, size_t Q, size_t L) {
+    DecimR4Plan pl;
+    // (=0: k_decim_poly_f64 as before; =8: R = 8 where its tile of 512 periods fits - A/B runs, tests.  Measured, f64 chain + f64
+    //  Downsampler per 2^24 samples: R = 4 in tiles of 256 periods (8 workgroups per CU) 145 us, R = 8 in tiles of 512 (4 per CU) 196,
+    //  one period per lane 158: a wave issues a v_fma_f64 every ~13 clocks on its own (scripts/ubench/valu_rate_f64: 23 TFLOP/s at one
+    //  wave per SIMD, 51 at four) - the waves per SIMD count for more than the LDS traffic saved.  Of R = 8's 196 us, 78 are staging
+    //  and stores (the tap loop cut to one step), 12 the stores alone)
+    const char *e = std::getenv("RR_DECIM_F64_R4");
+    const int mode = e ? std::atoi(e) : 4;
+    if (mode == 0 || P < 1 || P > 64 || Q < 1 || Q > 8 || L < 1) return pl;
+    const size_t CM = (L + P - 1) / P;  // taps of a row (the integers = r mod P in a run of L)
+    for (int R : {8, 4}) {
+        if (R > mode) continue;
+        const size_t steps = (CM + (R - 1) + 3) / 4 * 4;  // + the R - 1 steps that only the later periods' taps use
+        const size_t NCX = 2 + steps;                      // c_lo <= 1 (the phases' offsets stay below P): columns up to TA - R + 1 + steps - 1
+        const int ta = 64 * R;
+        size_t sr = (ta + NCX + R - 1) / R + 1;
+        if (!(sr & 1)) ++sr;
+        const size_t bytes = (R * P * sr + (Q > 1 ? (size_t)ta * Q : 0)) * 16;
+        if (bytes <= 48 * 1024) {
+            pl.R = R;
+            pl.TA = ta;
+            pl.SR = (int)sr;
+            pl.steps = (int)steps;
+            pl.NCX = (int)NCX;
+            pl.lds = bytes;
+            break;
+        }
+    }
+    return pl;
+}
+bool decim_poly_f64r4_supported(uint64_t P, uint64_t Q, size_t L) { return decim_r4_plan(P, Q, L).lds != 0; }
 
 static int decim_geometry(size_t P, size_t Q, size_t NC, int *TA, int *S, size_t esz = 8) {
     int best = 0;
@@ -460,6 +690,33 @@ void build_decim_poly_taps(const std::vector<double> &ir, uint64_t P, uint64_t Q
     const size_t L = ir.size(), Lp = (L + 7) / 8 * 8;
     int ta = 0, S = 0;
     const bool f64 = dtype == RR_F64;
+    if (f64) {
+        const DecimR4Plan pl = decim_r4_plan(P, Q, L);
+        if (pl.lds) {
+            // k_decim_poly_f64r<R>: c_lo per (b, r) (Q P ints, padded to an even count), then `steps` f64 taps per (b, r)
+            const size_t nh = (Q * P + 1) / 2 * 2, per = (size_t)pl.steps;
+            T.assign(nh + 2 * Q * P * per, 0u);
+            std::vector<double> te(Q * P * per, 0.0);
+            for (uint64_t b = 0; b < Q; ++b) {
+                const size_t d = (size_t)(e_first[b] - e_first[0]);
+                for (size_t r = 0; r < P; ++r) {
+                    // the row's taps: idx = d + j = P c + r, j < L
+                    const size_t c_lo = d > r ? (d - r + P - 1) / P : 0;
+                    T[b * P + r] = (uint32_t)c_lo;
+                    for (size_t c = c_lo;; ++c) {
+                        const size_t idx = P * c + r;
+                        if (idx < d) continue;
+                        const size_t j = idx - d;
+                        if (j >= L) break;
+                        te[(b * P + r) * per + (c - c_lo)] = ir[j];
+                    }
+                }
+            }
+            std::memcpy(T.data() + nh, te.data(), te.size() * 8);
+            *Lp_out = -1;  // (the table is k_decim_poly_f64r4's)
+            return;
+        }
+    }
     decim_geometry(P, Q, decim_nc(P, L), &ta, &S, f64 ? 16 : 8);
     T.assign((size_t)Q * Lp * (f64 ? 4 : 2), 0u);
     for (uint64_t b = 0; b < Q; ++b) {
@@ -489,6 +746,40 @@ int launch_decim_poly(hipStream_t s, const void *hist, size_t hist_len, const vo
     // would flip to hist_out afterwards must not come here (rr_downsampler::process_dev: `produce &&`)
     if (n_out == 0) {
         if (hist_out) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: k_decim_poly cannot leave a history without producing outputs");
+        return RR_OK;
+    }
+    if (dtype == RR_F64 && Lp == -1) {
+        const DecimR4Plan pl = decim_r4_plan(P, Q, L);
+        if (!pl.lds) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: the tap table is k_decim_poly_f64r4's, the tile is not");
+        DecimArgsR4 a;
+        a.nco = (const double2 *)nco;
+        a.denom = nco ? denom : 0;
+        a.idx0 = idx0;
+        a.hist = (const double2 *)hist;
+        a.hist_len = (int)hist_len;
+        a.in = (const double2 *)in;
+        a.n_in = (long)n_in;
+        a.P = (int)P;
+        a.Q = (int)Q;
+        a.p_ref = (long)e_first0 - (long)(L - 1);
+        a.out = (double2 *)out;
+        a.n_out = (long)n_out;
+        a.hist_out = (double2 *)hist_out;
+        a.hist_out_len = (int)hist_out_len;
+        a.TA = pl.TA;
+        a.SR = pl.SR;
+        a.steps = pl.steps;
+        a.NCX = pl.NCX;
+        a.CL = (const int *)T;
+        a.TE = (const double *)((const uint32_t *)T + (Q * P + 1) / 2 * 2);
+        const size_t per_tile = (size_t)a.TA * Q;
+        const size_t ntiles = (n_out + per_tile - 1) / per_tile;
+        if (ntiles > 0x7ffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: too many tiles");
+        a.ntiles = (unsigned)ntiles;
+        const unsigned grid = (unsigned)((ntiles + 63) / 64 * 64);
+        if (pl.R == 8) hipLaunchKernelGGL(k_decim_poly_f64r<8>, dim3(grid), dim3(256), pl.lds, s, a);
+        else hipLaunchKernelGGL(k_decim_poly_f64r<4>, dim3(grid), dim3(256), pl.lds, s, a);
+        RR_HIP(hipGetLastError());
         return RR_OK;
     }
     if (dtype == RR_F64) {
