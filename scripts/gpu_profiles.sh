@@ -6,6 +6,7 @@
 #   cfg5_kernel_stats.csv, cfg5_pmc_*.summary.txt   the same for BASELINE configs[4] (scripts/prof_cfg5.py)
 #   blocks.txt, cfg5.txt, cfg3.txt   scripts/bench_blocks.py, bench_cfg5.py, bench_cfg3.py
 #   extras.txt, decim_ab.txt, meter.txt, meter_kernel_stats.csv   bench_extras.py, bench_decim_ab.py, bench_meter.py, prof_meter.py
+#   shapes_kernel_stats.csv         per-kernel averages of the two-kernel chain shapes (scripts/prof_shapes.py)
 # usage: scripts/gpu_profiles.sh TAG
 set -u -o pipefail
 TAG="${1:-prof}"
@@ -58,6 +59,8 @@ step decim_ab 300 python3 scripts/bench_decim_ab.py
 step meter 200 python3 scripts/bench_meter.py
 step meterprof 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/meterprof" -- python3 scripts/prof_meter.py
 find "$OUT/meterprof" -name '*kernel_stats*.csv' | head -1 | xargs -r -I{} cp {} "$OUT/meter_kernel_stats.csv"
+step shapes 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/shapesprof" -- python3 scripts/prof_shapes.py
+find "$OUT/shapesprof" -name '*kernel_stats*.csv' | head -1 | xargs -r -I{} cp {} "$OUT/shapes_kernel_stats.csv"
 step clock 300 python3 scripts/clock_probe.py --seconds 4 idle cfg5 chain copy cfg5 chain
 grep -h '^CLOCK_PROBE_JSON' "$OUT/clock.log" | python3 scripts/clock_summary.py > "$OUT/clock_power.txt" || true
 step bank 300 python3 scripts/callsize_probe.py bank 64 12 14 16 18

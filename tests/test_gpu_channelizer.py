@@ -162,7 +162,9 @@ def overlapped_spectra(oracle, chunks, P, window, center_dc, flt, history=None):
                                                   (1024, 1, True, np.float32, 1e-5), (1024, 2, False, np.float32, 1e-5), (512, 4, True, np.float32, 1e-5), (128, 4, True, np.float32, 1e-5), (256, 2, False, np.float32, 1e-5), (2048, 4, True, np.float32, 1e-5), (250, 4, True, np.float32, 1e-5), (100, 3, False, np.float32, 1e-5),
                                                   (100, 3, True, np.float64, 1e-11), (1500, 4, False, np.float32, 1e-5),
                                                   # spans 2^a 3^b 5^c (7 ..): overlapping frames through k_fft_mixed / the two passes of k_fft_tilem
-                                                  (3000, 4, True, np.float32, 1e-5), (2500, 2, False, np.float64, 1e-11), (1001, 4, False, np.float32, 1e-5)])
+                                                  (3000, 4, True, np.float32, 1e-5), (2500, 2, False, np.float64, 1e-11), (1001, 4, False, np.float32, 1e-5),
+                                                  # 16 384-point spans: k_fft16384 with a hop
+                                                  (4096, 4, True, np.float32, 1e-5), (2048, 8, False, np.float32, 1e-5)])
 def test_stft_parity(rr, oracle, M, P, center, dtype, tol):
     """rr_stft_*: Rechunker -> Overlapper -> Fourier on the device (4096-point spans run k_fft4096
     with a hop, the others the generic power-of-two kernel) against the oracle composition."""
@@ -231,7 +233,9 @@ def test_stft_contract(rr):
     with pytest.raises(BackendError):
         rr.Stft(5, 3)  # 15 points: overlapping chunks need a power-of-two span (one LDS tile) or 32 points and more (Bluestein)
     with pytest.raises(BackendError):
-        rr.Stft(4096, 4)  # 16384 points: a power of two beyond the overlapped kernels
+        rr.Stft(8192, 4)  # 32768 points: a power of two beyond the overlapped kernels (one image in LDS: up to 16384 in f32)
+    with pytest.raises(BackendError):
+        rr.Stft(4096, 2, dtype=np.float64)  # (f64: up to 4096)
 
 
 def test_stft_rechunks_arbitrary_input(rr, oracle):
