@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DESIGN = os.path.join(ROOT, "DESIGN.md")
 PROFILES = os.path.join(ROOT, "profiles")
 BLOCK = re.compile(r"(<!-- extract: (\S+)((?: \w+=\S+)*) -->\n)(.*?)(<!-- /extract -->)", re.S)
-CITE = re.compile(r"(?<![\w.])(\d[\d ,.]*\d|\d)\s*(?:ms|us|ns|%|x|W|MHz|GHz|MB|KB|GB/s|TB/s|GSamples/s|MSamples/s|launches|bytes)?\s*\[((?:r\d\d_|traffic_)[\w.]+)\]")
+CITE = re.compile(r"(?<![\w.])(\d[\d ,.]*\d|\d)\s*(?:ms|us|µs|ns|%|x|W|MHz|GHz|MB|KB|GB/s|TB/s|GSamples/s|MSamples/s|launches|bytes)?\s*\[((?:r\d\d[a-z]?_|traffic_)[\w.]+)\]")
 
 
 def render(fname, opts):

@@ -19,12 +19,13 @@ def test_design_quotes_enough_to_be_worth_checking():
 
     text = open(de.DESIGN).read()
     cites = de.citations(text)
-    assert len(de.BLOCK.findall(text)) >= 8 and len(cites) >= 20
+    # (the headline figures are extract blocks of profiles/r03_summary.txt and r03a_summary.txt; the prose carries the rest)
+    assert len(de.BLOCK.findall(text)) >= 11 and len(cites) >= 10
     # every cited file exists and belongs to the round's set (or is the traffic file the bench line reads)
     for _fig, fname in cites:
         assert os.path.exists(os.path.join(de.PROFILES, fname)), fname
     # no profiles/rNN_* path is named in the text without existing
     import re
 
-    for m in re.finditer(r"profiles/((?:r\d\d_|traffic_)[\w.]+?\.(?:txt|csv|json))", text):
+    for m in re.finditer(r"profiles/((?:r\d\d[a-z]?_|traffic_)[\w.]+?\.(?:txt|csv|json))", text):
         assert os.path.exists(os.path.join(de.PROFILES, m.group(1))), m.group(1)
