@@ -40,7 +40,8 @@ struct BigFftLane {
 };
 
 // in: v[k] = x[j + T k]; out: v[k] = X[j + T k].  `late` runs in front of the last butterflies, where few registers are live.
-template <int N, class Late>
+// HIBASE (16 384 points, a kernel that runs the transform twice): see below
+template <int N, bool HIBASE = false, class Late>
 __device__ __forceinline__ void big_fft(f2 (&v)[16], f2 *img, const BigFftLane<N> &ln, int j, bool pre_barrier, Late &&late) {
     constexpr int T = N / 16, R3 = N / 4096, NB = 16 / R3;
     static_assert(N == 8192 || N == 16384, "8192 or 16384 points");
@@ -49,13 +50,17 @@ __device__ __forceinline__ void big_fft(f2 (&v)[16], f2 *img, const BigFftLane<N
     f2 *const w1 = img + ((j >> 4) * 256 + (j & 15));           // + 16 k
     f2 *const w2 = img + ((j >> 8) * 4096 + (j & 255));         // + 256 k
     const f2 *const rd1 = img + j;                              // j + T k = rd1 + T k
+    // (16 384 points: the reads k >= 8 lie more than 64 KiB - the reach of an LDS instruction's offset field - behind their base;
+    //  a second base each, opaque to the compiler, instead of eight addresses per pattern kept in registers across both transforms)
+    const f2 *rdh = rd + (T + T / 16) * 8, *rd1h = rd1 + T * 8;
+    if constexpr (N == 16384 && HIBASE) asm volatile("" : "+v"(rdh), "+v"(rd1h));
     dft16(v);
     if (pre_barrier) big_lds_bar();  // the previous transform's last reads are done
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds_stv(w0 + k, v[k]);
     big_lds_bar();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = lds_ldv(rd + (T + T / 16) * k);
+    for (int k = 0; k < 16; ++k) v[k] = k < 8 ? lds_ldv(rd + (T + T / 16) * k) : lds_ldv(rdh + (T + T / 16) * (k - 8));
 #pragma unroll
     for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], lds_ldv(ln.trow + k));
     dft16(v);
@@ -64,7 +69,7 @@ __device__ __forceinline__ void big_fft(f2 (&v)[16], f2 *img, const BigFftLane<N
     for (int k = 0; k < 16; ++k) lds_stv(w1 + 16 * k, v[k]);
     big_lds_bar();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = lds_ldv(rd1 + T * k);
+    for (int k = 0; k < 16; ++k) v[k] = k < 8 ? lds_ldv(rd1 + T * k) : lds_ldv(rd1h + T * (k - 8));
     twiddle16(v, ln.s2);
     dft16(v);
     big_lds_bar();
@@ -72,7 +77,7 @@ __device__ __forceinline__ void big_fft(f2 (&v)[16], f2 *img, const BigFftLane<N
     for (int k = 0; k < 16; ++k) lds_stv(w2 + 256 * k, v[k]);
     big_lds_bar();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = lds_ldv(rd1 + T * k);
+    for (int k = 0; k < 16; ++k) v[k] = k < 8 ? lds_ldv(rd1 + T * k) : lds_ldv(rd1h + T * (k - 8));
     late();
     constexpr float WR[8] = {1.f, 0.92387953251128673848f, 0.70710678118654752440f, 0.38268343236508978178f,
                              0.f, -0.38268343236508978178f, -0.70710678118654752440f, -0.92387953251128673848f};

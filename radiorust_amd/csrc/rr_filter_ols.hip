@@ -384,17 +384,35 @@ __global__ __launch_bounds__(N / 16) void k_filter_blkbig(BlkBigArgs a) {
     }
 
     const __amdgpu_buffer_rsrc_t rsG = rsrc_of(a.G, 8u * N);
+    // the lane's 16 G values: 8 reads of 16 bytes; 8192 points: requested in front of the forward transform's last butterflies; 16 384
+    // points (128 registers per lane at 1024 lanes): in two halves behind it - kept through the last pass they spilled 10 registers,
+    // and scratch is HBM traffic
     float4 g4[8];
-    big_fft<N>(v, img, ln, j, false, [&] {
+    big_fft<N, true>(v, img, ln, j, false, [&] {
+        if constexpr (N == 8192) {
 #pragma unroll
-        for (int kp = 0; kp < 8; ++kp) g4[kp] = buf_ld_f4<0>(rsG, 16u * j, 16u * T * kp);
+            for (int kp = 0; kp < 8; ++kp) g4[kp] = buf_ld_f4<0>(rsG, 16u * j, 16u * T * kp);
+        }
     });
+    if constexpr (N == 8192) {
 #pragma unroll
-    for (int kp = 0; kp < 8; ++kp) {
-        v[2 * kp] = cmul(v[2 * kp], (f2){g4[kp].x, g4[kp].y});
-        v[2 * kp + 1] = cmul(v[2 * kp + 1], (f2){g4[kp].z, g4[kp].w});
+        for (int kp = 0; kp < 8; ++kp) {
+            v[2 * kp] = cmul(v[2 * kp], (f2){g4[kp].x, g4[kp].y});
+            v[2 * kp + 1] = cmul(v[2 * kp + 1], (f2){g4[kp].z, g4[kp].w});
+        }
+    } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) g4[kp] = buf_ld_f4<0>(rsG, 16u * j, 16u * T * (4 * h + kp));
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) {
+                v[8 * h + 2 * kp] = cmul(v[8 * h + 2 * kp], (f2){g4[kp].x, g4[kp].y});
+                v[8 * h + 2 * kp + 1] = cmul(v[8 * h + 2 * kp + 1], (f2){g4[kp].z, g4[kp].w});
+            }
+        }
     }
-    big_fft<N>(v, img, ln, j, true, [] {});
+    big_fft<N, true>(v, img, ln, j, true, [] {});
 
     // y[t] = v[k] with t = (N - (j + T k)) mod N; valid for t >= V: output mbase + t - V = mbase + hop - j - T k
     // (t = 0 lands on `hop`, t < V wraps to a huge offset: the descriptor's range check drops both)

@@ -1167,6 +1167,9 @@ constexpr int kFrameBlocks = 20;
 // One 1024-sample block of k_ols_wave<4, POLY> as a function (the fused frame kernel's waves run five of them in a
 // row): v = mixed samples in the pair layout, hv = the lane's 16 entries of the polyphase tables G_p; y[c] =
 // result[l + 64 c] of the 256-point inverse.  See k_ols_wave for the passes and the two exchange images.
+#ifndef RR_V_FRAME_PAIRS
+#define RR_V_FRAME_PAIRS 1  // poly4_block: the phases' values two phases at a time (0: all four at once, which spills - A/B)
+#endif
 #ifndef RR_V_FRAME_GLDS
 #define RR_V_FRAME_GLDS 1  // k_ols_frame: the first half of the tables G_p in LDS (0: all of it from L2, for A/B)
 #endif
@@ -1223,6 +1226,53 @@ __device__ __forceinline__ void poly4_block(f2 (&v)[16], f2 (&y)[4], f2 *lds, in
     wave_sync();
     // the lane's 16 entries of G_p are requested HERE, in two halves (phases 0, 1 / 2, 3), not in front of the transform as
     // k_ols_wave does: kept through the passes they are 32 registers the frame kernel does not have
+#if RR_V_FRAME_PAIRS
+    // ... and the phases are taken two at a time (a = 0: phases 0, 1 with the half of G_p in LDS; a = 1: phases 2, 3 with the half
+    // from L2, requested in front of the first pair's arithmetic): 16 values of the exchange image in registers instead of 32 -
+    // with all four phases' values live beside the five blocks' results the kernel spilled two results of its first block, and
+    // scratch is HBM traffic (4 KiB written and read back per workgroup: 17 MB of the launch's 151 MB of writes)
+    float4 ga[4], gb[4];
+#pragma unroll
+    for (int kp = 0; kp < 4; ++kp) ga[kp] = RR_V_FRAME_GLDS ? Glds[l + 64 * kp] : reinterpret_cast<const float4 *>(G)[l + 64 * kp];
+#pragma unroll
+    for (int kp = 0; kp < 4; ++kp) gb[kp] = reinterpret_cast<const float4 *>(G)[l + 64 * (4 + kp)];
+    const f2 w1 = t_p2, w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        f2 d[2][4];
+#pragma unroll
+        for (int m1 = 0; m1 < 4; ++m1) {
+            const float4 r = *reinterpret_cast<const float4 *>(lds + 2 * l + 130 * (a + 2 * m1));
+            d[0][m1] = (f2){r.x, r.y};
+            d[1][m1] = (f2){r.z, r.w};
+        }
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            d[pp][1] = cmul(d[pp][1], w1);
+            d[pp][2] = cmul(d[pp][2], w2);
+            d[pp][3] = cmul(d[pp][3], w3);
+            dft4(d[pp][0], d[pp][1], d[pp][2], d[pp][3]);
+        }
+        // entry i = 4 p + c is half (i & 1) of piece i >> 1: phase 0 = pieces 0, 1; phase 1 = 2, 3; ..
+        const float4 *gp = a == 0 ? ga : gb;
+        if (a == 0) {
+            y[0] = cmul(d[0][0], (f2){gp[0].x, gp[0].y});
+            y[1] = cmul(d[0][1], (f2){gp[0].z, gp[0].w});
+            y[2] = cmul(d[0][2], (f2){gp[1].x, gp[1].y});
+            y[3] = cmul(d[0][3], (f2){gp[1].z, gp[1].w});
+        } else {
+            y[0] = cmac(y[0], d[0][0], (f2){gp[0].x, gp[0].y});
+            y[1] = cmac(y[1], d[0][1], (f2){gp[0].z, gp[0].w});
+            y[2] = cmac(y[2], d[0][2], (f2){gp[1].x, gp[1].y});
+            y[3] = cmac(y[3], d[0][3], (f2){gp[1].z, gp[1].w});
+        }
+        y[0] = cmac(y[0], d[1][0], (f2){gp[2].x, gp[2].y});
+        y[1] = cmac(y[1], d[1][1], (f2){gp[2].z, gp[2].w});
+        y[2] = cmac(y[2], d[1][2], (f2){gp[3].x, gp[3].y});
+        y[3] = cmac(y[3], d[1][3], (f2){gp[3].z, gp[3].w});
+        if (a == 0) __builtin_amdgcn_sched_barrier(0);  // (the second pair's values are not read in front of the first pair's sums)
+    }
+#else
     float4 ga[4], gb[4];
 #pragma unroll
     for (int kp = 0; kp < 4; ++kp) ga[kp] = RR_V_FRAME_GLDS ? Glds[l + 64 * kp] : reinterpret_cast<const float4 *>(G)[l + 64 * kp];
@@ -1264,6 +1314,7 @@ __device__ __forceinline__ void poly4_block(f2 (&v)[16], f2 (&y)[4], f2 *lds, in
     y[1] = cmac(y[1], d[3][1], (f2){gb[2].z, gb[2].w});
     y[2] = cmac(y[2], d[3][2], (f2){gb[3].x, gb[3].y});
     y[3] = cmac(y[3], d[3][3], (f2){gb[3].z, gb[3].w});
+#endif
     if (SW) {
         const f2 t0 = y[0], t1 = y[1];
         y[0] = y[2];
