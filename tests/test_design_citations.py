@@ -20,7 +20,7 @@ def test_design_quotes_enough_to_be_worth_checking():
     text = open(de.DESIGN).read()
     cites = de.citations(text)
     # (the headline figures are extract blocks of profiles/r03_summary.txt and r03a_summary.txt; the prose carries the rest)
-    assert len(de.BLOCK.findall(text)) >= 11 and len(cites) >= 10
+    assert len(de.BLOCK.findall(text)) >= 12 and len(cites) >= 6
     # every cited file exists and belongs to the round's set (or is the traffic file the bench line reads)
     for _fig, fname in cites:
         assert os.path.exists(os.path.join(de.PROFILES, fname)), fname
