@@ -500,6 +500,8 @@ FAST_CASES = [
     (48000.0, 44100.0, 40000.0, 3.0, 10),     # 160 : 147, L = 71
     (1024000.0, 44100.0, 20000.0, 3.0, 10),   # 10240 : 441, L = 255
     (220500.0, 48000.0, 40000.0, 2.0, 10),    # 147 : 32, L = 111
+    (48000.0, 44100.5, 30000.0, 2.0, 10),     # rates on the 2^-1 grid: 96000 : 88201, closed form (the sample loop before)
+    (1000.25, 333.125, 200.0, 2.0, 10),       # 2^-3 grid: 8002 : 2665
     (1024000.0, 44100.0, 30000.0, 3.0, 0),    # L = 436: beyond k_filter_wave's overlap -> k_fir with the emission list
 ]
 
@@ -628,6 +630,22 @@ def test_downsampler_rate_change_resets(rr, oracle):
     x = oracle.synth_iq(10, 0, 4000)
     for rate, a, b in ((96000.0, 0, 1500), (192000.0, 1500, 3000), (96000.0, 3000, 4000)):
         check(g.process_raw(rate, x[a:b]), o.process(rate, x[a:b]))
+
+
+@pytest.mark.parametrize("fin,fout,bw,q", [(48000.0, 44100.0, 40000.0, 3.0), (48000.0, 44100.5, 30000.0, 2.0), (48000.0, 44100.1, 30000.0, 2.0)])
+def test_downsampler_f64_long_periods(rr, oracle, fin, fout, bw, q):
+    """Complex<f64> beyond k_decim_poly_f64's 8 phases: k_fir with the periodic schedule in closed form (160 : 147, 96000 : 88201
+    on the 2^-1 grid) and with the emission list (44100.1: off every grid the f64 sums stay exact on); ragged calls."""
+    n = 60000
+    x = oracle.synth_iq(18, 0, n).astype(np.complex128)
+    g = rr.Downsampler.with_quality(1000, fout, bw, q, dtype=np.float64)
+    o = oracle.Downsampler(1000, fout, bw, q, flt=np.float64)
+    cuts = [0, 5000, 5003, 40000, 40001, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        y, r = g.process_raw(fin, x[a:b]), o.process(fin, x[a:b])
+        assert len(y) == len(r) and g.last_kernel() == 0
+        if len(y) > 8:
+            assert rms_rel(y, r) <= 1e-12
 
 
 def test_downsampler_f64(rr, oracle):
