@@ -215,14 +215,15 @@ int launch_fft4096(hipStream_t s, const void *head, size_t n_head, const void *i
 
 // the 4096-bin polyphase channelizer (see k_fft4096<true>)
 // ---------------------------------------------------------------------------
-// Kernel 2y  k_fft16384: window * v -> 16 384-point forward DFT in ONE pass over HBM: a workgroup of 1024 lanes per frame, 16
+// Kernel 2y  k_fft_big<16384> ("k_fft16384"): window * v -> 16 384-point forward DFT in ONE pass over HBM: a workgroup of 1024 lanes per frame, 16
 // values per lane, the transform of rr_fft_big.hpp (radix 16 x 16 x 16 x 4 through one 136 KiB image in LDS, one workgroup per
 // CU) - the two passes of k_fft_tile move every sample through HBM twice.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_fft16384(const float2 *__restrict__ head, long n_head, const float2 *__restrict__ in,
-                                                   float2 *__restrict__ out, const float *__restrict__ window,
-                                                   const float2 *__restrict__ tw, int center_dc, long hop) {
-    constexpr int N = 16384, T = N / 16;
+template <int N>
+__global__ __launch_bounds__(N / 16) void k_fft_big(const float2 *__restrict__ head, long n_head, const float2 *__restrict__ in,
+                                                    float2 *__restrict__ out, const float *__restrict__ window,
+                                                    const float2 *__restrict__ tw, int center_dc, long hop) {
+    constexpr int T = N / 16;
     extern __shared__ __attribute__((aligned(16))) f2 fft16k_smem[];
     f2 *const img = fft16k_smem;
     const int j = threadIdx.x;
@@ -244,17 +245,28 @@ __global__ __launch_bounds__(1024) void k_fft16384(const float2 *__restrict__ he
     for (int k = 0; k < 16; ++k) __builtin_nontemporal_store(v[k], dst + ((j + T * k + rot) & (N - 1)));
 }
 
-int launch_fft16384(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count, const void *window,
-                    const void *tw16384, bool center_dc, size_t hop) {
+template <int N>
+static int launch_fft_big_n(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count, const void *window,
+                            const void *twN, bool center_dc, size_t hop) {
     if (count == 0) return RR_OK;
-    if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fft16384: too many frames");
-    constexpr size_t lds = (size_t)big_fft_lds_elems<16384>() * sizeof(f2);
+    if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fft_big: too many frames");
+    constexpr size_t lds = (size_t)big_fft_lds_elems<N>() * sizeof(f2);
     // (per launch: the attribute belongs to the device the call runs on)
-    RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft16384), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_fft16384, dim3((unsigned)count), dim3(1024), lds, s, (const float2 *)head, (long)n_head, (const float2 *)in,
-                       (float2 *)out, (const float *)window, (const float2 *)tw16384, (int)center_dc, (long)hop);
+    RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_big<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_fft_big<N>, dim3((unsigned)count), dim3(N / 16), lds, s, (const float2 *)head, (long)n_head, (const float2 *)in,
+                       (float2 *)out, (const float *)window, (const float2 *)twN, (int)center_dc, (long)hop);
     RR_HIP(hipGetLastError());
     return RR_OK;
+}
+int launch_fft16384(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count, const void *window,
+                    const void *tw16384, bool center_dc, size_t hop) {
+    return launch_fft_big_n<16384>(s, head, n_head, in, out, count, window, tw16384, center_dc, hop);
+}
+// 8192 points through the same transform, 512 lanes with 16 values each: the default since it measured 69 % against the 58 % of
+// k_fft8192's 256 lanes with 32 values (RR_FOURIER_8K=regs)
+int launch_fft8192_big(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count, const void *window,
+                       const void *tw8192, bool center_dc, size_t hop) {
+    return launch_fft_big_n<8192>(s, head, n_head, in, out, count, window, tw8192, center_dc, hop);
 }
 
 __global__ __launch_bounds__(256) void k_chan4096_pair(const float2 *__restrict__ head, long n_head, const float2 *__restrict__ in,

@@ -1896,8 +1896,13 @@ int launch_fourier_overlapped(int dtype, hipStream_t s, const void *head, size_t
         return launch_fft4096(s, head, n_head, in, out, count, window, twiddle, center_dc, hop);
     if (dtype == RR_F32 && (n == 64 || n == 128) && hop == n && n_head == 0 && !generic)
         return launch_fft_small(s, in, out, n, count, window, twiddle, center_dc);
-    if (dtype == RR_F32 && n == 8192 && !generic)
-        return launch_fft8192(s, head, n_head, in, out, count, window, twiddle, center_dc, hop);
+    if (dtype == RR_F32 && n == 8192 && !generic) {
+        // 512 lanes with 16 values each (rr_fft_big.hpp) instead of k_fft8192's 256 lanes with 32: 0.194 against 0.230 ms per 2^26
+        // samples in one session (RR_FOURIER_8K=regs keeps k_fft8192 - A/B runs, tests)
+        const char *e8 = std::getenv("RR_FOURIER_8K");
+        if (e8 && !std::strcmp(e8, "regs")) return launch_fft8192(s, head, n_head, in, out, count, window, twiddle, center_dc, hop);
+        return launch_fft8192_big(s, head, n_head, in, out, count, window, twiddle, center_dc, hop);
+    }
     if (dtype == RR_F32 && n == 16384)  // (pow2_limit: only without RR_FOURIER_GENERIC / RR_FOURIER_16K=0)
         return launch_fft16384(s, head, n_head, in, out, count, window, twiddle, center_dc, hop);
     if (dtype == RR_F32 && n == 512 && !generic)

@@ -234,6 +234,8 @@ int launch_fft_big(int dtype, hipStream_t s, const void *in, void *out, void *ws
 // k_fft16384: 1024 lanes per 16384-sample frame (rr_fft_big.hpp), plain window and twiddle tables
 int launch_fft16384(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count, const void *window,
                     const void *tw16384, bool center_dc, size_t hop);
+int launch_fft8192_big(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count, const void *window,
+                       const void *tw8192, bool center_dc, size_t hop);
 // k_fft8192: 256 lanes per 8192-sample frame, 32 values per lane (plain window and twiddle tables)
 int launch_fft8192(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count,
                    const void *window, const void *tw8192, bool center_dc, size_t hop);

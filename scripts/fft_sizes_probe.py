@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import radiorust_amd as rr
 N = 1 << 26
@@ -7,7 +7,7 @@ st = torch.cuda.current_stream().cuda_stream
 d_in = torch.empty(N, dtype=torch.complex64, device="cuda")
 rr.synth_iq_dev(0, st, 1, 0, N, d_in.data_ptr())
 d_out = torch.empty(N, dtype=torch.complex64, device="cuda")
-for n in (64, 128, 256, 512, 1024, 2048, 4096, 8192, 1000):
+for n in (64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 1000):
     fo = rr.Fourier.with_window(rr.Kaiser.with_null_at_bin(2.0))
     fo.set_stream(st)
     M = N // n * n

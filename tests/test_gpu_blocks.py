@@ -872,6 +872,24 @@ def test_fourier_batched_device_api(rr, oracle):
     check(d_out.cpu().numpy(), ref)
 
 
+def test_fourier_8192_register_kernel_on_request(rr, oracle, monkeypatch):
+    """RR_FOURIER_8K=regs: k_fft8192 (256 lanes with 32 values each), the default before k_fft_big<8192>."""
+    import torch
+
+    monkeypatch.setenv("RR_FOURIER_8K", "regs")
+    n, k = 8192, 9
+    x = oracle.synth_iq(16, 0, n * k)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.empty_like(d_in)
+    for center in (False, True):
+        g = rr.Fourier(rr.Kaiser.with_null_at_bin(2.0), center)
+        assert g.process_dev(n, d_in.data_ptr(), n * k, d_out.data_ptr(), n * k) == n * k
+        torch.cuda.synchronize()
+        o64 = oracle.Fourier(oracle.Kaiser.with_null_at_bin(2.0), center, flt=np.float64)
+        ref = np.concatenate([o64.process(x[i * n:(i + 1) * n]) for i in range(k)])
+        check(d_out.cpu().numpy(), ref)
+
+
 @pytest.mark.parametrize("n,center", [(1024, False), (1024, True), (256, False), (2048, False), (2048, True), (512, False), (512, True), (8192, True), (64, False), (64, True), (128, False), (128, True),
                                       (16384, False), (16384, True)])
 def test_fourier_wave_kernels_batched(rr, oracle, n, center, monkeypatch):
