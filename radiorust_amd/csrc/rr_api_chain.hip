@@ -254,6 +254,10 @@ int rr_chain::pick_fused_kernel(uint64_t D, size_t lc, bool real_taps, size_t ff
     if (can_direct) return FK_DIRECT;
     if (can_wave) return FK_OLSW;
     if (can_ols) return FK_OLS;
+    // every other integer ratio (the example's 10 : 1, examples/bandwidth_meter/main.rs:56): mixer + combined response + decimation
+    // as one pass of the polyphase decimator, as the f64 chain (real taps; RR_CHAIN_POLY=0 keeps the four blocks)
+    static const bool poly_off = [] { const char *pe = std::getenv("RR_CHAIN_POLY"); return pe && std::atoi(pe) == 0; }();
+    if (!poly_off && real_taps && D >= 2 && decim_poly_supported(RR_F32, D, 1, lc)) return FK_POLY;
     return FK_NONE;
 }
 
@@ -449,14 +453,15 @@ int rr_chain::ensure_ctaps() {
             cc[j + k] += a * (fl->real_taps ? cd(fl->taps_f64[k].real(), 0.0) : fl->taps_f64[k]);
         }
     }
-    if (dtype == RR_F64) {
-        // k_decim_poly_f64's tap list for ir = reverse(c): out[m] = sum_j ir[j] xs[e_m - (Lc - 1) + j] = sum_i c[i] xs[e_m - i]
+    const int fk = dtype == RR_F64 ? (int)FK_POLY : pick_fused_kernel(ds->sched.D, lc, fl->real_taps, p.fft_len);
+    if (fk == FK_POLY) {
+        // k_decim_poly(_f64)'s tap list for ir = reverse(c): out[m] = sum_j ir[j] xs[e_m - (Lc - 1) + j] = sum_i c[i] xs[e_m - i]
         std::vector<double> ir(lc);
         for (size_t j = 0; j < lc; ++j) ir[j] = c[lc - 1 - j];
         std::vector<uint32_t> T;
         const int64_t e0 = 0;
         int lp = 0;
-        build_decim_poly_taps(ir, ds->sched.D, 1, &e0, T, &lp, RR_F64);
+        build_decim_poly_taps(ir, ds->sched.D, 1, &e0, T, &lp, dtype);
         RR_TRY(upload(d_ctaps, T.data(), T.size() * sizeof(uint32_t), stream));
         poly64_Lp = lp;
         use_poly64 = true;
@@ -467,7 +472,6 @@ int rr_chain::ensure_ctaps() {
         return RR_OK;
     }
     use_poly64 = false;
-    const int fk = pick_fused_kernel(ds->sched.D, lc, fl->real_taps, p.fft_len);
     FusedFirTables t;
     build_fused_fir_tables(fk, ds->sched.D, c, cc, t);
     use_frame = fk == FK_OLSF;
@@ -614,9 +618,9 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
         tk = timers.begin(ST_FUSED_FIR, stream);
     if (use_poly64) {
         RR_TRY(launch_decim_poly(stream, a.xh, HX, d_in, n_in, d_ctaps.p, ds->sched.D, 1, poly64_Lp, Lc, a.e0, newv, dec, a.xh_out, HX,
-                                 a.nco, a.denom, a.idx0, RR_F64));
+                                 a.nco, a.denom, a.idx0, dtype));
         if (dec == 0)  // (no output, no tile: the history by a launch of its own)
-            RR_FAIL(RR_ERR_BAD_ARG, "Chain: a fused f64 call must produce output");
+            RR_FAIL(RR_ERR_BAD_ARG, "Chain: a call through the polyphase decimator must produce output");
     } else if (use_ols && ols_N == 1024) {
         if (ols_poly) RR_TRY(fold_mixer(a, 0));
         RR_TRY(launch_ols_wave(stream, a));

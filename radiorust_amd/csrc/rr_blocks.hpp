@@ -349,7 +349,7 @@ struct rr_chain : rr_block {
     bool use_frame = false;      // FK_OLSF: k_ols_frame (FIR stage + Fourier in one kernel)
     // Complex<f64>: mixer + combined FIR + decimation as ONE pass of k_decim_poly_f64 (the polyphase kernel with the phase table
     // riding along: 16 B read + 16 / D written per sample instead of the four blocks' 84), then the Fourier block
-    bool use_poly64 = false;
+    bool use_poly64 = false;  // the front end through k_decim_poly(_f64): Complex<f64>, and f32 at integer ratios without an overlap-save kernel
     int poly64_Lp = 0;
     // k_ols_frame with the mixer folded into the tables (NCO periods that divide 8): G'_p[k] = G_p[(k + s) mod 256] e^{j 2 pi p numer / R}
     std::vector<rr::cd> olsG64;

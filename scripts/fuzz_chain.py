@@ -13,7 +13,8 @@ worst, used = 0.0, {}
 for case in range(cases):
     fs = 200e6
     filter_len = int(rng.choice([64, 128, 256]))
-    out_rate, bw = [(50e6, 30e6), (50e6, 40e6), (50e6, 44e6), (100e6, 80e6), (25e6, 20e6)][int(rng.integers(0, 5))]
+    # (20 MS/s and 40 MS/s: 10 : 1 and 5 : 1 - the chain's front end through k_decim_poly)
+    out_rate, bw = [(50e6, 30e6), (50e6, 40e6), (50e6, 44e6), (100e6, 80e6), (25e6, 20e6), (20e6, 12e6), (40e6, 30e6)][int(rng.integers(0, 7))]
     precision = float(rng.choice([1.0, 1e3, 1e5, 12345.0]))
     shift = float(rng.uniform(-60e6, 60e6)) if rng.random() < 0.7 else float(rng.choice([25e6, 12.5e6, 0.0, -50e6]))
     cut = float(rng.uniform(2e6, 24e6))
