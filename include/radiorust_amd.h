@@ -217,7 +217,7 @@ int rr_filter_process_dev_f16(rr_filter *h, double sample_rate, const void *d_in
  * (2n-point overlap-save, the reference's recipe), 2 k_filter_blk4096 (4096-point blocks),
  * 3 k_filter_wave (a wave per 1024-sample block; f32, n <= 385, calls of >= 16384 outputs),
  * 4 the blocks of 2^14 .. 2^18 points through the tile transform (n >= 16384), 5 k_filter_blk16k
- * (16384-point blocks in LDS; f32, n = 2049 .. 8192).
+ * (16384-point blocks in LDS; f32, n = 2049 .. 8192), 6 k_ols4096_f64 (Complex<f64>, n <= 2049, calls of >= 4096 outputs).
  * RR_FILTER_KERNEL=ols4096|fir|parts in the environment (read at design time) keeps the older kernels. */
 int rr_filter_last_kernel(const rr_filter *h, int *kernel);
 int rr_filter_destroy(rr_filter *h);
@@ -323,7 +323,7 @@ int rr_chain_process_dev(rr_chain *h, double sample_rate, const void *d_in,
  * (1 direct-form k_mix_fir_decim, 2 overlap-save k_ols_decim4, 3 overlap-save
  * k_ols_wave, each followed by k_fft4096; 4 k_ols_frame: both stages in one kernel; 6 / 7 k_ols_frame / k_ols_wave
  * with the mixer folded into the response tables - NCO periods that divide 8; 8 / 9 k_ols_frame / k_ols_wave with the
- * mixer moved behind the filter - every other NCO period). */
+ * mixer moved behind the filter - every other NCO period; 5 k_decim_poly(_f64); 11 k_ols4096_f64: Complex<f64> overlap-save). */
 /* as rr_stft_set_metering (the rate of the spectra is the chain's output_rate): bandwidth and energy of every spectrum the
  * chain produces, computed in the kernel that makes it (k_ols_frame / k_fft4096 for 4096-point spectra) */
 int rr_chain_set_metering(rr_chain *h, double double_percentile, double *d_bandwidth,

@@ -509,7 +509,7 @@ class Chain(_Block):
         """Name of the mix + FIR + decimate kernel the last call ran ("" = block-by-block)."""
         v = C.c_int()
         _lib.check(_lib.lib().rr_chain_last_path(self._h, C.byref(v)))
-        return ["", "k_mix_fir_decim", "k_ols_decim4", "k_ols_wave", "k_ols_frame", "k_decim_poly", "k_ols_frame", "k_ols_wave", "k_ols_frame", "k_ols_wave"][v.value]
+        return ["", "k_mix_fir_decim", "k_ols_decim4", "k_ols_wave", "k_ols_frame", "k_decim_poly", "k_ols_frame", "k_ols_wave", "k_ols_frame", "k_ols_wave", "", "k_ols4096_f64"][v.value]
 
     def last_path_mixer_folded(self) -> bool:
         """True if the last call ran k_ols_frame<true> or k_ols_wave<4, true, true>: the mixer folded into the response tables

@@ -287,6 +287,19 @@ int rr_filter::build_tables(bool reset_history) {
         RR_TRY(upload(d_tww, t.tw.data(), t.tw.size() * sizeof(float), stream));
         wave_V = t.V;
     }
+    // Complex<f64>, up to 2049 taps: blocks of 4096 points (k_ols4096_f64; RR_FILTER_KERNEL=fir|ols keeps k_fir / k_filter_ols<double>)
+    use_ols64 = false;
+    {
+        const char *e = std::getenv("RR_FILTER_KERNEL");
+        if (dtype == RR_F64 && len >= 2 && len - 1 <= 2048 && !use_conv && !(e && (!std::strcmp(e, "fir") || !std::strcmp(e, "ols")))) {
+            std::vector<double> G, tw;
+            ols64_tables(g, G, tw);
+            RR_TRY(upload(d_G64, G.data(), G.size() * sizeof(double), stream));
+            RR_TRY(upload(d_tw64, tw.data(), tw.size() * sizeof(double), stream));
+            V64 = std::max<size_t>(64, (len - 1 + 63) / 64 * 64);
+            use_ols64 = true;
+        }
+    }
     use_ols = !use_ols4096 && !big_ols4096 && !npart && ols_supported(dtype, len);
     if (use_ols) {
         // the reference's extended response (filters.rs:220-238), transformed in f64 here
@@ -444,6 +457,14 @@ int rr_filter::process_dev(double sample_rate, const void *d_in, size_t n_in, vo
         hist_valid = true;
         if (n_out) *n_out = produce;
         return RR_OK;
+    } else if (produce && use_ols64 && produce >= 4096) {
+        last_kernel = 6;
+        RR_TRY(launch_ols4096_f64(stream, hist[cur].p, hist_valid ? n : 0, d_in, n_in, d_G64.p, d_tw64.p, V64, 1, d_out, produce,
+                                  hist_valid ? 0 : (long)n, hist[cur ^ 1].p, n, nullptr, 0, 0));
+        cur ^= 1;
+        hist_valid = true;
+        if (n_out) *n_out = produce;
+        return RR_OK;
     } else if (produce && use_ols) {
         last_kernel = 1;
         RR_TRY(launch_filter_ols(dtype, stream, hist[cur].p, d_in, n, produce / n, hist_valid ? 0 : 1, d_H.p, d_olstw.p, d_out));
@@ -567,6 +588,17 @@ int rr_downsampler::process_dev(double input_rate, const void *d_in, size_t n_in
             return RR_OK;
         }
         if (nco) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: a mixer can only ride along with k_decim_poly (can_fuse_mixer)");
+        if (fast_kind == rr_chain::FK_OLS64) {
+            // out[m] = sum_i c[i] x[e0 + D m - i], c = reverse(ir); the kernel's last workgroup leaves the last L samples as the history
+            next.advance(n_in, nullptr);
+            RR_TRY(launch_ols4096_f64(stream, hist[cur].p, L, d_in, n_in, f_H.p, f_tw.p, f_V64, sched.D, d_out, produce,
+                                      (long)sched.first_emit(), hist[cur ^ 1].p, L, nullptr, 0, 0));
+            sched = next;
+            cur ^= 1;
+            last_kernel = fast_kind;
+            if (n_out) *n_out = produce;
+            return RR_OK;
+        }
         if (fast_kind == rr_chain::FK_SELECT) {
             next.advance(n_in, nullptr);
             RR_TRY(launch_decim_select(stream, hist[cur].p, L, d_in, n_in, f_H.p, f_tw.p, f_V, d_out, produce, sched.ra, sched.rb,
@@ -699,6 +731,22 @@ int rr_downsampler::ensure_fast() {
         // RR_DOWNSAMPLER_POLY=1: k_decim_poly also where a fused kernel applies (A/B runs)
         const char *pe = std::getenv("RR_DOWNSAMPLER_POLY");
         if (pe && std::atoi(pe) != 0 && decim_poly_supported(dtype, sched.P, sched.Q, L)) kind = rr_chain::FK_NONE;
+    }
+    // Complex<f64> at integer ratios: overlap-save in blocks of 4096 points (k_ols4096_f64; RR_DOWNSAMPLER_POLY=1 keeps the decimator)
+    if (dtype == RR_F64 && sched.integer_ratio && !force_select) {
+        const char *pe = std::getenv("RR_DOWNSAMPLER_POLY");
+        const size_t V = ols4096_f64_overlap(L, sched.D);
+        if (V && !(pe && std::atoi(pe) != 0)) {
+            std::vector<cd> cc(L);
+            for (size_t i = 0; i < L; ++i) cc[i] = cd(ir_f64[L - 1 - i], 0.0);
+            std::vector<double> G, tw;
+            ols64_tables(cc, G, tw);
+            RR_TRY(upload(f_H, G.data(), G.size() * sizeof(double), stream));
+            RR_TRY(upload(f_tw, tw.data(), tw.size() * sizeof(double), stream));
+            f_V64 = V;
+            fast_kind = rr_chain::FK_OLS64;
+            return RR_OK;
+        }
     }
     if (kind == rr_chain::FK_NONE) {
         // every other integer ratio, and rational ratios with a short period (the tap table follows per call)

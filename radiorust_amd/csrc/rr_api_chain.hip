@@ -192,9 +192,18 @@ int rr_chain::peek(double sample_rate, size_t n_in, size_t *n_frames) {
 }
 
 // parameters for which the fused kernels exist at all (independent of stream state)
+// Complex<f64>: overlap-save in blocks of 4096 points (any taps, Lc <= 2049; RR_CHAIN_F64_FUSED=poly keeps the decimator), else
+// the polyphase decimator (real taps)
+static bool chain_ols64_ok(const rr_chain *c, size_t lc) {
+    const char *e = std::getenv("RR_CHAIN_F64_FUSED");  // ("0": the four blocks; "poly": the decimator; read per design)
+    if (e && (!std::strcmp(e, "0") || !std::strcmp(e, "poly"))) return false;
+    return c->ds->sched.D >= 1 && ols4096_f64_overlap(lc, c->ds->sched.D) != 0;
+}
 static bool chain_poly64_ok(const rr_chain *c, size_t lc) {
-    static const bool off = [] { const char *e = std::getenv("RR_CHAIN_F64_FUSED"); return e && std::atoi(e) == 0; }();
-    return !off && c->fl->real_taps && c->ds->sched.D >= 2 && decim_poly_supported(RR_F64, c->ds->sched.D, 1, lc);
+    const char *e = std::getenv("RR_CHAIN_F64_FUSED");
+    if (e && !std::strcmp(e, "0")) return false;
+    if (chain_ols64_ok(c, lc)) return true;
+    return c->fl->real_taps && c->ds->sched.D >= 2 && decim_poly_supported(RR_F64, c->ds->sched.D, 1, lc);
 }
 
 bool rr_chain::fused_candidate(double sample_rate) const {
@@ -453,6 +462,20 @@ int rr_chain::ensure_ctaps() {
             cc[j + k] += a * (fl->real_taps ? cd(fl->taps_f64[k].real(), 0.0) : fl->taps_f64[k]);
         }
     }
+    use_ols64 = false;
+    if (dtype == RR_F64 && chain_ols64_ok(this, lc)) {
+        std::vector<double> G, tw;
+        ols64_tables(cc, G, tw);
+        RR_TRY(upload(d_olsH, G.data(), G.size() * sizeof(double), stream));
+        RR_TRY(upload(d_tw4096, tw.data(), tw.size() * sizeof(double), stream));
+        ols_V = (int)ols4096_f64_overlap(lc, ds->sched.D);
+        use_ols64 = true;
+        use_poly64 = use_frame = use_ols = false;
+        Lc = lc;
+        ctaps_fl = fl->design_version;
+        ctaps_ds = ds->design_version;
+        return RR_OK;
+    }
     const int fk = dtype == RR_F64 ? (int)FK_POLY : pick_fused_kernel(ds->sched.D, lc, fl->real_taps, p.fft_len);
     if (fk == FK_POLY) {
         // k_decim_poly(_f64)'s tap list for ir = reverse(c): out[m] = sum_j ir[j] xs[e_m - (Lc - 1) + j] = sum_i c[i] xs[e_m - i]
@@ -616,7 +639,11 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
         timers.begin_ext(ST_FUSED_FIR, &a.ev_start, &a.ev_stop);
     else
         tk = timers.begin(ST_FUSED_FIR, stream);
-    if (use_poly64) {
+    if (use_ols64) {
+        if (dec == 0) RR_FAIL(RR_ERR_BAD_ARG, "Chain: a call through k_ols4096_f64 must produce output");
+        RR_TRY(launch_ols4096_f64(stream, a.xh, HX, d_in, n_in, d_olsH.p, d_tw4096.p, (size_t)ols_V, ds->sched.D, newv, dec, (long)a.e0,
+                                  a.xh_out, HX, a.nco, a.denom, a.idx0));
+    } else if (use_poly64) {
         RR_TRY(launch_decim_poly(stream, a.xh, HX, d_in, n_in, d_ctaps.p, ds->sched.D, 1, poly64_Lp, Lc, a.e0, newv, dec, a.xh_out, HX,
                                  a.nco, a.denom, a.idx0, dtype));
         if (dec == 0)  // (no output, no tile: the history by a launch of its own)
@@ -673,7 +700,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     }
     if (!ext) timers.end(tk, stream);
     pending_len = rest;
-    last_fused = use_poly64 ? FK_POLY : use_ols ? (ols_N == 1024 ? (a.genfold ? 9 : a.mixfold ? 7 : FK_OLSW) : FK_OLS) : FK_DIRECT;  // (7: k_ols_wave<4, true, true>)
+    last_fused = use_ols64 ? (int)FK_OLS64 : use_poly64 ? FK_POLY : use_ols ? (ols_N == 1024 ? (a.genfold ? 9 : a.mixfold ? 7 : FK_OLSW) : FK_OLS) : FK_DIRECT;  // (7: k_ols_wave<4, true, true>)
     if (n_out) *n_out = wrote;
     return RR_OK;
 }

@@ -88,3 +88,19 @@ static inline int set_sink(MeterSink &k, double double_percentile, double sample
 
 // which kernels transform a chunk of `len` points (rr_api_fourier.hip; also behind rr_fourier_route)
 struct FourierRoute;
+
+// k_ols4096_f64's tables for combined taps c (complex): G = DFT_4096(c) / 4096 in natural order, tw = e^{-j 2 pi k / 4096}, both f64
+inline void ols64_tables(const std::vector<rr::cd> &c, std::vector<double> &G, std::vector<double> &tw) {
+    std::vector<rr::cd> gg(4096, rr::cd(0, 0));
+    for (size_t i = 0; i < c.size() && i < 4096; ++i) gg[i] = c[i];
+    rr::fft_f64(gg, false);
+    G.resize(2 * 4096);
+    tw.resize(2 * 4096);
+    for (size_t i = 0; i < 4096; ++i) {
+        G[2 * i] = gg[i].real() / 4096.0;
+        G[2 * i + 1] = gg[i].imag() / 4096.0;
+        const double ang = -2.0 * M_PI * (double)i / 4096.0;
+        tw[2 * i] = std::cos(ang);
+        tw[2 * i + 1] = std::sin(ang);
+    }
+}

@@ -50,6 +50,9 @@ struct rr_filter : rr_block {
     bool use_ols4096 = false;      // f32, n = 129 .. 2048: 4096-point blocks, radix-16 kernel
     size_t npart = 0;              // f32, n > 2048: that kernel once per partition of 2048 taps, accumulating
     bool big_ols4096 = false;      // f32, n in {64, 128}: the same for calls of >= 16384 outputs
+    bool use_ols64 = false;        // f64, n = 2 .. 2049: k_ols4096_f64 (rr_f64.hip), for calls of >= 4096 outputs
+    rr::DevBuf d_G64, d_tw64;
+    size_t V64 = 0;
     bool use_ols16k = false;       // f32, n = 2049 .. 8192: k_filter_blkbig<N> (blocks of 8192 / 16 384 points in LDS)
     rr::DevBuf d_G16k, d_tw16k;
     size_t V16k = 0, N16k = 0;
@@ -110,6 +113,7 @@ struct rr_downsampler : rr_block {
     bool f_poly = false;
     // k_decim_poly (any integer ratio, short-period rational ratios): taps in f_ctaps, laid out for the schedule phase
     int f_NC = 0;
+    size_t f_V64 = 0;  // FK_OLS64 (Complex<f64>, integer ratio): k_ols4096_f64's overlap; its tables in f_H / f_tw
     uint64_t poly_version = ~0ull;
     std::vector<int64_t> poly_delta;
     int ensure_poly_taps(const int64_t *e_first);
@@ -344,11 +348,12 @@ struct rr_chain : rr_block {
     int ols_N = 4096;  // 4096: k_ols_decim4 (workgroup per block), 1024: k_ols_wave (wave per block)
     rr::DevBuf d_olsH, d_tw4096;
     bool fused_candidate(double sample_rate) const;
-    enum { FK_NONE = 0, FK_DIRECT, FK_OLS, FK_OLSW, FK_OLSF, FK_POLY, FK_SELECT = 10 };  // FK_POLY: k_decim_poly, FK_SELECT: k_filter_wave<true> (Downsampler only)
+    enum { FK_NONE = 0, FK_DIRECT, FK_OLS, FK_OLSW, FK_OLSF, FK_POLY, FK_SELECT = 10, FK_OLS64 = 11 };  // FK_POLY: k_decim_poly, FK_SELECT: k_filter_wave<true> (Downsampler only)
     static int pick_fused_kernel(uint64_t D, size_t lc, bool real_taps, size_t fft_len);
     bool use_frame = false;      // FK_OLSF: k_ols_frame (FIR stage + Fourier in one kernel)
     // Complex<f64>: mixer + combined FIR + decimation as ONE pass of k_decim_poly_f64 (the polyphase kernel with the phase table
     // riding along: 16 B read + 16 / D written per sample instead of the four blocks' 84), then the Fourier block
+    bool use_ols64 = false;   // Complex<f64>: the front end through k_ols4096_f64 (tables in d_olsH / d_tw4096, overlap ols_V)
     bool use_poly64 = false;  // the front end through k_decim_poly(_f64): Complex<f64>, and f32 at integer ratios without an overlap-save kernel
     int poly64_Lp = 0;
     // k_ols_frame with the mixer folded into the tables (NCO periods that divide 8): G'_p[k] = G_p[(k + s) mod 256] e^{j 2 pi p numer / R}

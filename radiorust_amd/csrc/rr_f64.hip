@@ -139,6 +139,154 @@ __global__ __launch_bounds__(256) void k_fft4096_f64(const double2 *__restrict__
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// k_ols4096_f64: overlap-save fast convolution for Complex<f64> - the Filter (D = 1), the Downsampler at integer ratios and the
+// f64 chain's front end (a phase table riding along on the load) in one kernel:
+//   y = IDFT_4096(DFT_4096(x_block) * G),  G = DFT_4096(c) / 4096,  overlap V >= Lc - 1 with (4096 - V) a multiple of D,
+//   out[m] = y[e0 + D m]: of a block's 4096 - V valid results every D-th is stored.
+// The transforms are k_fft4096_f64's (16 values per lane in registers, radix 16 x 16 x 16 through one 68 KiB image, two
+// workgroups per CU); the inverse is the forward routine with the result index reversed.  The direct forms this replaces sit on
+// the f64 FMA issue rate (rr_decim.hip: 368 FMAs per output at the chain's 184 taps); here a block costs 2 x 12 x 4096 butterfly
+// levels whatever the response, and the kernel is bound by its 16 + 16 / D bytes per sample.
+// ---------------------------------------------------------------------------
+struct Ols64Args {
+    const double2 *hist;   // the samples in front of the call (already mixed where a phase table rides along)
+    int hist_len;
+    const double2 *in;
+    long n_in;
+    const double2 *G;      // DFT_4096(c) / 4096, natural order
+    const double2 *tw;     // e^{-j 2 pi k / 4096}
+    int V;
+    double2 *out;
+    long n_out;
+    long e0;               // out[m] = y[e0 + D m]
+    unsigned D, per_block; // per_block = (4096 - V) / D outputs per block
+    unsigned nblocks;
+    double2 *hist_out;     // receives the last hist_out_len (mixed) samples of [ hist | in ] (may be null)
+    int hist_out_len;
+    const double2 *nco;    // denom entries + entry 0 once more + the rotations by 128 k samples (rr_freqshifter::prepare); denom = 0: no mixer
+    unsigned denom, idx0;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ols4096_f64(Ols64Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem64[];
+    cd2 *const lds = reinterpret_cast<cd2 *>(smem64);  // 4096 + 256 elements
+    const int j = threadIdx.x;
+    const int hop = 4096 - a.V;
+    // neighbouring blocks (which share V samples) on one XCD, in a window of 8 x 8 blocks
+    constexpr unsigned W = 8;
+    const unsigned grp = blockIdx.x / (8 * W), rem = blockIdx.x % (8 * W);
+    const unsigned blk = grp * 8 * W + (rem & 7) * W + (rem >> 3);
+    if (blk >= a.nblocks) return;
+    const long b0 = a.e0 - a.V + (long)blk * hop;
+    auto mixed = [&](long pos) -> cd2 {  // sample `pos` of [ hist | in ], mixed
+        cd2 h = {0.0, 0.0};
+        if (pos >= 0) {
+            if (pos < a.n_in) {
+                const double2 x = a.in[pos];
+                h = {x.x, x.y};
+                if (a.denom) {
+                    const double2 pp = a.nco[(unsigned)(((long)a.idx0 + pos) % (long)a.denom)];
+                    h = cmul(h, cd2{pp.x, pp.y});
+                }
+            }
+        } else if (pos >= -(long)a.hist_len) {
+            const double2 x = a.hist[a.hist_len + pos];
+            h = {x.x, x.y};
+        }
+        return h;
+    };
+    if (a.hist_out && blk == a.nblocks - 1)
+        for (int i = j; i < a.hist_out_len; i += 256) {
+            const cd2 h = mixed(a.n_in - a.hist_out_len + i);
+            a.hist_out[i] = double2{h.x, h.y};
+        }
+    cd2 v[16];
+    if (b0 >= 0 && b0 + 4096 <= a.n_in) {
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        const double2 *src = a.in + b0 + j;
+        d2v x[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(src + 256 * k));
+        if (a.denom) {
+            // the lane's phasor at the block start from the table, the 15 steps of 256 samples by the pure rotation behind it
+            const double2 p0 = a.nco[(unsigned)(((long)a.idx0 + b0 + j) % (long)a.denom)];
+            const double2 rt = a.nco[a.denom + 1 + 2];
+            cd2 pp = {p0.x, p0.y};
+            const cd2 rot = {rt.x, rt.y};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                v[k] = cmul(cd2{x[k].x, x[k].y}, pp);
+                pp = cmul(pp, rot);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = {x[k].x, x[k].y};
+        }
+    } else {
+        // edge blocks (history in front, nothing behind the input): one sample at a time through the image - unrolled beside the
+        // interior path, the 16 index computations cost more registers than both transforms
+#pragma unroll 1
+        for (int k = 0; k < 16; ++k) lds[j + 256 * k] = mixed(b0 + j + 256 * k);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = lds[j + 256 * k];  // (the lane's own elements: no barrier)
+        __syncthreads();                                       // ... but one in front of the first exchange's stores
+    }
+    const double2 s1 = a.tw[16 * (j & 15)], s2 = a.tw[j];
+    auto transform = [&](bool pre_barrier) {
+        dft16(v);
+        if (pre_barrier) __syncthreads();  // the previous transform's last reads are done
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lds[pad16(16 * j + k)] = v[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = lds[pad16(j + 256 * k)];
+        twiddle16(v, cd2{s1.x, s1.y});
+        dft16(v);
+        __syncthreads();
+        {
+            const int b2 = (j >> 4) * 256 + (j & 15);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) lds[b2 + 16 * k] = v[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = lds[j + 256 * k];
+        twiddle16(v, cd2{s2.x, s2.y});
+        dft16(v);
+    };
+    transform(false);
+    // (G in two halves behind the transform: requested in front of its last butterflies, 16 more values of 16 bytes beside the lane's
+    //  16 and the twiddles' 16 went past the 256 registers of two waves per SIMD - and scratch is HBM traffic)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        asm volatile("" ::: "memory");
+        double2 g[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[k] = a.G[j + 256 * (8 * h + k)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[8 * h + k] = cmul(v[8 * h + k], cd2{g[k].x, g[k].y});
+    }
+    transform(true);
+    // y[t] = v[k] with t = (4096 - (j + 256 k)) mod 4096; valid for t >= V; stored if D divides t - V: out[blk per_block + (t - V) / D]
+    const long mbase = (long)blk * a.per_block;
+    typedef double d2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int t = (4096 - j - 256 * k) & 4095;
+        const int u = t - a.V;
+        if (u < 0) continue;
+        unsigned i = (unsigned)u;
+        if (a.D > 1) {
+            if (i % a.D) continue;
+            i /= a.D;
+        }
+        const long m = mbase + i;
+        if (m < a.n_out) __builtin_nontemporal_store((d2v){v[k].x, v[k].y}, reinterpret_cast<d2v *>(a.out + m));
+    }
+}
+
 }  // namespace
 
 int launch_fft4096_f64(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count, const void *window,
@@ -153,6 +301,55 @@ int launch_fft4096_f64(hipStream_t s, const void *head, size_t n_head, const voi
     }
     hipLaunchKernelGGL(k_fft4096_f64, dim3((unsigned)count), dim3(256), lds, s, (const double2 *)head, (long)n_head, (const double2 *)in,
                        (double2 *)out, (const double *)window, (const double2 *)tw4096, (int)center_dc, (long)hop);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// V: the overlap for a response of Lc taps at decimation D - at least Lc - 1, 4096 - V a multiple of D (0: does not fit)
+size_t ols4096_f64_overlap(size_t Lc, uint64_t D) {
+    if (Lc < 1 || Lc - 1 > 2048 || D < 1 || D > 1024) return 0;
+    size_t V = Lc - 1;
+    while (V < 4096 && (4096 - V) % D) ++V;
+    if (V < 1) V = (4096 % D == 0 && D > 1) ? D : 1;  // (a response of one tap: still a block with a hop the ratio divides)
+    while (V < 4096 && (4096 - V) % D) ++V;
+    return (V <= 3072) ? V : 0;
+}
+
+// out[m] = sum_i c[i] x[e0 + D m - i] over [ hist | in ], optionally x * nco on the load (hist / hist_out then hold mixed samples)
+int launch_ols4096_f64(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *G, const void *tw4096,
+                       size_t V, uint64_t D, void *out, size_t n_out, long e0, void *hist_out, size_t hist_out_len, const void *nco,
+                       uint32_t denom, uint32_t idx0) {
+    if (n_out == 0) {
+        if (hist_out) RR_FAIL(RR_ERR_BAD_ARG, "k_ols4096_f64 cannot leave a history without producing outputs");
+        return RR_OK;
+    }
+    if (V < 1 || V > 3072 || D < 1 || (4096 - V) % D) RR_FAIL(RR_ERR_BAD_ARG, "k_ols4096_f64: overlap %zu at decimation %llu", V, (unsigned long long)D);
+    Ols64Args a;
+    a.hist = (const double2 *)hist;
+    a.hist_len = (int)hist_len;
+    a.in = (const double2 *)in;
+    a.n_in = (long)n_in;
+    a.G = (const double2 *)G;
+    a.tw = (const double2 *)tw4096;
+    a.V = (int)V;
+    a.out = (double2 *)out;
+    a.n_out = (long)n_out;
+    a.e0 = e0;
+    a.D = (unsigned)D;
+    a.per_block = (unsigned)((4096 - V) / D);
+    const size_t nblocks = (n_out + a.per_block - 1) / a.per_block;
+    if (nblocks > 0x7ffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "k_ols4096_f64: too many blocks");
+    a.nblocks = (unsigned)nblocks;
+    a.hist_out = (double2 *)hist_out;
+    a.hist_out_len = (int)hist_out_len;
+    a.nco = (const double2 *)nco;
+    a.denom = nco ? denom : 0;
+    a.idx0 = idx0;
+    constexpr size_t lds = (4096 + 256) * 16;
+    // (per launch: the attribute belongs to the device the call runs on)
+    RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ols4096_f64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned grid = (unsigned)((nblocks + 63) / 64 * 64);
+    hipLaunchKernelGGL(k_ols4096_f64, dim3(grid), dim3(256), lds, s, a);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }

@@ -231,6 +231,12 @@ bool fft_big_supported(size_t n);
 void fft_big_split(size_t n, size_t *N1, size_t *N2);
 int launch_fft_big(int dtype, hipStream_t s, const void *in, void *out, void *ws, size_t n, size_t count, const void *window,
                    const void *tw1, const void *tw2, bool center_dc);
+// k_ols4096_f64 (rr_f64.hip): Complex<f64> overlap-save in blocks of 4096 points - the Filter (D = 1), integer-ratio Downsamplers
+// and the f64 chain's front end; G = DFT_4096(c) / 4096 in natural order, V from ols4096_f64_overlap (0: the response does not fit)
+size_t ols4096_f64_overlap(size_t Lc, uint64_t D);
+int launch_ols4096_f64(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *G, const void *tw4096,
+                       size_t V, uint64_t D, void *out, size_t n_out, long e0, void *hist_out, size_t hist_out_len, const void *nco,
+                       uint32_t denom, uint32_t idx0);
 // k_fft16384: 1024 lanes per 16384-sample frame (rr_fft_big.hpp), plain window and twiddle tables
 int launch_fft16384(hipStream_t s, const void *head, size_t n_head, const void *in, void *out, size_t count, const void *window,
                     const void *tw16384, bool center_dc, size_t hop);

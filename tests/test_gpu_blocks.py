@@ -320,6 +320,41 @@ def test_filter_blocks_of_16384_points(rr, oracle, n):
         pos += k * n
 
 
+@pytest.mark.parametrize("n,onesided", [(64, False), (100, True), (1000, False), (2048, True), (2049, False)])
+def test_filter_f64_blocks_of_4096_points(rr, oracle, n, onesided):
+    """Complex<f64>, 2 .. 2049 taps, calls of >= 4096 outputs: k_ols4096_f64 (kernel 6) - real and complex (one-sided response)
+    taps, several chunks per call, short calls on the other kernels in between, an interrupt; against the f64 oracle."""
+    import torch
+
+    fs = 1024000.0
+    per = max(1, (9000 + n - 1) // n)  # chunks per long call
+    plan = [(per, False), (1, False), (3 * per, False), (per, True), (2, False), (2 * per, False)]
+    chunks = sum(k for k, _ in plan)
+    x = oracle.synth_iq(29, 0, n * chunks).astype(np.complex128)
+    resp = (lambda b, f: 1.0 if 0 <= f <= 100e3 else 0.0) if onesided else lowpass(100e3)
+    g = rr.Filter.new(resp, dtype=np.float64)
+    o = oracle.Filter(resp, flt=np.float64)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.zeros(n * chunks, dtype=d_in.dtype, device="cuda")
+    pos, seen = 0, set()
+    for k, interrupt in plan:
+        if interrupt:
+            g.process(rr.EventSignal(rr.SamplesLost()))
+            o.interrupt()
+        w = g.process_dev(fs, n, d_in.data_ptr() + 16 * pos, k * n, d_out.data_ptr(), k * n)
+        torch.cuda.synchronize()
+        seen.add(g.last_kernel())
+        ref = [o.process(fs, x[pos + i * n:pos + (i + 1) * n]) for i in range(k)]
+        ref = np.concatenate([r for r in ref if r is not None] or [np.empty(0, np.complex128)])
+        assert w == len(ref)
+        if w >= 4096:
+            assert g.last_kernel() == 6, g.last_kernel()
+        if w:
+            assert rms_rel(d_out[:w].cpu().numpy(), ref) <= 1e-12, (k, rms_rel(d_out[:w].cpu().numpy(), ref))
+        pos += k * n
+    assert 6 in seen
+
+
 def test_filter_deemphasis_of_simple_receiver(rr, oracle):
     """examples/relm_app/simple_receiver.rs:43-49: the audio Filter behind the FM demodulator - rectangular window,
     complex response built from blocks::filters::deemphasis_factor(50e-6, f) on 20 Hz .. 16 kHz, DC bin blocked -
@@ -533,9 +568,14 @@ def test_downsampler_fast_paths(rr, oracle, fin, fout, bw, q, kernel):
 
 @pytest.mark.parametrize("fin,fout,bw,q", [(200e6, 50e6, 40e6, 3.0), (1024000.0, 102400.0, 60000.0, 3.0), (1024000.0, 384000.0, 200000.0, 3.0),
                                           (48000.0, 32000.0, 20000.0, 2.0)])
-def test_downsampler_f64_polyphase_kernel(rr, oracle, fin, fout, bw, q):
-    """Complex<f64>: every periodic ratio the LDS tile fits runs k_decim_poly_f64 in long calls (kernel 5), k_fir in short
-    ones; the history is handed over between them."""
+@pytest.mark.parametrize("poly", [False, True])
+def test_downsampler_f64_polyphase_kernel(rr, oracle, monkeypatch, fin, fout, bw, q, poly):
+    """Complex<f64>: integer ratios run k_ols4096_f64 (kernel 11; RR_DOWNSAMPLER_POLY=1: the decimator), every other periodic
+    ratio the LDS tile fits k_decim_poly_f64 (kernel 5) in long calls, k_fir in short ones; the history is handed over between
+    them."""
+    if poly:
+        monkeypatch.setenv("RR_DOWNSAMPLER_POLY", "1")
+    want = 11 if (fin / fout).is_integer() and not poly else 5
     n = 90000
     x = oracle.synth_iq(17, 0, n).astype(np.complex128)
     g = rr.Downsampler.with_quality(1000, fout, bw, q, dtype=np.float64)
@@ -548,7 +588,7 @@ def test_downsampler_f64_polyphase_kernel(rr, oracle, fin, fout, bw, q):
         assert len(y) == len(r)
         if len(y) > 8:
             assert rms_rel(y, r) <= 1e-12
-    assert kernels == [5, 0, 5, 0, 5], kernels
+    assert kernels == [want, 0, want, 0, want], kernels
 
 
 @pytest.mark.parametrize("fin,fout,bw,q", [(200e6, 50e6, 40e6, 3.0), (1024000.0, 384000.0, 200000.0, 3.0), (48000.0, 32000.0, 20000.0, 2.0),

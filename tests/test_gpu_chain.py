@@ -192,11 +192,15 @@ def test_chain_f64(rr, oracle):
         assert rms_rel(a.chunk, b) <= 1e-12
 
 
+@pytest.mark.parametrize("kernel", ["k_ols4096_f64", "k_decim_poly"])
 @pytest.mark.parametrize("shift,precision", [(25e6, 1.0), (12.345e6, 1e3)])
-def test_chain_f64_fused_front_end(rr, oracle, shift, precision):
-    """Complex<f64>: mixer + Filter + Downsampler as ONE pass of k_decim_poly_f64 (the phase table riding along, combined
-    taps) once the chain is in its steady state, then the register-resident 4096-point transform; ragged calls, an
-    interrupt and a retune, against the f64 oracle at 1e-11."""
+def test_chain_f64_fused_front_end(rr, oracle, monkeypatch, shift, precision, kernel):
+    """Complex<f64>: mixer + Filter + Downsampler as ONE pass once the chain is in its steady state - overlap-save in blocks of
+    4096 points (k_ols4096_f64, the default) or the polyphase decimator (RR_CHAIN_F64_FUSED=poly), the phase table riding along,
+    combined taps - then the register-resident 4096-point transform; ragged calls, an interrupt and a retune, against the f64
+    oracle at 1e-11."""
+    if kernel == "k_decim_poly":
+        monkeypatch.setenv("RR_CHAIN_F64_FUSED", "poly")
     fs, n = 200e6, 1 << 18
     params = dict(CFG2, shift=shift)
     x = oracle.synth_iq(14, 0, n).astype(np.complex128)
@@ -206,7 +210,7 @@ def test_chain_f64_fused_front_end(rr, oracle, shift, precision):
     cuts = [0, 20000, 20001, 70007, 70071, 150000, 200064, n]
     for a, b in zip(cuts[:-1], cuts[1:]):
         out += g.process(rr.Samples(fs, x[a:b]))
-        fused_calls += g.last_path_kernel() == "k_decim_poly"
+        fused_calls += g.last_path_kernel() == kernel
     assert fused_calls >= 4, fused_calls
     assert len(out) == len(ref) == 15
     for a, b in zip(out, ref):
