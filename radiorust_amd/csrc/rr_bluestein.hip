@@ -84,7 +84,7 @@ int launch_bluestein8192(hipStream_t s, const void *head, size_t n_head, const v
     if (count == 0) return RR_OK;
     if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: too many chunks in one call");
     const size_t lds = (8192 + 512) * sizeof(float2);
-    RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bluestein8192), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RR_TRY(dyn_lds_optin(reinterpret_cast<const void *>(k_bluestein8192), lds));
     hipLaunchKernelGGL(k_bluestein8192, dim3((unsigned)count), dim3(256), lds, s, (const float2 *)head, (long)n_head,
                        (const float2 *)in, (long)hop, (int)n, (const float2 *)c, (const float2 *)B, (const float2 *)w,
                        (const float2 *)tw8192, (float2 *)out, (int)center_dc, (unsigned)count);

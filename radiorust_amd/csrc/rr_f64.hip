@@ -294,11 +294,7 @@ int launch_fft4096_f64(hipStream_t s, const void *head, size_t n_head, const voi
     if (count == 0) return RR_OK;
     if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fft4096 (f64): too many frames");
     constexpr size_t lds = (4096 + 256) * 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft4096_f64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    RR_TRY(dyn_lds_optin(reinterpret_cast<const void *>(k_fft4096_f64), lds));
     hipLaunchKernelGGL(k_fft4096_f64, dim3((unsigned)count), dim3(256), lds, s, (const double2 *)head, (long)n_head, (const double2 *)in,
                        (double2 *)out, (const double *)window, (const double2 *)tw4096, (int)center_dc, (long)hop);
     RR_HIP(hipGetLastError());
@@ -346,8 +342,7 @@ int launch_ols4096_f64(hipStream_t s, const void *hist, size_t hist_len, const v
     a.denom = nco ? denom : 0;
     a.idx0 = idx0;
     constexpr size_t lds = (4096 + 256) * 16;
-    // (per launch: the attribute belongs to the device the call runs on)
-    RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ols4096_f64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RR_TRY(dyn_lds_optin(reinterpret_cast<const void *>(k_ols4096_f64), lds));
     const unsigned grid = (unsigned)((nblocks + 63) / 64 * 64);
     hipLaunchKernelGGL(k_ols4096_f64, dim3(grid), dim3(256), lds, s, a);
     RR_HIP(hipGetLastError());

@@ -251,8 +251,7 @@ static int launch_fft_big_n(hipStream_t s, const void *head, size_t n_head, cons
     if (count == 0) return RR_OK;
     if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fft_big: too many frames");
     constexpr size_t lds = (size_t)big_fft_lds_elems<N>() * sizeof(f2);
-    // (per launch: the attribute belongs to the device the call runs on)
-    RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_big<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RR_TRY(dyn_lds_optin(reinterpret_cast<const void *>(k_fft_big<N>), lds));
     hipLaunchKernelGGL(k_fft_big<N>, dim3((unsigned)count), dim3(N / 16), lds, s, (const float2 *)head, (long)n_head, (const float2 *)in,
                        (float2 *)out, (const float *)window, (const float2 *)twN, (int)center_dc, (long)hop);
     RR_HIP(hipGetLastError());
@@ -822,11 +821,7 @@ int launch_fft8192(hipStream_t s, const void *head, size_t n_head, const void *i
     if (count == 0) return RR_OK;
     if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fft8192: too many frames");
     const size_t lds = (8192 + 512) * sizeof(float2);
-    static bool attr_set = false;  // (more than 64 KiB of dynamic LDS needs the opt-in once per process and device; harmless to repeat)
-    if (!attr_set) {
-        RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft8192), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    RR_TRY(dyn_lds_optin(reinterpret_cast<const void *>(k_fft8192), lds));
     hipLaunchKernelGGL(k_fft8192, dim3((unsigned)count), dim3(256), lds, s, (const float2 *)head, (long)n_head,
                        (const float2 *)in, (float2 *)out, (const float *)window, (const float2 *)tw8192, (int)center_dc,
                        (long)hop);

@@ -498,8 +498,7 @@ static int launch_filter_blkbig_n(hipStream_t s, BlkBigArgs &a, size_t n_in, siz
         a.blk_hi = (unsigned)hi;
     }
     constexpr size_t lds = (size_t)big_fft_lds_elems<N>() * sizeof(f2);
-    // (per launch: the attribute belongs to the device the call runs on)
-    RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_filter_blkbig<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RR_TRY(dyn_lds_optin(reinterpret_cast<const void *>(k_filter_blkbig<N>), lds));
     const unsigned grid = (unsigned)((nblocks + 31) / 32 * 32);
     hipLaunchKernelGGL(k_filter_blkbig<N>, dim3(grid), dim3(N / 16), lds, s, a);
     RR_HIP(hipGetLastError());

@@ -10,6 +10,8 @@
 #include "rr_kernels.hpp"
 
 #include <cstdlib>
+#include <mutex>
+#include <tuple>
 
 namespace rr {
 
@@ -39,10 +41,25 @@ template <class T> __device__ __forceinline__ v2<T> cmul(v2<T> a, v2<T> b) {
 
 static bool is_pow2_n(size_t n) { return n && (n & (n - 1)) == 0; }
 
-static int set_dyn_lds(const void *fn, size_t bytes) {
-    if (bytes > 64 * 1024) RR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+// More than 64 KiB of dynamic LDS needs an opt-in per kernel AND per device (a process may hold handles on several devices, every
+// entry point selects its own): done once per (kernel, device, size), remembered under a lock that a launch holds for nanoseconds.
+int dyn_lds_optin(const void *fn, size_t bytes) {
+    if (bytes <= 64 * 1024) return RR_OK;
+    int dev = 0;
+    RR_HIP(hipGetDevice(&dev));
+    static std::mutex mu;
+    static std::vector<std::tuple<const void *, int, size_t>> done;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (const auto &d : done)
+            if (std::get<0>(d) == fn && std::get<1>(d) == dev && std::get<2>(d) >= bytes) return RR_OK;
+    }
+    RR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    std::lock_guard<std::mutex> lk(mu);
+    done.emplace_back(fn, dev, bytes);
     return RR_OK;
 }
+static int set_dyn_lds(const void *fn, size_t bytes) { return dyn_lds_optin(fn, bytes); }
 
 // ---------------------------------------------------------------------------
 // FreqShifter: y[t] = x[t] * p[(idx0 + t) mod denom]          transform.rs:341-348

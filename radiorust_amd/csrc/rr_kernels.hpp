@@ -18,6 +18,9 @@ int launch_freqshift(int dtype, hipStream_t s, const void *in, void *out, size_t
 //   e_m = e0 + m*D (emit == nullptr) or emit[m]   (indices relative to in[0])
 // complex_taps: w is K complex values (Filter, direct form), else K real values
 // (Downsampler, resampling.rs:112-120, oldest sample times ir[0]).
+// opt-in for more than 64 KiB of dynamic LDS, once per (kernel, device) (rr_kernels.hip)
+int dyn_lds_optin(const void *fn, size_t bytes);
+
 struct FirArgs {
     const void *hist = nullptr;
     size_t hist_len = 0;

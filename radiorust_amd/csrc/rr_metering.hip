@@ -147,12 +147,12 @@ int launch_meter(int dtype, hipStream_t s, int mode, double double_percentile, d
     const size_t lds = n * sizeof(double);
     if (dtype == RR_F32) {
         auto fn = k_meter<float>;
-        if (lds > 64 * 1024) RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        RR_TRY(dyn_lds_optin(reinterpret_cast<const void *>(fn), lds));
         hipLaunchKernelGGL(fn, dim3((unsigned)count), dim3(256), lds, s, (const float2 *)frames, (int)n, mode,
                            double_percentile, sample_rate, out);
     } else {
         auto fn = k_meter<double>;
-        if (lds > 64 * 1024) RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        RR_TRY(dyn_lds_optin(reinterpret_cast<const void *>(fn), lds));
         hipLaunchKernelGGL(fn, dim3((unsigned)count), dim3(256), lds, s, (const double2 *)frames, (int)n, mode,
                            double_percentile, sample_rate, out);
     }

@@ -328,8 +328,7 @@ static int launch_mfd(hipStream_t s, const FusedFirArgs &a) {
     const size_t lds = 32 + (size_t)lds_rows * G::STRIDE + ((size_t)a.Gp * D + 3 * G::RD) * sizeof(float);
     if ((rows * G::RD + 2) / 2 > npf_for(G::RD) * T) RR_FAIL(RR_ERR_BAD_ARG, "fused FIR: %d tap groups exceed the prefetch window", a.Gp);
     auto fn = k_mix_fir_decim<D, R, T>;
-    if (lds > 64 * 1024)
-        RR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RR_TRY(dyn_lds_optin(reinterpret_cast<const void *>(fn), lds));
     const size_t ntiles = (a.n_out + OUTS - 1) / OUTS;
     if (ntiles > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "fused FIR: too many tiles");
     // persistent grid: 8 waves per CU (LDS-limited), 256 CUs
