@@ -577,7 +577,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     //  row, 25 us even for one frame, where the two kernels take 12; from 2^24 samples on the frame kernel is ahead)
     const char *fke = std::getenv("RR_FUSED_KERNEL");  // (tests force the frame kernel on short streams)
     const bool frame_forced = fke && !std::strcmp(fke, "olsf");
-    if (use_frame && n_in >= (frame_forced ? (size_t)1024 : (size_t)1 << 23)) {
+    if (use_frame && !(LF != 4096 && sink.on) && n_in >= (frame_forced ? (size_t)1024 : (size_t)1 << 23)) {
         // one kernel: FIR stage + Fourier; the decimated samples stay on chip, only the unfinished
         // frame goes to a small pending buffer
         if (store && nfr * LF > cap) RR_FAIL(RR_ERR_CAPACITY, "Chain: out_cap %zu < %zu", cap, nfr * LF);
@@ -595,7 +595,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
         if (timers.on && !sink.on) timers.begin_ext(ST_FUSED_FIR, &a.ev_start, &a.ev_stop);
         const rr::FrameMeter fmv = sink.frame_meter();
         RR_TRY(launch_ols_frame(stream, a, pin, pending_len, pendbuf[po].p, d_out, fo->d_window.p, fo->d_tw.p,
-                                fo->center_dc, sink.on ? &fmv : nullptr));
+                                fo->center_dc, sink.on ? &fmv : nullptr, LF));
         xh_cur ^= 1;
         if (left) RR_HIP(hipMemcpyAsync(carry.p, xh[xh_cur].as<char>() + (HX - left) * esz, left * esz, hipMemcpyDeviceToDevice, stream));
         const uint64_t den0 = (uint64_t)fs->denom;

@@ -184,7 +184,7 @@ struct FrameMeter {
     int store = 1;             // 0: the spectra are not written at all (the caller only wants the figures)
 };
 int launch_ols_frame(hipStream_t s, const FusedFirArgs &a, const void *pend_in, size_t pl, void *pend_out, void *spectra,
-                     const void *window, const void *tw4096, bool center_dc, const FrameMeter *fm = nullptr);
+                     const void *window, const void *tw4096, bool center_dc, const FrameMeter *fm = nullptr, size_t fft_len = 4096);
 bool fused_fir_supported(uint64_t D, size_t Lc);
 int fused_fir_R(uint64_t D);  // outputs per lane of the instantiation for D
 int launch_fused_fir(hipStream_t s, const FusedFirArgs &a);

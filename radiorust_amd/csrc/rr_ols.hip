@@ -1232,7 +1232,7 @@ __device__ __forceinline__ void poly4_block(f2 (&v)[16], f2 (&y)[4], f2 *lds, in
     // scratch is HBM traffic (4 KiB written and read back per workgroup: 17 MB of the launch's 151 MB of writes)
     float4 ga[4], gb[4];
 #pragma unroll
-    for (int kp = 0; kp < 4; ++kp) ga[kp] = RR_V_FRAME_GLDS ? Glds[l + 64 * kp] : reinterpret_cast<const float4 *>(G)[l + 64 * kp];
+    for (int kp = 0; kp < 4; ++kp) ga[kp] = (RR_V_FRAME_GLDS && Glds) ? Glds[l + 64 * kp] : reinterpret_cast<const float4 *>(G)[l + 64 * kp];
 #pragma unroll
     for (int kp = 0; kp < 4; ++kp) gb[kp] = reinterpret_cast<const float4 *>(G)[l + 64 * (4 + kp)];
     const f2 w1 = t_p2, w2 = cmul(w1, w1), w3 = cmul(w2, w1);
@@ -1274,7 +1274,7 @@ __device__ __forceinline__ void poly4_block(f2 (&v)[16], f2 (&y)[4], f2 *lds, in
 #else
     float4 ga[4], gb[4];
 #pragma unroll
-    for (int kp = 0; kp < 4; ++kp) ga[kp] = RR_V_FRAME_GLDS ? Glds[l + 64 * kp] : reinterpret_cast<const float4 *>(G)[l + 64 * kp];
+    for (int kp = 0; kp < 4; ++kp) ga[kp] = (RR_V_FRAME_GLDS && Glds) ? Glds[l + 64 * kp] : reinterpret_cast<const float4 *>(G)[l + 64 * kp];
     f2 d[4][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -1412,23 +1412,41 @@ struct FrameArgs {
 // the blocks transform the samples as they are with the tables of the response c[i] w^-i (host, rr_chain::ensure_genfold), and the
 // 4 results a lane keeps per block are multiplied by p at their own positions (one table read per lane and block + the three
 // rotations by 256 samples kept behind the table): 14 packed instructions per block instead of the 60 of the mixer in front.
-template <bool MF, bool SW, bool FULL = true, bool METER = false, bool GP = false>
+// LF = 1024: 1024-point spectra - ONE WAVE per frame: its five blocks one after the other (five blocks of 208 .. 240 results
+// cover the 1024), the results dropped into the wave's own image, then the wave-level 1024-point transform of k_fft1024 on it;
+// no workgroup barrier at all, the four waves of a workgroup are four neighbouring frames.  (No room for half of G_p in LDS beside
+// four images of the 1024-point transform's size: all of it from L2.)
+template <bool MF, bool SW, bool FULL = true, bool METER = false, bool GP = false, int LF = 4096>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ols_frame(FrameArgs a_) {
+    static_assert(LF == 4096 || (LF == 1024 && FULL && !METER), "4096-point frames, or 1024-point frames without the metering epilogue");
+    constexpr bool WF = LF == 1024;                       // a wave per frame
+    constexpr int kImg = WF ? kWaveLds : kPolyLds;        // a wave's image
+    constexpr int NL = WF ? 64 : 256;                     // lanes that work on one frame
     const FrameArgs &a = a_;
     const FrameArgs *ka = (const FrameArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-    __shared__ __attribute__((aligned(16))) f2 smem[4 * kPolyLds];  // 4544 elements >= the 4352 of the padded frame image
+    __shared__ __attribute__((aligned(16))) f2 smem[4 * kImg];  // LF = 4096: 4544 elements >= the 4352 of the padded frame image
 #if RR_V_FRAME_GLDS
     // the first half of the response tables G_p (phases 0 and 1: 4 KiB) in LDS, in the 4.5 KiB per workgroup that four workgroups per
     // CU leave: every block otherwise pulls all 8 KiB from L2 - as many bytes as its samples, in 8 of its 16 vector-memory instructions
-    __shared__ __attribute__((aligned(16))) float4 gl[256];
+    __shared__ __attribute__((aligned(16))) float4 gl[WF ? 1 : 256];
 #endif
-    f2 *const fr = smem;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    f2 *const fr = WF ? smem + w * kImg : smem;
+    const int fl_ = WF ? l : tid;                         // the lane's index among the frame's lanes
     // The frame that does not fill (its samples go to pend_out) is workgroup 0: dispatched first it runs beside the first
     // round of frames; as the LAST workgroup it ran alone behind the four full rounds of a 2^26-sample call.
     // The others: frames dealt to the XCDs in a moving window, RR_V_FRAMEWIN neighbouring frames per XCD.
+    // (LF = 1024: wave 0 of workgroup 0 is that frame, wave g takes frame g - 1.)
     unsigned f;
-    if (blockIdx.x == 0) {
+    if constexpr (WF) {
+        const unsigned g = 4u * blockIdx.x + (unsigned)w;
+        if (g == 0) {
+            f = a.nfr;
+        } else {
+            f = g - 1;
+            if (f >= a.nfr) return;
+        }
+    } else if (blockIdx.x == 0) {
         f = a.nfr;
     } else {
         const unsigned bx = blockIdx.x - 1;
@@ -1436,12 +1454,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (f >= a.nfr) return;
     }
     const bool tail = f == a.nfr;  // the frame that does not fill: goes to pend_out
-    const long F0 = 4096l * f - a.pl;  // decimated index (of this call) of the frame's first sample
+    const long F0 = (long)LF * f - a.pl;  // decimated index (of this call) of the frame's first sample
     const int hop = 1024 - a.V, per_block = hop >> 2, first = a.V >> 2;
 
     if (tail && ka->xh_out) {  // mixed-sample history for the next call
         const int hxe = ka->hx;
-        for (int i = tid; i < hxe; i += 256) {
+        for (int i = fl_; i < hxe; i += NL) {
             const long pos = a.n_in - hxe + i;
             float2 v;
             if (pos >= 0) {
@@ -1467,13 +1485,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         t_inv[1] = (f2){s7.z, s7.w};
         t_inv[2] = (f2){s8.x, s8.y};
     }
-    f2 *const lds = smem + w * kPolyLds;
+    f2 *const lds = smem + w * kImg;
+    const float4 *glp = nullptr;
 #if RR_V_FRAME_GLDS
-    gl[tid] = reinterpret_cast<const float4 *>(a.H)[tid];
-    __syncthreads();
-    const float4 *const glp = gl;
-#else
-    const float4 *const glp = nullptr;
+    if constexpr (!WF) {
+        gl[tid] = reinterpret_cast<const float4 *>(a.H)[tid];
+        __syncthreads();
+        glp = gl;
+    }
 #endif
     const long n_clamp = a.n_in - 1024;  // the launcher guarantees n_in >= 1024
     // mixer folded into the tables (MF): the blocks transform the samples as they are; the phasor of a block's first sample (the same
@@ -1482,7 +1501,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // phase of a block's first sample: (idx0 + b0) mod denom, b0 = const + 4 (4096 f + per_block jb)
     auto block_phase = [&](int jb) -> unsigned {
         const double dn = (double)a.denom;
-        const double prod = (double)a.ph0 + 16384.0 * (double)f + (double)(4 * per_block * jb);
+        const double prod = (double)a.ph0 + (4.0 * LF) * (double)f + (double)(4 * per_block * jb);
         const double qd = __builtin_floor(prod * a.inv_denom);
         double rd = __builtin_fma(-qd, dn, prod);
         if (rd < 0.0) rd += dn;
@@ -1504,7 +1523,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         glane = (f2){gl_.x, gl_.y};
 #pragma unroll
         for (int kb = 0; kb < kFrameBlocks / 4; ++kb) {
-            rdv[kb] = __builtin_amdgcn_readfirstlane(block_phase(RR_V_FRAME_CONSEC ? 5 * w + kb : w + 4 * kb));
+            rdv[kb] = __builtin_amdgcn_readfirstlane(block_phase(WF ? kb : RR_V_FRAME_CONSEC ? 5 * w + kb : w + 4 * kb));
             pgv[kb] = ld_uniform(a.nco + rdv[kb]);
         }
 #pragma unroll
@@ -1512,7 +1531,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 #pragma unroll
     for (int kb = 0; kb < kFrameBlocks / 4; ++kb) {
-        const int jb = RR_V_FRAME_CONSEC ? 5 * w + kb : w + 4 * kb;  // (five neighbouring blocks per wave instead: measured 0.171 against 0.159 ms)
+        const int jb = WF ? kb : RR_V_FRAME_CONSEC ? 5 * w + kb : w + 4 * kb;  // (five neighbouring blocks per wave instead: measured 0.171 against 0.159 ms)
         // (shorter responses: V = 64 / 128, 240 / 224 results per block - 18 / 19 blocks cover the frame, the last round's other waves idle)
         if (!FULL && kb >= 3 && __builtin_amdgcn_readfirstlane(jb) >= a.nb) continue;  // (a wave-uniform branch; rounds 0 .. 2 are always full)
         const long b0 = a.e0 - a.V + 4 * (F0 + (long)per_block * jb);
@@ -1601,34 +1620,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // (one block at a time: without this the five unrolled blocks' loads are all hoisted to the front)
         asm volatile("" : "+v"(keep[kb][0]), "+v"(keep[kb][1]), "+v"(keep[kb][2]), "+v"(keep[kb][3]));
     }
-    __syncthreads();  // every wave is done with its exchange images: they become the frame
+    if constexpr (WF) wave_sync();  // the wave is done with its exchange image: it becomes the frame
+    else __syncthreads();            // every wave is done with its exchange images: they become the frame
     // the part of frame 0 that was pending
     if (f == 0)
-        for (int i = tid; i < a.pl; i += 256) {
+        for (int i = fl_; i < a.pl; i += NL) {
             const float2 p = ka->pend_in[i];
             fr[i] = (f2){p.x, p.y};
         }
     // valid results tau = l + 64 c >= first; frame-relative index i = per_block * jb + tau - first
 #pragma unroll
     for (int kb = 0; kb < kFrameBlocks / 4; ++kb) {
-        const int jb = RR_V_FRAME_CONSEC ? 5 * w + kb : w + 4 * kb;
+        const int jb = WF ? kb : RR_V_FRAME_CONSEC ? 5 * w + kb : w + 4 * kb;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int tau = l + 64 * c;
             const int i = per_block * jb + tau - first;
             const long m = F0 + i;
-            if (tau >= first && m >= 0 && m < a.n_dec && (FULL || jb < a.nb)) fr[i] = keep[kb][c];
+            // (LF = 1024: the five blocks' 1040 .. 1200 results end behind the frame - the next frame's wave computes those too)
+            if (tau >= first && m >= 0 && m < a.n_dec && (FULL || jb < a.nb) && (!WF || i < LF)) fr[i] = keep[kb][c];
         }
     }
-    __syncthreads();
+    if constexpr (WF) wave_sync();
+    else __syncthreads();
     if (tail) {
-        const long have = a.pl + a.n_dec - 4096l * a.nfr;  // samples of the unfinished frame
-        for (int i = tid; i < have; i += 256) {
+        const long have = a.pl + a.n_dec - (long)LF * a.nfr;  // samples of the unfinished frame
+        for (int i = fl_; i < have; i += NL) {
             float2 o;
             o.x = fr[i].x;
             o.y = fr[i].y;
             ka->pend_out[i] = o;
         }
+        return;
+    }
+    if constexpr (WF) {
+        // ---- Fourier: window, DFT_1024 by this wave (k_fft1024's network: sample pairs x[2 l + 128 k], + 1), optional DC centring ----
+        f2 v[16];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float4 x = *reinterpret_cast<const float4 *>(fr + 2 * l + 128 * k);
+            const float2 wn = *reinterpret_cast<const float2 *>(ka->window + 2 * l + 128 * k);
+            v[2 * k] = (f2){x.x * wn.x, x.y * wn.x};
+            v[2 * k + 1] = (f2){x.z * wn.y, x.w * wn.y};
+        }
+        f2 f_p1, f_p2[2];
+        {
+            const float4 *tl = reinterpret_cast<const float4 *>(ka->tw4096 + 1024) + l;  // (the Fourier block's 1024-point table + lane seeds)
+            const float4 s0 = tl[0], s1 = tl[64];
+            f_p1 = (f2){s0.x, s0.y};
+            f_p2[0] = (f2){s0.z, s0.w};
+            f_p2[1] = (f2){s1.x, s1.y};
+        }
+        wave_sync();  // the frame has been read: it becomes the transform's exchange image
+        f2 X[16];
+        wave_dft1024(v, X, fr, l, f_p1, f_p2, [] {});
+        f2 *dst = reinterpret_cast<f2 *>(ka->spectra) + (size_t)f * 1024;
+        const int rot = ka->center_dc ? 512 : 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) __builtin_nontemporal_store(X[k], dst + ((l + 64 * k + rot) & 1023));
         return;
     }
     // ---- Fourier: window, DFT_4096 (radix 16 x 3 as k_fft4096), optional DC centring ---------------
@@ -1669,13 +1718,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 bool ols_frame_supported(uint64_t D, size_t Lc, size_t fft_len) {
     // overlaps of 64 / 128 / 192 samples = 240 / 224 / 208 results per block, 18 / 19 / 20 blocks per frame (at most kFrameBlocks)
-    return D == 4 && fft_len == 4096 && Lc >= 1 && ols_wave_overlap(Lc, 64) <= 192;
+    // (1024-point spectra: a wave per frame, five blocks each - RR_FRAME_1K=0 keeps the two kernels)
+    static const bool no1k = [] { const char *e = std::getenv("RR_FRAME_1K"); return e && std::atoi(e) == 0; }();
+    return D == 4 && (fft_len == 4096 || (fft_len == 1024 && !no1k)) && Lc >= 1 && ols_wave_overlap(Lc, 64) <= 192;
 }
 
 int launch_ols_frame(hipStream_t s, const FusedFirArgs &a, const void *pend_in, size_t pl, void *pend_out, void *spectra,
-                     const void *window, const void *tw4096, bool center_dc, const FrameMeter *fm) {
+                     const void *window, const void *tw4096, bool center_dc, const FrameMeter *fm, size_t fft_len) {
     if (a.V != 64 && a.V != 128 && a.V != 192) RR_FAIL(RR_ERR_BAD_ARG, "fused frame kernel: overlap %d not supported", a.V);
-    const size_t total = pl + a.n_out, nfr = total / 4096;
+    if (fft_len != 4096 && fft_len != 1024) RR_FAIL(RR_ERR_BAD_ARG, "fused frame kernel: %zu-point spectra not instantiated", fft_len);
+    if (fft_len == 1024 && fm) RR_FAIL(RR_ERR_BAD_ARG, "fused frame kernel: the metering epilogue rides on 4096-point spectra only");
+    const size_t total = pl + a.n_out, nfr = total / fft_len;
     if (total == 0) return RR_OK;
     if (a.n_in < 1024) RR_FAIL(RR_ERR_BAD_ARG, "fused frame kernel: needs at least 1024 input samples per call");
     if (nfr > 0x7ffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "fused frame kernel: too many frames");
@@ -1711,11 +1764,30 @@ int launch_ols_frame(hipStream_t s, const FusedFirArgs &a, const void *pend_in, 
     f.sigma = a.sigma;
     {
         const int per_block = (1024 - a.V) / 4;
-        f.nb = (4096 + per_block - 1) / per_block;
-        if (f.nb > kFrameBlocks) RR_FAIL(RR_ERR_BAD_ARG, "fused frame kernel: %d blocks per frame", f.nb);
+        f.nb = (int)((fft_len + per_block - 1) / per_block);
+        if (f.nb > kFrameBlocks || (fft_len == 1024 && f.nb > kFrameBlocks / 4))
+            RR_FAIL(RR_ERR_BAD_ARG, "fused frame kernel: %d blocks per frame", f.nb);
+    }
+    f.fm = fm ? *fm : FrameMeter{};
+    if (fft_len == 1024) {
+        // a wave per frame, wave 0 of the grid the frame that does not fill: nfr + 1 waves in workgroups of four
+        const unsigned grid1k = (unsigned)((nfr + 1 + 3) / 4);
+#define RR_FRAME1K_LAUNCH(MF_, SW_, GP_)                                                                                                     \
+    do {                                                                                                                                      \
+        if (a.ev_start && a.ev_stop)                                                                                                          \
+            hipExtLaunchKernelGGL((k_ols_frame<MF_, SW_, true, false, GP_, 1024>), dim3(grid1k), dim3(256), 0, s, a.ev_start, a.ev_stop, 0, f); \
+        else                                                                                                                                  \
+            hipLaunchKernelGGL((k_ols_frame<MF_, SW_, true, false, GP_, 1024>), dim3(grid1k), dim3(256), 0, s, f);                           \
+    } while (0)
+        if (a.genfold) RR_FRAME1K_LAUNCH(true, false, true);
+        else if (a.mixfold && a.sigma < 0.f) RR_FRAME1K_LAUNCH(true, true, false);
+        else if (a.mixfold) RR_FRAME1K_LAUNCH(true, false, false);
+        else RR_FRAME1K_LAUNCH(false, false, false);
+#undef RR_FRAME1K_LAUNCH
+        RR_HIP(hipGetLastError());
+        return RR_OK;
     }
     const unsigned grid = 1u + (unsigned)((nfr + 8 * RR_V_FRAMEWIN - 1) / (8 * RR_V_FRAMEWIN) * (8 * RR_V_FRAMEWIN));
-    f.fm = fm ? *fm : FrameMeter{};
 #define RR_FRAME_LAUNCH(MF_, SW_, FU_, GP_)                                                                                            \
     do {                                                                                                                                \
         if (fm)                                                                                                                         \

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the fused frame kernel (k_ols_frame: the whole chain in one kernel) against the f64
-oracle: the shapes it is compiled for (4 : 1, 4096-point Fourier stage, combined response of 129 .. 193 taps), random
+oracle: the shapes it is compiled for (4 : 1, 4096- or 1024-point Fourier stage, combined response of up to 193 taps), random
 shifts and NCO periods, real / one-sided / complex responses, ragged call sizes.  RR_FUSED_KERNEL=olsf is set here,
 so that it also runs on the short calls of a test stream (by default it takes calls of 2^23 samples and more).
 usage: fuzz_frame.py [cases] [seed]"""
@@ -27,7 +27,8 @@ for case in range(cases):
             lambda b, f, c=cut: 1.0 if 0 <= f <= c else 0.0,
             lambda b, f, c=cut: complex(np.exp(-abs(f) / c), 0.3 * np.sign(f) * np.exp(-abs(f) / c))][kind]
     center = bool(rng.integers(0, 2))
-    params = dict(shift=shift, filter_len=filter_len, freq_resp=resp, output_rate=out_rate, bandwidth=bw, fft_len=4096)
+    fft_len = int(rng.choice([4096, 1024]))  # (1024: a wave per frame)
+    params = dict(shift=shift, filter_len=filter_len, freq_resp=resp, output_rate=out_rate, bandwidth=bw, fft_len=fft_len)
     n = int(rng.integers(1 << 16, 1 << 18))
     x = o.synth_iq(300 + case, 0, n)
     ref = o.run_chain(x, fs, flt=np.float64, fft_window=o.Kaiser.with_null_at_bin(2.0), precision=precision, center_dc=center, **params)[3]

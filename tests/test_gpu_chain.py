@@ -640,6 +640,31 @@ def test_chain_frame_kernel_with_the_mixer_folded_into_its_tables(rr, oracle, mo
         assert rms_rel(a, b) <= 1e-5
 
 
+@pytest.mark.parametrize("shift,precision,bw,filter_len", [(25e6, 1.0, 40e6, 64), (-50e6, 1.0, 30e6, 64), (12.345e6, 1e3, 40e6, 64),
+                                                           (7e6, 1e3, 20e6, 20), (0.0, 1.0, 30e6, 30)])
+def test_chain_frame_kernel_with_1024_point_spectra(rr, oracle, monkeypatch, shift, precision, bw, filter_len):
+    """k_ols_frame<.., 1024>: 1024-point spectra, ONE WAVE per frame (five blocks, then the wave-level transform) - the mixer folded
+    into the tables (periods 8 and 4), behind the filter (40000, 200) and absent; the three overlaps; ragged calls with the
+    frame kernel forced onto short calls, an interrupt, calls without a whole frame; centred and plain; against the f64 oracle."""
+    monkeypatch.setenv("RR_FUSED_KERNEL", "olsf")
+    fs, n = 200e6, 1 << 18
+    params = dict(shift=shift, filter_len=filter_len, freq_resp=lowpass(10e6), output_rate=50e6, bandwidth=bw, fft_len=1024)
+    x = oracle.synth_iq(41, 0, n)
+    for center in (False, True):
+        ref = oracle.run_chain(x, fs, flt=np.float64, fft_window=oracle.Kaiser.with_null_at_bin(2.0), precision=precision,
+                               center_dc=center, **params)[3]
+        g = rr.Chain(**params, precision=precision, fft_window=rr.Kaiser.with_null_at_bin(2.0), center_dc=center)
+        out, frame_calls = [], 0
+        cuts = [0, 30000, 30001, 31000, 90007, 90071, 150000, 200064, 200100, n]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            out += g.process(rr.Samples(fs, x[a:b]))
+            frame_calls += g.last_path_kernel() == "k_ols_frame"
+        assert frame_calls >= 4, frame_calls
+        assert len(out) == len(ref) and len(out) >= 60
+        for a, b in zip(out, ref):
+            assert len(a.chunk) == 1024 and rms_rel(a.chunk, b) <= 1e-5
+
+
 @pytest.mark.parametrize("kernel,out_rate,bw", [("olsf", 50e6, 40e6), ("olsw", 50e6, 40e6), ("olsw", 25e6, 20e6), ("olsw", 100e6, 80e6)])
 def test_chain_frame_kernel_with_the_mixer_behind_the_filter(rr, oracle, monkeypatch, kernel, out_rate, bw):
     """Every NCO period that does not divide 8 (and every period at 2 : 1 and 8 : 1): k_ols_frame<.., GP> and
