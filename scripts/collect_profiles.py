@@ -42,7 +42,7 @@ def write_summary(dst, rnd):
                 out.append(f"{label}: {kn} {row['Calls']} launches, average {avg:.0f} ns (min {row['MinNs']}, max {row['MaxNs']}) = "
                            f"{bps * (1 << 26) / (avg * 1e-9) / 8e12:.3f} of {bps:.0f} B/sample x 2^26 samples at 8 TB/s")
     tj = os.path.join(dst, "traffic_fused_fir.json")
-    if os.path.exists(tj) and not rnd.endswith("a"):
+    if os.path.exists(tj) and rnd[-1].isdigit():
         t = json.load(open(tj))
         out.append(f"PMC passes: {t['kernel']} FETCH_SIZE {t['FETCH_SIZE_KB_raw']:.0f} KB x 2 + WRITE_SIZE {t['WRITE_SIZE_KB']:.0f} KB = {t['hbm_bytes_per_launch']:.0f} bytes "
                    f"per launch = {t['ratio']:.3f} x the algorithmic {t['algorithmic_bytes_per_launch']:.0f}")
