@@ -1175,7 +1175,8 @@ constexpr int kFrameBlocks = 20;
 constexpr int kPolyLds = 1136;  // 2 (63 + 72 * 7) + 2 elements
 // SW: the spectrum is taken 128 bins further on (y[0] <-> y[2], y[1] <-> y[3] in front of the inverse): the results' signs
 // alternate - k_ols_frame<true>'s fold of a mixer with s = 128 (rr_chain::ensure_mixfold)
-template <bool SW>
+// NG: how many of the four 16-byte pieces of the first half of G_p a lane finds in LDS (Glds; the rest comes from L2)
+template <bool SW, int NG = 4>
 __device__ __forceinline__ void poly4_block(f2 (&v)[16], f2 (&y)[4], f2 *lds, int l, f2 t_p1, f2 t_p2, const f2 (&t_inv)[3],
                                             const float2 *__restrict__ G, const float4 *Glds) {
     const int g = l >> 4, q = l & 15;
@@ -1232,7 +1233,7 @@ __device__ __forceinline__ void poly4_block(f2 (&v)[16], f2 (&y)[4], f2 *lds, in
     // scratch is HBM traffic (4 KiB written and read back per workgroup: 17 MB of the launch's 151 MB of writes)
     float4 ga[4], gb[4];
 #pragma unroll
-    for (int kp = 0; kp < 4; ++kp) ga[kp] = (RR_V_FRAME_GLDS && Glds) ? Glds[l + 64 * kp] : reinterpret_cast<const float4 *>(G)[l + 64 * kp];
+    for (int kp = 0; kp < 4; ++kp) ga[kp] = (RR_V_FRAME_GLDS && kp < NG) ? Glds[l + 64 * kp] : reinterpret_cast<const float4 *>(G)[l + 64 * kp];
 #pragma unroll
     for (int kp = 0; kp < 4; ++kp) gb[kp] = reinterpret_cast<const float4 *>(G)[l + 64 * (4 + kp)];
     const f2 w1 = t_p2, w2 = cmul(w1, w1), w3 = cmul(w2, w1);
@@ -1274,7 +1275,7 @@ __device__ __forceinline__ void poly4_block(f2 (&v)[16], f2 (&y)[4], f2 *lds, in
 #else
     float4 ga[4], gb[4];
 #pragma unroll
-    for (int kp = 0; kp < 4; ++kp) ga[kp] = (RR_V_FRAME_GLDS && Glds) ? Glds[l + 64 * kp] : reinterpret_cast<const float4 *>(G)[l + 64 * kp];
+    for (int kp = 0; kp < 4; ++kp) ga[kp] = (RR_V_FRAME_GLDS && kp < NG) ? Glds[l + 64 * kp] : reinterpret_cast<const float4 *>(G)[l + 64 * kp];
     f2 d[4][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -1428,7 +1429,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #if RR_V_FRAME_GLDS
     // the first half of the response tables G_p (phases 0 and 1: 4 KiB) in LDS, in the 4.5 KiB per workgroup that four workgroups per
     // CU leave: every block otherwise pulls all 8 KiB from L2 - as many bytes as its samples, in 8 of its 16 vector-memory instructions
-    __shared__ __attribute__((aligned(16))) float4 gl[WF ? 1 : 256];
+    __shared__ __attribute__((aligned(16))) float4 gl[WF ? 192 : 256];  // (LF = 1024: three of the four pieces fit beside the four images)
 #endif
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     f2 *const fr = WF ? smem + w * kImg : smem;
@@ -1440,12 +1441,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     unsigned f;
     if constexpr (WF) {
         const unsigned g = 4u * blockIdx.x + (unsigned)w;
-        if (g == 0) {
-            f = a.nfr;
-        } else {
-            f = g - 1;
-            if (f >= a.nfr) return;
-        }
+        f = g == 0 ? a.nfr : g - 1;  // (waves without a frame leave behind the workgroup's one barrier, below)
     } else if (blockIdx.x == 0) {
         f = a.nfr;
     } else {
@@ -1488,12 +1484,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     f2 *const lds = smem + w * kImg;
     const float4 *glp = nullptr;
 #if RR_V_FRAME_GLDS
-    if constexpr (!WF) {
-        gl[tid] = reinterpret_cast<const float4 *>(a.H)[tid];
-        __syncthreads();
-        glp = gl;
-    }
+    if (!WF || tid < 192) gl[tid] = reinterpret_cast<const float4 *>(a.H)[tid];
+    __syncthreads();
+    glp = gl;
 #endif
+    if constexpr (WF) {
+        if (f > a.nfr) return;
+    }
     const long n_clamp = a.n_in - 1024;  // the launcher guarantees n_in >= 1024
     // mixer folded into the tables (MF): the blocks transform the samples as they are; the phasor of a block's first sample (the same
     // for every block of the call) is in the table the host picked for this call, the alternating sign in poly4_block<SW>
@@ -1609,7 +1606,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 if (r >= a.denom) r -= a.denom;
             }
         }
-        poly4_block<SW>(v, keep[kb], lds, l, t_p1, t_p2, t_inv, a.H, glp);
+        poly4_block<SW, WF ? 3 : 4>(v, keep[kb], lds, l, t_p1, t_p2, t_inv, a.H, glp);
         if constexpr (GP) {
             // result tau = l + 64 c of the block sits at input position b0 + 4 tau
             const f2 gph = cmul((f2){pgv[kb].x, pgv[kb].y}, glane);
