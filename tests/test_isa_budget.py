@@ -34,7 +34,7 @@ def kernels(src, tmp_path):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
 def test_the_headline_kernels_do_not_spill(tmp_path):
     ols = kernels("rr_ols.hip", tmp_path)
-    frame = {k: v for k, v in ols.items() if "k_ols_frame" in k}
+    frame = {k: v for k, v in kernels("rr_ols_frame.hip", tmp_path).items() if "k_ols_frame" in k}
     assert len(frame) >= 16
     for name, k in frame.items():
         mixer_folded_or_behind = "k_ols_frameILb1E" in name  # MF = true: every instance but the mixer-in-front one
