@@ -433,6 +433,9 @@ __global__ __launch_bounds__(256) void k_decim_poly_f64(DecimArgs64 a, const Tap
 // Taps: per (phase b, row r) the first column c_lo and a run of `steps` f64 taps (zeros behind the row's own), read through the
 // scalar cache (from LDS they cost the same 1 KiB per wave as a sample: uniform or not, a read returns 16 bytes to every lane).
 // P >= 1 (P = Q = 1: a plain FIR).
+// (The same form for Complex<f32> - measured in round 3, with the LDS offsets precomputed per step as k_decim_poly has them - was
+//  SLOWER than k_decim_poly: 10 : 1 / 145 taps 0.187 against 0.136 ms per 2^26 samples, 8 : 3 0.178 against 0.149, 3 : 2 0.269
+//  against 0.209; only 5 : 1 with 183 taps came out level.  k_decim_poly's staging and tile sizes carry it; not kept.)
 // ---------------------------------------------------------------------------
 struct DecimArgsR4 {
     const double2 *hist;
