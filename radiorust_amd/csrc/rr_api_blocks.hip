@@ -275,7 +275,11 @@ int rr_filter::build_tables(bool reset_history) {
     if (use_conv) use_ols4096 = big_ols4096 = use_ols16k = false, npart = 0;
     {
         const char *e = std::getenv("RR_FILTER_KERNEL");  // "ols4096" / "fir" keep the older kernels (A/B runs, tests)
-        use_wave = filter_wave_supported(dtype, len) && !(e && (!std::strcmp(e, "ols4096") || !std::strcmp(e, "fir")));
+        // (k_filter_wave up to 256 taps: beyond them its 1024-sample blocks keep less than 75 % and the 4096-point blocks are ahead -
+        //  320 taps 0.218 against 0.207 ms per 2^26 samples, 384 taps 0.235 against 0.205, 256 taps 0.207 against 0.203: scripts/filter_ab_probe.py;
+        //  RR_FILTER_KERNEL=wave keeps it up to its 385)
+        const bool wave_all = e && !std::strcmp(e, "wave");
+        use_wave = filter_wave_supported(dtype, len) && (len <= 256 || wave_all) && !(e && (!std::strcmp(e, "ols4096") || !std::strcmp(e, "fir")));
         if (e && !std::strcmp(e, "fir")) big_ols4096 = false;
     }
     if (use_wave) {

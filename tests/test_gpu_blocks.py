@@ -431,7 +431,7 @@ def test_filter_overlap_save_f64_and_batched(rr, oracle):
     check(d_out.cpu().numpy()[:wrote], np.concatenate(r64), np.concatenate(r32))
 
 
-@pytest.mark.parametrize("n,forced", [(64, None), (128, None), (48, None), (256, None), (385, None), (64, "ols4096"), (128, "ols4096")])
+@pytest.mark.parametrize("n,forced", [(64, None), (128, None), (48, None), (256, None), (385, "wave"), (300, "wave"), (64, "ols4096"), (128, "ols4096")])
 def test_filter_short_power_of_two_long_calls(rr, oracle, n, forced, monkeypatch):
     """Short filters in f32: calls that produce >= 16384 samples run k_filter_wave (a wave per 1024-sample
     block; RR_FILTER_KERNEL=ols4096: k_filter_ols4096 for n = 64 / 128), shorter ones the small-call kernels;
@@ -455,7 +455,7 @@ def test_filter_short_power_of_two_long_calls(rr, oracle, n, forced, monkeypatch
         kernels.append(g.last_kernel())
         off += n * k
     torch.cuda.synchronize()
-    big = 2 if forced else 3
+    big = 2 if forced == "ols4096" else 3  # (k_filter_wave by default up to 256 taps; RR_FILTER_KERNEL=wave: up to its 385)
     assert kernels[1] == big and kernels[3] == big and 3 not in (kernels[0], kernels[2], kernels[4]), kernels
     assert wrote == n * (sum(ks) - 1)
     o64 = oracle.Filter(lowpass(20e6), flt=np.float64)
