@@ -53,3 +53,11 @@ def test_the_headline_kernels_do_not_spill(tmp_path):
     for name, k in fo.items():
         if "k_filter_blk" in name:
             assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (name, k)
+    # Complex<f64>: the register transform and the overlap-save kernel on it (two waves per SIMD: at most 256 registers)
+    f64 = kernels("rr_f64.hip", tmp_path)
+    seen = 0
+    for name, k in f64.items():
+        if "k_fft4096_f64" in name or "k_ols4096_f64" in name:
+            seen += 1
+            assert k["vgpr_spill_count"] == 0 and k["vgpr_count"] <= 256, (name, k)
+    assert seen == 2
