@@ -605,6 +605,10 @@ int rr_downsampler::process_dev(double input_rate, const void *d_in, size_t n_in
         }
         if (fast_kind == rr_chain::FK_SELECT) {
             next.advance(n_in, nullptr);
+            if (f_V == 0)
+                RR_TRY(launch_decim_select_blk(stream, hist[cur].p, L, d_in, n_in, f_H.p, f_tw.p, L, d_out, produce, sched.ra, sched.rb,
+                                               sched.pos_units()));
+            else
             RR_TRY(launch_decim_select(stream, hist[cur].p, L, d_in, n_in, f_H.p, f_tw.p, f_V, d_out, produce, sched.ra, sched.rb,
                                        sched.pos_units()));
             RR_TRY(launch_update_hist(dtype, stream, hist[cur].p, hist[cur ^ 1].p, L, d_in, n_in));
@@ -729,7 +733,8 @@ int rr_downsampler::ensure_fast() {
     if (kind == rr_chain::FK_OLSF) kind = rr_chain::FK_OLSW;
     // RR_DOWNSAMPLER_SELECT=1: k_filter_wave<true> for every pair of integer rates it takes (A/B runs, tests)
     const char *se = std::getenv("RR_DOWNSAMPLER_SELECT");
-    const bool force_select = se && std::atoi(se) != 0 && decim_select_supported(dtype, sched.ra, sched.rb, L);
+    const bool force_select = se && std::atoi(se) != 0 &&
+                              (decim_select_supported(dtype, sched.ra, sched.rb, L) || decim_select_blk_supported(dtype, sched.ra, sched.rb, L));
     if (force_select) kind = rr_chain::FK_NONE;
     {
         // RR_DOWNSAMPLER_POLY=1: k_decim_poly also where a fused kernel applies (A/B runs)
@@ -757,6 +762,24 @@ int rr_downsampler::ensure_fast() {
         if (decim_poly_supported(dtype, sched.P, sched.Q, L) && !force_select) {
             fast_kind = rr_chain::FK_POLY;
             poly_version = ~0ull;
+        } else if (!decim_select_supported(dtype, sched.ra, sched.rb, L) && decim_select_blk_supported(dtype, sched.ra, sched.rb, L)) {
+            // the same with responses of 386 .. 2048 taps: 4096-point blocks (k_filter_blk4096<.., SEL>); the Filter's table layout
+            std::vector<cd> gg(4096, cd(0, 0));
+            for (size_t i = 0; i < L; ++i) gg[i] = cd(ir_f64[L - 1 - i], 0.0);
+            fft_f64(gg, false);
+            std::vector<float> gb(2 * 4096), twb(2 * 4096);
+            for (size_t i = 0; i < 4096; ++i) {
+                const size_t kp = i / 512, r = i % 512, dst = (kp * 256 + r % 256) * 2 + r / 256;
+                gb[2 * dst] = (float)(gg[i].real() / 4096.0);
+                gb[2 * dst + 1] = (float)(gg[i].imag() / 4096.0);
+                const double ang = -2.0 * M_PI * (double)i / 4096.0;
+                twb[2 * i] = (float)std::cos(ang);
+                twb[2 * i + 1] = (float)std::sin(ang);
+            }
+            RR_TRY(upload(f_H, gb.data(), gb.size() * sizeof(float), stream));
+            RR_TRY(upload(f_tw, twb.data(), twb.size() * sizeof(float), stream));
+            f_V = 0;  // (0: the 4096-point blocks)
+            fast_kind = rr_chain::FK_SELECT;
         } else if (decim_select_supported(dtype, sched.ra, sched.rb, L)) {
             // every other pair of integer rates (48 000 -> 44 100: 160 : 147): the response at every position, as the Filter's
             // k_filter_wave, and the results of the releasing positions stored (k_filter_wave<true>)

@@ -97,6 +97,7 @@ struct Blk4096Args {
     float2 *hist_out;         // receives the last hist_out_len samples of [ hist | in ] (may be null)
     int hist_out_len;
     int nparts;               // PARTS: partitions of 2048 taps, G holds their tables one behind the other
+    SelectArgs sel;           // SEL: the Downsampler's periodic schedule (launch_decim_select_blk)
 };
 
 // ACC: the block's results are added to what `out` holds (responses longer than 2048 taps run as partitions of 2048,
@@ -105,7 +106,10 @@ struct Blk4096Args {
 // y_block = IDFT( sum_p DFT(x_block delayed by 2048 p) G_p ): the workgroup transforms its block of the stream at the
 // nparts delays, sums the products in registers and runs ONE inverse - nparts + 1 transforms per block where a launch per
 // partition (the first form, kept as ACC) takes 2 nparts and reads and rewrites the output nparts - 1 times.
-template <bool OUT16, bool G16, bool ACC, bool PARTS = false>
+// SEL: the Downsampler for ANY periodic schedule with responses of up to 2048 taps (k_filter_wave<true> serves up to 385): the
+// response at every input position, the results of the releasing positions stored - see k_filter_wave<true> in rr_ols.hip for
+// the schedule's arithmetic; here every one of a lane's 16 results reduces its own F(t) = Rb + t rb (exact in f64).
+template <bool OUT16, bool G16, bool ACC, bool PARTS = false, bool SEL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PARTS ? 3 : 4, PARTS ? 3 : 4))) void k_filter_blk4096(Blk4096Args a) {
     __shared__ __attribute__((aligned(16))) f2 img[kImg];
     __shared__ __attribute__((aligned(16))) f2 tab[kTab];
@@ -275,6 +279,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PARTS ? 3 :
     }
     transform(true, [] {});
 
+    if constexpr (SEL) {
+        // F(t) = base0 + blk hop rb + t rb for the block's element t (position blk hop + t - V), base0 = pos + V (ra - rb): element t
+        // releases iff (F mod ra) + rb >= ra and then carries m = floor(F / ra) - V
+        const SelectArgs &sel = a.sel;
+        const double dra = (double)sel.ra;
+        auto reduce = [&](double x, unsigned &r) -> unsigned {  // x = q ra + r, exact
+            double q = __builtin_floor(x * sel.inv_ra);
+            double rr = __builtin_fma(-q, dra, x);
+            if (rr < 0.0) { rr += dra; q -= 1.0; }
+            if (rr >= dra) { rr -= dra; q += 1.0; }
+            r = (unsigned)rr;
+            return (unsigned)q;
+        };
+        unsigned Rb;
+        const unsigned qb = reduce((double)sel.base_r + (double)blk * (double)sel.hr, Rb);
+        const long mb = (long)sel.base_q + (long)blk * (long)sel.hq + (long)qb - a.V;  // m of a release at the block's F = Rb
+        const long lft = a.n_out - mb;
+        const unsigned rec = (unsigned)(lft < 8192 ? (lft > 0 ? lft : 0) : 8192) * 8u;
+        const __amdgpu_buffer_rsrc_t rsel = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float2 *>(a.out) + mb, 0, rec, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (256 * k > hop) continue;  // (no lane's index reaches V)
+            const int t = (4096 - j - 256 * k) & 4095;
+            unsigned R;
+            const unsigned C = reduce((double)Rb + (double)t * (double)sel.rb, R);
+            const bool em = t >= a.V && R + sel.rb >= sel.ra;
+            __builtin_amdgcn_raw_buffer_store_b64(v[k], rsel, em ? C * 8u : 0xffffffffu, 0, 0);
+        }
+        return;
+    }
     // y[t] = v[k] with t = (4096 - (j + 256 k)) mod 4096; valid for t >= V: output mbase + t - V.
     // Offsets in the block's output window: (hop - j - 256 k) elements; t = 0 lands on `hop` (past the
     // window), t < V wraps to a huge offset: the descriptor's range check drops both.
@@ -476,6 +510,60 @@ int launch_filter_blk4096(hipStream_t s, const void *hist, size_t hist_len, cons
         if (g_f16) hipLaunchKernelGGL((k_filter_blk4096<false, true, false>), dim3(grid), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_filter_blk4096<false, false, false>), dim3(grid), dim3(256), 0, s, a);
     }
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// The Downsampler through k_filter_blk4096<.., SEL>: out[m] = sum_i c[i] x[e_m - i] for the releases e_m of the periodic schedule
+// (ra, rb, pos) among the n_in positions of the call; G / tw4096 = the tables of c = reverse(ir) as the Filter's, L <= 2048 taps.
+bool decim_select_blk_supported(int dtype, uint64_t ra, uint64_t rb, size_t L) {
+    return dtype == RR_F32 && L >= 2 && L <= 2048 && rb >= 1 && rb < ra && ra < (1ull << 31);
+}
+int launch_decim_select_blk(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *G, const void *tw4096,
+                            size_t L, void *out, size_t n_out, uint64_t ra, uint64_t rb, uint64_t pos) {
+    if (n_out == 0 || n_in == 0) return RR_OK;
+    if (!decim_select_blk_supported(RR_F32, ra, rb, L) || pos >= ra)
+        RR_FAIL(RR_ERR_BAD_ARG, "Downsampler (select, 4096-point blocks): rates %llu : %llu, pos %llu, %zu taps", (unsigned long long)ra,
+                (unsigned long long)rb, (unsigned long long)pos, L);
+    Blk4096Args a;
+    a.hist = (const float2 *)hist;
+    a.hist_len = (int)hist_len;
+    a.in = (const float2 *)in;
+    a.n_in = (long)n_in;
+    a.G = G;
+    a.tw = (const float2 *)tw4096;
+    a.V = (int)L;  // V >= L - 1
+    a.out = out;
+    a.n_out = (long)n_out;
+    a.e0 = 0;
+    a.hist_out = nullptr;
+    a.hist_out_len = 0;
+    a.nparts = 1;
+    const size_t hop = 4096 - a.V;
+    const size_t nblocks = (n_in + hop - 1) / hop;  // the response at every position of the call
+    if (nblocks > 0x3fffffull) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler (select): too many blocks");
+    a.nblocks = (unsigned)nblocks;
+    {
+        const long first = -(long)a.V;
+        long lo = (-first + (long)hop - 1) / (long)hop;
+        long hi = ((long)n_in - 4096 - first) >= 0 ? ((long)n_in - 4096 - first) / (long)hop + 1 : 0;
+        if (hi > (long)nblocks) hi = (long)nblocks;
+        if (lo > hi) lo = hi;
+        a.blk_lo = (unsigned)lo;
+        a.blk_hi = (unsigned)hi;
+    }
+    SelectArgs &q = a.sel;
+    q.ra = (uint32_t)ra;
+    q.rb = (uint32_t)rb;
+    q.inv_ra = 1.0 / (double)ra;
+    q.kr = q.kq = 0;  // (k_filter_wave<true>'s steps of 128 positions: not used here)
+    q.hr = (uint32_t)((hop * rb) % ra);
+    q.hq = (uint32_t)((hop * rb) / ra);
+    const uint64_t base0 = pos + (uint64_t)a.V * (ra - rb);
+    q.base_r = (uint32_t)(base0 % ra);
+    q.base_q = (uint32_t)(base0 / ra);
+    const unsigned grid = (unsigned)((nblocks + 127) / 128 * 128);
+    hipLaunchKernelGGL((k_filter_blk4096<false, false, false, false, true>), dim3(grid), dim3(256), 0, s, a);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }

@@ -146,6 +146,10 @@ struct SelectArgs {
 bool decim_select_supported(int dtype, uint64_t ra, uint64_t rb, size_t L);
 int launch_decim_select(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *H, const void *tw,
                         int V, void *out, size_t n_out, uint64_t ra, uint64_t rb, uint64_t pos);
+// the same through k_filter_blk4096<.., SEL> for responses of 386 .. 2048 taps (G: the Filter's 4096-point table of c = reverse(ir))
+bool decim_select_blk_supported(int dtype, uint64_t ra, uint64_t rb, size_t L);
+int launch_decim_select_blk(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *G, const void *tw4096,
+                            size_t L, void *out, size_t n_out, uint64_t ra, uint64_t rb, uint64_t pos);
 int launch_filter_wave(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *H,
                        const void *tw, int V, void *out, size_t n_out, long e0);
 bool ols_wave_supported(uint64_t D, size_t Lc);

@@ -53,7 +53,8 @@ for name, fin, fout, bw, bps in (("Downsampler 1024->102.4 kS/s L=145 (10:1)", 1
                                  ("Downsampler 300->100 kS/s (3:1)", 300000.0, 100000.0, 60000.0, 8 + 8 / 3),
                                  ("Downsampler 48->32 kS/s (3:2)", 48000.0, 32000.0, 20000.0, 8 + 16 / 3),
                                  ("Downsampler 48->44.1 kS/s L=71 (160:147)", 48000.0, 44100.0, 40000.0, 8 + 8 * 147 / 160),
-                                 ("Downsampler 1024->44.1 kS/s L=255 (10240:441)", 1024000.0, 44100.0, 20000.0, 8 + 8 * 441 / 10240)):
+                                 ("Downsampler 1024->44.1 kS/s L=255 (10240:441)", 1024000.0, 44100.0, 20000.0, 8 + 8 * 441 / 10240),
+                                 ("Downsampler 1024->44.1 kS/s L=436 (10240:441)", 1024000.0, 44100.0, 30000.0, 8 + 8 * 441 / 10240)):
     for generic in (False, True):
         if generic:
             os.environ["RR_DOWNSAMPLER_GENERIC"] = "1"

@@ -537,7 +537,9 @@ FAST_CASES = [
     (220500.0, 48000.0, 40000.0, 2.0, 10),    # 147 : 32, L = 111
     (48000.0, 44100.5, 30000.0, 2.0, 10),     # rates on the 2^-1 grid: 96000 : 88201, closed form (the sample loop before)
     (1000.25, 333.125, 200.0, 2.0, 10),       # 2^-3 grid: 8002 : 2665
-    (1024000.0, 44100.0, 30000.0, 3.0, 0),    # L = 436: beyond k_filter_wave's overlap -> k_fir with the emission list
+    (1024000.0, 44100.0, 30000.0, 3.0, 10),   # L = 436: beyond k_filter_wave's overlap -> the 4096-point blocks (k_filter_blk4096<.., SEL>)
+    (1024000.0, 44100.0, 41000.0, 3.0, 10),   # L = 1982
+    (1024000.0, 44100.0, 42000.0, 3.0, 0),    # L = 2926: beyond those too -> k_fir, the periodic schedule in closed form
 ]
 
 
@@ -592,7 +594,8 @@ def test_downsampler_f64_polyphase_kernel(rr, oracle, monkeypatch, fin, fout, bw
 
 
 @pytest.mark.parametrize("fin,fout,bw,q", [(200e6, 50e6, 40e6, 3.0), (1024000.0, 384000.0, 200000.0, 3.0), (48000.0, 32000.0, 20000.0, 2.0),
-                                          (1024000.0, 102400.0, 60000.0, 3.0), (45000.0, 44999.0, 30000.0, 1.0), (2.0e9, 1.9e9, 1.0e9, 2.0)])
+                                          (1024000.0, 102400.0, 60000.0, 3.0), (45000.0, 44999.0, 30000.0, 1.0), (2.0e9, 1.9e9, 1.0e9, 2.0),
+                                          (200e6, 50e6, 47e6, 3.0), (2560000.0, 40000.0, 30000.0, 1.5), (48000.0, 32000.0, 31900.0, 1.0)])  # L = 400, 768, 960: the 4096-point blocks
 def test_downsampler_select_kernel_on_request(rr, oracle, monkeypatch, fin, fout, bw, q):
     """RR_DOWNSAMPLER_SELECT=1: k_filter_wave<true> for every pair of integer rates it takes - the ratios the other kernels
     serve by default, a period of 45 000 inputs (almost every position releases) and rates close to the kernel's 2^31 limit;
