@@ -75,7 +75,7 @@ static bool is_pow2_sz(size_t n) { return n && (n & (n - 1)) == 0; }
 
 // Which kernels transform a chunk of `len` points - ONE decision, used by prepare() and by rr_fourier_route() (host only).
 struct FourierRoute {
-    enum Kind { DIRECT, POW2, BIG_TILE, BIG_TRANSPOSE, BIG_GENERIC, MIXED, TILEM, BS_WAVE, BS_FUSED, BS_FUSED8K, BS_LDS, BS_LAUNCHES } kind = DIRECT;
+    enum Kind { DIRECT, POW2, BIG_TILE, BIG_TRANSPOSE, BIG_GENERIC, MIXED, TILEM, BS_WAVE, BS_FUSED, BS_FUSED8K, BS_BIG, BS_LDS, BS_LAUNCHES } kind = DIRECT;
     size_t N1 = 0, N2 = 0;  // the four-step / two-pass split
     size_t M = 0;           // Bluestein's power-of-two length
 };
@@ -128,9 +128,17 @@ static FourierRoute fourier_route(int dtype, size_t len, bool force_mixed, bool 
         } else if (!generic && bluestein1024_supported(dtype, len)) {
             r.kind = FourierRoute::BS_WAVE;
             M = 1024;
-        } else if (!generic && bluestein8192_supported(dtype, len)) {
-            r.kind = FourierRoute::BS_FUSED8K;  // f32, 2049 .. 4096 points: one kernel around two 8192-point register transforms
+        } else if (!generic && bluestein8192_supported(dtype, len) &&
+                   [] { const char *e = std::getenv("RR_FOURIER_BS8K"); return e && std::strcmp(e, "regs") == 0; }()) {
+            // (on request: f32, 2049 .. 4096 points around two 8192-point register transforms at 256 lanes - 0.224 ms per 2^24 samples
+            //  of 3001-point chunks against 0.161 by the workgroup transform below)
+            r.kind = FourierRoute::BS_FUSED8K;
             M = 8192;
+        } else if (size_t Mb = 0; !generic && bluestein_big_supported(dtype, len, &Mb) && fourier_pow2_path(dtype, Mb) &&
+                                  ![] { const char *e = std::getenv("RR_FOURIER_BS_BIG"); return e && std::atoi(e) == 0; }()) {
+            // f32, 2049 .. 8192 points: one kernel around two workgroup transforms of 8192 / 16 384 points (rr_fft_big.hpp)
+            r.kind = FourierRoute::BS_BIG;
+            M = Mb;
         } else if (!generic && bluestein_lds_supported(dtype, len, M) &&
                    ![] { const char *e = std::getenv("RR_FOURIER_BS_LDS"); return e && std::atoi(e) == 0; }()) {
             // f64 up to 2048 points: one kernel with the transforms as Stockham passes between two LDS images
@@ -162,7 +170,8 @@ int rr_fourier::prepare(size_t len) {
     const bool generic = route.kind == FR::BIG_GENERIC;  // (only consulted on the `big` branches below)
     const bool use_mixed = route.kind == FR::MIXED, use_tilem = route.kind == FR::TILEM;
     const size_t tmN1 = route.N1, tmN2 = route.N2;
-    const bool use_bs = route.kind == FR::BS_WAVE || route.kind == FR::BS_FUSED || route.kind == FR::BS_FUSED8K || route.kind == FR::BS_LDS ||
+    const bool use_bs = route.kind == FR::BS_WAVE || route.kind == FR::BS_FUSED || route.kind == FR::BS_FUSED8K || route.kind == FR::BS_BIG ||
+                        route.kind == FR::BS_LDS ||
                         route.kind == FR::BS_LAUNCHES;
     auto cast = [&](const std::vector<double> &src, std::vector<unsigned char> &dst) {
         if (dtype == RR_F32) cast_to<float>(src.data(), src.size(), dst);
@@ -296,7 +305,7 @@ int rr_fourier::prepare(size_t len) {
     mixed = use_mixed;
     tilem = use_tilem;
     bs_M = 0;
-    bs_fused = bs_wave = bs_lds = bs_fused8k = false;
+    bs_fused = bs_wave = bs_lds = bs_fused8k = bs_big = false;
     big = use_big;
     if (use_bs) {
         const size_t M = route.M;
@@ -304,6 +313,7 @@ int rr_fourier::prepare(size_t len) {
         bs_wave = route.kind == FR::BS_WAVE;    // k_bluestein1024
         bs_lds = route.kind == FR::BS_LDS;      // k_bluestein_lds
         bs_fused8k = route.kind == FR::BS_FUSED8K;  // k_bluestein8192
+        bs_big = route.kind == FR::BS_BIG;          // k_bluestein_big<M>
         // chirp w_m = e^{+j pi m^2 / n}, the phase reduced exactly (m^2 mod 2n) before it is evaluated
         std::vector<cd> w(len);
         for (size_t m = 0; m < len; ++m) {
@@ -330,6 +340,10 @@ int rr_fourier::prepare(size_t len) {
                 const size_t l = m % 64, j = (m / 64) % 2, kp = m / 128;
                 dst = (kp * 64 + l) * 2 + j;
             }
+            if (bs_big) {  // [kp][j][h] = B[j + T (2 kp + h)], T = M / 16 lanes
+                const size_t T = M / 16, j = m % T, k = m / T;
+                dst = ((k / 2) * T + j) * 2 + k % 2;
+            }
             Bf[2 * dst] = bb[m].real() / (double)M;
             Bf[2 * dst + 1] = bb[m].imag() / (double)M;
         }
@@ -345,7 +359,7 @@ int rr_fourier::prepare(size_t len) {
             RR_TRY(bs_fft->init_base(K_FOURIER, dtype, device));
         }
         bs_fft->stream = stream;
-        bs_fft->prefer_tile = true;
+        bs_fft->prefer_tile = !bs_big;  // (k_bluestein_big reads the whole table W_M^i)
         RR_TRY(bs_fft->prepare(M));  // rectangular window: all ones
         bs_M = M;
     }
@@ -438,6 +452,9 @@ int rr_fourier::transform_dev(const void *head, size_t n_head, const void *in, v
     if (!bs_M) return launch_fourier_overlapped(dtype, stream, head, n_head, in, out, n, hop, count, d_window.p, d_tw.p, center_dc);
     if (bs_wave)
         return launch_bluestein1024(stream, head, n_head, in, hop, n, d_bs_c.p, d_bs_B.p, d_bs_w.p, bs_fft->d_tw.p, out, center_dc, count);
+    if (bs_big)
+        return launch_bluestein_big(stream, bs_M, head, n_head, in, hop, n, d_bs_c.p, d_bs_B.p, d_bs_w.p, bs_fft->d_tw.p, out, center_dc,
+                                    count);
     if (bs_fused8k)
         return launch_bluestein8192(stream, head, n_head, in, hop, n, d_bs_c.p, d_bs_B.p, d_bs_w.p, bs_fft->d_tw.p, out, center_dc, count);
     if (bs_lds)
@@ -726,6 +743,7 @@ int rr_fourier_route(int dtype, size_t n, char *buf, size_t cap) {
         case FR::BS_WAVE: std::snprintf(buf, cap, "bluestein wave M=%zu", r.M); break;
         case FR::BS_FUSED: std::snprintf(buf, cap, "bluestein one kernel M=%zu", r.M); break;
         case FR::BS_FUSED8K:
+        case FR::BS_BIG:
         case FR::BS_LDS: std::snprintf(buf, cap, "bluestein one kernel M=%zu", r.M); break;
         case FR::BS_LAUNCHES: {
             // around the nested power-of-two transform: one launch each (M <= 8192 / 4096: five in all), its two passes with the

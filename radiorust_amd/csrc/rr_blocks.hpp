@@ -248,7 +248,8 @@ struct rr_fourier : rr_block {
     size_t bs_M = 0;
     bool bs_fused = false;  // f32, 513 .. 2048 points: k_bluestein4096 (one launch per call)
     bool bs_wave = false;   // f32, 32 .. 512 points: k_bluestein1024 (a wave per chunk)
-    bool bs_fused8k = false;  // f32, 2049 .. 4096 points: k_bluestein8192
+    bool bs_fused8k = false;  // f32, 2049 .. 4096 points: k_bluestein8192 (RR_FOURIER_BS8K=regs)
+    bool bs_big = false;      // f32, 2049 .. 8192 points: k_bluestein_big<8192 / 16384>
     bool bs_lds = false;    // M <= 8192 (f32) / 4096 (f64): k_bluestein_lds (one kernel, Stockham passes between two LDS images)
     rr_fourier *bs_fft = nullptr;
     rr::DevBuf d_bs_c, d_bs_B, d_bs_w, bs_ws[2];

@@ -1,11 +1,12 @@
 // rr_bluestein.hip — Bluestein's algorithm in ONE kernel for the Fourier block's chunk lengths that are not powers of two,
 // Complex<f32> (analysis.rs:82-115 accepts any length): k_bluestein1024 (32 .. 512 points, a wave per chunk),
-// k_bluestein4096 (513 .. 2048), k_bluestein8192 (2049 .. 4096 with a prime factor beyond 13).
+// k_bluestein4096 (513 .. 2048), k_bluestein_big<M> (2049 .. 8192 with a prime factor beyond 13; k_bluestein8192 on request).
 // (split out of rr_fused.hip in round 3; derivations and dropped variants: DESIGN_HISTORY.md 4)
 #include "rr_blocks.hpp"
 #include "rr_wave_math.hpp"
 #include "rr_meter_dev.hpp"
 #include "rr_fft_regs.hpp"
+#include "rr_fft_big.hpp"
 
 #include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
@@ -90,6 +91,132 @@ int launch_bluestein8192(hipStream_t s, const void *head, size_t n_head, const v
                        (const float2 *)tw8192, (float2 *)out, (int)center_dc, (unsigned)count);
     RR_HIP(hipGetLastError());
     return RR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Kernel 2z  k_bluestein_big<N>: the same algorithm around two transforms of N = 8192 / 16 384 points by rr_fft_big.hpp's
+// workgroup transform (N / 16 lanes with 16 values each): 4097 .. 8192 points with a prime factor beyond 13 in ONE kernel instead of
+// four launches of the two-pass tile transform through HBM (which move 4 x 16 384 x 16 bytes per chunk for 16 n algorithmic ones),
+// and 2049 .. 4096 points around 8192-point ones (k_bluestein8192's register transforms stay behind RR_FOURIER_BS8K=regs).  Lane j's results X[j + T k] of the first transform are the second
+// one's inputs at the same index: between the two the values stay in their registers.  B is read in pairs:
+// Bp[(kp T + j) 2 + h] = B[j + T (2 kp + h)] (as k_filter_blkbig's G).
+// ---------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(N / 16) void k_bluestein_big(const float2 *__restrict__ head, long n_head, const float2 *__restrict__ in,
+                                                          long hop, int n, const float2 *__restrict__ c, const void *__restrict__ Bp,
+                                                          const float2 *__restrict__ w, const float2 *__restrict__ tw,
+                                                          float2 *__restrict__ out, int center_dc, unsigned count) {
+    constexpr int T = N / 16;
+    extern __shared__ __attribute__((aligned(16))) f2 bsbig_smem[];
+    f2 *const img = bsbig_smem;
+    f2 *const tab = bsbig_smem + (N + N / 16);
+    const int j = threadIdx.x;
+    const unsigned fr = blockIdx.x;
+    if (fr >= count) return;
+    const long base = (long)fr * hop - n_head;
+    f2 v[16];
+    {
+        // n <= N / 2: the values k >= 8 are the zero padding; loads at a clamped index and selected afterwards (k_bluestein4096)
+        float2 xs[8], cs[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int m = j + T * k;
+            const int mc = m < n ? m : n - 1;
+            const long i = base + mc;
+            xs[k] = (i >= 0) ? in[i] : head[n_head + i];
+            cs[k] = c[mc];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f2 p = cmul((f2){xs[k].x, xs[k].y}, (f2){cs[k].x, cs[k].y});
+            v[k] = (j + T * k < n) ? p : (f2){0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 8; k < 16; ++k) v[k] = (f2){0.f, 0.f};
+    }
+    BigFftLane<N> ln;
+    ln.init(tw, tab, j);
+    const __amdgpu_buffer_rsrc_t rsB = rsrc_of(Bp, 8u * N);
+    float4 g4[8];
+    big_fft<N, true>(v, img, ln, j, false, [&] {
+        if constexpr (N == 8192) {
+#pragma unroll
+            for (int kp = 0; kp < 8; ++kp) g4[kp] = buf_ld_f4<0>(rsB, 16u * j, 16u * T * kp);
+        }
+    });
+    if constexpr (N == 8192) {
+#pragma unroll
+        for (int kp = 0; kp < 8; ++kp) {
+            v[2 * kp] = cmul(v[2 * kp], (f2){g4[kp].x, g4[kp].y});
+            v[2 * kp + 1] = cmul(v[2 * kp + 1], (f2){g4[kp].z, g4[kp].w});
+        }
+    } else {  // (128 registers per lane at 1024 lanes: B in two halves, as k_filter_blkbig)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) g4[kp] = buf_ld_f4<0>(rsB, 16u * j, 16u * T * (4 * h + kp));
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) {
+                v[8 * h + 2 * kp] = cmul(v[8 * h + 2 * kp], (f2){g4[kp].x, g4[kp].y});
+                v[8 * h + 2 * kp + 1] = cmul(v[8 * h + 2 * kp + 1], (f2){g4[kp].z, g4[kp].w});
+            }
+        }
+    }
+    // the chirp values of the bins this lane stores: tau = (N - j - T k) mod N < n needs j + T k > N / 2 (k >= 8), or j = k = 0
+    float2 wt[9];
+    big_fft<N, true>(v, img, ln, j, true, [&] {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int k = q == 0 ? 0 : q + 7;
+            const int tau = (N - j - T * k) & (N - 1);
+            wt[q] = w[tau < n ? tau : 0];
+        }
+    });
+    float2 *dst = out + (size_t)fr * n;
+    const int rot = center_dc ? n / 2 : 0;  // rotate_right(n / 2)
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const int k = q == 0 ? 0 : q + 7;
+        const int tau = (N - j - T * k) & (N - 1);
+        const f2 r = cmul_conj(v[k], (f2){wt[q].x, wt[q].y});
+        int o = tau + rot;
+        if (o >= n) o -= n;
+        if (tau < n) dst[o] = float2{r.x, r.y};
+    }
+}
+
+bool bluestein_big_supported(int dtype, size_t n, size_t *M) {
+    if (dtype != RR_F32 || (n & (n - 1)) == 0) return false;
+    if (n > 4096 && n <= 8192) {
+        *M = 16384;
+        return true;
+    }
+    if (n > 2048 && n <= 4096) {
+        *M = 8192;
+        return true;
+    }
+    return false;
+}
+
+template <int N>
+static int launch_bluestein_big_n(hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n, const void *c,
+                                  const void *Bp, const void *w, const void *twN, void *out, bool center_dc, size_t count) {
+    constexpr size_t lds = (size_t)big_fft_lds_elems<N>() * sizeof(f2);
+    RR_TRY(dyn_lds_optin(reinterpret_cast<const void *>(k_bluestein_big<N>), lds));
+    hipLaunchKernelGGL(k_bluestein_big<N>, dim3((unsigned)count), dim3(N / 16), lds, s, (const float2 *)head, (long)n_head,
+                       (const float2 *)in, (long)hop, (int)n, (const float2 *)c, Bp, (const float2 *)w, (const float2 *)twN,
+                       (float2 *)out, (int)center_dc, (unsigned)count);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+int launch_bluestein_big(hipStream_t s, size_t M, const void *head, size_t n_head, const void *in, size_t hop, size_t n, const void *c,
+                         const void *Bp, const void *w, const void *twM, void *out, bool center_dc, size_t count) {
+    if (count == 0) return RR_OK;
+    if (count > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: too many chunks in one call");
+    if (n > M / 2 || (M != 8192 && M != 16384)) RR_FAIL(RR_ERR_BAD_ARG, "Fourier: %zu points around transforms of %zu", n, M);
+    return M == 8192 ? launch_bluestein_big_n<8192>(s, head, n_head, in, hop, n, c, Bp, w, twM, out, center_dc, count)
+                     : launch_bluestein_big_n<16384>(s, head, n_head, in, hop, n, c, Bp, w, twM, out, center_dc, count);
 }
 
 // ---------------------------------------------------------------------------

@@ -21,6 +21,24 @@ constexpr int big_fft_lds_elems() { return N + N / 16 + kBigTab; }  // (pad16(N 
 // LDS-only workgroup barrier: the plain __syncthreads() also drains vmcnt, i.e. it would wait for the table loads in flight
 __device__ __forceinline__ void big_lds_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Loads through a buffer descriptor: one lane offset in a VGPR, the per-load offset in an SGPR - no 64-bit
+// per-lane address arithmetic.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+template <int AUX>
+__device__ __forceinline__ f2 buf_ld_f2(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 r = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, AUX);
+    return (f2){__uint_as_float(r.x), __uint_as_float(r.y)};
+}
+template <int AUX>
+__device__ __forceinline__ float4 buf_ld_f4(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const u4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, AUX);
+    return float4{__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
+}
+
 // the lane's constants: seeds of passes 2 and 3 and its row of the pass-1 table; fills the table (read behind the first barrier)
 template <int N>
 struct BigFftLane {

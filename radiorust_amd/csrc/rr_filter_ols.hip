@@ -63,24 +63,6 @@ __device__ __forceinline__ void img_st(f2 *p, f2 v) {
 // table loads in flight at every exchange.
 __device__ __forceinline__ void lds_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Loads through a buffer descriptor: one lane offset in a VGPR, the per-load offset in an SGPR - no 64-bit
-// per-lane address arithmetic.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void *base, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
-}
-template <int AUX>
-__device__ __forceinline__ f2 buf_ld_f2(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
-    typedef unsigned u2 __attribute__((ext_vector_type(2)));
-    const u2 r = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, AUX);
-    return (f2){__uint_as_float(r.x), __uint_as_float(r.y)};
-}
-template <int AUX>
-__device__ __forceinline__ float4 buf_ld_f4(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
-    typedef unsigned u4 __attribute__((ext_vector_type(4)));
-    const u4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, AUX);
-    return float4{__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
-}
-
 struct Blk4096Args {
     const float2 *hist;
     int hist_len;

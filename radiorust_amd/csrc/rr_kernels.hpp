@@ -271,6 +271,11 @@ void append_wave1024_seeds(std::vector<float> &twb);
 bool bluestein_lds_supported(int dtype, size_t n, size_t M);
 int launch_bluestein_lds(int dtype, hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n, size_t M,
                          const void *c, const void *B, const void *w, const void *tw, void *out, bool center_dc, size_t count);
+// k_bluestein_big<M>: 4097 .. 8192 points in f32 (M = 16 384) and 2049 .. 4096 (M = 8192): one kernel around two
+// transforms of rr_fft_big.hpp; B in k_filter_blkbig's pair layout, twM = W_M^i, i < M
+bool bluestein_big_supported(int dtype, size_t n, size_t *M);
+int launch_bluestein_big(hipStream_t s, size_t M, const void *head, size_t n_head, const void *in, size_t hop, size_t n, const void *c,
+                         const void *Bp, const void *w, const void *twM, void *out, bool center_dc, size_t count);
 // k_bluestein8192: 2049 .. 4096 points in f32, one kernel around two 8192-point register transforms
 bool bluestein8192_supported(int dtype, size_t n);
 int launch_bluestein8192(hipStream_t s, const void *head, size_t n_head, const void *in, size_t hop, size_t n, const void *c,

@@ -71,9 +71,11 @@ def test_every_route_is_consistent(route, dtype, monkeypatch):
             if "wave" in r:
                 assert dtype == np.float32 and M == 1024 and n <= 512
             elif "one kernel" in r:  # k_bluestein4096 (f32, 513 .. 2048 points) or k_bluestein_lds (two LDS images of M elements)
-                assert M <= one_image and (M < 4 * n or (dtype == np.float32 and M == 4096 and 512 < n <= 2048)), (n, r)
+                assert M <= pow2_image and (M < 4 * n or (dtype == np.float32 and M == 4096 and 512 < n <= 2048)), (n, r)
+                if M > one_image:  # k_bluestein_big<16384>: f32, 4097 .. 8192 points
+                    assert dtype == np.float32 and 4096 < n <= 8192, (n, r)
             else:
-                assert M < 4 * n and M > one_image, (n, r)  # the smallest power of two that holds the circular convolution
+                assert M < 4 * n and M > pow2_image, (n, r)  # the smallest power of two that holds the circular convolution
         else:
             assert r == "direct" and n < 32, (n, r)
         # a length the mixed-radix kernels can serve beyond 2048 points never falls back to the five launches
@@ -84,7 +86,10 @@ def test_every_route_is_consistent(route, dtype, monkeypatch):
 
 def test_switches(route, monkeypatch):
     monkeypatch.setenv("RR_FOURIER_MIXED", "0")
-    assert route(3000) == "bluestein one kernel M=8192" and route(5000) == "bluestein four launches M=16384"
+    assert route(3000) == "bluestein one kernel M=8192" and route(5000) == "bluestein one kernel M=16384"
+    monkeypatch.setenv("RR_FOURIER_BS_BIG", "0")
+    assert route(5000) == "bluestein four launches M=16384"
+    monkeypatch.delenv("RR_FOURIER_BS_BIG")
     assert route(20000) == "bluestein four launches M=65536" and route(200003) == "bluestein many launches M=524288"
     monkeypatch.setenv("RR_FOURIER_MIXED", "2")
     assert route(2000) == "mixed 5 5 5 4 4" and route(1001) == "mixed 13 11 7"

@@ -724,7 +724,8 @@ def test_fourier_reference_kat_on_gpu(rr):
                                       (1 << 21, False),                                                  # (beyond the tile kernel: transposes around the row kernels)
                                       (20000, False), (20000, True), (5000, False), (31, True),          # Bluestein beyond 4096 points; direct below 32
                                       (513, False), (1025, True), (1999, True), (2047, False),           # 513 .. 2048: Bluestein in one kernel (k_bluestein4096)
-                                      (2049, False), (3001, True), (4093, False), (4001, True),          # 2049 .. 4096 with a prime factor beyond 13: k_bluestein8192
+                                      (2049, False), (3001, True), (4093, False), (4001, True),          # 2049 .. 4096 with a prime factor beyond 13: k_bluestein_big<8192>
+                                      (4099, True), (5003, False), (6007, True), (8191, False), (8191, True),  # 4097 .. 8192 likewise: k_bluestein_big<16384>
                                       (33, False), (100, True), (255, False), (300, True), (511, True)])  # 32 .. 512: a wave per chunk (k_bluestein1024)
 def test_fourier_parity(rr, oracle, n, center):
     x = oracle.synth_iq(12, 0, n)
@@ -958,7 +959,26 @@ def test_fourier_wave_kernels_batched(rr, oracle, n, center, monkeypatch):
     check(got.reshape(-1), ref)
 
 
-@pytest.mark.parametrize("n,center,k", [(1000, True, 2100), (33, False, 500), (1500, False, 64), (4095, True, 9), (100, True, 300)])
+@pytest.mark.parametrize("n,center", [(2049, True), (3001, False), (4093, True), (4095, False)])
+def test_fourier_bluestein_8192_register_transform_on_request(rr, oracle, n, center, monkeypatch):
+    """RR_FOURIER_BS8K=regs: 2049 .. 4096 points around the two 8192-point register transforms of k_bluestein8192 (the default is
+    k_bluestein_big<8192>, the workgroup transforms of rr_fft_big.hpp): same results against the oracle."""
+    monkeypatch.setenv("RR_FOURIER_BS8K", "regs")
+    monkeypatch.setenv("RR_FOURIER_MIXED", "0")
+    assert rr.fourier_route(n) == "bluestein one kernel M=8192"
+    k = 21
+    x = oracle.synth_iq(31, 0, n * k)
+    gw, ow = rr.Kaiser.with_null_at_bin(2.0), oracle.Kaiser.with_null_at_bin(2.0)
+    g = rr.Fourier(gw, center)
+    o64 = oracle.Fourier(ow, center, flt=np.float64)
+    o32 = oracle.Fourier(ow, center, flt=np.float32)
+    for i in (0, 7, k - 1):
+        (out,) = g.process(rr.Samples(1e6, x[i * n : (i + 1) * n]))
+        check(out.chunk, o64.process(x[i * n : (i + 1) * n]), o32.process(x[i * n : (i + 1) * n]))
+
+
+@pytest.mark.parametrize("n,center,k", [(1000, True, 2100), (33, False, 500), (1500, False, 64), (4095, True, 9), (100, True, 300),
+                                        (5003, True, 300), (8191, False, 33)])
 def test_fourier_bluestein_batched(rr, oracle, n, center, k):
     """Chunk lengths that are not powers of two (32 and more) run Bluestein's algorithm over the power-of-two
     kernels, in passes of at most 2^22 workspace elements (n = 1000: 2048 chunks per pass, so 2100 chunks take

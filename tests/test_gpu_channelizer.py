@@ -163,6 +163,8 @@ def overlapped_spectra(oracle, chunks, P, window, center_dc, flt, history=None):
                                                   (100, 3, True, np.float64, 1e-11), (1500, 4, False, np.float32, 1e-5),
                                                   # spans 2^a 3^b 5^c (7 ..): overlapping frames through k_fft_mixed / the two passes of k_fft_tilem
                                                   (3000, 4, True, np.float32, 1e-5), (2500, 2, False, np.float64, 1e-11), (1001, 4, False, np.float32, 1e-5),
+                                                  # a span of 5001 = 3 x 1667 points: k_bluestein_big<16384> with a hop
+                                                  (1667, 3, True, np.float32, 1e-5),
                                                   # 16 384-point spans: k_fft16384 with a hop
                                                   (4096, 4, True, np.float32, 1e-5), (2048, 8, False, np.float32, 1e-5)])
 def test_stft_parity(rr, oracle, M, P, center, dtype, tol):
