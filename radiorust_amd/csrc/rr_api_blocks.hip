@@ -640,6 +640,7 @@ int rr_downsampler::process_dev(double input_rate, const void *d_in, size_t n_in
             f.tw4096 = f_tw.p;
             f.V = f_V;
             f.poly = f_poly;
+            f.blk = f_blk;
             f.mixfold = true;  // every phasor is 1: the instances without a mixer (k_ols_wave<D, true, true>)
             next.advance(n_in, nullptr);
             if (fast_kind == rr_chain::FK_OLSW)
@@ -814,6 +815,7 @@ int rr_downsampler::ensure_fast() {
         RR_TRY(upload(f_tw, t.tw.data(), t.tw.size() * sizeof(float), stream));
         f_V = t.V;
         f_poly = t.poly;
+        f_blk = t.blk;
     }
     // NCO table of period 1: entry, wrap entry and the 8 rotations behind them (rr_freqshifter::prepare)
     float ones[2 * 10];

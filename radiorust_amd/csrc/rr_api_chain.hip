@@ -241,7 +241,7 @@ int rr_chain::ensure_xh() {
 // runs and tests).
 int rr_chain::pick_fused_kernel(uint64_t D, size_t lc, bool real_taps, size_t fft_len) {
     const bool can_direct = real_taps && fused_fir_supported(D, lc);
-    const bool can_ols = ols_decim_supported(D, lc), can_wave = ols_wave_supported(D, lc);
+    const bool can_ols = ols_decim_supported(D, lc), can_wave = ols_wave_supported(D, lc) || ols_wave2k_supported(D, lc);
     const bool can_frame = can_wave && ols_frame_supported(D, lc, fft_len);
     const char *e = std::getenv("RR_FUSED_KERNEL");
     if (e) {
@@ -295,6 +295,38 @@ void build_fused_fir_tables(int kind, uint64_t D_, const std::vector<double> &c,
             twb[2 * i + 1] = (float)std::sin(ang);
         }
         static const bool no_poly = [] { const char *e = std::getenv("RR_OLSW_POLY"); return e && std::atoi(e) == 0; }();
+        t.blk = 1024;
+        if (kind == rr_chain::FK_OLSW && !no_poly && ols_wave2k_supported(D_, lc)) {
+            // k_ols_wave2k (8 : 1, a wave per 2048-sample block): Y[k] = sum_p X_p[k] G_p[k] over the 8 phases x_p[m] = xs[8 m + p]
+            // (X_p = DFT_256 x_p), G_p[k] = sum_q H[k + 256 q] W_2048^((k + 256 q) p), H = DFT_2048(c) / 2048, k < 256.  The kernel
+            // runs the phases in two halves of four (p = 4 hh + pp): half hh's 1024 entries one behind the other, lane l = k mod 64
+            // reads entry i = 4 pp + k / 64 as one half of the 16-byte piece [hh][i >> 1][l] - the layout of k_ols_wave<4, POLY> twice
+            std::vector<cd> h2(2048, cd(0, 0));
+            for (size_t i = 0; i < lc; ++i) h2[i] = cc[i];
+            fft_f64(h2, false);
+            std::vector<float> gp(2 * 2048);
+            for (size_t p8 = 0; p8 < 8; ++p8)
+                for (size_t k = 0; k < 256; ++k) {
+                    cd g(0, 0);
+                    for (size_t qq = 0; qq < 8; ++qq) {
+                        const size_t kk = k + 256 * qq;
+                        const double ang = -2.0 * M_PI * (double)((kk * p8) % 2048) / 2048.0;
+                        g += h2[kk] / 2048.0 * cd(std::cos(ang), std::sin(ang));
+                    }
+                    const size_t hh = p8 / 4, pp = p8 % 4, l = k % 64, c = k / 64, i = 4 * pp + c;
+                    const size_t dst = 1024 * hh + ((i >> 1) * 64 + l) * 2 + (i & 1);
+                    gp[2 * dst] = (float)g.real();
+                    gp[2 * dst + 1] = (float)g.imag();
+                }
+            append_wave1024_seeds(twb);
+            t.H.swap(gp);
+            t.tw.swap(twb);
+            t.poly = true;
+            t.blk = 2048;
+            t.V = ols_wave_overlap(lc, 16);
+            t.N = 1024;  // (the wave kernels' mark: rr_chain::ols_N)
+            return;
+        }
         // (the frame kernel exists in the polyphase form only)
         if ((kind == rr_chain::FK_OLSW && (D_ == 2 || D_ == 4 || D_ == 8) && !no_poly) || (kind == rr_chain::FK_OLSF && D_ == 4)) {
             // k_ols_wave<D, POLY>: Y[k] = sum_p X_p[k] G_p[k] over the D phases x_p[m] = xs[D m + p] (X_p = DFT_(1024/D) x_p),
@@ -506,6 +538,7 @@ int rr_chain::ensure_ctaps() {
         ols_V = t.V;
         ols_poly = t.poly;
         ols_N = t.N;
+        ols_blk = t.blk;
         olsG64.swap(t.G64);
     } else {
         RR_TRY(upload(d_ctaps, t.ctaps.data(), t.ctaps.size() * sizeof(float), stream));
@@ -590,6 +623,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
         a.tw4096 = d_tw4096.p;
         a.V = ols_V;
         a.poly = ols_poly;
+        a.blk = ols_blk;
         RR_TRY(fold_mixer(a, 4 * (int64_t)pending_len, true));  // (the frame's first block starts 4 pl samples earlier, as launch_ols_frame)
         // (the launch records its own start / end: marker packets would cost ~4 us of stream time each)
         if (timers.on && !sink.on) timers.begin_ext(ST_FUSED_FIR, &a.ev_start, &a.ev_stop);
@@ -631,6 +665,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     a.tw4096 = d_tw4096.p;
     a.V = ols_V;
     a.poly = ols_poly;
+    a.blk = ols_blk;
     // k_ols_wave + k_fft4096: the launches record their own start / end (no marker packets, which
     // cost ~4 us of stream time each); the other kernels are bracketed by recorded events
     const bool ext = timers.on && use_ols && ols_N == 1024 && split && dec > 0 && !sink.on;
@@ -770,6 +805,7 @@ int rr_chain::bank_plan(double sample_rate, size_t n_in, size_t cap, BankStep &s
     a.tw4096 = d_tw4096.p;
     a.V = ols_V;
     a.poly = ols_poly;
+    a.blk = ols_blk;
     RR_TRY(fold_mixer(a, 0));
     *ok = true;
     return RR_OK;

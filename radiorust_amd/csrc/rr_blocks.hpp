@@ -81,6 +81,7 @@ struct FusedFirTables {
     int kind = 0;
     std::vector<float> ctaps, H, tw;
     int Gp = 0, V = 0, N = 0;
+    int blk = 1024;     // the wave kernels' block: 2048 = k_ols_wave2k's tables (8 : 1)
     bool poly = false;  // H = the polyphase tables of k_ols_wave<4, POLY>
     std::vector<rr::cd> G64;  // D = 4, polyphase: G_p[k] at 256 p + k in f64 (for the variant with the mixer folded in)
 };
@@ -111,6 +112,7 @@ struct rr_downsampler : rr_block {
     rr::DevBuf f_ctaps, f_H, f_tw, f_one;
     int f_Gp = 0, f_V = 0;
     bool f_poly = false;
+    int f_blk = 1024;  // (k_ols_wave2k: 2048)
     // k_decim_poly (any integer ratio, short-period rational ratios): taps in f_ctaps, laid out for the schedule phase
     int f_NC = 0;
     size_t f_V64 = 0;  // FK_OLS64 (Complex<f64>, integer ratio): k_ols4096_f64's overlap; its tables in f_H / f_tw
@@ -347,6 +349,7 @@ struct rr_chain : rr_block {
     int ols_V = 0;
     bool ols_poly = false;
     int ols_N = 4096;  // 4096: k_ols_decim4 (workgroup per block), 1024: k_ols_wave (wave per block)
+    int ols_blk = 1024;  // the wave kernels' block: 2048 = k_ols_wave2k (8 : 1)
     rr::DevBuf d_olsH, d_tw4096;
     bool fused_candidate(double sample_rate) const;
     enum { FK_NONE = 0, FK_DIRECT, FK_OLS, FK_OLSW, FK_OLSF, FK_POLY, FK_SELECT = 10, FK_OLS64 = 11 };  // FK_POLY: k_decim_poly, FK_SELECT: k_filter_wave<true> (Downsampler only)

@@ -116,6 +116,7 @@ struct FusedFirArgs {
     const void *tw4096 = nullptr;  // e^{-j 2 pi k / 4096}
     int V = 0;                     // overlap (samples), multiple of 256
     bool poly = false;             // k_ols_wave<4>: H holds the polyphase tables G_p (build_fused_fir_tables)
+    int blk = 1024;                // k_ols_wave: samples per block; 2048 = k_ols_wave2k (8 : 1, rr_ols_wave2k.hip)
     // k_ols_frame only: the NCO's period divides 8 and H holds the tables with the mixer folded in - the kernel transforms the
     // samples as they are and multiplies its results by nco[ph0] sigma^(index): see rr_chain::ensure_mixfold
     bool mixfold = false;
@@ -178,6 +179,10 @@ struct BankTable {
 int launch_ols_wave_bank(hipStream_t s, const FusedFirArgs &a, const BankTable &tab, size_t channels);
 int launch_fft4096_bank(hipStream_t s, const BankTable &tab, size_t channels, size_t n_head, size_t count, const void *window,
                         const void *tw4096, bool center_dc);
+// k_ols_wave2k: 8 : 1 with a wave per 2048-sample block (combined responses up to 1025 taps); tables: build_fused_fir_tables (blk = 2048)
+bool ols_wave2k_supported(uint64_t D, size_t Lc);
+int launch_ols_wave2k(hipStream_t s, const FusedFirArgs &a);
+int launch_ols_wave2k_bank(hipStream_t s, const FusedFirArgs &a, const BankTable &tab, size_t channels);
 bool ols_frame_supported(uint64_t D, size_t Lc, size_t fft_len);
 // What a metered kernel needs beside its transform's arguments: metering::bandwidth (metering.rs:41-80) per spectrum, computed
 // behind the transform while the bins are in registers (rr_meter_dev.hpp), and the spectrum's energy sum |X|^2.

@@ -517,7 +517,8 @@ FAST_CASES = [
     (200e6, 50e6, 47e6, 3.0, 2),      # L = 400: beyond k_ols_wave's overlap -> k_ols_decim4
     (200e6, 50e6, 30e6, 3.0, 3),      # L = 60: short responses too (k_mix_fir_decim only on request since round 2)
     (384000.0, 48000.0, 40000.0, 3.0, 3),   # the reference's simple_receiver second stage: D = 8, L = 288 -> k_ols_wave<8>
-    (384000.0, 48000.0, 43000.0, 3.0, 3),   # D = 8, L = 461: overlap 512 of 1024
+    (384000.0, 48000.0, 43000.0, 3.0, 3),   # D = 8, L = 461: overlap 464 of k_ols_wave2k's 2048 (512 of k_ols_wave<8>'s 1024)
+    (384000.0, 48000.0, 45500.0, 3.0, 3),   # D = 8, L = 922: k_ols_wave2k alone reaches it
     (96000.0, 48000.0, 30000.0, 3.0, 3),    # D = 2, L = 32
     (96000.0, 48000.0, 44000.0, 3.0, 3),    # D = 2, L = 144 -> k_ols_wave<2>
     (96000.0, 48000.0, 46500.0, 3.0, 3),    # D = 2, L = 384
@@ -566,6 +567,28 @@ def test_downsampler_fast_paths(rr, oracle, fin, fout, bw, q, kernel):
     for y, r in zip(got, t64):
         if len(y) > 50:
             check(y, r)
+
+
+@pytest.mark.parametrize("bw", [30000.0, 40000.0, 43000.0])
+def test_downsampler_8_to_1_blocks_of_1024_on_request(rr, oracle, bw, monkeypatch):
+    """RR_OLSW_2K=0: 8 : 1 through k_ols_wave<8> (a wave per 1024-sample block) instead of k_ols_wave2k (2048-sample blocks): the
+    same results against the oracle, and the two kernels against each other."""
+    n = 200000
+    x = oracle.synth_iq(19, 0, n)
+    o64 = oracle.Downsampler(1000, 48000.0, bw, 3.0, flt=np.float64)
+    ref = o64.process(384000.0, x)
+    outs = []
+    for env in ("0", None):
+        if env is None:
+            monkeypatch.delenv("RR_OLSW_2K", raising=False)
+        else:
+            monkeypatch.setenv("RR_OLSW_2K", env)
+        g = rr.Downsampler.with_quality(1000, 48000.0, bw, 3.0)
+        y = np.concatenate([g.process_raw(384000.0, x[:70001]), g.process_raw(384000.0, x[70001:])])
+        assert g.last_kernel() == 3
+        check(y, ref)
+        outs.append(y)
+    assert rms_rel(outs[0], outs[1]) < 2e-6
 
 
 @pytest.mark.parametrize("fin,fout,bw,q", [(200e6, 50e6, 40e6, 3.0), (1024000.0, 102400.0, 60000.0, 3.0), (1024000.0, 384000.0, 200000.0, 3.0),

@@ -876,11 +876,11 @@ def test_meter_sample_rate_change_mid_stream(rr, oracle):
     assert n >= 20
 
 
-@pytest.mark.parametrize("shift,precision", [(25e6, 1.0), (12.345e6, 1e3)])
-def test_chainbank_lockstep_is_bit_identical_to_stand_alone_chains(rr, oracle, shift, precision):
+@pytest.mark.parametrize("shift,precision,out_rate,bw", [(25e6, 1.0, 50e6, 40e6), (12.345e6, 1e3, 50e6, 40e6), (12.345e6, 1e3, 25e6, 20e6)])
+def test_chainbank_lockstep_is_bit_identical_to_stand_alone_chains(rr, oracle, shift, precision, out_rate, bw):
     """rr_chainbank: K channels through TWO launches per call once they are in the steady state - every channel's spectra
     bit for bit those of a stand-alone Chain fed the same samples in the same calls (stream start lane by lane, an interrupt
-    and a retune in the middle, a ragged call that takes the bank out of lockstep and back)."""
+    and a retune in the middle, a ragged call that takes the bank out of lockstep and back).  8 : 1: k_ols_wave2k_bank."""
     import torch
 
     fs, K = 200e6, 5
@@ -890,7 +890,7 @@ def test_chainbank_lockstep_is_bit_identical_to_stand_alone_chains(rr, oracle, s
     for k in range(K):
         rr.synth_iq_dev(0, st, 100 + k, 0, n_total, d_in.data_ptr() + 8 * k * n_total)
     torch.cuda.synchronize()
-    params = dict(shift=shift, precision=precision, filter_len=64, freq_resp=lowpass(20e6), output_rate=50e6, bandwidth=40e6,
+    params = dict(shift=shift, precision=precision, filter_len=64, freq_resp=lowpass(20e6), output_rate=out_rate, bandwidth=bw,
                   fft_len=4096, fft_window=rr.Kaiser.with_null_at_bin(2.0))
     bank = rr.ChainBank(K, **params)
     bank.set_stream(st)

@@ -49,6 +49,11 @@ def test_the_headline_kernels_do_not_spill(tmp_path):
     for name, k in ols.items():
         if "k_ols_wave" in name or "k_filter_wave" in name:
             assert k["vgpr_spill_count"] == 0, (name, k)
+    # 8 : 1 with a wave per 2048-sample block: three waves per SIMD (at four it spilled 58 .. 66 registers)
+    w2k = kernels("rr_ols_wave2k.hip", tmp_path)
+    assert len(w2k) == 6
+    for name, k in w2k.items():
+        assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0 and k["vgpr_count"] <= 168, (name, k)
     fo = kernels("rr_filter_ols.hip", tmp_path)
     for name, k in fo.items():
         if "k_filter_blk" in name:
