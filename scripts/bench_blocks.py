@@ -47,6 +47,9 @@ os.environ.pop("RR_DOWNSAMPLER_GENERIC", None)
 ds8 = rr.Downsampler.new(4096, 48000.0, 40000.0)
 ds8.set_stream(st)
 run("Downsampler 384->48 kS/s L=288 (D=8)", 9, lambda: ds8.process_dev(384000.0, d_in.data_ptr(), N, d_out.data_ptr(), N))
+ds8l = rr.Downsampler.new(4096, 48000.0, 43000.0)
+ds8l.set_stream(st)
+run("Downsampler 384->48 kS/s L=461 (D=8)", 9, lambda: ds8l.process_dev(384000.0, d_in.data_ptr(), N, d_out.data_ptr(), N))
 # the reference's own pipelines: bandwidth_meter/main.rs:56 (10 : 1, L = 145) and simple_receiver.rs:28 (8 : 3, L = 34)
 for name, fin, fout, bw, bps in (("Downsampler 1024->102.4 kS/s L=145 (10:1)", 1024000.0, 102400.0, 60000.0, 8.8),
                                  ("Downsampler 1024->384 kS/s L=34 (8:3)", 1024000.0, 384000.0, 200000.0, 11.0),

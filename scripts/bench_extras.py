@@ -71,7 +71,7 @@ for nt, blk, kern in ((1536, 8192, None), (2048, 8192, None), (2048, 16384, None
 os.environ.pop("RR_FILTER_BLOCK", None)
 os.environ.pop("RR_FILTER_KERNEL", None)
 
-for nf in (8192, 16384, 32768, 65536, 96, 300, 500, 720, 1000, 1001, 1536, 1999, 2000, 3000, 3001, 4004, 4800, 5000, 8000, 20000, 250000, 20011):
+for nf in (8192, 16384, 32768, 65536, 96, 300, 500, 720, 1000, 1001, 1536, 1999, 2000, 3000, 3001, 4004, 4800, 5000, 5003, 8000, 8191, 20000, 250000, 20011):
     g = rr.Fourier.with_window(rr.Kaiser.with_null_at_bin(2.0))
     g.set_stream(st)
     n = min(N, 1 << 24) // nf * nf

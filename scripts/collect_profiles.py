@@ -59,7 +59,8 @@ names = {"bench.json": "bench.json", "bench_profiled.json": "bench_profiled.json
          "cfg5_kernel_stats.csv": "cfg5_kernel_stats.csv", "blocks.log": "blocks.txt", "fftsizes.log": "fft_sizes.txt",
          "cfg5.log": "cfg5.txt", "cfg3.log": "cfg3.txt", "extras.log": "extras.txt", "decim_ab.log": "decim_ab.txt",
          "meter.log": "meter.txt", "meter_kernel_stats.csv": "meter_kernel_stats.csv", "clock_power.txt": "clock_power.txt",
-         "bank.log": "bank.txt", "callsize.log": "callsize.txt", "shapes_kernel_stats.csv": "shapes_kernel_stats.csv"}
+         "bank.log": "bank.txt", "callsize.log": "callsize.txt", "shapes_kernel_stats.csv": "shapes_kernel_stats.csv",
+         "wave2k.log": "wave2k.txt", "bsbig.log": "bluestein_big.txt"}
 for p in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write", "cfg5_pmc_sq1", "cfg5_pmc_sq2", "cfg5_pmc_fetch", "cfg5_pmc_write"):
     names[p + ".summary.txt"] = p + ".summary.txt"
 for a, b in names.items():

@@ -7,6 +7,7 @@
 #   blocks.txt, cfg5.txt, cfg3.txt   scripts/bench_blocks.py, bench_cfg5.py, bench_cfg3.py
 #   extras.txt, decim_ab.txt, meter.txt, meter_kernel_stats.csv   bench_extras.py, bench_decim_ab.py, bench_meter.py, prof_meter.py
 #   shapes_kernel_stats.csv         per-kernel averages of the two-kernel chain shapes (scripts/prof_shapes.py)
+#   wave2k.txt, bluestein_big.txt   k_ols_wave2k against k_ols_wave<8>, k_bluestein_big against the routes it replaces
 # usage: scripts/gpu_profiles.sh TAG
 set -u -o pipefail
 TAG="${1:-prof}"
@@ -65,5 +66,7 @@ step clock 300 python3 scripts/clock_probe.py --seconds 4 idle cfg5 chain copy c
 grep -h '^CLOCK_PROBE_JSON' "$OUT/clock.log" | python3 scripts/clock_summary.py > "$OUT/clock_power.txt" || true
 step bank 300 python3 scripts/callsize_probe.py bank 64 12 14 16 18
 step callsize 300 python3 scripts/callsize_probe.py 14 16 18 20 22 24 26
+step wave2k 300 python3 scripts/wave2k_probe.py
+step bsbig 300 python3 scripts/bs_big_probe.py
 step smoke 300 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
 echo "=== done"
