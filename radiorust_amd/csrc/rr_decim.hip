@@ -20,7 +20,8 @@
 // (lane term) + a wave-uniform offset.  The host hands the taps over as a flat list per phase b,
 // T[b][j] = { ir[j], byte offset of (row, column) of tap j }, read through the scalar cache (8 taps per
 // s_load_dwordx16): exactly L taps per output whatever P is.  Per tap and lane: one 8-byte LDS read, one
-// address add and one packed FMA.
+// address add and one packed FMA (k_decim_poly<false>); with two neighbouring periods per lane one 16-byte read per
+// four products (k_decim_poly<true>, the default where its tile fits: see the kernel).
 //
 // LDS per workgroup: P (TA + NC) samples (10 : 1, L = 145: 21.8 KiB, 7 workgroups per CU).  HBM traffic:
 // 8 B read per input sample + 8 Q / P written = the algorithmic minimum; neighbouring tiles (which share
@@ -43,6 +44,7 @@ struct DecimArgs {
     const float2 *in;
     long n_in;
     int P, Q, NC, Lp;  // NC: tap columns (geometry only); Lp: taps per phase, padded to a multiple of 8
+    int Lp2;           // PAIR: entries per phase of T2, a multiple of 4
     long p_ref;        // position (relative to in[0]) of tap 0 of output 0
     float2 *out;
     long n_out;
@@ -63,10 +65,19 @@ struct DecimArgs {
 
 // (T is a parameter of its own, const and restrict: only then does the compiler read the wave-uniform taps through
 //  the scalar cache; as a member of the argument struct they came as per-lane vector loads, waited for in every trip)
-__global__ __launch_bounds__(256) void k_decim_poly(DecimArgs a, const uint2 *__restrict__ T) {
+// PAIR: a lane takes TWO neighbouring periods.  Period a + 1 reads, for the taps of a row, the columns one further on than period
+// a - so one 16-byte LDS read of the columns (a + k, a + k + 1) serves four products,
+//   acc(a) += t[k] x0 + t[k + 1] x1,   acc(a + 1) += t[k - 1] x0 + t[k] x1     (t = the row's taps by column, zero outside),
+// where the one-period form reads 8 bytes per product: the inner loop is bound by the LDS (ds_read_b64: 2 LDS cycles per wave and
+// tap against the 1 cycle per wave the four SIMDs need for its packed FMA), and ds_read_b128 moves 16 bytes per lane in 4.  The
+// host's table T2 holds per phase the entries { t[k - 1], t[k], t[k + 1], byte offset of (row, k) } with (row S + k) even (16-byte
+// aligned reads), k from c_lo - 1 to c_hi + 1: two more staged columns than the one-period form, all of the image initialised
+// (what lies beyond a row's taps is multiplied by zero, so it must be finite).
+template <bool PAIR>
+__global__ __launch_bounds__(256) void k_decim_poly(DecimArgs a, const uint2 *__restrict__ T, const uint4 *__restrict__ T2) {
     extern __shared__ __attribute__((aligned(16))) char decim_smem[];
-    f2 *const xs = reinterpret_cast<f2 *>(decim_smem);  // P rows of S samples
-    f2 *const ost = xs + (size_t)a.P * a.S;             // Q > 1: TA Q staged outputs
+    f2 *const xs = reinterpret_cast<f2 *>(decim_smem);  // P rows of S samples (PAIR: + 2 zeros behind them)
+    f2 *const ost = xs + (size_t)a.P * a.S + (PAIR ? 2 : 0);  // Q > 1: TA Q staged outputs
     const int t = threadIdx.x;
     // tiles dealt to the XCDs in a moving window of 8 x 8: workgroups b, b + 8, .. share an XCD
     constexpr unsigned G = 8;
@@ -225,10 +236,51 @@ __global__ __launch_bounds__(256) void k_decim_poly(DecimArgs a, const uint2 *__
             }
         }
     }
+    if constexpr (PAIR) {  // the columns no sample was staged into, and the two elements behind the last row
+        for (int i = t; i < P * (S - (TA + a.NC)); i += 256) {
+            const int r = i % P, c = TA + a.NC + i / P;
+            xs[r * S + c] = (f2){0.f, 0.f};
+        }
+        if (t < 2) xs[P * S + t] = (f2){0.f, 0.f};
+    }
     __syncthreads();
 
-    // ---- filter: a wave per (phase b, run of 64 periods); lane = period ----------------------------------
     const int w = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    if constexpr (PAIR) {
+        // ---- filter: a wave per (phase b, run of 128 periods); lane = the periods 2 lane, 2 lane + 1 ----------------
+        const int segs = TA >> 7, ntask = Q * segs;
+        for (int task = w; task < ntask; task += 4) {
+            const int b = task / segs, seg = task - b * segs;
+            const int al = seg * 128 + 2 * lane;
+            const char *base = reinterpret_cast<const char *>(xs + al);
+            const uint4 *tl = T2 + (size_t)b * a.Lp2;
+            f2 a0x = {0.f, 0.f}, a0y = {0.f, 0.f}, a1x = {0.f, 0.f}, a1y = {0.f, 0.f};
+            for (int i = 0; i < a.Lp2; i += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint4 e = tl[i + u];  // uniform address: a scalar read
+                    const float4 x = *reinterpret_cast<const float4 *>(base + e.w);
+                    const float tm = __uint_as_float(e.x), t0 = __uint_as_float(e.y), tp = __uint_as_float(e.z);
+                    const f2 x0 = {x.x, x.y}, x1 = {x.z, x.w};
+                    a0x = __builtin_elementwise_fma(x0, (f2){t0, t0}, a0x);
+                    a0y = __builtin_elementwise_fma(x1, (f2){tp, tp}, a0y);
+                    a1x = __builtin_elementwise_fma(x0, (f2){tm, tm}, a1x);
+                    a1y = __builtin_elementwise_fma(x1, (f2){t0, t0}, a1y);
+                }
+            }
+            const f2 r0 = a0x + a0y, r1 = a1x + a1y;
+            if (Q == 1) {
+                const long m = a0 + al;
+                typedef float f4s __attribute__((ext_vector_type(4), aligned(8)));
+                if (m + 1 < a.n_out) __builtin_nontemporal_store((f4s){r0.x, r0.y, r1.x, r1.y}, reinterpret_cast<f4s *>(a.out + m));
+                else if (m < a.n_out) __builtin_nontemporal_store(r0, reinterpret_cast<f2 *>(a.out) + m);
+            } else {
+                ost[Q * al + b] = r0;
+                ost[Q * (al + 1) + b] = r1;
+            }
+        }
+    } else {
+    // ---- filter: a wave per (phase b, run of 64 periods); lane = period ----------------------------------
     const int segs = TA >> 6, ntask = Q * segs;
     for (int task = w; task < ntask; task += 4) {
         const int b = task / segs, seg = task - b * segs;
@@ -254,6 +306,7 @@ __global__ __launch_bounds__(256) void k_decim_poly(DecimArgs a, const uint2 *__
         } else {
             ost[Q * al + b] = acc;
         }
+    }
     }
     if (Q > 1) {
         __syncthreads();
@@ -680,6 +733,25 @@ static int decim_geometry(size_t P, size_t Q, size_t NC, int *TA, int *S, size_t
     return best;
 }
 
+// k_decim_poly<true> (two periods per lane): two more staged columns, tiles of at least 128 periods, two zeros behind the image
+static int decim_geometry_pair(size_t P, size_t Q, size_t NC, int *TA, int *S) {
+    for (int ta : {1024, 512, 256, 128}) {
+        int s = ta + (int)NC + 2;
+        if (!(s & 1)) ++s;
+        const size_t bytes = (P * (size_t)s + 2 + (Q > 1 ? (size_t)ta * Q : 0)) * 8;
+        if (bytes <= kDecimLdsTarget) {
+            *TA = ta;
+            *S = s;
+            return (int)bytes;
+        }
+    }
+    return 0;
+}
+static bool decim_pair_enabled() {
+    const char *e = std::getenv("RR_DECIM_PAIR");  // (=0: one period per lane, A/B runs and tests; read per call)
+    return !(e && std::atoi(e) == 0);
+}
+
 bool decim_poly_supported(int dtype, uint64_t P, uint64_t Q, size_t L) {
     if ((dtype != RR_F32 && dtype != RR_F64) || P < 2 || P > 512 || Q < 1 || Q > 8 || Q >= P || L < 1) return false;
     int ta, s;
@@ -740,6 +812,46 @@ void build_decim_poly_taps(const std::vector<double> &ir, uint64_t P, uint64_t Q
         }
     }
     *Lp_out = (int)Lp;
+    if (f64) return;
+    // k_decim_poly<true>'s table behind it: per phase the entries { t[k - 1], t[k], t[k + 1], byte offset of (row, k) }, rows one
+    // behind the other, k in steps of 2 with (row S + k) even from c_lo - 1 (or c_lo) to c_hi + 1; Lp2 entries per phase (a multiple
+    // of 4, padded with zeros) travel in the upper half of *Lp_out
+    int ta2 = 0, S2 = 0;
+    if (!decim_geometry_pair(P, Q, decim_nc(P, L), &ta2, &S2) || Lp >= 65536) return;
+    std::vector<std::vector<uint32_t>> ent(Q);
+    size_t most = 0;
+    for (uint64_t b = 0; b < Q; ++b) {
+        const long d = (long)(e_first[b] - e_first[0]);
+        for (long r = 0; r < (long)P; ++r) {
+            // the row's taps: idx = d + j = P c + r, 0 <= j < L
+            const long c_lo = d > r ? (d - r + (long)P - 1) / (long)P : 0;
+            if (d + (long)L - 1 < r) continue;
+            const long c_hi = (d + (long)L - 1 - r) / (long)P;
+            if (c_lo > c_hi) continue;
+            auto tap = [&](long c) -> uint32_t {
+                float v = 0.f;
+                if (c >= c_lo && c <= c_hi) v = (float)ir[(size_t)((long)P * c + r - d)];
+                uint32_t bits;
+                std::memcpy(&bits, &v, 4);
+                return bits;
+            };
+            long k = c_lo - 1;
+            if ((r * (long)S2 + k) & 1) ++k;
+            for (; k <= c_hi + 1; k += 2) {
+                ent[b].push_back(tap(k - 1));
+                ent[b].push_back(tap(k));
+                ent[b].push_back(tap(k + 1));
+                ent[b].push_back((uint32_t)((r * (long)S2 + k) * 8));
+            }
+        }
+        most = std::max(most, ent[b].size() / 4);
+    }
+    const size_t Lp2 = (most + 3) / 4 * 4;
+    if (Lp2 == 0 || Lp2 >= 32768) return;
+    const size_t base = T.size();  // (Q Lp 2 words: a multiple of 16 words)
+    T.resize(base + Q * Lp2 * 4, 0u);
+    for (uint64_t b = 0; b < Q; ++b) std::memcpy(T.data() + base + b * Lp2 * 4, ent[b].data(), ent[b].size() * 4);
+    *Lp_out = (int)(Lp | (Lp2 << 16));
 }
 
 int launch_decim_poly(hipStream_t s, const void *hist, size_t hist_len, const void *in, size_t n_in, const void *T,
@@ -823,7 +935,10 @@ int launch_decim_poly(hipStream_t s, const void *hist, size_t hist_len, const vo
     a.P = (int)P;
     a.Q = (int)Q;
     a.NC = (int)decim_nc(P, L);
+    const int Lp2 = Lp >> 16;  // (build_decim_poly_taps: the two-periods-per-lane table behind the first one, if its tile fits)
+    Lp &= 0xffff;
     a.Lp = Lp;
+    a.Lp2 = Lp2;
     a.p_ref = (long)e_first0 - (long)(L - 1);
     a.out = (float2 *)out;
     a.n_out = (long)n_out;
@@ -834,7 +949,10 @@ int launch_decim_poly(hipStream_t s, const void *hist, size_t hist_len, const vo
     a.idx0 = idx0;
     a.ph_ref = a.ph_tile_step = 0;
     a.inv_denom = 0.0;
-    const int lds = decim_geometry(P, Q, (size_t)a.NC, &a.TA, &a.S);
+    int lds = 0;
+    const bool pair = Lp2 > 0 && decim_pair_enabled() && (lds = decim_geometry_pair(P, Q, (size_t)a.NC, &a.TA, &a.S)) != 0;
+    if (pair) a.NC += 2;
+    else lds = decim_geometry(P, Q, (size_t)a.NC, &a.TA, &a.S);
     if (!lds) RR_FAIL(RR_ERR_BAD_ARG, "Downsampler: %llu : %llu with %d tap columns does not fit the LDS tile",
                       (unsigned long long)P, (unsigned long long)Q, a.NC);
     const size_t per_tile = (size_t)a.TA * Q;
@@ -850,7 +968,9 @@ int launch_decim_poly(hipStream_t s, const void *hist, size_t hist_len, const vo
         a.inv_denom = 1.0 / (double)den;
     }
     const unsigned grid = (unsigned)((ntiles + 63) / 64 * 64);
-    hipLaunchKernelGGL(k_decim_poly, dim3(grid), dim3(256), (size_t)lds, s, a, (const uint2 *)T);
+    const uint4 *T2 = reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(T) + (size_t)Q * Lp * 2);
+    if (pair) hipLaunchKernelGGL(k_decim_poly<true>, dim3(grid), dim3(256), (size_t)lds, s, a, (const uint2 *)T, T2);
+    else hipLaunchKernelGGL(k_decim_poly<false>, dim3(grid), dim3(256), (size_t)lds, s, a, (const uint2 *)T, T2);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }

@@ -569,6 +569,31 @@ def test_downsampler_fast_paths(rr, oracle, fin, fout, bw, q, kernel):
             check(y, r)
 
 
+@pytest.mark.parametrize("fin,fout,bw,q", [(1024000.0, 102400.0, 60000.0, 3.0), (1024000.0, 384000.0, 200000.0, 3.0), (48000.0, 32000.0, 20000.0, 2.0),
+                                          (45000.0, 40000.0, 30000.0, 1.0), (2560000.0, 40000.0, 30000.0, 1.5), (300000.0, 100000.0, 97000.0, 3.0),
+                                          (500000.0, 100000.0, 10000.0, 1.0)])
+def test_downsampler_polyphase_kernel_one_period_per_lane_on_request(rr, oracle, fin, fout, bw, q, monkeypatch):
+    """RR_DECIM_PAIR=0: k_decim_poly with one period per lane (8-byte LDS reads, one product each) instead of two neighbouring
+    periods per lane (16-byte reads, four products each): both against the oracle and against each other, ragged calls (the tap
+    table is rebuilt when a call starts elsewhere in the period).  The last two cases: a long response at 3 : 1 (many columns per
+    row) and one shorter than the period (rows without taps)."""
+    n = 400000
+    x = oracle.synth_iq(23, 0, n)
+    ref = oracle.Downsampler(1000, fout, bw, q, flt=np.float64).process(fin, x)
+    outs = []
+    for env in ("0", None):
+        if env is None:
+            monkeypatch.delenv("RR_DECIM_PAIR", raising=False)
+        else:
+            monkeypatch.setenv("RR_DECIM_PAIR", env)
+        g = rr.Downsampler.with_quality(1000, fout, bw, q)
+        y = np.concatenate([g.process_raw(fin, x[:150001]), g.process_raw(fin, x[150001:150001 + 99999]), g.process_raw(fin, x[250000:])])
+        assert g.last_kernel() == 5, g.ir_len()
+        check(y, ref)
+        outs.append(y)
+    assert rms_rel(outs[0], outs[1]) < 2e-6
+
+
 @pytest.mark.parametrize("bw", [30000.0, 40000.0, 43000.0])
 def test_downsampler_8_to_1_blocks_of_1024_on_request(rr, oracle, bw, monkeypatch):
     """RR_OLSW_2K=0: 8 : 1 through k_ols_wave<8> (a wave per 1024-sample block) instead of k_ols_wave2k (2048-sample blocks): the
