@@ -140,6 +140,14 @@ int rr_downsampler_design(double input_rate, double output_rate, double bandwidt
 int rr_downsampler_schedule(double input_rate, double output_rate, size_t n_in,
                             double *pos, uint32_t *emit, size_t emit_cap, size_t *count);
 
+/* The interpolation schedule of resampling.rs:248-265 run over n_in inputs starting
+ * from *pos (0.0 for a fresh block): before[t] (capacity before_cap, may be NULL)
+ * receives the number of outputs released before input t is added; *count the
+ * number of outputs; *pos the carried-over position.  Without a list, rates that
+ * are whole multiples of 2^-s take the closed form the device kernel uses. */
+int rr_upsampler_schedule(double input_rate, double output_rate, size_t n_in,
+                          double *pos, int32_t *before, size_t before_cap, size_t *count);
+
 /* Fourier window, analysis.rs:88-101: values[i] = rel[i] * sqrt(n / sum rel^2). */
 int rr_fourier_design_window(size_t n, const double *window_rel, double *values);
 /* Which kernels transform a chunk of n samples (host only, no device needed; the same decision rr_fourier_process takes):

@@ -106,6 +106,7 @@ SIGNATURES = {
     "rr_filter_design_taps": (_i, [_sz, _vp, _vp, _vp]),
     "rr_downsampler_design": (_i, [_d, _d, _d, _d, _psz, _vp, _sz]),
     "rr_downsampler_schedule": (_i, [_d, _d, _sz, C.POINTER(_d), _vp, _sz, _psz]),
+    "rr_upsampler_schedule": (_i, [_d, _d, _sz, C.POINTER(_d), _vp, _sz, _psz]),
     "rr_fourier_design_window": (_i, [_sz, _vp, _vp]),
     "rr_fourier_route": (_i, [_i, _sz, C.c_char_p, _sz]),
     "rr_freqshifter_create": (_i, [_i, _d, _d, _i, C.POINTER(_vp)]),

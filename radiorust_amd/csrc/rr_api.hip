@@ -194,6 +194,27 @@ int rr_downsampler_schedule(double input_rate, double output_rate, size_t n_in, 
     RR_GUARD_END
 }
 
+int rr_upsampler_schedule(double input_rate, double output_rate, size_t n_in, double *pos, int32_t *before,
+                          size_t before_cap, size_t *count) {
+    RR_GUARD_BEGIN
+    if (!pos || !count) RR_FAIL(RR_ERR_BAD_ARG, "null");
+    if (!(input_rate > 0.0) || !(input_rate <= output_rate))
+        RR_FAIL(RR_ERR_CONTRACT, "input sample rate must be smaller than or equal to output sample rate");
+    UpSchedule sc;
+    sc.configure(input_rate, output_rate);
+    sc.pos = *pos;
+    std::vector<int32_t> b;
+    const size_t c = sc.advance(n_in, before ? &b : nullptr);
+    if (before) {
+        if (n_in > before_cap) RR_FAIL(RR_ERR_CAPACITY, "before_cap %zu < %zu", before_cap, n_in);
+        memcpy(before, b.data(), n_in * sizeof(int32_t));
+    }
+    *count = c;
+    *pos = sc.pos;
+    return RR_OK;
+    RR_GUARD_END
+}
+
 int rr_fourier_design_window(size_t n, const double *window_rel, double *values) {
     return rr::fourier_design_window(n, window_rel, values);
 }

@@ -855,6 +855,7 @@ int rr_upsampler::prepare(double input_rate) {
     RR_HIP(hipMemsetAsync(hist[0].p, 0, hb, stream));  // ringbuf = vec![0; ir_len]: nothing before the first input
     cur = 0;
     before_hist.assign(Hn, -(int32_t(1) << 30));  // far outside every output's window
+    before_hist_stale = false;
     return RR_OK;
 }
 
@@ -888,9 +889,34 @@ int rr_upsampler::process_dev(double input_rate, const void *d_in, size_t n_in, 
     rr::UpSchedule next = sched;
     std::vector<int32_t> next_before_hist;
     const int32_t *d_bef = nullptr;
+    // rates on a 2^-s grid (44 100 -> 48 000): the schedule in closed form on the device (RR_UPSAMPLER_GENERIC=1: the list, A/B runs and tests)
+    const bool closed = !sched.integer_ratio && sched.closed && sched.ra < (1ull << 31) && sched.rb < (1ull << 31) &&
+                        ![] { const char *e = std::getenv("RR_UPSAMPLER_GENERIC"); return e && std::atoi(e) != 0; }();
+    if (closed) {
+        const uint64_t p0 = sched.pos_units();
+        next.advance(n_in, nullptr);
+        RR_TRY(launch_upsample_closed(dtype, stream, hist[cur].p, Hn, d_in, d_ir.p, L, sched.ra, sched.rb, p0, d_out, produce));
+        RR_TRY(launch_update_hist(dtype, stream, hist[cur].p, hist[cur ^ 1].p, Hn, d_in, n_in));
+        sched = next;
+        before_hist_stale = true;
+        cur ^= 1;
+        if (n_out) *n_out = produce;
+        return RR_OK;
+    }
     if (sched.integer_ratio) {
         next.advance(n_in, nullptr);
     } else {
+        if (before_hist_stale) {
+            // closed-form calls do not keep the list: kept input v = i - Hn (relative to this call) had released
+            // ceil((v rb - pos) / ra) outputs (negative: before this call's first)
+            const __int128 p0 = (__int128)sched.pos_units();
+            for (size_t i = 0; i < Hn; ++i) {
+                const __int128 q = ((__int128)i - (__int128)Hn) * (__int128)sched.rb - p0;  // < 0
+                const __int128 c = -((-q) / (__int128)sched.ra);                             // ceil of a negative quotient
+                before_hist[i] = (int32_t)std::max<__int128>(c, -((__int128)1 << 30));
+            }
+            before_hist_stale = false;
+        }
         next.advance(n_in, &before);
         std::vector<int32_t> all(Hn + n_in);
         std::copy(before_hist.begin(), before_hist.end(), all.begin());

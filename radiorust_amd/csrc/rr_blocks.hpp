@@ -203,6 +203,7 @@ struct rr_upsampler : rr_block {
     rr::DevBuf hist[2];  // the last Hn inputs in time order
     int cur = 0;
     std::vector<int32_t> before_hist, before;  // generic ratio: outputs released before each kept / new input
+    bool before_hist_stale = false;            // (closed-form calls do not keep it)
     rr::DevBuf d_before;
     int prepare(double input_rate);
     int peek(double input_rate, size_t n_in, size_t *n_out);

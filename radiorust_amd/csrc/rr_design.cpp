@@ -379,6 +379,9 @@ void UpSchedule::configure(double in_rate, double out_rate) {
     pos = 0.0;
     integer_ratio = false;
     U = 0;
+    closed = false;
+    ra = rb = 0;
+    scale = 1.0;
     if (is_integral(in_rate) && is_integral(out_rate) && in_rate >= 1.0) {
         const uint64_t a = static_cast<uint64_t>(in_rate), b = static_cast<uint64_t>(out_rate);
         if (b % a == 0) {
@@ -386,10 +389,29 @@ void UpSchedule::configure(double in_rate, double out_rate) {
             U = b / a;
         }
     }
+    int sh = 0;
+    while (sh <= 40 && std::isfinite(in_rate) && std::isfinite(out_rate) && in_rate > 0.0 && out_rate > 0.0 &&
+           !(is_integral(std::ldexp(in_rate, sh)) && is_integral(std::ldexp(out_rate, sh))))
+        ++sh;
+    const double in_s = std::ldexp(in_rate, sh), out_s = std::ldexp(out_rate, sh);
+    if (sh <= 40 && is_integral(in_s) && is_integral(out_s) && in_s >= 1.0 && out_s >= 1.0 && in_s + out_s <= 9007199254740992.0) {
+        closed = true;
+        scale = std::ldexp(1.0, sh);
+        ra = static_cast<uint64_t>(in_s);
+        rb = static_cast<uint64_t>(out_s);
+    }
+}
+
+// closed form: the outputs released by the next n inputs = ceil((n rb - pos) / ra)
+static inline size_t up_closed_count(uint64_t p0, uint64_t ra, uint64_t rb, size_t n) {
+    const unsigned __int128 tot = (unsigned __int128)rb * n;
+    if (tot <= p0) return 0;
+    return (size_t)((tot - p0 + ra - 1) / ra);
 }
 
 size_t UpSchedule::count(size_t n_in) const {
     if (integer_ratio) return n_in * U;
+    if (closed) return up_closed_count(pos_units(), ra, rb, n_in);
     double p = pos;
     size_t c = 0;
     for (size_t t = 0; t < n_in; ++t) {
@@ -408,6 +430,14 @@ size_t UpSchedule::advance(size_t n_in, std::vector<int32_t> *before) {
         if (before)
             for (size_t t = 0; t < n_in; ++t) (*before)[t] = static_cast<int32_t>(t * U);
         return n_in * U;
+    }
+    if (closed && !before) {
+        const uint64_t p0 = pos_units();
+        const size_t c = up_closed_count(p0, ra, rb, n_in);
+        // pos + c ra - n rb, in [0, ra)
+        const unsigned __int128 np = (unsigned __int128)p0 + (unsigned __int128)ra * c - (unsigned __int128)rb * n_in;
+        pos = static_cast<double>(static_cast<uint64_t>(np)) / scale;
+        return c;
     }
     size_t c = 0;
     for (size_t t = 0; t < n_in; ++t) {  // resampling.rs:248-265, verbatim arithmetic

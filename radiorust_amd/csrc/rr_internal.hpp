@@ -119,6 +119,13 @@ struct UpSchedule {
     double pos = 0;
     bool integer_ratio = false;  // both rates integral and output_rate % input_rate == 0
     uint64_t U = 0;              // output_rate / input_rate
+    // Both rates whole multiples of 2^-s with (in + out) 2^s <= 2^53: every sum of resampling.rs:252-265 is exact in f64 and the
+    // schedule has a closed form - with pos in [0, ra) in units of 2^-s, the outputs released before input t of a call are
+    // before[t] = ceil((t rb - pos) / ra)  (the smallest c with pos + c ra - t rb >= 0), ra / rb = the rates times `scale`.
+    bool closed = false;
+    uint64_t ra = 0, rb = 0;
+    double scale = 1.0;
+    uint64_t pos_units() const { return static_cast<uint64_t>(pos * scale); }
     void configure(double in_rate, double out_rate);
     size_t count(size_t n_in) const;
     // Advances over n_in inputs; if `before` is non-null it receives, per input, the number of

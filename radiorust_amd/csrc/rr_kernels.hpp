@@ -342,6 +342,9 @@ int launch_channelizer256(hipStream_t s, const void *hist, size_t hist_len, cons
 // `ringbuf[i] += sample * ir` (product, then sum).  The virtual input stream is [hist (hn) | in];
 // integer ratio: before[t] = U * t, `before` may be null; otherwise before[] has hn + n_in entries.
 // (rr_metering.hip: built without a*b+c contraction)
+// k_upsample_closed: any pair of rates on a 2^-s grid below 2^31 (UpSchedule::closed), no list of the call's length
+int launch_upsample_closed(int dtype, hipStream_t s, const void *hist, size_t hn, const void *in, const void *ir, size_t L,
+                           uint64_t ra, uint64_t rb, uint64_t pos0, void *out, size_t n_out);
 int launch_upsample(int dtype, hipStream_t s, const void *hist, size_t hn, const void *in, size_t n_in,
                     const void *ir, size_t L, uint64_t U, const int32_t *before, void *out, size_t n_out);
 // FmDemod (modulation.rs:121-130): out[t] = (arg(x[t] * conj(x[t-1])) * factor, 0); st_in / st_out:

@@ -231,6 +231,66 @@ __global__ __launch_bounds__(256) void k_upsample(const CT *__restrict__ hist, l
     out[m] = o;
 }
 
+// Any pair of rates on a 2^-s grid (44 100 -> 48 000: ra : rb = 147 : 160), closed form: input t of the call has released
+// before[t] = ceil((t rb - pos) / ra) outputs when it is added (UpSchedule), so output m sums over the inputs v with
+// 0 <= m - before[v] < L, i.e. from v0 = floor(((m - L) ra + pos) / rb) + 1 to t_hi = floor((m ra + pos) / rb), in ascending order
+// (the reference's order of additions), with before[v + 1] = before[v] + rb div ra + carry by whole-number steps.  No list of
+// the call's length from the host (the gather form above took one: a host loop over the samples, an upload and a stream
+// synchronisation per call), no search.
+template <class T, class CT>
+__global__ __launch_bounds__(256) void k_upsample_closed(const CT *__restrict__ hist, long hn, const CT *__restrict__ in,
+                                                         const T *__restrict__ ir, int L, long ra, long rb, long pos0,
+                                                         CT *__restrict__ out, long n_out) {
+    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_out) return;
+    auto floordiv = [](long a, long b) -> long {  // b > 0
+        long q = a / b;
+        if (a % b < 0) --q;
+        return q;
+    };
+    const long t_hi = floordiv(m * ra + pos0, rb);
+    long v = floordiv((m - L) * ra + pos0, rb) + 1;
+    if (v < -hn) v = -hn;  // (older inputs are not kept: their responses have ended)
+    const long q0 = v * rb - pos0;
+    long B = -floordiv(-q0, ra);  // ceil(q0 / ra) = before[v]
+    long e = B * ra - q0;         // in [0, ra)
+    const long kq = rb / ra, kr = rb % ra;
+    T ar = 0, ai = 0;
+    for (; v <= t_hi; ++v) {
+        const long off = m - B;
+        if (off >= 0 && off < L) {
+            const CT x = v >= 0 ? in[v] : hist[hn + v];
+            const T c = ir[off];
+            ar = add_rn(ar, mul_rn(x.x, c));
+            ai = add_rn(ai, mul_rn(x.y, c));
+        }
+        const bool carry = kr > e;
+        B += kq + (carry ? 1 : 0);
+        e += (carry ? ra : 0) - kr;
+    }
+    CT o;
+    o.x = ar;
+    o.y = ai;
+    out[m] = o;
+}
+
+int launch_upsample_closed(int dtype, hipStream_t s, const void *hist, size_t hn, const void *in, const void *ir, size_t L,
+                           uint64_t ra, uint64_t rb, uint64_t pos0, void *out, size_t n_out) {
+    if (n_out == 0) return RR_OK;
+    if (ra == 0 || rb == 0 || ra >= (1ull << 31) || rb >= (1ull << 31) || n_out >= (1ull << 31) || L >= (1ull << 30))
+        RR_FAIL(RR_ERR_BAD_ARG, "Upsampler: closed-form schedule out of range");
+    const unsigned blocks = (unsigned)((n_out + 255) / 256);
+    if (dtype == RR_F32)
+        hipLaunchKernelGGL((k_upsample_closed<float, float2>), dim3(blocks), dim3(256), 0, s, (const float2 *)hist, (long)hn,
+                           (const float2 *)in, (const float *)ir, (int)L, (long)ra, (long)rb, (long)pos0, (float2 *)out, (long)n_out);
+    else
+        hipLaunchKernelGGL((k_upsample_closed<double, double2>), dim3(blocks), dim3(256), 0, s, (const double2 *)hist, (long)hn,
+                           (const double2 *)in, (const double *)ir, (int)L, (long)ra, (long)rb, (long)pos0, (double2 *)out,
+                           (long)n_out);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
 // Integer ratios U = 2 .. 8, f32: a lane produces the U outputs that one input releases (m = U t + p, p < U).
 // They all sum over the same inputs t - jmax .. t, so a workgroup stages its 256 + J inputs
 // in LDS once (the taps come as scalar loads) and every input read serves U outputs (the one-output-per-lane form above reads 30 inputs

@@ -81,6 +81,16 @@ def up_call():
     up.process_dev(50e6, d_in.data_ptr(), NU, d_out.data_ptr(), NO)
 N = NU  # (the rates of this line are per input sample: 8 B in + 32 B out)
 run("Upsampler 50->200 MS/s", 40, up_call)
+# 44 100 -> 48 000 (147 : 160): the schedule in closed form on the device (k_upsample_closed); RR_UPSAMPLER_GENERIC=1: a list from the host per call
+for generic in (False, True):
+    if generic:
+        os.environ["RR_UPSAMPLER_GENERIC"] = "1"
+    up2 = rr.Upsampler.new(4096, 48000.0, 40000.0)
+    up2.set_stream(st)
+    N = 1 << 24
+    n_o = N * 160 // 147 + 16
+    run(f"Upsampler 44.1->48 kS/s{' (list from the host)' if generic else ''}", round(8 + 8 * 160 / 147, 2), lambda: up2.process_dev(44100.0, d_in.data_ptr(), N, d_out.data_ptr(), n_o), K=3)
+os.environ.pop("RR_UPSAMPLER_GENERIC", None)
 N = NO
 # the reference example's analysis stage (bandwidth_meter/main.rs:66-69): chunks of 1024, Overlapper(4), Fourier with
 # Kaiser(null at bin 4): one 4096-point spectrum per 1024 new samples: 8 B in + 32 B out per input sample

@@ -29,7 +29,8 @@ CUTS = [0, 1, 1, 7, 2048, 2049, 9000, 20000]
 @pytest.mark.parametrize("flt", [np.float32, np.float64])
 @pytest.mark.parametrize("fi,fo,bw,q", [(48000.0, 384000.0, 40000.0, 3.0), (102400.0, 1024000.0, 60000.0, 3.0),
                                         (44100.0, 48000.0, 30000.0, 3.0), (48000.0, 48000.0, 20000.0, 1.0),
-                                        (50e6, 200e6, 40e6, 3.0), (3.0, 7.0, 1.0, 2.0)])
+                                        (50e6, 200e6, 40e6, 3.0), (3.0, 7.0, 1.0, 2.0),
+                                        (44100.5, 48000.0, 30000.0, 3.0), (333.125, 1000.25, 100.0, 2.0), (44100.1, 48000.0, 30000.0, 2.0)])
 def test_upsampler_bit_exact(rr, oracle, fi, fo, bw, q, flt):
     cdt = np.complex64 if flt == np.float32 else np.complex128
     x = oracle.synth_iq(12, 0, CUTS[-1]).astype(cdt)
@@ -40,6 +41,26 @@ def test_upsampler_bit_exact(rr, oracle, fi, fo, bw, q, flt):
         assert len(y) == len(r)  # identical release schedule, chunk by chunk
         assert np.array_equal(y.view(flt), r.view(flt)), (a, b)
     assert g.ir_len() == len(o.ir())
+
+
+@pytest.mark.parametrize("fi,fo,bw", [(44100.0, 48000.0, 30000.0), (44100.5, 48000.0, 30000.0), (3.0, 7.0, 1.0)])
+def test_upsampler_closed_form_schedule_long_stream(rr, oracle, fi, fo, bw, monkeypatch):
+    """Rates on a 2^-s grid: k_upsample_closed (the schedule in closed form on the device, no list from the host) over a long
+    ragged stream, bit-equal to the oracle; RR_UPSAMPLER_GENERIC=1 switched on and off in the middle of the stream (the list form
+    rebuilds what the closed-form calls did not keep)."""
+    n = 300000
+    x = oracle.synth_iq(41, 0, n)
+    g = rr.Upsampler.with_quality(1000, fo, bw, 3.0)
+    o = oracle.Upsampler(1000, fo, bw, 3.0, flt=np.float32)
+    cuts = [0, 1, 70001, 70002, 150000, 150007, 220000, 299999, n]
+    for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        if i in (3, 4, 6):
+            monkeypatch.setenv("RR_UPSAMPLER_GENERIC", "1")
+        else:
+            monkeypatch.delenv("RR_UPSAMPLER_GENERIC", raising=False)
+        y, r = g.process_raw(fi, x[a:b]), o.process(fi, x[a:b])
+        assert len(y) == len(r)
+        assert np.array_equal(y.view(np.float32), r.view(np.float32)), (i, a, b)
 
 
 @pytest.mark.parametrize("U", [2, 3, 5, 6, 7])

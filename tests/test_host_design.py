@@ -173,6 +173,24 @@ def test_schedule_closed_form_for_dyadic_rates(L, fin, fout):
         assert c1.value == c2.value and pos_loop.value == pos_closed.value, (n, c1.value, c2.value, pos_loop.value, pos_closed.value)
 
 
+@pytest.mark.parametrize("fin,fout", [(44100.0, 48000.0), (44100.5, 48000.0), (3.0, 7.0), (333.125, 1000.25), (1.0, 1.0), (48000.0, 384000.0),
+                                      (2.0 ** 39 + 0.25, 2.0 ** 40 + 0.5), (44100.1, 48000.0)])
+def test_upsampler_schedule_closed_form_for_dyadic_rates(L, fin, fout):
+    """The interpolation schedule (resampling.rs:248-265) for rates on a 2^-s grid: counts and the carried position of the closed
+    form (no list) equal the sample loop's (the call with a list), ragged pieces; the list itself is ceil((t out - pos) / in)."""
+    pos_loop, pos_closed = C.c_double(0.0), C.c_double(0.0)
+    for n in (1, 2, 997, 1000, 4097, 30000, 1, 0, 5):
+        c1, c2 = C.c_size_t(), C.c_size_t()
+        before = np.empty(n + 1, dtype=np.int32)
+        p0 = pos_loop.value
+        assert L.rr_upsampler_schedule(fin, fout, n, C.byref(pos_loop), before.ctypes.data, before.size, C.byref(c1)) == 0
+        assert L.rr_upsampler_schedule(fin, fout, n, C.byref(pos_closed), None, 0, C.byref(c2)) == 0
+        assert c1.value == c2.value and pos_loop.value == pos_closed.value, (n, c1.value, c2.value, pos_loop.value, pos_closed.value)
+        if fin == 44100.0 and n:  # integers: the closed form in exact arithmetic
+            want = [-((-(t * int(fout) - int(p0))) // int(fin)) for t in range(n)]
+            assert before[:n].tolist() == want
+
+
 @pytest.mark.parametrize("n", [1, 3, 4, 256, 1000, 4096])
 def test_fourier_window_vs_oracle(L, oracle, n):
     import radiorust_amd as rr
