@@ -543,6 +543,17 @@ __global__ __launch_bounds__(256) void k_ols_decim4(const float2 *__restrict__ x
                             // itself is as fast, but the Fourier stage behind it in the chain then reads its 134 MB from HBM
                             // instead of (mostly) the memory-side cache: k_fft4096 0.048 -> 0.043 ms, chain step 0.1764 -> 0.173 ms
 #endif
+// The last V samples of a block are the first V of the next one: the 128-sample pieces of a block that reach into them are loaded
+// WITHOUT the streaming hint, so that the neighbour finds them in L2 (k_ols_frame: RR_V_FRAME_LD_TAILK).  8 = by the block's
+// overlap (a wave-uniform test per piece); 0 .. 7: the pieces from that one on, whatever the overlap (A/B runs).  One session, ms
+// per 2^26 samples, hint on every piece / by the overlap: Downsampler 4 : 1 with 299 taps (V = 304) 0.153 - 0.157 / 0.146 - 0.147;
+// with 120 taps 0.125 / 0.121; 2 : 1 and the Filter of 64 .. 256 taps inside the noise (scripts/tailk_probe.py).
+#ifndef RR_V_OLSW_TAILK
+#define RR_V_OLSW_TAILK 8
+#endif
+#ifndef RR_V_FLTW_TAILK
+#define RR_V_FLTW_TAILK 8
+#endif
 constexpr unsigned kWaveWin = 64;  // blocks dealt to the XCDs in a moving window, that many neighbouring blocks per XCD
                                    // (one contiguous eighth of the stream per XCD: 0.1375 -> 0.135 ms; 16 .. 1024 alike)
 // D = 4 is the benchmark's form.  D = 2 and D = 8 fold the spectrum into 2 resp. 8 parts instead of 4 (decimation =
@@ -633,7 +644,7 @@ __device__ __forceinline__ void ols_wave_body(
     if (interior) {
         const f4u *src = reinterpret_cast<const f4u *>(in + b0) + l;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = ld_stream(src + 64 * k);
+        for (int k = 0; k < 8; ++k) x[k] = (RR_V_OLSW_TAILK == 8 ? 128 * (k + 1) <= hop : k < RR_V_OLSW_TAILK) ? ld_stream(src + 64 * k) : *(src + 64 * k);
     }
     [[maybe_unused]] f2 gph = {1.f, 0.f};  // GP: the phasor of the lane's result c = 0
     [[maybe_unused]] float2 gpb, gpl;
@@ -1252,7 +1263,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RR_V_FLTWOCC
         const f4u *src = reinterpret_cast<const f4u *>(in + b0) + l;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const f4u x = (RR_V_FLTWNT & 2) ? __builtin_nontemporal_load(src + 64 * k) : *(src + 64 * k);
+            const f4u x = ((RR_V_FLTWNT & 2) && (RR_V_FLTW_TAILK == 8 ? 128 * (k + 1) <= hop : k < RR_V_FLTW_TAILK)) ? __builtin_nontemporal_load(src + 64 * k)
+                                                                                                                  : *(src + 64 * k);
             v[2 * k] = (f2){x.x, x.y};
             v[2 * k + 1] = (f2){x.z, x.w};
         }
