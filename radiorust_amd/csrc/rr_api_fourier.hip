@@ -107,7 +107,24 @@ static FourierRoute fourier_route(int dtype, size_t len, bool force_mixed, bool 
     // SLOWER than k_fft_pow2's Stockham passes: 4096 points 0.355 against 0.241 ms per 2^24 samples, 256 points 0.237 against 0.133.)
     if (!generic && mixed_env != 0) {
         if (fft_mixed_supported(dtype, len)) {
-            if (mixed_env == 2 || force_mixed || fft_mixed_preferred(dtype, len)) {
+            // 2049 .. 8192 points in f32: against k_bluestein_big<M>, one kernel around two workgroup transforms whose cost per chunk
+            // does not depend on n (450 / n ms per 2^24 samples around M = 8192, 1240 / n around 16 384), the mixed passes cost by
+            // their number: ~0.0275 ms each, a tenth more from seven passes on, + 0.1 with a radix 7 / 11 / 13 (2100 points 0.246 / 0.220, 2800 0.222 / 0.164, 7000 0.270 / 0.168).  One session
+            // (scripts/mixed_vs_bluestein_probe.py), mixed / Bluestein: 2500 points 0.150 / 0.181, 3000 0.164 / 0.152, 4000 0.163 / 0.120,
+            // 4004 0.224 / 0.118, 5000 0.173 / 0.218, 6000 0.164 / 0.182, 6144 (seven passes) 0.215 / 0.181, 7200 0.205 / 0.166, 8000 0.182 / 0.157
+            bool prefer = fft_mixed_preferred(dtype, len);
+            size_t Mb = 0;
+            if (dtype == RR_F32 && len > 2048 && bluestein_big_supported(dtype, len, &Mb) && fourier_pow2_path(dtype, Mb) &&
+                ![] { const char *e = std::getenv("RR_FOURIER_BS_BIG"); return e && std::atoi(e) == 0; }() &&
+                !(Mb == 8192 && [] { const char *e = std::getenv("RR_FOURIER_BS8K"); return e && std::strcmp(e, "regs") == 0; }())) {
+                const bool slow_radix = len % 7 == 0 || len % 11 == 0 || len % 13 == 0;
+                unsigned char rad[16];
+                const int passes = fft_mixed_radices(dtype, len, rad, 16);
+                const double t_mixed = 0.0275 * passes * (passes >= 7 ? 1.1 : 1.0) + (slow_radix ? 0.1 : 0.0);
+                const double t_bs = (Mb == 8192 ? 450.0 : 1240.0) / (double)len;
+                prefer = passes > 0 && t_mixed < t_bs;
+            }
+            if (mixed_env == 2 || force_mixed || prefer) {
                 r.kind = FourierRoute::MIXED;
                 return r;
             }
