@@ -788,7 +788,8 @@ int rr_chain::bank_plan(double sample_rate, size_t n_in, size_t cap, BankStep &s
     st.nfr = have / 4096;
     st.rest = have - st.nfr * 4096;
     st.n_head = pending_len;
-    if (st.nfr == 0 || st.dec == 0) return RR_OK;  // (no frame completes: the pending chunk is appended to, lane by lane)
+    if (st.dec == 0) return RR_OK;
+    // (no frame completes: the step's one kernel appends to the pending chunk in the chain's own buffer - rr_chainbank::process_dev)
     if (st.nfr * 4096 > cap) RR_FAIL(RR_ERR_CAPACITY, "Chain: out_cap %zu < %zu", cap, st.nfr * 4096);
     RR_TRY(fo->prepare(4096));
     rr::FusedFirArgs &a = st.a;
@@ -817,6 +818,7 @@ int rr_chain::bank_pointers(const BankStep &st, const void *d_in, void *d_out, r
     bp.xh = xh[xh_cur].p;
     bp.in = d_in;
     bp.dec = buf.p;
+    if (st.nfr == 0) bp.dec = pending.as<char>() + pending_len * elem_size(dtype);  // (behind the pending samples: pending_len + dec < 4096)
     bp.xh_out = xh[xh_cur ^ 1].p;
     bp.head = pend_ptr ? pend_ptr : pending.p;
     bp.out = d_out;
@@ -834,8 +836,12 @@ void rr_chain::bank_commit(const BankStep &st, size_t n_in) {
     ds->sched.advance(st.whole, nullptr);
     zrun += st.whole;
     blocks_stale = true;
-    pend_ptr = newv + (st.nfr * 4096 - pending_len) * esz;
-    dec_cur ^= 1;
+    if (st.nfr == 0) {
+        pend_ptr = nullptr;  // (the pending chunk - copied there by the bank if it was not - and the new samples behind it)
+    } else {
+        pend_ptr = newv + (st.nfr * 4096 - pending_len) * esz;
+        dec_cur ^= 1;
+    }
     pending_len = st.rest;
     frame_table_version = fs->table_version;
     last_fused = st.a.genfold ? 9 : st.a.mixfold ? 7 : FK_OLSW;
@@ -908,6 +914,17 @@ int rr_chainbank::process_dev(double rate, const void *d_in, size_t in_stride, s
         for (size_t k = 0; k < G; ++k)
             RR_TRY(lanes[k0 + k]->bank_pointers(st, static_cast<const char *>(d_in) + (k0 + k) * in_stride * esz,
                                                 static_cast<char *>(d_out) + (k0 + k) * out_stride * esz, tab.c[k]));
+        if (st.nfr == 0) {
+            // no frame completes: the new samples go behind the pending ones in the chains' own buffers - where those are moved
+            // first if the last step left them in its output (one launch for the group's channels)
+            if (c0->pend_ptr && st.n_head) {
+                rr::BankTable cp = tab;
+                for (size_t k = 0; k < G; ++k) cp.c[k].out = lanes[k0 + k]->pending.p;  // (head = pend_ptr: bank_pointers)
+                RR_TRY(launch_bank_copy(stream, cp, G, st.n_head));
+            }
+            RR_TRY(launch_ols_wave_bank(stream, st.a, tab, G));
+            continue;
+        }
         RR_TRY(launch_ols_wave_bank(stream, st.a, tab, G));
         RR_TRY(launch_fft4096_bank(stream, tab, G, st.n_head, st.nfr, c0->fo->d_window.p, c0->fo->d_tw.p, c0->fo->center_dc));
     }

@@ -177,6 +177,8 @@ struct BankTable {
 // k_ols_wave / k_fft4096 for `channels` <= kBankGroup streams in ONE launch each: the shared launch parameters in `a` (its
 // xh / in / out / xh_out are ignored), the per-channel buffers in `tab`
 int launch_ols_wave_bank(hipStream_t s, const FusedFirArgs &a, const BankTable &tab, size_t channels);
+// BankPtrs::head[0 .. n) -> BankPtrs::out for every channel in one launch (the pending chunks in front of a step without a frame)
+int launch_bank_copy(hipStream_t s, const BankTable &tab, size_t channels, size_t n);
 int launch_fft4096_bank(hipStream_t s, const BankTable &tab, size_t channels, size_t n_head, size_t count, const void *window,
                         const void *tw4096, bool center_dc);
 // k_ols_wave2k: 8 : 1 with a wave per 2048-sample block (combined responses up to 1025 taps); tables: build_fused_fir_tables (blk = 2048)

@@ -1216,6 +1216,22 @@ static int launch_ols_wave_bank_d(hipStream_t s, const FusedFirArgs &a, const Ba
     return RR_OK;
 }
 
+// The channels' pending samples (BankPtrs::head, n of them) copied to BankPtrs::out in ONE launch: a bank step in which no frame
+// completes appends to the pending chunk, which must then live in the chain's own buffer (64 copies of a few KiB as 64 calls cost
+// more than the step's kernel)
+__global__ __launch_bounds__(256) void k_bank_copy(const BankTable chan, long n) {
+    const BankPtrs c = chan.c[blockIdx.y];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) reinterpret_cast<float2 *>(c.out)[i] = reinterpret_cast<const float2 *>(c.head)[i];
+}
+int launch_bank_copy(hipStream_t s, const BankTable &d_chan, size_t channels, size_t n) {
+    if (n == 0 || channels == 0) return RR_OK;
+    if (channels > kBankGroup || n > 0x7fffffffull) RR_FAIL(RR_ERR_BAD_ARG, "bank copy: too many channels or samples");
+    hipLaunchKernelGGL(k_bank_copy, dim3((unsigned)((n + 255) / 256), (unsigned)channels), dim3(256), 0, s, d_chan, (long)n);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
 int launch_ols_wave_bank(hipStream_t s, const FusedFirArgs &a, const BankTable &d_chan, size_t channels) {
     if (a.n_out == 0 || channels == 0) return RR_OK;
     if (!a.poly) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS bank: polyphase tables only");

@@ -876,6 +876,48 @@ def test_meter_sample_rate_change_mid_stream(rr, oracle):
     assert n >= 20
 
 
+@pytest.mark.parametrize("shift,precision,out_rate,bw", [(25e6, 1.0, 50e6, 40e6), (12.345e6, 1e3, 25e6, 20e6)])
+def test_chainbank_small_chunks_stay_in_lockstep(rr, oracle, shift, precision, out_rate, bw):
+    """Chunks so small that most calls complete no frame (1024 .. 8192 samples per channel at 4 : 1 / 8 : 1): the bank's step is then
+    ONE launch that appends every channel's decimated samples to its pending chunk (plus one launch that moves the pending
+    chunks into the chains' own buffers behind a frame-completing step) - bit for bit the stand-alone chains, in lockstep."""
+    import torch
+
+    fs, K = 200e6, 6
+    sizes = [65536, 65536] + [4096] * 9 + [1024] * 13 + [8192] * 5 + [2048, 4096, 1024, 512, 512, 16384, 4096, 4096]
+    n_total = sum(sizes)
+    st = torch.cuda.current_stream().cuda_stream
+    d_in = torch.empty(K * n_total, dtype=torch.complex64, device="cuda")
+    for k in range(K):
+        rr.synth_iq_dev(0, st, 300 + k, 0, n_total, d_in.data_ptr() + 8 * k * n_total)
+    torch.cuda.synchronize()
+    params = dict(shift=shift, precision=precision, filter_len=64, freq_resp=lowpass(20e6), output_rate=out_rate, bandwidth=bw,
+                  fft_len=4096, fft_window=rr.Kaiser.with_null_at_bin(2.0))
+    bank = rr.ChainBank(K, **params)
+    bank.set_stream(st)
+    solo = [rr.Chain(**params) for _ in range(K)]
+    for c in solo:
+        c.set_stream(st)
+    cap = 1 << 16
+    out_b = torch.zeros(K * cap, dtype=torch.complex64, device="cuda")
+    out_s = torch.zeros(K * cap, dtype=torch.complex64, device="cuda")
+    pos, lock, frames = 0, [], 0
+    for i, n in enumerate(sizes):
+        wb = bank.process_dev(fs, d_in.data_ptr() + 8 * pos, n_total, n, out_b.data_ptr(), cap, cap)
+        lock.append(bank.last_path_lockstep())
+        for k, c in enumerate(solo):
+            ws = c.process_dev(fs, d_in.data_ptr() + 8 * (k * n_total + pos), n, out_s.data_ptr() + 8 * k * cap, cap)
+            assert ws == wb, (i, k, ws, wb)
+        torch.cuda.synchronize()
+        for k in range(K):
+            assert torch.equal(out_b[k * cap : k * cap + wb], out_s[k * cap : k * cap + wb]), (i, k)
+        frames += wb // 4096
+        pos += n
+    assert frames >= 6
+    # lane by lane only while the histories fill; every small call afterwards in lockstep, with or without a frame
+    assert all(lock[2:]), lock
+
+
 @pytest.mark.parametrize("shift,precision,out_rate,bw", [(25e6, 1.0, 50e6, 40e6), (12.345e6, 1e3, 50e6, 40e6), (12.345e6, 1e3, 25e6, 20e6)])
 def test_chainbank_lockstep_is_bit_identical_to_stand_alone_chains(rr, oracle, shift, precision, out_rate, bw):
     """rr_chainbank: K channels through TWO launches per call once they are in the steady state - every channel's spectra
