@@ -647,10 +647,20 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
     }
     char *newv = nullptr;
     char *dbase = nullptr;
+    // a call that completes no frame, through the wave kernels (8-byte stores): the decimated samples go straight behind the pending
+    // ones in the chain's own buffer instead of through a copy (chunks of a few thousand samples: most calls)
+    const bool append = split && nfr == 0 && dec > 0 && use_ols && ols_N == 1024 && !use_ols64 && !use_poly64;
     if (split) {
         DevBuf &buf = dec2[dec_cur ^ 1];  // never the buffer the pending samples live in
         RR_TRY(buf.reserve((dec + 2) * esz));
         newv = buf.as<char>();
+        if (append) {
+            if (pend_ptr) {
+                if (pending_len) RR_HIP(hipMemcpyAsync(pending.p, pend_ptr, pending_len * esz, hipMemcpyDeviceToDevice, stream));
+                pend_ptr = nullptr;
+            }
+            newv = pending.as<char>() + pending_len * esz;
+        }
     } else {
         // pending outputs in front of the new ones; shifted by one sample when needed so
         // that the kernel's 16-byte stores of the new outputs are aligned
@@ -720,7 +730,7 @@ int rr_chain::process_fused(double sample_rate, const void *d_in, size_t n_in, v
         if (nfr) {  // the leftover is the tail of the new outputs
             pend_ptr = newv + (nfr * LF - pending_len) * esz;
             dec_cur ^= 1;
-        } else if (dec) {
+        } else if (dec && !append) {
             // no frame completed: append the new outputs to the pending chunk
             RR_TRY(materialize_pending_append(newv, dec));
         }

@@ -65,7 +65,7 @@ find "$OUT/shapesprof" -name '*kernel_stats*.csv' | head -1 | xargs -r -I{} cp {
 step clock 300 python3 scripts/clock_probe.py --seconds 4 idle cfg5 chain copy cfg5 chain
 grep -h '^CLOCK_PROBE_JSON' "$OUT/clock.log" | python3 scripts/clock_summary.py > "$OUT/clock_power.txt" || true
 step bank 300 python3 scripts/callsize_probe.py bank 64 10 12 14 16 18
-step callsize 300 python3 scripts/callsize_probe.py 14 16 18 20 22 24 26
+step callsize 300 python3 scripts/callsize_probe.py 10 12 14 16 18 20 22 24 26
 step wave2k 300 python3 scripts/wave2k_probe.py
 step bsbig 300 python3 scripts/bs_big_probe.py
 step smoke 300 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
