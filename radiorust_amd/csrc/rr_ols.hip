@@ -552,8 +552,8 @@ __global__ __launch_bounds__(256) void k_ols_decim4(const float2 *__restrict__ x
 #define RR_V_OLSW_TAILK 8
 #endif
 #ifndef RR_V_FLTW_TAILK
-#define RR_V_FLTW_TAILK 8
-#endif
+#define RR_V_FLTW_TAILK 9  // k_filter_wave: the hint on every piece (9) - by the overlap (8) the Filter of 64 taps measured 5 - 9 % slower
+#endif                     // (0.225 - 0.230 against 0.241 - 0.245 ms in the A/B session, 0.191 against 0.208 between two profile sessions)
 constexpr unsigned kWaveWin = 64;  // blocks dealt to the XCDs in a moving window, that many neighbouring blocks per XCD
                                    // (one contiguous eighth of the stream per XCD: 0.1375 -> 0.135 ms; 16 .. 1024 alike)
 // D = 4 is the benchmark's form.  D = 2 and D = 8 fold the spectrum into 2 resp. 8 parts instead of 4 (decimation =
