@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libradiorust_amd.so")
-SOURCES = ["rr_design.cpp", "rr_kernels.hip", "rr_ols.hip", "rr_ols_frame.hip", "rr_ols_wave2k.hip", "rr_fft_regs.hip", "rr_bluestein.hip", "rr_channelizer.hip", "rr_filter_ols.hip", "rr_decim.hip", "rr_metering.hip", "rr_f64.hip", "rr_api.hip", "rr_api_blocks.hip", "rr_api_fourier.hip", "rr_api_chain.hip"]
+SOURCES = ["rr_design.cpp", "rr_kernels.hip", "rr_ols.hip", "rr_ols_frame.hip", "rr_ols_wave2k.hip", "rr_ols_wg.hip", "rr_fft_regs.hip", "rr_bluestein.hip", "rr_channelizer.hip", "rr_filter_ols.hip", "rr_decim.hip", "rr_metering.hip", "rr_f64.hip", "rr_api.hip", "rr_api_blocks.hip", "rr_api_fourier.hip", "rr_api_chain.hip"]
 ARCH = "gfx950"
 
 

@@ -241,7 +241,7 @@ int rr_chain::ensure_xh() {
 // runs and tests).
 int rr_chain::pick_fused_kernel(uint64_t D, size_t lc, bool real_taps, size_t fft_len) {
     const bool can_direct = real_taps && fused_fir_supported(D, lc);
-    const bool can_ols = ols_decim_supported(D, lc), can_wave = ols_wave_supported(D, lc) || ols_wave2k_supported(D, lc);
+    const bool can_ols = ols_decim_supported(D, lc), can_wave = ols_wave_supported(D, lc) || ols_wave2k_supported(D, lc) || ols_wg_supported(D, lc);
     const bool can_frame = can_wave && ols_frame_supported(D, lc, fft_len);
     const char *e = std::getenv("RR_FUSED_KERNEL");
     if (e) {
@@ -284,7 +284,7 @@ void build_fused_fir_tables(int kind, uint64_t D_, const std::vector<double> &c,
         // H = DFT_N(c) / N (the inverse transform in the kernel is unnormalised)
         const size_t N = wave ? 1024 : 4096;
         std::vector<cd> h(N, cd(0, 0));
-        for (size_t i = 0; i < lc; ++i) h[i] = cc[i];
+        for (size_t i = 0; i < lc && i < N; ++i) h[i] = cc[i];  // (k_ols_wave2k / k_ols_wg take longer responses: their own transforms below)
         fft_f64(h, false);
         std::vector<float> hb(2 * N), twb(2 * N);
         for (size_t i = 0; i < N; ++i) {
@@ -296,6 +296,41 @@ void build_fused_fir_tables(int kind, uint64_t D_, const std::vector<double> &c,
         }
         static const bool no_poly = [] { const char *e = std::getenv("RR_OLSW_POLY"); return e && std::atoi(e) == 0; }();
         t.blk = 1024;
+        if (kind == rr_chain::FK_OLSW && !no_poly && ols_wg_supported(D_, lc)) {
+            // k_ols_wg (16 / 32 / 64 : 1, a workgroup per block of N = 256 D samples): Y[k] = sum_p X_p[k] G_p[k] over the D phases
+            // x_p[m] = xs[D m + p] (X_p = DFT_256 x_p), G_p[k] = sum_q H[k + 256 q] W_N^((k + 256 q) p), H = DFT_N(c) / N, k < 256.
+            // Run h = p / 4 (four phases): its 1024 entries one behind the other in k_ols_wave<4, POLY>'s layout, as k_ols_wave2k's
+            const size_t D = (size_t)D_, NN = 256 * D;
+            std::vector<cd> hN(NN, cd(0, 0));
+            for (size_t i = 0; i < lc; ++i) hN[i] = cc[i];
+            fft_f64(hN, false);
+            std::vector<cd> wN(NN);
+            for (size_t i = 0; i < NN; ++i) {
+                const double ang = -2.0 * M_PI * (double)i / (double)NN;
+                wN[i] = cd(std::cos(ang), std::sin(ang));
+            }
+            std::vector<float> gp(2 * NN);
+            for (size_t pD = 0; pD < D; ++pD)
+                for (size_t k = 0; k < 256; ++k) {
+                    cd g(0, 0);
+                    for (size_t qq = 0; qq < D; ++qq) {
+                        const size_t kk = k + 256 * qq;
+                        g += hN[kk] / (double)NN * wN[(kk * pD) % NN];
+                    }
+                    const size_t hh = pD / 4, pp = pD % 4, l = k % 64, c = k / 64, i = 4 * pp + c;
+                    const size_t dst = 1024 * hh + ((i >> 1) * 64 + l) * 2 + (i & 1);
+                    gp[2 * dst] = (float)g.real();
+                    gp[2 * dst + 1] = (float)g.imag();
+                }
+            append_wave1024_seeds(twb);
+            t.H.swap(gp);
+            t.tw.swap(twb);
+            t.poly = true;
+            t.blk = (int)NN;
+            t.V = ols_wg_overlap(D_, lc);
+            t.N = 1024;  // (the wave kernels' mark: rr_chain::ols_N)
+            return;
+        }
         if (kind == rr_chain::FK_OLSW && !no_poly && ols_wave2k_supported(D_, lc)) {
             // k_ols_wave2k (8 : 1, a wave per 2048-sample block): Y[k] = sum_p X_p[k] G_p[k] over the 8 phases x_p[m] = xs[8 m + p]
             // (X_p = DFT_256 x_p), G_p[k] = sum_q H[k + 256 q] W_2048^((k + 256 q) p), H = DFT_2048(c) / 2048, k < 256.  The kernel
@@ -788,7 +823,7 @@ int rr_chain::bank_plan(double sample_rate, size_t n_in, size_t cap, BankStep &s
     RR_TRY(select());
     RR_TRY(fs->prepare(sample_rate));
     RR_TRY(ensure_ctaps());
-    if (!(use_ols && ols_N == 1024 && ols_poly)) return RR_OK;
+    if (!(use_ols && ols_N == 1024 && ols_poly && ols_blk <= 2048)) return RR_OK;  // (k_ols_wg - 16 / 32 / 64 : 1 - has no bank form)
     const char *fke = std::getenv("RR_FUSED_KERNEL");
     const bool frame_forced = fke && !std::strcmp(fke, "olsf");
     if (use_frame && n_in >= (frame_forced ? (size_t)1024 : (size_t)1 << 23)) return RR_OK;  // (the frame kernel's calls: lane by lane)

@@ -116,7 +116,7 @@ struct FusedFirArgs {
     const void *tw4096 = nullptr;  // e^{-j 2 pi k / 4096}
     int V = 0;                     // overlap (samples), multiple of 256
     bool poly = false;             // k_ols_wave<4>: H holds the polyphase tables G_p (build_fused_fir_tables)
-    int blk = 1024;                // k_ols_wave: samples per block; 2048 = k_ols_wave2k (8 : 1, rr_ols_wave2k.hip)
+    int blk = 1024;                // k_ols_wave: samples per block; 2048 = k_ols_wave2k (8 : 1, rr_ols_wave2k.hip); 256 D = k_ols_wg (16 / 32 / 64 : 1)
     // k_ols_frame only: the NCO's period divides 8 and H holds the tables with the mixer folded in - the kernel transforms the
     // samples as they are and multiplies its results by nco[ph0] sigma^(index): see rr_chain::ensure_mixfold
     bool mixfold = false;
@@ -185,6 +185,11 @@ int launch_fft4096_bank(hipStream_t s, const BankTable &tab, size_t channels, si
 bool ols_wave2k_supported(uint64_t D, size_t Lc);
 int launch_ols_wave2k(hipStream_t s, const FusedFirArgs &a);
 int launch_ols_wave2k_bank(hipStream_t s, const FusedFirArgs &a, const BankTable &tab, size_t channels);
+// k_ols_wg: 16 / 32 / 64 : 1 with a workgroup of four waves per block of 256 D samples (combined responses up to 128 D + 1 taps);
+// tables: build_fused_fir_tables (blk = 256 D), V = ols_wg_overlap
+bool ols_wg_supported(uint64_t D, size_t Lc);
+int ols_wg_overlap(uint64_t D, size_t Lc);
+int launch_ols_wg(hipStream_t s, const FusedFirArgs &a);
 bool ols_frame_supported(uint64_t D, size_t Lc, size_t fft_len);
 // What a metered kernel needs beside its transform's arguments: metering::bandwidth (metering.rs:41-80) per spectrum, computed
 // behind the transform while the bins are in registers (rr_meter_dev.hpp), and the spectrum's energy sum |X|^2.

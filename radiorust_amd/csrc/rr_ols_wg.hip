@@ -1,0 +1,330 @@
+// rr_ols_wg.hip — k_ols_wg<NRW>: the fused mixer + FIR + decimation by D = 16, 32, 64 (rr_chain's front end, the stand-alone
+// Downsampler; transform.rs:171-260, filters.rs:240-259, resampling.rs:20-134 in one pass) by overlap-save with ONE WORKGROUP of four
+// waves per block of N = 256 D samples.
+//
+// At these ratios the polyphase decimator (k_decim_poly, direct form) pays L / D products per input sample, and L grows with D
+// (16 : 1 with 960 taps 0.41 ms per 2^26 samples, 64 : 1 with 3840 taps 2.2 ms); overlap-save costs the same whatever L.  In
+// polyphase form (as k_ols_wave2k, rr_ols_wave2k.hip), with x_p[m] = xs[D m + p], p < D, m < 256:
+//   Y[k] = sum_p X_p[k] G_p[k],  X_p = DFT_256 x_p,  G_p[k] = sum_q H[k + 256 q] W_N^((k + 256 q) p),  H = DFT_N(c) / N,
+//   result[tau] = IDFT_256(Y)[tau] = sum_i c[i] xs[D tau - i]   (tau >= V / D)
+// - D transforms of 256 points = D / 4 runs of the four-phase forward transform of k_ols_wave<4, POLY> (radix 8 x 8 x 4 through two
+// wave-local exchanges).  A run reads 4 of every D samples: ONE wave running all of them would touch every 128-byte line D / 4
+// times, each time for 32 of its bytes.  So the four waves of a workgroup take the runs h = 4 r + w side by side (r < NRW = D / 16
+// steps): in step r they read the phases 16 r .. 16 r + 15 of every period - whole lines, each line once, at the same time.  Each
+// wave sums its runs' products X_p G_p in the four bins Y[l + 64 c] it keeps; the waves 1 .. 3 then leave their sums in their
+// exchange images, and wave 0 adds them up, runs the 256-point inverse (k_ols_wave<4>'s) and stores the (N - V) / D results.
+//
+// Mixer: MF = the samples as they are (the Downsampler), GP = the mixer BEHIND the filter for any NCO period (tables of
+// c[i] w^-i, rr_chain::ensure_genfold; a result at b0 + D tau is multiplied by the phase table's own entry at that position),
+// otherwise the mixer in front of the transform by a walk through the phase table (the call behind a retune: slow and plain).
+#include "rr_blocks.hpp"
+#include "rr_wave_math.hpp"
+#include "rr_fft_regs.hpp"
+#include "rr_ols_dev.hpp"
+
+#include <hip/hip_ext.h>
+
+#include <cstdlib>
+
+namespace rr {
+
+constexpr unsigned kWgWin = 8;  // blocks dealt to the XCDs in a moving window, that many neighbouring blocks per XCD
+constexpr int kWgImg = 1136;    // a wave's exchange image (k_ols_wave<4, POLY>'s: 2 (63 + 72 * 7) + 2 elements)
+
+template <int NRW, bool MF, bool GP>
+__global__ __launch_bounds__(256) void k_ols_wg(const float2 *__restrict__ xh, int hx, const float2 *__restrict__ in, long n_in,
+                                                const float2 *__restrict__ nco, unsigned denom, unsigned idx0,
+                                                const float2 *__restrict__ G, const float2 *__restrict__ tw, int V,
+                                                float2 *__restrict__ out, long n_out, long e0, float2 *__restrict__ xh_out, int hx_out,
+                                                unsigned nblocks, unsigned ph0, unsigned hopm, unsigned kstep, double inv_denom) {
+    static_assert(!GP || MF, "the mixer behind the filter: the blocks transform the samples as they are");
+    constexpr int D = 16 * NRW, N = 256 * D;
+    __shared__ __attribute__((aligned(16))) f2 smem[4 * kWgImg];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    f2 *const lds = smem + w * kWgImg;
+    const unsigned bx = blockIdx.x;
+    const unsigned grp = bx / (8 * kWgWin), rem = bx % (8 * kWgWin);
+    const unsigned blk = grp * 8 * kWgWin + (rem & 7) * kWgWin + (rem >> 3);
+    if (blk >= nblocks) return;
+    const int hop = N - V, per_block = hop / D;
+    const long b0 = e0 - V + (long)blk * hop;
+
+    if (xh_out && blk == nblocks - 1) {  // mixed-sample history for the next call
+        for (int i = tid; i < hx_out; i += 256) {
+            const long pos = n_in - hx_out + i;
+            float2 v;
+            if (pos >= 0) {
+                const float2 xx = in[pos];
+                const float2 pp = nco[(unsigned)(((long)idx0 + pos) % (long)denom)];
+                v.x = xx.x * pp.x - xx.y * pp.y;
+                v.y = xx.x * pp.y + xx.y * pp.x;
+            } else {
+                v = (pos >= -(long)hx) ? xh[hx + pos] : float2{0.f, 0.f};
+            }
+            xh_out[i] = v;
+        }
+    }
+    // NCO phase of the block's first sample: (idx0 + b0) mod denom = (ph0 + blk hopm) mod denom, reduced in f64 (exact below 2^53)
+    unsigned base = ph0;
+    if (hopm != 0) {
+        const double dn = (double)denom;
+        const double prod = __builtin_fma((double)blk, (double)hopm, (double)ph0);
+        const double qd = __builtin_floor(prod * inv_denom);
+        double rd = __builtin_fma(-qd, dn, prod);
+        if (rd < 0.0) rd += dn;
+        if (rd >= dn) rd -= dn;
+        base = (unsigned)rd;
+    }
+    const bool interior = b0 >= 0 && b0 + N <= n_in;
+    // lane constants: tw[4 (l >> 1)], tw[32 (l >> 3)] and the three seeds of the inverse (append_wave1024_seeds, as k_ols_wave<4, POLY>)
+    f2 t_p1, t_p2, t_inv[3];
+    {
+        const float4 *tl = reinterpret_cast<const float4 *>(tw + 1024) + l;
+        const float4 s6 = tl[384], s7 = tl[448], s8 = tl[512];
+        t_p1 = (f2){s6.x, s6.y};
+        t_p2 = (f2){s6.z, s6.w};
+        t_inv[0] = (f2){s7.x, s7.y};
+        t_inv[1] = (f2){s7.z, s7.w};
+        t_inv[2] = (f2){s8.x, s8.y};
+    }
+    f2 y[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll 1
+    for (int r = 0; r < NRW; ++r) {
+        const int h = 4 * r + w;                                   // this wave's run: the phases 4 h .. 4 h + 3
+        const int off = D * (l >> 1) + 4 * h + 2 * (l & 1);        // the lane's first sample (j = 0, k' = 0); k': + 32 D
+        // the lane's 16 entries of G_p for the run's four phases: piece [h][i >> 1][l], entry i = 4 pp + c in half (i & 1)
+        float4 ga[8];
+#pragma unroll
+        for (int kp = 0; kp < 8; ++kp) ga[kp] = reinterpret_cast<const float4 *>(G)[512 * h + l + 64 * kp];
+        f2 e0_[8], e1_[8];
+        if (MF && interior) {
+            const f4u *src = reinterpret_cast<const f4u *>(in + b0 + off);
+            f4u x[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = *(src + 16 * D * k);  // (no streaming hint: the line's other phases belong to the other waves)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                e0_[k] = (f2){x[k].x, x[k].y};
+                e1_[k] = (f2){x[k].z, x[k].w};
+            }
+        } else {
+            // edges (history - already mixed - in front, nothing behind the input) and the mixer in front: element by element, every
+            // lane reads some valid address and selects afterwards; the phase index walks the table in steps of 32 D samples
+            unsigned rr_ = (unsigned)(((unsigned long long)base + (unsigned)off) % denom);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const f4u pp = *reinterpret_cast<const f4u *>(nco + rr_);  // (entry 0 once more behind entry denom - 1)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const long pos = b0 + off + j + 32 * D * k;
+                    const bool inr = pos >= 0 && pos < n_in;
+                    const bool hst = pos < 0 && pos >= -(long)hx;
+                    const float2 *ptr = inr ? in + pos : xh + (hst ? hx + pos : 0);
+                    const float2 xx = *ptr;
+                    const f2 p = j ? (f2){pp.z, pp.w} : (f2){pp.x, pp.y};
+                    // (MF: the block wants the samples UNMIXED - the history, which holds mixed ones, times conj(p))
+                    const f2 pk = MF ? (f2){inr ? 1.f : (hst ? p.x : 0.f), hst ? -p.y : 0.f}
+                                     : (f2){inr ? p.x : (hst ? 1.f : 0.f), inr ? p.y : 0.f};
+                    const f2 xv = {(inr || hst) ? xx.x : 0.f, (inr || hst) ? xx.y : 0.f};
+                    (j ? e1_[k] : e0_[k]) = cmul(xv, pk);
+                }
+                rr_ += kstep;
+                if (rr_ >= denom) rr_ -= denom;
+            }
+        }
+        dft8(e0_);
+        dft8(e1_);
+        {   // * W_256^(mu kappa1): powers of one seed
+            const f2 w1 = t_p1, w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+            const f2 w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+            e0_[1] = cmul(e0_[1], w1); e1_[1] = cmul(e1_[1], w1);
+            e0_[2] = cmul(e0_[2], w2); e1_[2] = cmul(e1_[2], w2);
+            e0_[3] = cmul(e0_[3], w3); e1_[3] = cmul(e1_[3], w3);
+            e0_[4] = cmul(e0_[4], w4); e1_[4] = cmul(e1_[4], w4);
+            e0_[5] = cmul(e0_[5], w5); e1_[5] = cmul(e1_[5], w5);
+            e0_[6] = cmul(e0_[6], w6); e1_[6] = cmul(e1_[6], w6);
+            e0_[7] = cmul(e0_[7], w7); e1_[7] = cmul(e1_[7], w7);
+        }
+        if (r) wave_sync();  // the previous run's last reads are done
+        {
+            f2 *row = lds + 2 * l;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) *reinterpret_cast<float4 *>(row + 144 * k) = (float4){e0_[k].x, e0_[k].y, e1_[k].x, e1_[k].y};
+        }
+        wave_sync();
+        {
+            const f2 *col = lds + 2 * ((l & 7) + 72 * (l >> 3));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float4 q4 = *reinterpret_cast<const float4 *>(col + 16 * k);
+                e0_[k] = (f2){q4.x, q4.y};
+                e1_[k] = (f2){q4.z, q4.w};
+            }
+        }
+        dft8(e0_);
+        dft8(e1_);
+        wave_sync();
+        {
+            f2 *row = lds + 2 * ((l >> 3) + 65 * (l & 7));  // (planes 130 elements apart: k_ols_wave's exchange 2)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) *reinterpret_cast<float4 *>(row + 16 * k) = (float4){e0_[k].x, e0_[k].y, e1_[k].x, e1_[k].y};
+        }
+        wave_sync();
+        const f2 w1 = t_p2, w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            f2 d[2][4];
+#pragma unroll
+            for (int m1 = 0; m1 < 4; ++m1) {
+                const float4 q4 = *reinterpret_cast<const float4 *>(lds + 2 * l + 130 * (a + 2 * m1));
+                d[0][m1] = (f2){q4.x, q4.y};
+                d[1][m1] = (f2){q4.z, q4.w};
+            }
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                d[pp][1] = cmul(d[pp][1], w1);
+                d[pp][2] = cmul(d[pp][2], w2);
+                d[pp][3] = cmul(d[pp][3], w3);
+                dft4(d[pp][0], d[pp][1], d[pp][2], d[pp][3]);
+            }
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const float4 g0 = ga[4 * a + 2 * pp], g1 = ga[4 * a + 2 * pp + 1];
+                y[0] = cmac(y[0], d[pp][0], (f2){g0.x, g0.y});
+                y[1] = cmac(y[1], d[pp][1], (f2){g0.z, g0.w});
+                y[2] = cmac(y[2], d[pp][2], (f2){g1.x, g1.y});
+                y[3] = cmac(y[3], d[pp][3], (f2){g1.z, g1.w});
+            }
+        }
+    }
+    // ---- the waves' sums into wave 0: the waves 1 .. 3 leave theirs in their own images ----
+    wave_sync();  // the wave's last reads of its image are done
+    if (w) {
+        *reinterpret_cast<float4 *>(lds + 2 * l) = (float4){y[0].x, y[0].y, y[1].x, y[1].y};
+        *reinterpret_cast<float4 *>(lds + 128 + 2 * l) = (float4){y[2].x, y[2].y, y[3].x, y[3].y};
+    }
+    __syncthreads();
+    if (w) return;
+#pragma unroll
+    for (int o = 1; o < 4; ++o) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(smem + o * kWgImg + 2 * l);
+        const float4 b4 = *reinterpret_cast<const float4 *>(smem + o * kWgImg + 128 + 2 * l);
+        y[0] += (f2){a4.x, a4.y};
+        y[1] += (f2){a4.z, a4.w};
+        y[2] += (f2){b4.x, b4.y};
+        y[3] += (f2){b4.z, b4.w};
+    }
+    // ---- inverse DFT_256 (radix 4 x 4 x 4 x 4, as k_ols_wave<4>: one image layout per exchange, inv256_rd) ----
+    const int g = l >> 4, q = l & 15;
+    idft4(y[0], y[1], y[2], y[3]);
+    wave_sync();
+    {
+        f2 *row = lds + 2 * l;
+        *reinterpret_cast<float4 *>(row) = (float4){y[0].x, y[0].y, y[1].x, y[1].y};
+        *reinterpret_cast<float4 *>(row + 144) = (float4){y[2].x, y[2].y, y[3].x, y[3].y};
+    }
+    wave_sync();
+#pragma unroll
+    for (int pass = 1; pass < 4; ++pass) {
+        const f2 *const rd = inv256_rd(lds, l, pass);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) y[c] = lds_ld(rd + ((pass == 1 ? 32 : 80) * c));
+        const f2 w1 = t_inv[pass - 1];
+        const f2 w2 = cmul(w1, w1);
+        const f2 w3 = cmul(w2, w1);
+        y[1] = cmul_conj(y[1], w1);
+        y[2] = cmul_conj(y[2], w2);
+        y[3] = cmul_conj(y[3], w3);
+        idft4(y[0], y[1], y[2], y[3]);
+        if (pass == 3) break;  // natural order: y[c] = result[l + 64 c]
+        wave_sync();
+        if (pass == 1) {
+            f2 *col = lds + (20 * (l >> 2) + (l & 3));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) lds_st(col + (4 * c), y[c]);
+        } else {
+            f2 *col = lds + (80 * g + q);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) lds_st(col + (16 * c), y[c]);
+        }
+        wave_sync();
+    }
+    if constexpr (GP) {  // result tau = l + 64 c at b0 + D tau: the phase table's own entry there
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned idx = (unsigned)(((unsigned long long)base + (unsigned)(D * (l + 64 * c))) % denom);
+            const float2 p = nco[idx];
+            y[c] = cmul(y[c], (f2){p.x, p.y});
+        }
+    }
+    // the valid part by buffer stores: lanes outside it (and behind the end of the output) carry an out-of-range offset
+    const int first = V / D;
+    const long mb = (long)blk * per_block;
+    const long left = n_out - mb;
+    const unsigned recs = (unsigned)(left < per_block ? left : per_block) * 8u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + mb, 0, recs, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int tau = l + 64 * c;
+        const unsigned o = tau >= first ? (unsigned)(tau - first) * 8u : 0xffffffffu;
+        __builtin_amdgcn_raw_buffer_store_b64(y[c], rs, o, 0, (MF && !GP) ? 2 : 0);
+    }
+}
+
+// D = 16 / 32 / 64 with a combined response of up to N / 2 + 1 taps (N = 256 D); RR_OLS_WG=0 keeps k_decim_poly
+bool ols_wg_supported(uint64_t D, size_t Lc) {
+    const char *e = std::getenv("RR_OLS_WG");  // (read per design: tests switch it within one process)
+    if (e && std::atoi(e) == 0) return false;
+    return (D == 16 || D == 32 || D == 64) && Lc >= 1 && Lc - 1 <= 128 * D;
+}
+// the overlap: Lc - 1 rounded up to a multiple of D (whole periods; 16, 32, 64: block starts on 128-byte lines)
+int ols_wg_overlap(uint64_t D, size_t Lc) {
+    const size_t v = (Lc - 1 + D - 1) / D * D;
+    return v == 0 ? (int)D : (int)v;
+}
+
+template <int NRW>
+static int launch_ols_wg_n(hipStream_t s, const FusedFirArgs &a) {
+    constexpr int D = 16 * NRW, N = 256 * D;
+    if (a.V < D || a.V > N / 2 || a.V % D) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS (%d-sample blocks): overlap %d", N, a.V);
+    const int per_block = (N - a.V) / D;
+    const size_t nblocks = (a.n_out + per_block - 1) / per_block;
+    if (nblocks > 0x7ffffff0ull) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS: too many blocks");
+    const int64_t den = (int64_t)a.denom;
+    int64_t ph = ((int64_t)a.idx0 + a.e0 - a.V) % den;
+    if (ph < 0) ph += den;
+    const unsigned hopm = (unsigned)((int64_t)(N - a.V) % den), kstep = (unsigned)((32 * D) % den);
+    const unsigned grid = (unsigned)((nblocks + 8 * kWgWin - 1) / (8 * kWgWin) * (8 * kWgWin));
+#define RR_OLSWG_LAUNCH(MF_, GP_)                                                                                                    \
+    do {                                                                                                                             \
+        if (a.ev_start && a.ev_stop)                                                                                                 \
+            hipExtLaunchKernelGGL((k_ols_wg<NRW, MF_, GP_>), dim3(grid), dim3(256), 0, s, a.ev_start, a.ev_stop, 0,                  \
+                                  (const float2 *)a.xh, (int)a.hx, (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco,        \
+                                  a.denom, a.idx0, (const float2 *)a.H, (const float2 *)a.tw4096, a.V, (float2 *)a.out,              \
+                                  (long)a.n_out, (long)a.e0, (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm,   \
+                                  kstep, 1.0 / (double)den);                                                                         \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((k_ols_wg<NRW, MF_, GP_>), dim3(grid), dim3(256), 0, s, (const float2 *)a.xh, (int)a.hx,              \
+                               (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0, (const float2 *)a.H,     \
+                               (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out, (long)a.e0, (float2 *)a.xh_out,       \
+                               (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, kstep, 1.0 / (double)den);                         \
+    } while (0)
+    if (a.genfold) RR_OLSWG_LAUNCH(true, true);
+    else if (a.mixfold) RR_OLSWG_LAUNCH(true, false);
+    else RR_OLSWG_LAUNCH(false, false);
+#undef RR_OLSWG_LAUNCH
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+int launch_ols_wg(hipStream_t s, const FusedFirArgs &a) {
+    if (a.n_out == 0) return RR_OK;
+    switch (a.D) {
+    case 16: return launch_ols_wg_n<1>(s, a);
+    case 32: return launch_ols_wg_n<2>(s, a);
+    case 64: return launch_ols_wg_n<4>(s, a);
+    }
+    RR_FAIL(RR_ERR_BAD_ARG, "fused OLS: decimation %u has no workgroup kernel", a.D);
+}
+
+}  // namespace rr

@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/.."
 python radiorust_amd/build.py >/dev/null
 OBJS=""
-for f in rr_ols rr_ols_frame rr_ols_wave2k rr_fft_regs rr_bluestein rr_channelizer rr_kernels rr_filter_ols; do
+for f in rr_ols rr_ols_frame rr_ols_wave2k rr_ols_wg rr_fft_regs rr_bluestein rr_channelizer rr_kernels rr_filter_ols; do
   hipcc -O3 -std=c++20 -fPIC --offload-arch=gfx950 $2 -c radiorust_amd/csrc/$f.hip -o /tmp/${f}_$1.o &
   OBJS="$OBJS /tmp/${f}_$1.o"
 done

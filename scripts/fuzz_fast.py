@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the long-call kernels of the stand-alone blocks: Downsampler with integer
-ratios 2 / 4 / 8 (k_mix_fir_decim / k_ols_wave / k_ols_decim4 by L) and Filter with n <= 385 (k_filter_wave),
+ratios 2 / 4 / 8 / 16 / 32 / 64 (k_mix_fir_decim / k_ols_wave / k_ols_wave2k / k_ols_wg / k_ols_decim4 by ratio and L) and Filter with n <= 385 (k_filter_wave),
 mixed with short calls, against the f64 oracle.  usage: fuzz_fast.py [cases] [seed]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,7 +22,7 @@ worst = {"down": 0.0, "filter": 0.0}
 seen = {"down": set(), "filter": set()}
 for case in range(cases):
     # ---- Downsampler -------------------------------------------------------------------------------
-    D = int(rng.choice([2, 4, 4, 4, 8]))
+    D = int(rng.choice([2, 4, 4, 4, 8, 8, 16, 32, 64]))
     fo = float(rng.choice([48000.0, 50e6, 1.0]))
     fi = fo * D
     if rng.random() < 0.4:  # aim at the selection boundaries (L = ceil(fi / margin * q), margin = (fo - bw) / 2)

@@ -519,6 +519,11 @@ FAST_CASES = [
     (384000.0, 48000.0, 40000.0, 3.0, 3),   # the reference's simple_receiver second stage: D = 8, L = 288 -> k_ols_wave<8>
     (384000.0, 48000.0, 43000.0, 3.0, 3),   # D = 8, L = 461: overlap 464 of k_ols_wave2k's 2048 (512 of k_ols_wave<8>'s 1024)
     (384000.0, 48000.0, 45500.0, 3.0, 3),   # D = 8, L = 922: k_ols_wave2k alone reaches it
+    (1638400.0, 102400.0, 61440.0, 3.0, 3),   # D = 16, L = 240 -> k_ols_wg (a workgroup of four waves per block of 4096 samples)
+    (1638400.0, 102400.0, 92160.0, 3.0, 3),   # D = 16, L = 960
+    (3276800.0, 102400.0, 81920.0, 3.0, 3),   # D = 32, L = 960: blocks of 8192 samples, two runs per wave
+    (6553600.0, 102400.0, 92160.0, 3.0, 3),   # D = 64, L = 3840: blocks of 16 384 samples, four runs per wave
+    (6553600.0, 102400.0, 98304.0, 3.0, 0),   # D = 64, L = 9600: beyond half a block (and k_decim_poly's tile) -> k_fir
     (96000.0, 48000.0, 30000.0, 3.0, 3),    # D = 2, L = 32
     (96000.0, 48000.0, 44000.0, 3.0, 3),    # D = 2, L = 144 -> k_ols_wave<2>
     (96000.0, 48000.0, 46500.0, 3.0, 3),    # D = 2, L = 384
@@ -528,7 +533,7 @@ FAST_CASES = [
     (300000.0, 100000.0, 60000.0, 3.0, 5),    # 3 : 1
     (48000.0, 32000.0, 20000.0, 2.0, 5),      # 3 : 2
     (700000.0, 300000.0, 100000.0, 3.5, 5),   # 7 : 3
-    (2560000.0, 40000.0, 30000.0, 1.5, 5),    # 64 : 1, L = 768: tiles of 64 periods
+    (2560000.0, 40000.0, 30000.0, 1.5, 3),    # 64 : 1, L = 768: k_ols_wg (k_decim_poly with tiles of 64 periods on request: the test below)
     (45000.0, 40000.0, 30000.0, 1.0, 5),      # 9 : 8, the longest period served
     (512000.0, 1000.0, 700.0, 2.0, 0),        # 512 : 1, L = 6827: beyond k_decim_poly's LDS -> k_fir, 8 outputs per workgroup, the taps in passes
     # every other pair of integer rates: the response at every position, the releasing ones stored - k_filter_wave<true> (10)
@@ -580,6 +585,7 @@ def test_downsampler_polyphase_kernel_one_period_per_lane_on_request(rr, oracle,
     n = 400000
     x = oracle.synth_iq(23, 0, n)
     ref = oracle.Downsampler(1000, fout, bw, q, flt=np.float64).process(fin, x)
+    monkeypatch.setenv("RR_OLS_WG", "0")  # (64 : 1 would otherwise run k_ols_wg)
     outs = []
     for env in ("0", None):
         if env is None:
@@ -589,6 +595,29 @@ def test_downsampler_polyphase_kernel_one_period_per_lane_on_request(rr, oracle,
         g = rr.Downsampler.with_quality(1000, fout, bw, q)
         y = np.concatenate([g.process_raw(fin, x[:150001]), g.process_raw(fin, x[150001:150001 + 99999]), g.process_raw(fin, x[250000:])])
         assert g.last_kernel() == 5, g.ir_len()
+        check(y, ref)
+        outs.append(y)
+    assert rms_rel(outs[0], outs[1]) < 2e-6
+
+
+@pytest.mark.parametrize("D,bwf", [(16, 0.6), (16, 0.9), (32, 0.8), (64, 0.6), (64, 0.9)])
+def test_downsampler_power_of_two_ratios_polyphase_decimator_on_request(rr, oracle, D, bwf, monkeypatch):
+    """RR_OLS_WG=0: 16 / 32 / 64 : 1 through k_decim_poly (direct form) instead of k_ols_wg (overlap-save, a workgroup per block of
+    256 D samples): the same results against the oracle, and the two kernels against each other; ragged calls."""
+    fo = 102400.0
+    fi, bw = fo * D, fo * bwf
+    n = 700000
+    x = oracle.synth_iq(29, 0, n)
+    ref = oracle.Downsampler(1000, fo, bw, 3.0, flt=np.float64).process(fi, x)
+    outs = []
+    for env, want in (("0", 5), (None, 3)):
+        if env is None:
+            monkeypatch.delenv("RR_OLS_WG", raising=False)
+        else:
+            monkeypatch.setenv("RR_OLS_WG", env)
+        g = rr.Downsampler.with_quality(1000, fo, bw, 3.0)
+        y = np.concatenate([g.process_raw(fi, x[:300001]), g.process_raw(fi, x[300001:300001 + 131071]), g.process_raw(fi, x[431072:])])
+        assert g.last_kernel() == want, (g.last_kernel(), g.ir_len())
         check(y, ref)
         outs.append(y)
     assert rms_rel(outs[0], outs[1]) < 2e-6

@@ -665,7 +665,8 @@ def test_chain_frame_kernel_with_1024_point_spectra(rr, oracle, monkeypatch, shi
             assert len(a.chunk) == 1024 and rms_rel(a.chunk, b) <= 1e-5
 
 
-@pytest.mark.parametrize("kernel,out_rate,bw", [("olsf", 50e6, 40e6), ("olsw", 50e6, 40e6), ("olsw", 25e6, 20e6), ("olsw", 100e6, 80e6)])
+@pytest.mark.parametrize("kernel,out_rate,bw", [("olsf", 50e6, 40e6), ("olsw", 50e6, 40e6), ("olsw", 25e6, 20e6), ("olsw", 100e6, 80e6),
+                                                ("olsw", 12.5e6, 10e6)])  # (16 : 1: k_ols_wg)
 def test_chain_frame_kernel_with_the_mixer_behind_the_filter(rr, oracle, monkeypatch, kernel, out_rate, bw):
     """Every NCO period that does not divide 8 (and every period at 2 : 1 and 8 : 1): k_ols_frame<.., GP> and
     k_ols_wave<D, .., GP> transform the samples as they are with the tables of the
