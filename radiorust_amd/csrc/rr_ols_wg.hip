@@ -1,6 +1,6 @@
-// rr_ols_wg.hip — k_ols_wg<NRW>: the fused mixer + FIR + decimation by D = 16, 32, 64 (rr_chain's front end, the stand-alone
-// Downsampler; transform.rs:171-260, filters.rs:240-259, resampling.rs:20-134 in one pass) by overlap-save with ONE WORKGROUP of four
-// waves per block of N = 256 D samples.
+// rr_ols_wg.hip — k_ols_wg<NW>: the fused mixer + FIR + decimation by D = 16, 32, 64 (rr_chain's front end, the stand-alone
+// Downsampler; transform.rs:171-260, filters.rs:240-259, resampling.rs:20-134 in one pass) by overlap-save with ONE WORKGROUP of
+// NW = D / 4 waves per block of N = 256 D samples.
 //
 // At these ratios the polyphase decimator (k_decim_poly, direct form) pays L / D products per input sample, and L grows with D
 // (16 : 1 with 960 taps 0.41 ms per 2^26 samples, 64 : 1 with 3840 taps 2.2 ms); overlap-save costs the same whatever L.  In
@@ -8,11 +8,20 @@
 //   Y[k] = sum_p X_p[k] G_p[k],  X_p = DFT_256 x_p,  G_p[k] = sum_q H[k + 256 q] W_N^((k + 256 q) p),  H = DFT_N(c) / N,
 //   result[tau] = IDFT_256(Y)[tau] = sum_i c[i] xs[D tau - i]   (tau >= V / D)
 // - D transforms of 256 points = D / 4 runs of the four-phase forward transform of k_ols_wave<4, POLY> (radix 8 x 8 x 4 through two
-// wave-local exchanges).  A run reads 4 of every D samples: ONE wave running all of them would touch every 128-byte line D / 4
-// times, each time for 32 of its bytes.  So the four waves of a workgroup take the runs h = 4 r + w side by side (r < NRW = D / 16
-// steps): in step r they read the phases 16 r .. 16 r + 15 of every period - whole lines, each line once, at the same time.  Each
-// wave sums its runs' products X_p G_p in the four bins Y[l + 64 c] it keeps; the waves 1 .. 3 then leave their sums in their
+// wave-local exchanges), ONE RUN PER WAVE: wave w takes the phases 4 w .. 4 w + 3.  The block's samples come in by loads that are
+// contiguous across the workgroup and go through LDS to the wave and lane that transform them (a run reads 4 of every D samples:
+// 32 bytes of every line - loaded by the waves themselves, every line was requested NW times).  Each wave multiplies its four
+// transforms by its G_p into the four bins Y[l + 64 c] a lane keeps; the waves 1 .. NW - 1 then leave their bins in their
 // exchange images, and wave 0 adds them up, runs the 256-point inverse (k_ols_wave<4>'s) and stores the (N - V) / D results.
+// LDS: NW images of 9 KiB - 4 / 2 / 1 workgroups = 16 waves per CU.
+//
+// Measured, the stand-alone Downsampler per 2^26 samples (scripts/decim_pow2_probe.py, one session; k_decim_poly -> this kernel):
+//   16 : 1 with 240 / 480 / 960 taps      0.146 / 0.230 / 0.411  ->  0.116 / 0.123 / 0.138 ms
+//   32 : 1 with 480 / 960 / 1920 taps     0.191 / 0.363 / 0.728  ->  0.140 / 0.143 / 0.161
+//   64 : 1 with 960 / 1920 / 3840 taps    0.323 / 0.587 / 2.247  ->  0.163 / 0.177 / 0.196
+// First forms, one session each: four waves with D / 16 runs each, every wave loading its own phases: 16 : 1 0.135, 32 : 1 0.162,
+// 64 : 1 0.167 ms - TCP -> L2 requests 2 - 3 x those of k_ols_wave2k (PMC); the same with the workgroup-contiguous loads per step:
+// 16 : 1 0.115 (one step), but 32 : 1 0.179 and 64 : 1 0.176 (two barriers per step, the loads' latency in front of every step).
 //
 // Mixer: MF = the samples as they are (the Downsampler), GP = the mixer BEHIND the filter for any NCO period (tables of
 // c[i] w^-i, rr_chain::ensure_genfold; a result at b0 + D tau is multiplied by the phase table's own entry at that position),
@@ -28,18 +37,22 @@
 
 namespace rr {
 
+#ifndef RR_V_OLSWG_COOP
+#define RR_V_OLSWG_COOP 1  // the block's samples by workgroup-contiguous loads and through LDS to their lanes (0: every wave loads its own phases)
+#endif
 constexpr unsigned kWgWin = 8;  // blocks dealt to the XCDs in a moving window, that many neighbouring blocks per XCD
-constexpr int kWgImg = 1136;    // a wave's exchange image (k_ols_wave<4, POLY>'s: 2 (63 + 72 * 7) + 2 elements)
+constexpr int kWgImg = 1140;    // a wave's exchange image (k_ols_wave<4, POLY>'s 1136 elements: 2 (63 + 72 * 7) + 2) + 4: the images 8 banks apart
 
-template <int NRW, bool MF, bool GP>
-__global__ __launch_bounds__(256) void k_ols_wg(const float2 *__restrict__ xh, int hx, const float2 *__restrict__ in, long n_in,
-                                                const float2 *__restrict__ nco, unsigned denom, unsigned idx0,
-                                                const float2 *__restrict__ G, const float2 *__restrict__ tw, int V,
-                                                float2 *__restrict__ out, long n_out, long e0, float2 *__restrict__ xh_out, int hx_out,
-                                                unsigned nblocks, unsigned ph0, unsigned hopm, unsigned kstep, double inv_denom) {
+template <int NW, bool MF, bool GP>
+__global__ __launch_bounds__(64 * NW) void k_ols_wg(const float2 *__restrict__ xh, int hx, const float2 *__restrict__ in, long n_in,
+                                                   const float2 *__restrict__ nco, unsigned denom, unsigned idx0,
+                                                   const float2 *__restrict__ G, const float2 *__restrict__ tw, int V,
+                                                   float2 *__restrict__ out, long n_out, long e0, float2 *__restrict__ xh_out, int hx_out,
+                                                   unsigned nblocks, unsigned ph0, unsigned hopm, unsigned kstep, double inv_denom) {
     static_assert(!GP || MF, "the mixer behind the filter: the blocks transform the samples as they are");
-    constexpr int D = 16 * NRW, N = 256 * D;
-    __shared__ __attribute__((aligned(16))) f2 smem[4 * kWgImg];
+    constexpr int D = 4 * NW, N = 256 * D, NT = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) f2 wg_smem[];  // NW images
+    f2 *const smem = wg_smem;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     f2 *const lds = smem + w * kWgImg;
     const unsigned bx = blockIdx.x;
@@ -50,7 +63,7 @@ __global__ __launch_bounds__(256) void k_ols_wg(const float2 *__restrict__ xh, i
     const long b0 = e0 - V + (long)blk * hop;
 
     if (xh_out && blk == nblocks - 1) {  // mixed-sample history for the next call
-        for (int i = tid; i < hx_out; i += 256) {
+        for (int i = tid; i < hx_out; i += NT) {
             const long pos = n_in - hx_out + i;
             float2 v;
             if (pos >= 0) {
@@ -76,6 +89,7 @@ __global__ __launch_bounds__(256) void k_ols_wg(const float2 *__restrict__ xh, i
         base = (unsigned)rd;
     }
     const bool interior = b0 >= 0 && b0 + N <= n_in;
+    const bool fast = MF && interior;
     // lane constants: tw[4 (l >> 1)], tw[32 (l >> 3)] and the three seeds of the inverse (append_wave1024_seeds, as k_ols_wave<4, POLY>)
     f2 t_p1, t_p2, t_inv[3];
     {
@@ -88,24 +102,42 @@ __global__ __launch_bounds__(256) void k_ols_wg(const float2 *__restrict__ xh, i
         t_inv[2] = (f2){s8.x, s8.y};
     }
     f2 y[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll 1
-    for (int r = 0; r < NRW; ++r) {
-        const int h = 4 * r + w;                                   // this wave's run: the phases 4 h .. 4 h + 3
+    {
+        constexpr int r = 0;
+        const int h = w;                                           // this wave's run: the phases 4 w .. 4 w + 3
         const int off = D * (l >> 1) + 4 * h + 2 * (l & 1);        // the lane's first sample (j = 0, k' = 0); k': + 32 D
-        // the lane's 16 entries of G_p for the run's four phases: piece [h][i >> 1][l], entry i = 4 pp + c in half (i & 1)
-        float4 ga[8];
-#pragma unroll
-        for (int kp = 0; kp < 8; ++kp) ga[kp] = reinterpret_cast<const float4 *>(G)[512 * h + l + 64 * kp];
         f2 e0_[8], e1_[8];
-        if (MF && interior) {
-            const f4u *src = reinterpret_cast<const f4u *>(in + b0 + off);
-            f4u x[8];
+        if (RR_V_OLSWG_COOP && fast) {
+            // the block's N samples by loads that are contiguous across the workgroup (thread t takes the 16-byte chunks t, t + NT,
+            // ..: every line is requested once, by one instruction - a wave that loads its own 4 of every D samples asks for 32 bytes
+            // of each line, and the NW requests for a line reach L2 one by one: 2 - 3 x the requests, PMC), then through LDS to the
+            // wave and lane that transform them: chunk c of period m is the pair a = c & 1 of wave c >> 1, lane 2 (m & 31) + a, value
+            // k' = m >> 5 - the slot that lane's first exchange writes anyway
+            const f4u *src = reinterpret_cast<const f4u *>(in + b0);
+            f4u ch[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) x[k] = *(src + 16 * D * k);  // (no streaming hint: the line's other phases belong to the other waves)
+            for (int u = 0; u < 8; ++u) ch[u] = ld_stream(src + tid + NT * u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = tid + NT * u, m = q / (D / 2), c = q % (D / 2);
+                f2 *dst = smem + (c >> 1) * kWgImg + 2 * (2 * (m & 31) + (c & 1)) + 144 * (m >> 5);
+                *reinterpret_cast<float4 *>(dst) = (float4){ch[u].x, ch[u].y, ch[u].z, ch[u].w};
+            }
+            __syncthreads();
+            const f2 *row = lds + 2 * l;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                e0_[k] = (f2){x[k].x, x[k].y};
-                e1_[k] = (f2){x[k].z, x[k].w};
+                const float4 q4 = *reinterpret_cast<const float4 *>(row + 144 * k);
+                e0_[k] = (f2){q4.x, q4.y};
+                e1_[k] = (f2){q4.z, q4.w};
+            }
+        } else if (fast) {
+            const f4u *src = reinterpret_cast<const f4u *>(in + b0 + off);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const f4u x = *(src + 16 * D * k);
+                e0_[k] = (f2){x.x, x.y};
+                e1_[k] = (f2){x.z, x.w};
             }
         } else {
             // edges (history - already mixed - in front, nothing behind the input) and the mixer in front: element by element, every
@@ -145,7 +177,6 @@ __global__ __launch_bounds__(256) void k_ols_wg(const float2 *__restrict__ xh, i
             e0_[6] = cmul(e0_[6], w6); e1_[6] = cmul(e1_[6], w6);
             e0_[7] = cmul(e0_[7], w7); e1_[7] = cmul(e1_[7], w7);
         }
-        if (r) wave_sync();  // the previous run's last reads are done
         {
             f2 *row = lds + 2 * l;
 #pragma unroll
@@ -169,6 +200,12 @@ __global__ __launch_bounds__(256) void k_ols_wg(const float2 *__restrict__ xh, i
 #pragma unroll
             for (int k = 0; k < 8; ++k) *reinterpret_cast<float4 *>(row + 16 * k) = (float4){e0_[k].x, e0_[k].y, e1_[k].x, e1_[k].y};
         }
+        // the lane's 16 entries of G_p for the run's four phases: piece [h][i >> 1][l], entry i = 4 pp + c in half (i & 1) - requested
+        // here, behind the second exchange's stores (in front of the run they were 32 more registers through both exchanges, beside the
+        // 32 of the next step's samples)
+        float4 ga[8];
+#pragma unroll
+        for (int kp = 0; kp < 8; ++kp) ga[kp] = reinterpret_cast<const float4 *>(G)[512 * h + l + 64 * kp];
         wave_sync();
         const f2 w1 = t_p2, w2 = cmul(w1, w1), w3 = cmul(w2, w1);
 #pragma unroll
@@ -206,7 +243,7 @@ __global__ __launch_bounds__(256) void k_ols_wg(const float2 *__restrict__ xh, i
     __syncthreads();
     if (w) return;
 #pragma unroll
-    for (int o = 1; o < 4; ++o) {
+    for (int o = 1; o < NW; ++o) {
         const float4 a4 = *reinterpret_cast<const float4 *>(smem + o * kWgImg + 2 * l);
         const float4 b4 = *reinterpret_cast<const float4 *>(smem + o * kWgImg + 128 + 2 * l);
         y[0] += (f2){a4.x, a4.y};
@@ -283,9 +320,9 @@ int ols_wg_overlap(uint64_t D, size_t Lc) {
     return v == 0 ? (int)D : (int)v;
 }
 
-template <int NRW>
+template <int NW>
 static int launch_ols_wg_n(hipStream_t s, const FusedFirArgs &a) {
-    constexpr int D = 16 * NRW, N = 256 * D;
+    constexpr int D = 4 * NW, N = 256 * D;
     if (a.V < D || a.V > N / 2 || a.V % D) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS (%d-sample blocks): overlap %d", N, a.V);
     const int per_block = (N - a.V) / D;
     const size_t nblocks = (a.n_out + per_block - 1) / per_block;
@@ -295,16 +332,18 @@ static int launch_ols_wg_n(hipStream_t s, const FusedFirArgs &a) {
     if (ph < 0) ph += den;
     const unsigned hopm = (unsigned)((int64_t)(N - a.V) % den), kstep = (unsigned)((32 * D) % den);
     const unsigned grid = (unsigned)((nblocks + 8 * kWgWin - 1) / (8 * kWgWin) * (8 * kWgWin));
+    constexpr size_t lds = (size_t)NW * kWgImg * sizeof(f2);
 #define RR_OLSWG_LAUNCH(MF_, GP_)                                                                                                    \
     do {                                                                                                                             \
+        RR_TRY(dyn_lds_optin(reinterpret_cast<const void *>(k_ols_wg<NW, MF_, GP_>), lds));                                          \
         if (a.ev_start && a.ev_stop)                                                                                                 \
-            hipExtLaunchKernelGGL((k_ols_wg<NRW, MF_, GP_>), dim3(grid), dim3(256), 0, s, a.ev_start, a.ev_stop, 0,                  \
+            hipExtLaunchKernelGGL((k_ols_wg<NW, MF_, GP_>), dim3(grid), dim3(64 * NW), lds, s, a.ev_start, a.ev_stop, 0,             \
                                   (const float2 *)a.xh, (int)a.hx, (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco,        \
                                   a.denom, a.idx0, (const float2 *)a.H, (const float2 *)a.tw4096, a.V, (float2 *)a.out,              \
                                   (long)a.n_out, (long)a.e0, (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm,   \
                                   kstep, 1.0 / (double)den);                                                                         \
         else                                                                                                                         \
-            hipLaunchKernelGGL((k_ols_wg<NRW, MF_, GP_>), dim3(grid), dim3(256), 0, s, (const float2 *)a.xh, (int)a.hx,              \
+            hipLaunchKernelGGL((k_ols_wg<NW, MF_, GP_>), dim3(grid), dim3(64 * NW), lds, s, (const float2 *)a.xh, (int)a.hx,         \
                                (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0, (const float2 *)a.H,     \
                                (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out, (long)a.e0, (float2 *)a.xh_out,       \
                                (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, kstep, 1.0 / (double)den);                         \
@@ -320,9 +359,9 @@ static int launch_ols_wg_n(hipStream_t s, const FusedFirArgs &a) {
 int launch_ols_wg(hipStream_t s, const FusedFirArgs &a) {
     if (a.n_out == 0) return RR_OK;
     switch (a.D) {
-    case 16: return launch_ols_wg_n<1>(s, a);
-    case 32: return launch_ols_wg_n<2>(s, a);
-    case 64: return launch_ols_wg_n<4>(s, a);
+    case 16: return launch_ols_wg_n<4>(s, a);
+    case 32: return launch_ols_wg_n<8>(s, a);
+    case 64: return launch_ols_wg_n<16>(s, a);
     }
     RR_FAIL(RR_ERR_BAD_ARG, "fused OLS: decimation %u has no workgroup kernel", a.D);
 }

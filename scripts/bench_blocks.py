@@ -50,6 +50,11 @@ run("Downsampler 384->48 kS/s L=288 (D=8)", 9, lambda: ds8.process_dev(384000.0,
 ds8l = rr.Downsampler.new(4096, 48000.0, 43000.0)
 ds8l.set_stream(st)
 run("Downsampler 384->48 kS/s L=461 (D=8)", 9, lambda: ds8l.process_dev(384000.0, d_in.data_ptr(), N, d_out.data_ptr(), N))
+for D16, fo16, bw16 in ((16, 102400.0, 81920.0), (64, 102400.0, 81920.0)):
+    dsw = rr.Downsampler.new(4096, fo16, bw16)
+    dsw.set_stream(st)
+    run(f"Downsampler {D16}:1 (bandwidth 0.8)", 8 + 8 / D16, lambda: dsw.process_dev(fo16 * D16, d_in.data_ptr(), N, d_out.data_ptr(), N))
+    print("   kernel:", dsw.last_kernel(), " L =", dsw.ir_len())
 # the reference's own pipelines: bandwidth_meter/main.rs:56 (10 : 1, L = 145) and simple_receiver.rs:28 (8 : 3, L = 34)
 for name, fin, fout, bw, bps in (("Downsampler 1024->102.4 kS/s L=145 (10:1)", 1024000.0, 102400.0, 60000.0, 8.8),
                                  ("Downsampler 1024->384 kS/s L=34 (8:3)", 1024000.0, 384000.0, 200000.0, 11.0),

@@ -28,6 +28,10 @@ for case in range(cases):
     if rng.random() < 0.4:  # aim at the selection boundaries (L = ceil(fi / margin * q), margin = (fo - bw) / 2)
         L_t = int(rng.choice([110, 111, 112, 113, 384, 385, 386, 387, 60, 500]))
         bw = fo - 2.0 * fi * 3.0 / (L_t - 0.5)
+        if bw <= 0.05 * fo:  # (the larger ratios: aim at lengths that scale with the ratio instead)
+            bw = fo - 2.0 * fi * 3.0 / (L_t * D / 4 - 0.5)
+        if bw <= 0.05 * fo:
+            bw = fo * float(rng.uniform(0.3, 0.97))
     else:
         bw = fo * float(rng.uniform(0.3, 0.97))
     q = 3.0
