@@ -297,19 +297,24 @@ void build_fused_fir_tables(int kind, uint64_t D_, const std::vector<double> &c,
         static const bool no_poly = [] { const char *e = std::getenv("RR_OLSW_POLY"); return e && std::atoi(e) == 0; }();
         t.blk = 1024;
         if (kind == rr_chain::FK_OLSW && !no_poly && ols_wg_supported(D_, lc)) {
-            // k_ols_wg (16 / 32 / 64 : 1, a workgroup per block of N = 256 D samples): Y[k] = sum_p X_p[k] G_p[k] over the D phases
+            // k_ols_wg (even ratios 10 .. 64, a workgroup per block of N = 256 D samples): Y[k] = sum_p X_p[k] G_p[k] over the D phases
             // x_p[m] = xs[D m + p] (X_p = DFT_256 x_p), G_p[k] = sum_q H[k + 256 q] W_N^((k + 256 q) p), H = DFT_N(c) / N, k < 256.
-            // Run h = p / 4 (four phases): its 1024 entries one behind the other in k_ols_wave<4, POLY>'s layout, as k_ols_wave2k's
-            const size_t D = (size_t)D_, NN = 256 * D;
-            std::vector<cd> hN(NN, cd(0, 0));
-            for (size_t i = 0; i < lc; ++i) hN[i] = cc[i];
-            fft_f64(hN, false);
+            // N need not be a power of two: H[k] = sum_(n2 < D) W_N^(n2 k) F_n2[k mod 256], F_n2 = DFT_256 of c[D n1 + n2].
+            // Run h = p / 4 (four phases; the runs beyond D hold zeros): its 1024 entries one behind the other in
+            // k_ols_wave<4, POLY>'s layout, as k_ols_wave2k's
+            const size_t D = (size_t)D_, NN = 256 * D, runs = (size_t)ols_wg_runs(D_);
             std::vector<cd> wN(NN);
             for (size_t i = 0; i < NN; ++i) {
                 const double ang = -2.0 * M_PI * (double)i / (double)NN;
                 wN[i] = cd(std::cos(ang), std::sin(ang));
             }
-            std::vector<float> gp(2 * NN);
+            std::vector<cd> hN(NN, cd(0, 0)), F(256);
+            for (size_t n2 = 0; n2 < D; ++n2) {
+                for (size_t n1 = 0; n1 < 256; ++n1) F[n1] = D * n1 + n2 < lc ? cc[D * n1 + n2] : cd(0, 0);
+                fft_f64(F, false);
+                for (size_t k = 0; k < NN; ++k) hN[k] += wN[(n2 * k) % NN] * F[k & 255];
+            }
+            std::vector<float> gp(2 * 1024 * runs, 0.f);
             for (size_t pD = 0; pD < D; ++pD)
                 for (size_t k = 0; k < 256; ++k) {
                     cd g(0, 0);
@@ -1405,6 +1410,7 @@ int rr_meter_create(const rr_meter_params *p, int device, rr_meter **out) {
     h->ds->output_rate = p->output_rate;
     h->ds->bandwidth = p->bandwidth;
     h->ds->quality = p->quality;
+    h->ds->mixer_rides = true;  // (the FreqShifter in front rides along with k_decim_poly: rr_meter::process)
     h->chunk_len = p->chunk_len;
     h->overlap = p->overlap;
     h->output_rate = p->output_rate;

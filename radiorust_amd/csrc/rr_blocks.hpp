@@ -128,6 +128,9 @@ struct rr_downsampler : rr_block {
     int process_dev(double input_rate, const void *d_in, size_t n_in, void *d_out, size_t cap, size_t *n_out,
                     const void *nco = nullptr, uint32_t nco_denom = 0, uint32_t nco_idx0 = 0);
     bool can_fuse_mixer(double input_rate, size_t n_in);
+    // set by rr_meter: a FreqShifter in front is to ride along (k_decim_poly takes it in its staging) - at the ratios where both
+    // k_ols_wg and the decimator apply the decimator is kept, the mixed stream is never written
+    bool mixer_rides = false;
 };
 
 // metering::bandwidth as the last step of a pipeline (examples/bandwidth_meter/main.rs:78): while `on`, every spectrum a call

@@ -185,10 +185,11 @@ int launch_fft4096_bank(hipStream_t s, const BankTable &tab, size_t channels, si
 bool ols_wave2k_supported(uint64_t D, size_t Lc);
 int launch_ols_wave2k(hipStream_t s, const FusedFirArgs &a);
 int launch_ols_wave2k_bank(hipStream_t s, const FusedFirArgs &a, const BankTable &tab, size_t channels);
-// k_ols_wg: 16 / 32 / 64 : 1 with a workgroup of four waves per block of 256 D samples (combined responses up to 128 D + 1 taps);
+// k_ols_wg: even ratios 10 .. 64 with a workgroup of ~D / 4 waves per block of 256 D samples (combined responses up to 128 D + 1 taps);
 // tables: build_fused_fir_tables (blk = 256 D), V = ols_wg_overlap
 bool ols_wg_supported(uint64_t D, size_t Lc);
 int ols_wg_overlap(uint64_t D, size_t Lc);
+int ols_wg_runs(uint64_t D);  // the runs of four phases the tables hold (= the kernel's waves)
 int launch_ols_wg(hipStream_t s, const FusedFirArgs &a);
 bool ols_frame_supported(uint64_t D, size_t Lc, size_t fft_len);
 // What a metered kernel needs beside its transform's arguments: metering::bandwidth (metering.rs:41-80) per spectrum, computed

@@ -48,9 +48,12 @@ __global__ __launch_bounds__(64 * NW) void k_ols_wg(const float2 *__restrict__ x
                                                    const float2 *__restrict__ nco, unsigned denom, unsigned idx0,
                                                    const float2 *__restrict__ G, const float2 *__restrict__ tw, int V,
                                                    float2 *__restrict__ out, long n_out, long e0, float2 *__restrict__ xh_out, int hx_out,
-                                                   unsigned nblocks, unsigned ph0, unsigned hopm, unsigned kstep, double inv_denom) {
+                                                   unsigned nblocks, unsigned ph0, unsigned hopm, unsigned kstep, double inv_denom,
+                                                   const int D) {
     static_assert(!GP || MF, "the mixer behind the filter: the blocks transform the samples as they are");
-    constexpr int D = 4 * NW, N = 256 * D, NT = 64 * NW;
+    // D: the decimation, even, 4 (NW - 1) < D <= 4 NW as a rule (more waves than runs: the last ones find no phase and add zeros)
+    constexpr int NT = 64 * NW;
+    const int N = 256 * D, Dh = D >> 1;
     extern __shared__ __attribute__((aligned(16))) f2 wg_smem[];  // NW images
     f2 *const smem = wg_smem;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
@@ -103,9 +106,9 @@ __global__ __launch_bounds__(64 * NW) void k_ols_wg(const float2 *__restrict__ x
     }
     f2 y[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
     {
-        constexpr int r = 0;
         const int h = w;                                           // this wave's run: the phases 4 w .. 4 w + 3
         const int off = D * (l >> 1) + 4 * h + 2 * (l & 1);        // the lane's first sample (j = 0, k' = 0); k': + 32 D
+        const bool live = 4 * h + 2 * (l & 1) < D;                 // (D = 4 NW - 2: the last wave's odd lanes have no phases - zeros)
         f2 e0_[8], e1_[8];
         if (RR_V_OLSWG_COOP && fast) {
             // the block's N samples by loads that are contiguous across the workgroup (thread t takes the 16-byte chunks t, t + NT,
@@ -114,30 +117,34 @@ __global__ __launch_bounds__(64 * NW) void k_ols_wg(const float2 *__restrict__ x
             // wave and lane that transform them: chunk c of period m is the pair a = c & 1 of wave c >> 1, lane 2 (m & 31) + a, value
             // k' = m >> 5 - the slot that lane's first exchange writes anyway
             const f4u *src = reinterpret_cast<const f4u *>(in + b0);
+            const int nch = 128 * D;  // 16-byte chunks of the block: at most 8 per thread (2 D / NW)
             f4u ch[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) ch[u] = ld_stream(src + tid + NT * u);
+            for (int u = 0; u < 8; ++u) {
+                const int q = tid + NT * u;
+                ch[u] = ld_stream(src + (q < nch ? q : nch - 1));
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int q = tid + NT * u, m = q / (D / 2), c = q % (D / 2);
+                const int q = tid + NT * u, m = q / Dh, c = q - m * Dh;
                 f2 *dst = smem + (c >> 1) * kWgImg + 2 * (2 * (m & 31) + (c & 1)) + 144 * (m >> 5);
-                *reinterpret_cast<float4 *>(dst) = (float4){ch[u].x, ch[u].y, ch[u].z, ch[u].w};
+                if (q < nch) *reinterpret_cast<float4 *>(dst) = (float4){ch[u].x, ch[u].y, ch[u].z, ch[u].w};
             }
             __syncthreads();
             const f2 *row = lds + 2 * l;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float4 q4 = *reinterpret_cast<const float4 *>(row + 144 * k);
-                e0_[k] = (f2){q4.x, q4.y};
-                e1_[k] = (f2){q4.z, q4.w};
+                e0_[k] = live ? (f2){q4.x, q4.y} : (f2){0.f, 0.f};
+                e1_[k] = live ? (f2){q4.z, q4.w} : (f2){0.f, 0.f};
             }
         } else if (fast) {
-            const f4u *src = reinterpret_cast<const f4u *>(in + b0 + off);
+            const f4u *src = reinterpret_cast<const f4u *>(in + b0 + (live ? off : 0));
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const f4u x = *(src + 16 * D * k);
-                e0_[k] = (f2){x.x, x.y};
-                e1_[k] = (f2){x.z, x.w};
+                e0_[k] = live ? (f2){x.x, x.y} : (f2){0.f, 0.f};
+                e1_[k] = live ? (f2){x.z, x.w} : (f2){0.f, 0.f};
             }
         } else {
             // edges (history - already mixed - in front, nothing behind the input) and the mixer in front: element by element, every
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(64 * NW) void k_ols_wg(const float2 *__restrict__ x
                     // (MF: the block wants the samples UNMIXED - the history, which holds mixed ones, times conj(p))
                     const f2 pk = MF ? (f2){inr ? 1.f : (hst ? p.x : 0.f), hst ? -p.y : 0.f}
                                      : (f2){inr ? p.x : (hst ? 1.f : 0.f), inr ? p.y : 0.f};
-                    const f2 xv = {(inr || hst) ? xx.x : 0.f, (inr || hst) ? xx.y : 0.f};
+                    const f2 xv = {((inr || hst) && live) ? xx.x : 0.f, ((inr || hst) && live) ? xx.y : 0.f};
                     (j ? e1_[k] : e0_[k]) = cmul(xv, pk);
                 }
                 rr_ += kstep;
@@ -308,21 +315,38 @@ __global__ __launch_bounds__(64 * NW) void k_ols_wg(const float2 *__restrict__ x
     }
 }
 
-// D = 16 / 32 / 64 with a combined response of up to N / 2 + 1 taps (N = 256 D); RR_OLS_WG=0 keeps k_decim_poly
+// Even ratios from 10 to 64 with a combined response of up to 128 D + 1 taps (N = 256 D); RR_OLS_WG=0 keeps k_decim_poly.  Powers of
+// two always (16 : 1 with 240 taps: 0.146 -> 0.116 ms per 2^26 samples); the others - which the decimator serves well while the
+// response is short - from 12 .. 24 taps per period on (10 : 1 with 145 taps, and the chain's 208 taps at 10 : 1, stay with
+// k_decim_poly).
 bool ols_wg_supported(uint64_t D, size_t Lc) {
     const char *e = std::getenv("RR_OLS_WG");  // (read per design: tests switch it within one process)
     if (e && std::atoi(e) == 0) return false;
-    return (D == 16 || D == 32 || D == 64) && Lc >= 1 && Lc - 1 <= 128 * D;
+    if (D < 10 || D > 64 || (D & 1) || Lc < 1 || Lc - 1 > 128 * D) return false;
+    if (D == 16 || D == 32 || D == 64) return true;
+    // taps per period from which this kernel is ahead of the decimator (scripts/decim_pow2_probe.py, ms per 2^26 samples, decimator /
+    // this kernel: 10 : 1 with 15 / 30 taps per period 0.132 / 0.199 against 0.157 / 0.167; 12 : 1 0.132 / 0.217 against 0.137 / 0.144;
+    // 20 : 1 0.162 / 0.223 against 0.149 / 0.158; 48 : 1 0.233 / 0.455 against 0.184 / 0.195): a last wave with half of its lanes
+    // empty (D = 4 NW - 2) moves the border up
+    const size_t per = (D < 20 ? 16 : 12) + ((D & 3) == 2 ? 8 : 0);
+    return (e && std::atoi(e) == 2) || Lc >= per * D;  // (=2: every even ratio whatever the length - tests, A/B runs)
 }
-// the overlap: Lc - 1 rounded up to a multiple of D (whole periods; 16, 32, 64: block starts on 128-byte lines)
+// the overlap: Lc - 1 rounded up to a multiple of D (whole periods)
 int ols_wg_overlap(uint64_t D, size_t Lc) {
     const size_t v = (Lc - 1 + D - 1) / D * D;
     return v == 0 ? (int)D : (int)v;
 }
+// waves per workgroup: the runs (D + 3) / 4, rounded up to an instantiated count
+static int ols_wg_waves(uint64_t D) {
+    const int need = (int)((D + 3) / 4);
+    for (int nw : {3, 4, 5, 6, 8, 12, 16})
+        if (need <= nw) return nw;
+    return 0;
+}
 
 template <int NW>
 static int launch_ols_wg_n(hipStream_t s, const FusedFirArgs &a) {
-    constexpr int D = 4 * NW, N = 256 * D;
+    const int D = (int)a.D, N = 256 * D;
     if (a.V < D || a.V > N / 2 || a.V % D) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS (%d-sample blocks): overlap %d", N, a.V);
     const int per_block = (N - a.V) / D;
     const size_t nblocks = (a.n_out + per_block - 1) / per_block;
@@ -341,12 +365,12 @@ static int launch_ols_wg_n(hipStream_t s, const FusedFirArgs &a) {
                                   (const float2 *)a.xh, (int)a.hx, (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco,        \
                                   a.denom, a.idx0, (const float2 *)a.H, (const float2 *)a.tw4096, a.V, (float2 *)a.out,              \
                                   (long)a.n_out, (long)a.e0, (float2 *)a.xh_out, (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm,   \
-                                  kstep, 1.0 / (double)den);                                                                         \
+                                  kstep, 1.0 / (double)den, D);                                                                      \
         else                                                                                                                         \
             hipLaunchKernelGGL((k_ols_wg<NW, MF_, GP_>), dim3(grid), dim3(64 * NW), lds, s, (const float2 *)a.xh, (int)a.hx,         \
                                (const float2 *)a.in, (long)a.n_in, (const float2 *)a.nco, a.denom, a.idx0, (const float2 *)a.H,     \
                                (const float2 *)a.tw4096, a.V, (float2 *)a.out, (long)a.n_out, (long)a.e0, (float2 *)a.xh_out,       \
-                               (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, kstep, 1.0 / (double)den);                         \
+                               (int)a.hx, (unsigned)nblocks, (unsigned)ph, hopm, kstep, 1.0 / (double)den, D);                      \
     } while (0)
     if (a.genfold) RR_OLSWG_LAUNCH(true, true);
     else if (a.mixfold) RR_OLSWG_LAUNCH(true, false);
@@ -356,12 +380,19 @@ static int launch_ols_wg_n(hipStream_t s, const FusedFirArgs &a) {
     return RR_OK;
 }
 
+int ols_wg_runs(uint64_t D) { return ols_wg_waves(D); }
+
 int launch_ols_wg(hipStream_t s, const FusedFirArgs &a) {
     if (a.n_out == 0) return RR_OK;
-    switch (a.D) {
-    case 16: return launch_ols_wg_n<4>(s, a);
-    case 32: return launch_ols_wg_n<8>(s, a);
-    case 64: return launch_ols_wg_n<16>(s, a);
+    if (a.D < 10 || a.D > 64 || (a.D & 1)) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS: decimation %u has no workgroup kernel", a.D);
+    switch (ols_wg_waves(a.D)) {
+    case 3: return launch_ols_wg_n<3>(s, a);
+    case 4: return launch_ols_wg_n<4>(s, a);
+    case 5: return launch_ols_wg_n<5>(s, a);
+    case 6: return launch_ols_wg_n<6>(s, a);
+    case 8: return launch_ols_wg_n<8>(s, a);
+    case 12: return launch_ols_wg_n<12>(s, a);
+    case 16: return launch_ols_wg_n<16>(s, a);
     }
     RR_FAIL(RR_ERR_BAD_ARG, "fused OLS: decimation %u has no workgroup kernel", a.D);
 }

@@ -1,3 +1,5 @@
+"""The stand-alone Downsampler at 8 .. 64 : 1 (even ratios) with responses of 15 / 30 / 60 taps per period: ms per 2^26 samples.
+RR_OLS_WG=0: k_decim_poly for the ratios from 10 : 1 on; =2: k_ols_wg whatever the length."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch
@@ -12,7 +14,7 @@ def timed(call, K=10):
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(K): call()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / K
-for D in (8, 16, 32, 64):
+for D in (8, 10, 12, 16, 20, 24, 32, 48, 64):
     for bwf in (0.6, 0.8, 0.9):
         fo = 102400.0
         ds = rr.Downsampler.new(4096, fo, fo * bwf); ds.set_stream(st)
