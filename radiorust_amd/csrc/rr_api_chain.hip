@@ -828,7 +828,7 @@ int rr_chain::bank_plan(double sample_rate, size_t n_in, size_t cap, BankStep &s
     RR_TRY(select());
     RR_TRY(fs->prepare(sample_rate));
     RR_TRY(ensure_ctaps());
-    if (!(use_ols && ols_N == 1024 && ols_poly && ols_blk <= 2048)) return RR_OK;  // (k_ols_wg - 16 / 32 / 64 : 1 - has no bank form)
+    if (!(use_ols && ols_N == 1024 && ols_poly && (ols_blk == 1024 || ols_blk == 2048))) return RR_OK;  // (k_ols_wg has no bank form)
     const char *fke = std::getenv("RR_FUSED_KERNEL");
     const bool frame_forced = fke && !std::strcmp(fke, "olsf");
     if (use_frame && n_in >= (frame_forced ? (size_t)1024 : (size_t)1 << 23)) return RR_OK;  // (the frame kernel's calls: lane by lane)

@@ -1183,7 +1183,7 @@ static int launch_ols_wave_d(hipStream_t s, const FusedFirArgs &a) {
 int launch_ols_wave(hipStream_t s, const FusedFirArgs &a) {
     if (a.n_out == 0) return RR_OK;
     if (a.blk == 2048) return launch_ols_wave2k(s, a);
-    if (a.blk > 2048) return launch_ols_wg(s, a);
+    if (a.blk != 1024) return launch_ols_wg(s, a);  // (256 D samples: 1536 at 6 : 1, 2560 .. 16 384 from 10 : 1 on)
     switch (a.D) {
     case 2: return a.poly ? launch_ols_wave_d<2, true>(s, a) : launch_ols_wave_d<2, false>(s, a);
     case 4: return a.poly ? launch_ols_wave_d<4, true>(s, a) : launch_ols_wave_d<4, false>(s, a);
@@ -1237,7 +1237,7 @@ int launch_ols_wave_bank(hipStream_t s, const FusedFirArgs &a, const BankTable &
     if (a.n_out == 0 || channels == 0) return RR_OK;
     if (!a.poly) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS bank: polyphase tables only");
     if (a.blk == 2048) return launch_ols_wave2k_bank(s, a, d_chan, channels);
-    if (a.blk > 2048) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS bank: no bank form of the workgroup kernel (16 / 32 / 64 : 1)");
+    if (a.blk != 1024) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS bank: no bank form of the workgroup kernel (6 : 1, 10 .. 64 : 1)");
     switch (a.D) {
     case 2: return launch_ols_wave_bank_d<2>(s, a, d_chan, channels);
     case 4: return launch_ols_wave_bank_d<4>(s, a, d_chan, channels);

@@ -315,14 +315,14 @@ __global__ __launch_bounds__(64 * NW) void k_ols_wg(const float2 *__restrict__ x
     }
 }
 
-// Even ratios from 10 to 64 with a combined response of up to 128 D + 1 taps (N = 256 D); RR_OLS_WG=0 keeps k_decim_poly.  Powers of
+// Even ratios 6 and 10 .. 64 with a combined response of up to 128 D + 1 taps (N = 256 D); RR_OLS_WG=0 keeps k_decim_poly.  Powers of
 // two always (16 : 1 with 240 taps: 0.146 -> 0.116 ms per 2^26 samples); the others - which the decimator serves well while the
 // response is short - from 12 .. 24 taps per period on (10 : 1 with 145 taps, and the chain's 208 taps at 10 : 1, stay with
 // k_decim_poly).
 bool ols_wg_supported(uint64_t D, size_t Lc) {
     const char *e = std::getenv("RR_OLS_WG");  // (read per design: tests switch it within one process)
     if (e && std::atoi(e) == 0) return false;
-    if (D < 10 || D > 64 || (D & 1) || Lc < 1 || Lc - 1 > 128 * D) return false;
+    if (D < 6 || D == 8 || D > 64 || (D & 1) || Lc < 1 || Lc - 1 > 128 * D) return false;  // (8 : 1: k_ols_wave2k)
     if (D == 16 || D == 32 || D == 64) return true;
     // taps per period from which this kernel is ahead of the decimator (scripts/decim_pow2_probe.py, ms per 2^26 samples, decimator /
     // this kernel: 10 : 1 with 15 / 30 taps per period 0.132 / 0.199 against 0.157 / 0.167; 12 : 1 0.132 / 0.217 against 0.137 / 0.144;
@@ -339,7 +339,7 @@ int ols_wg_overlap(uint64_t D, size_t Lc) {
 // waves per workgroup: the runs (D + 3) / 4, rounded up to an instantiated count
 static int ols_wg_waves(uint64_t D) {
     const int need = (int)((D + 3) / 4);
-    for (int nw : {3, 4, 5, 6, 8, 12, 16})
+    for (int nw : {2, 3, 4, 5, 6, 8, 12, 16})
         if (need <= nw) return nw;
     return 0;
 }
@@ -384,8 +384,9 @@ int ols_wg_runs(uint64_t D) { return ols_wg_waves(D); }
 
 int launch_ols_wg(hipStream_t s, const FusedFirArgs &a) {
     if (a.n_out == 0) return RR_OK;
-    if (a.D < 10 || a.D > 64 || (a.D & 1)) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS: decimation %u has no workgroup kernel", a.D);
+    if (a.D < 6 || a.D > 64 || (a.D & 1)) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS: decimation %u has no workgroup kernel", a.D);
     switch (ols_wg_waves(a.D)) {
+    case 2: return launch_ols_wg_n<2>(s, a);
     case 3: return launch_ols_wg_n<3>(s, a);
     case 4: return launch_ols_wg_n<4>(s, a);
     case 5: return launch_ols_wg_n<5>(s, a);

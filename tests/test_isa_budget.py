@@ -56,7 +56,7 @@ def test_the_headline_kernels_do_not_spill(tmp_path):
         assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0 and k["vgpr_count"] <= 168, (name, k)
     # 16 / 32 / 64 : 1 with a workgroup of 4 / 8 / 16 waves per block: no scratch, 16 waves per CU (128 registers)
     wg = kernels("rr_ols_wg.hip", tmp_path)
-    assert len(wg) == 21  # 7 workgroup sizes x 3 mixer forms
+    assert len(wg) == 24  # 8 workgroup sizes x 3 mixer forms
     for name, k in wg.items():
         assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0 and k["vgpr_count"] <= 128, (name, k)
     fo = kernels("rr_filter_ols.hip", tmp_path)
