@@ -891,6 +891,8 @@ int rr_upsampler::process_dev(double input_rate, const void *d_in, size_t n_in, 
     std::vector<int32_t> next_before_hist;
     const int32_t *d_bef = nullptr;
     // rates on a 2^-s grid (44 100 -> 48 000): the schedule in closed form on the device (RR_UPSAMPLER_GENERIC=1: the list, A/B runs and tests)
+    // (integer ratios stay with k_upsample_int / the plain gather: routed here they measured slower - 10 x 0.62 against 0.43 ms per
+    //  2^22 samples, Complex<f64> 4 x 0.25 against 0.20)
     const bool closed = !sched.integer_ratio && sched.closed && sched.ra < (1ull << 31) && sched.rb < (1ull << 31) &&
                         ![] { const char *e = std::getenv("RR_UPSAMPLER_GENERIC"); return e && std::atoi(e) != 0; }();
     if (closed) {

@@ -378,7 +378,7 @@ int launch_upsample_closed(int dtype, hipStream_t s, const void *hist, size_t hn
     return RR_OK;
 }
 
-// Integer ratios U = 2 .. 8, f32: a lane produces the U outputs that one input releases (m = U t + p, p < U).
+// Integer ratios U = 2 .. 16, f32: a lane produces the U outputs that one input releases (m = U t + p, p < U).
 // They all sum over the same inputs t - jmax .. t, so a workgroup stages its 256 + J inputs
 // in LDS once (the taps come as scalar loads) and every input read serves U outputs (the one-output-per-lane form above reads 30 inputs
 // and 30 taps from L1/L2 per output: 1.38 ms for 2^24 inputs at U = 4).  Per output the same products in
@@ -468,15 +468,24 @@ int launch_upsample(int dtype, hipStream_t s, const void *hist, size_t hn, const
     if (n_out == 0) return RR_OK;
     if (L > 0x7fffffffull || n_out > 0x7fffffffull * 256) RR_FAIL(RR_ERR_BAD_ARG, "Upsampler: size out of range");
     if (U == 0 && !before) RR_FAIL(RR_ERR_BAD_ARG, "Upsampler: schedule missing");
-    if (dtype == RR_F32 && U >= 2 && U <= 8 && (L - 1) / U <= (size_t)kUpJmax && n_out >= 4096 && !std::getenv("RR_UPSAMPLER_GENERIC")) {
+    if (dtype == RR_F32 && U >= 2 && U <= 16 && (L - 1) / U <= (size_t)kUpJmax && n_out >= 4096 && !std::getenv("RR_UPSAMPLER_GENERIC")) {
         switch (U) {
+            case 9: launch_upsample_int<9>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
+            case 10: launch_upsample_int<10>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
+            case 11: launch_upsample_int<11>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
+            case 12: launch_upsample_int<12>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
+            case 13: launch_upsample_int<13>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
+            case 14: launch_upsample_int<14>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
+            case 15: launch_upsample_int<15>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
+            case 16: launch_upsample_int<16>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
             case 2: launch_upsample_int<2>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
             case 3: launch_upsample_int<3>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
             case 4: launch_upsample_int<4>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
             case 5: launch_upsample_int<5>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
             case 6: launch_upsample_int<6>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
             case 7: launch_upsample_int<7>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
-            default: launch_upsample_int<8>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
+            case 8: launch_upsample_int<8>(s, hist, hn, in, n_in, ir, L, out, n_out); break;
+            default: RR_FAIL(RR_ERR_BAD_ARG, "Upsampler: ratio %llu", (unsigned long long)U);
         }
         RR_HIP(hipGetLastError());
         return RR_OK;

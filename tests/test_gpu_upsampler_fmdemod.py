@@ -63,9 +63,9 @@ def test_upsampler_closed_form_schedule_long_stream(rr, oracle, fi, fo, bw, monk
         assert np.array_equal(y.view(np.float32), r.view(np.float32)), (i, a, b)
 
 
-@pytest.mark.parametrize("U", [2, 3, 5, 6, 7])
+@pytest.mark.parametrize("U", [2, 3, 5, 6, 7, 10, 13, 16])
 def test_upsampler_integer_ratio_kernel_bit_exact(rr, oracle, U):
-    """Integer ratios 2 .. 8 in f32 run k_upsample_int for calls of >= 4096 outputs (a lane produces the U
+    """Integer ratios 2 .. 16 in f32 run k_upsample_int for calls of >= 4096 outputs (a lane produces the U
     outputs one input releases, inputs staged in LDS, outputs leave through LDS in order): still bit-equal
     to the reference's scatter-add order, also at ragged call sizes and across the switch between kernels."""
     fi, fo = 1000.0, 1000.0 * U
