@@ -732,7 +732,7 @@ int rr_downsampler::ensure_fast() {
     // (f64: no fused overlap-save kernels, the polyphase kernel for every periodic ratio it fits)
     int kind = (dtype == RR_F32 && sched.integer_ratio) ? rr_chain::pick_fused_kernel(sched.D, L, true, 0) : rr_chain::FK_NONE;
     if (kind == rr_chain::FK_OLSF) kind = rr_chain::FK_OLSW;
-    if (mixer_rides && kind == rr_chain::FK_OLSW && (sched.D == 6 || sched.D >= 10) && decim_poly_supported(dtype, sched.P, sched.Q, L)) kind = rr_chain::FK_NONE;
+    if (mixer_rides && kind == rr_chain::FK_OLSW && sched.D >= 5 && sched.D != 8 && decim_poly_supported(dtype, sched.P, sched.Q, L)) kind = rr_chain::FK_NONE;
     // RR_DOWNSAMPLER_SELECT=1: k_filter_wave<true> for every pair of integer rates it takes (A/B runs, tests)
     const char *se = std::getenv("RR_DOWNSAMPLER_SELECT");
     const bool force_select = se && std::atoi(se) != 0 &&

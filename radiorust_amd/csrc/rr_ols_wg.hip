@@ -1,4 +1,4 @@
-// rr_ols_wg.hip — k_ols_wg<NW>: the fused mixer + FIR + decimation by D = 16, 32, 64 (rr_chain's front end, the stand-alone
+// rr_ols_wg.hip — k_ols_wg<NW>: the fused mixer + FIR + decimation by D = 5 .. 64 (first 16, 32, 64; rr_chain's front end, the stand-alone
 // Downsampler; transform.rs:171-260, filters.rs:240-259, resampling.rs:20-134 in one pass) by overlap-save with ONE WORKGROUP of
 // NW = D / 4 waves per block of N = 256 D samples.
 //
@@ -108,7 +108,8 @@ __global__ __launch_bounds__(64 * NW) void k_ols_wg(const float2 *__restrict__ x
     {
         const int h = w;                                           // this wave's run: the phases 4 w .. 4 w + 3
         const int off = D * (l >> 1) + 4 * h + 2 * (l & 1);        // the lane's first sample (j = 0, k' = 0); k': + 32 D
-        const bool live = 4 * h + 2 * (l & 1) < D;                 // (D = 4 NW - 2: the last wave's odd lanes have no phases - zeros)
+        // (phases beyond D - the last wave's, where D is no multiple of 4 - are zeros: live0 / live1 = the lane's phases j = 0 / 1 exist)
+        const bool live0 = 4 * h + 2 * (l & 1) < D, live1 = 4 * h + 2 * (l & 1) + 1 < D, live = live0;
         f2 e0_[8], e1_[8];
         if (RR_V_OLSWG_COOP && fast) {
             // the block's N samples by loads that are contiguous across the workgroup (thread t takes the 16-byte chunks t, t + NT,
@@ -116,6 +117,24 @@ __global__ __launch_bounds__(64 * NW) void k_ols_wg(const float2 *__restrict__ x
             // of each line, and the NW requests for a line reach L2 one by one: 2 - 3 x the requests, PMC), then through LDS to the
             // wave and lane that transform them: chunk c of period m is the pair a = c & 1 of wave c >> 1, lane 2 (m & 31) + a, value
             // k' = m >> 5 - the slot that lane's first exchange writes anyway
+            if (D & 1) {
+                // odd D: a period is no whole number of 16-byte chunks - sample by sample (8-byte loads, still contiguous across the
+                // workgroup): sample n = D m + p goes to wave p >> 2, lane 2 (m & 31) + ((p >> 1) & 1), value k' = m >> 5, half p & 1
+                const f2 *src1 = reinterpret_cast<const f2 *>(in + b0);
+                const int ns = 256 * D;  // at most 16 per thread (4 D / NW)
+                f2 s1[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int n = tid + NT * u;
+                    s1[u] = __builtin_nontemporal_load(src1 + (n < ns ? n : ns - 1));
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int n = tid + NT * u, m = n / D, pq = n - m * D;
+                    f2 *dst = smem + (pq >> 2) * kWgImg + 2 * (2 * (m & 31) + ((pq >> 1) & 1)) + (pq & 1) + 144 * (m >> 5);
+                    if (n < ns) lds_st(dst, s1[u]);
+                }
+            } else {
             const f4u *src = reinterpret_cast<const f4u *>(in + b0);
             const int nch = 128 * D;  // 16-byte chunks of the block: at most 8 per thread (2 D / NW)
             f4u ch[8];
@@ -130,21 +149,22 @@ __global__ __launch_bounds__(64 * NW) void k_ols_wg(const float2 *__restrict__ x
                 f2 *dst = smem + (c >> 1) * kWgImg + 2 * (2 * (m & 31) + (c & 1)) + 144 * (m >> 5);
                 if (q < nch) *reinterpret_cast<float4 *>(dst) = (float4){ch[u].x, ch[u].y, ch[u].z, ch[u].w};
             }
+            }
             __syncthreads();
             const f2 *row = lds + 2 * l;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float4 q4 = *reinterpret_cast<const float4 *>(row + 144 * k);
-                e0_[k] = live ? (f2){q4.x, q4.y} : (f2){0.f, 0.f};
-                e1_[k] = live ? (f2){q4.z, q4.w} : (f2){0.f, 0.f};
+                e0_[k] = live0 ? (f2){q4.x, q4.y} : (f2){0.f, 0.f};
+                e1_[k] = live1 ? (f2){q4.z, q4.w} : (f2){0.f, 0.f};
             }
         } else if (fast) {
             const f4u *src = reinterpret_cast<const f4u *>(in + b0 + (live ? off : 0));
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const f4u x = *(src + 16 * D * k);
-                e0_[k] = live ? (f2){x.x, x.y} : (f2){0.f, 0.f};
-                e1_[k] = live ? (f2){x.z, x.w} : (f2){0.f, 0.f};
+                e0_[k] = live0 ? (f2){x.x, x.y} : (f2){0.f, 0.f};
+                e1_[k] = live1 ? (f2){x.z, x.w} : (f2){0.f, 0.f};
             }
         } else {
             // edges (history - already mixed - in front, nothing behind the input) and the mixer in front: element by element, every
@@ -164,7 +184,8 @@ __global__ __launch_bounds__(64 * NW) void k_ols_wg(const float2 *__restrict__ x
                     // (MF: the block wants the samples UNMIXED - the history, which holds mixed ones, times conj(p))
                     const f2 pk = MF ? (f2){inr ? 1.f : (hst ? p.x : 0.f), hst ? -p.y : 0.f}
                                      : (f2){inr ? p.x : (hst ? 1.f : 0.f), inr ? p.y : 0.f};
-                    const f2 xv = {((inr || hst) && live) ? xx.x : 0.f, ((inr || hst) && live) ? xx.y : 0.f};
+                    const bool lv = j ? live1 : live0;
+                    const f2 xv = {((inr || hst) && lv) ? xx.x : 0.f, ((inr || hst) && lv) ? xx.y : 0.f};
                     (j ? e1_[k] : e0_[k]) = cmul(xv, pk);
                 }
                 rr_ += kstep;
@@ -322,8 +343,13 @@ __global__ __launch_bounds__(64 * NW) void k_ols_wg(const float2 *__restrict__ x
 bool ols_wg_supported(uint64_t D, size_t Lc) {
     const char *e = std::getenv("RR_OLS_WG");  // (read per design: tests switch it within one process)
     if (e && std::atoi(e) == 0) return false;
-    if (D < 6 || D == 8 || D > 64 || (D & 1) || Lc < 1 || Lc - 1 > 128 * D) return false;  // (8 : 1: k_ols_wave2k)
+    if (D < 5 || D == 8 || D > 64 || Lc < 1 || Lc - 1 > 128 * D) return false;  // (8 : 1: k_ols_wave2k)
     if (D == 16 || D == 32 || D == 64) return true;
+    if (D & 1) {
+        // odd ratios (the block staged sample by sample; 1 or 3 of the last wave's four phases empty): from 24 resp. 32 taps per period on
+        const size_t per_odd = ((D & 3) == 3 ? 24 : 32);
+        return (e && std::atoi(e) == 2) || Lc >= per_odd * D;
+    }
     // taps per period from which this kernel is ahead of the decimator (scripts/decim_pow2_probe.py, ms per 2^26 samples, decimator /
     // this kernel: 10 : 1 with 15 / 30 taps per period 0.132 / 0.199 against 0.157 / 0.167; 12 : 1 0.132 / 0.217 against 0.137 / 0.144;
     // 20 : 1 0.162 / 0.223 against 0.149 / 0.158; 48 : 1 0.233 / 0.455 against 0.184 / 0.195): a last wave with half of its lanes
@@ -384,7 +410,7 @@ int ols_wg_runs(uint64_t D) { return ols_wg_waves(D); }
 
 int launch_ols_wg(hipStream_t s, const FusedFirArgs &a) {
     if (a.n_out == 0) return RR_OK;
-    if (a.D < 6 || a.D > 64 || (a.D & 1)) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS: decimation %u has no workgroup kernel", a.D);
+    if (a.D < 5 || a.D > 64) RR_FAIL(RR_ERR_BAD_ARG, "fused OLS: decimation %u has no workgroup kernel", a.D);
     switch (ols_wg_waves(a.D)) {
     case 2: return launch_ols_wg_n<2>(s, a);
     case 3: return launch_ols_wg_n<3>(s, a);

@@ -14,7 +14,7 @@ def timed(call, K=10):
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(K): call()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / K
-for D in (6, 8, 10, 12, 16, 20, 24, 32, 48, 64):
+for D in (5, 6, 7, 8, 9, 10, 12, 15, 16, 20, 24, 32, 48, 64):
     for bwf in (0.6, 0.8, 0.9):
         fo = 102400.0
         ds = rr.Downsampler.new(4096, fo, fo * bwf); ds.set_stream(st)

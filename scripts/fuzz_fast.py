@@ -22,7 +22,7 @@ worst = {"down": 0.0, "filter": 0.0}
 seen = {"down": set(), "filter": set()}
 for case in range(cases):
     # ---- Downsampler -------------------------------------------------------------------------------
-    D = int(rng.choice([2, 4, 4, 4, 8, 8, 16, 32, 64, 10, 12, 14, 20, 24, 30, 48, 62]))
+    D = int(rng.choice([2, 4, 4, 4, 8, 8, 16, 32, 64, 10, 12, 14, 20, 24, 30, 48, 62, 5, 7, 9, 15, 21, 33]))
     fo = float(rng.choice([48000.0, 50e6, 1.0]))
     fi = fo * D
     if rng.random() < 0.4:  # aim at the selection boundaries (L = ceil(fi / margin * q), margin = (fo - bw) / 2)

@@ -603,6 +603,7 @@ def test_downsampler_polyphase_kernel_one_period_per_lane_on_request(rr, oracle,
 @pytest.mark.parametrize("D,bwf", [(16, 0.6), (16, 0.9), (32, 0.8), (64, 0.6), (64, 0.9),
                                    # even ratios that are no powers of two (from 16 taps per period on): 3 .. 16 waves, the last one
                                    # with half of its lanes empty where D = 4 NW - 2
+                                   (5, 0.9), (7, 0.9), (9, 0.9), (15, 0.9), (25, 0.9), (63, 0.9),  # odd ratios: the block staged sample by sample
                                    (6, 0.9), (10, 0.9), (12, 0.8), (14, 0.9), (20, 0.9), (22, 0.8), (24, 0.8), (34, 0.8), (48, 0.8), (62, 0.9)])
 def test_downsampler_power_of_two_ratios_polyphase_decimator_on_request(rr, oracle, D, bwf, monkeypatch):
     """RR_OLS_WG=0: 16 / 32 / 64 : 1 through k_decim_poly (direct form) instead of k_ols_wg (overlap-save, a workgroup per block of
