@@ -347,7 +347,9 @@ bool ols_wg_supported(uint64_t D, size_t Lc) {
     if (D == 16 || D == 32 || D == 64) return true;
     if (D & 1) {
         // odd ratios (the block staged sample by sample; 1 or 3 of the last wave's four phases empty): from 24 resp. 32 taps per period on
-        const size_t per_odd = ((D & 3) == 3 ? 24 : 32);
+        // (5 : 1 - two waves, three of eight phase slots empty - only for very long responses: the chain's 183 taps at 5 : 1 measured
+        //  0.304 ms through this kernel against the decimator's 0.251)
+        const size_t per_odd = D == 5 ? 56 : ((D & 3) == 3 ? 24 : 32);
         return (e && std::atoi(e) == 2) || Lc >= per_odd * D;
     }
     // taps per period from which this kernel is ahead of the decimator (scripts/decim_pow2_probe.py, ms per 2^26 samples, decimator /
