@@ -253,7 +253,8 @@ int rr_downsampler_process_dev(rr_downsampler *h, double input_rate,
 int rr_downsampler_ir_len(const rr_downsampler *h, size_t *ir_len);
 /* Which kernel the last process call ran: 0 = k_fir (any ratio, any dtype); integer ratios 2, 4, 8
  * in f32 and calls of >= 4096 samples take the chain's fused kernels with an all-ones NCO table
- * (1 k_mix_fir_decim, 2 k_ols_decim4, 3 k_ols_wave); every other integer ratio P : 1 and rational
+ * (1 k_mix_fir_decim, 2 k_ols_decim4, 3 the wave / workgroup overlap-save kernels: k_ols_wave at 2 and 4 : 1,
+ * k_ols_wave2k at 8 : 1, k_ols_wg at the ratios 5 .. 64 with long responses); every other integer ratio P : 1 and rational
  * ratios P : Q with Q <= 8 (both rates integral; e.g. 10 : 1, 8 : 3) take 5 = k_decim_poly (direct form,
  * polyphase LDS layout): same result within rounding (tests: 1e-5 RMS against the f64 oracle).
  * RR_DOWNSAMPLER_GENERIC=1 in the environment keeps k_fir. */
