@@ -40,7 +40,13 @@ namespace rr {
 #ifndef RR_V_OLSWG_COOP
 #define RR_V_OLSWG_COOP 1  // the block's samples by workgroup-contiguous loads and through LDS to their lanes (0: every wave loads its own phases)
 #endif
-constexpr unsigned kWgWin = 8;  // blocks dealt to the XCDs in a moving window, that many neighbouring blocks per XCD
+#ifndef RR_V_OLSWG_WIN
+#define RR_V_OLSWG_WIN 8
+#endif
+#ifndef RR_V_OLSWG_NT
+#define RR_V_OLSWG_NT 1  // the streaming hint on the staging loads (windows of 2 / 8 / 32 blocks per XCD, the hint on / off: all within 2 %)
+#endif
+constexpr unsigned kWgWin = RR_V_OLSWG_WIN;  // blocks dealt to the XCDs in a moving window, that many neighbouring blocks per XCD
 constexpr int kWgImg = 1140;    // a wave's exchange image (k_ols_wave<4, POLY>'s 1136 elements: 2 (63 + 72 * 7) + 2) + 4: the images 8 banks apart
 
 template <int NW, bool MF, bool GP>
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(64 * NW) void k_ols_wg(const float2 *__restrict__ x
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int q = tid + NT * u;
-                ch[u] = ld_stream(src + (q < nch ? q : nch - 1));
+                ch[u] = RR_V_OLSWG_NT ? ld_stream(src + (q < nch ? q : nch - 1)) : *(src + (q < nch ? q : nch - 1));
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
