@@ -325,7 +325,16 @@ __global__ __launch_bounds__(64 * NW) void k_ols_wg(const float2 *__restrict__ x
     if constexpr (GP) {  // result tau = l + 64 c at b0 + D tau: the phase table's own entry there
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const unsigned idx = (unsigned)(((unsigned long long)base + (unsigned)(D * (l + 64 * c))) % denom);
+            // (base < denom, the step below 2^14: one conditional subtraction where the table is longer than that, a 32-bit
+            //  remainder otherwise - a 64-bit remainder per result cost as much as the inverse transform)
+            const unsigned add = (unsigned)(D * (l + 64 * c));
+            unsigned idx;
+            if (denom > 16320u) {
+                const unsigned long long r64 = (unsigned long long)base + add;
+                idx = (unsigned)(r64 >= denom ? r64 - denom : r64);
+            } else {
+                idx = (base + add) % denom;
+            }
             const float2 p = nco[idx];
             y[c] = cmul(y[c], (f2){p.x, p.y});
         }

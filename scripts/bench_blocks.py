@@ -117,7 +117,9 @@ for name, kw, D in (("chain 4:1 / FFT 4096, Lc 183 (cfg2)", dict(shift=25e6, fil
                     ("chain 4:1 / FFT 1024", dict(shift=25e6, filter_len=64, output_rate=50e6, bandwidth=40e6, fft_len=1024), 4),
                     ("chain 8:1 / FFT 4096", dict(shift=25e6, filter_len=64, output_rate=25e6, bandwidth=20e6, fft_len=4096), 8),
                     ("chain 10:1 / FFT 4096 (the example's ratio)", dict(shift=12.5e6, filter_len=64, output_rate=20e6, bandwidth=12e6, fft_len=4096), 10),
-                    ("chain 5:1 / FFT 4096", dict(shift=12.5e6, filter_len=64, output_rate=40e6, bandwidth=30e6, fft_len=4096), 5)):
+                    ("chain 5:1 / FFT 4096", dict(shift=12.5e6, filter_len=64, output_rate=40e6, bandwidth=30e6, fft_len=4096), 5),
+                    ("chain 16:1 / FFT 4096 (k_ols_wg)", dict(shift=12.345e6, precision=1e3, filter_len=64, output_rate=12.5e6, bandwidth=10e6, fft_len=4096), 16),
+                    ("chain 20:1 / FFT 1024 (k_ols_wg)", dict(shift=12.5e6, filter_len=64, output_rate=10e6, bandwidth=8e6, fft_len=1024), 20)):
     ch = rr.Chain(freq_resp=lp, fft_window=rr.Kaiser.with_null_at_bin(2.0), **kw)
     ch.set_stream(st)
     cap = N // D + 2 * kw["fft_len"]
